@@ -1,0 +1,283 @@
+"""Pins the CPU restatement (oracle/rs_oracle.c) before anything trusts it.
+
+Sources of truth, in order: the reference's own known-answer material
+(radix_tests.cpp literals, stdout tables of Listings 4-6, README.md:612-623),
+the committed golden table generated from the real headers
+(tests/golden/kat_table.json, tools/gen_golden.py), and -- where
+oracle/_ref/libref.so is present -- the real reference itself on randomized sweeps.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLDEN, "kat_table.json")) as f:
+    KAT = json.load(f)
+
+needs_ref = pytest.mark.skipif(ol.ref() is None, reason="oracle/_ref/libref.so not built (no /root/reference)")
+
+
+def _id(row):
+    return "%s-n%d-s%d-m%s-o%d" % (row["dtype"], row["n"], row["seed"], row["mask"].lstrip("0") or "0", row.get("order", 0))
+
+
+@pytest.mark.parametrize("row", KAT["scalar"] + KAT["scalar_extra"], ids=_id)
+def test_oracle_matches_golden_table(row):
+    dt = row["dtype_code"]
+    a = ol.splitmix_fill(row["n"], dt, row["seed"], int(row["mask"], 16))
+    assert "%016x" % ol.fnv1a64(a) == row["fnv_in"]
+    res, in_aux, info = ol.oracle_sort(a, dt, row["order"])
+    assert "%016x" % ol.fnv1a64(res) == row["fnv_out"]
+    assert in_aux == row["result_in_aux"]
+    assert info.result_in_aux == in_aux
+    # net effect == stable sort by KDF key
+    if row["n"]:
+        assert np.array_equal(res, a[ol.stable_argsort_by_kdf(a, dt, row["order"])])
+
+
+@pytest.mark.parametrize("row", KAT["rank"], ids=_id)
+def test_oracle_rank_matches_golden(row):
+    dt = row["dtype_code"]
+    a = ol.splitmix_fill(row["n"], dt, row["seed"], int(row["mask"], 16))
+    ranks, half, info, _ = ol.oracle_rank(a, dt, 4)
+    assert "%016x" % ol.fnv1a64(ranks) == row["fnv_stable_argsort"]
+    if row["reference_is_correct"]:
+        # where the header is right it and Listing 6 agree, including the returned half
+        assert half == row["reference_result_half"]
+        assert row["fnv_reference_output"] == row["fnv_stable_argsort"]
+    # the header's own loop restated (rso_sort_rank_asheader) reproduces the header's output bit for bit
+    hr, hhalf, _, _ = ol.oracle_rank(a, dt, 4, asheader=True)
+    assert "%016x" % ol.fnv1a64(hr) == row["fnv_reference_output"]
+    assert hhalf == row["reference_result_half"]
+
+
+def test_oracle_kv_records_pin():
+    kv = KAT["kv"][0]
+    n = kv["n"]
+    k = ol.splitmix_fill(n, ol.U32, kv["seed"], int(kv["mask"], 16))
+    rec = np.empty((n, 2), dtype=np.uint32)
+    rec[:, 0] = k
+    rec[:, 1] = np.arange(n, dtype=np.uint32)
+    assert "%016x" % ol.fnv1a64(rec) == kv["fnv_in"]
+    src, aux = rec.copy(), np.zeros_like(rec)
+    info = ol.Info()
+    r = ol.oracle().rso_sort_records(ol.ptr(src), ol.ptr(aux), n, 8, 0, ol.F32, 0, C.byref(info))
+    res = aux if r else src
+    assert r == kv["result_in_aux"]
+    assert "%016x" % ol.fnv1a64(res) == kv["fnv_out_aos"]
+    assert "%016x" % ol.fnv1a64(np.ascontiguousarray(res[:, 1])) == kv["fnv_out_payloads"]
+    # and the rank path on the bare keys gives the same payload column
+    ranks, _, _, _ = ol.oracle_rank(k, ol.F32, 4)
+    assert "%016x" % ol.fnv1a64(ranks) == kv["fnv_out_payloads"]
+
+
+def test_oracle_test_int_fixture():
+    """radix_tests.cpp:179-207 on the captured input: ascending, then descending re-sort."""
+    ti = KAT["test_int"]
+    a = np.fromfile(os.path.join(GOLDEN, ti["file"]), dtype=np.uint32)
+    assert a.size == ti["n"] and "%016x" % ol.fnv1a64(a) == ti["fnv_in"]
+    asc, r1, _ = ol.oracle_sort(a, ol.I32, ol.ASC)
+    assert "%016x" % ol.fnv1a64(asc) == ti["fnv_ascending"] and r1 == ti["ascending_in_aux"]
+    assert np.all(np.diff(asc.view(np.int32).astype(np.int64)) >= 0)          # :194 is_sorted
+    desc, r2, _ = ol.oracle_sort(asc, ol.I32, ol.DESC)                        # :175-177,:198
+    assert "%016x" % ol.fnv1a64(desc) == ti["fnv_descending"] and r2 == ti["descending_in_aux"]
+    assert np.all(np.diff(desc.view(np.int32).astype(np.int64)) <= 0)         # :199 greater<int>
+
+
+# ---- the reference's literal known-answer material -------------------------------------------
+
+def test_float_order_readme():
+    """radix_tests.cpp:156-173 input; expected order printed at README.md:612-623."""
+    vals = np.array([128.0, 646464.0, 0.0, -0.0, -0.5, 0.5, -128.0, -np.inf, np.nan, np.inf], dtype=np.float32)
+    res, in_aux, _ = ol.oracle_sort(vals.view(np.uint32), ol.F32)
+    expect = [0xff800000, 0xc3000000, 0xbf000000, 0x80000000, 0x00000000, 0x3f000000, 0x43000000,
+              0x491dd400, 0x7f800000, 0x7fc00000]
+    assert [int(x) for x in res] == expect
+
+
+def test_kdf_known_values():
+    """SURVEY.md 8a row a8 (probed from radix_sort_basic_kdf.hpp)."""
+    def kdf(bits, dt, order=0):
+        a = np.array([bits], dtype=ol.NP_BITS[dt])
+        return int(ol.oracle().rso_kdf(ol.ptr(a), dt, order))
+    assert kdf(0x00000000, ol.F32) == 0x80000000
+    assert kdf(0x80000000, ol.F32) == 0x7fffffff
+    assert kdf(0xff800000, ol.F32) == 0x007fffff
+    assert kdf(0x7f800000, ol.F32) == 0xff800000
+    assert kdf(0x7fc00000, ol.F32) == 0xffc00000
+    assert kdf(0xffc00000, ol.F32) == 0x003fffff
+    assert kdf(0xffffffff, ol.I32) == 0x7fffffff
+    assert kdf(0x80000000, ol.I32) == 0
+    assert kdf(0x8000000000000000, ol.F64) == 0x7fffffffffffffff
+    assert kdf(0x0000000000000000, ol.F64) == 0x8000000000000000
+    assert kdf(0x12, ol.U8, ol.DESC) == 0xED
+    assert kdf(0x80, ol.I8) == 0
+
+
+SORTREC = [(255, "1st 255"), (45, "1st 45"), (3, "3"), (45, "2nd 45"), (2, "2"), (45, "3rd 45"),
+           (1, "1"), (255, "2nd 255")]   # radix_tests.cpp:20-29
+
+
+def _sortrec_array():
+    rec = np.zeros(len(SORTREC), dtype=np.dtype([("key", np.uint8), ("pad", np.uint8, 7), ("name", np.uint64)]))
+    rec["key"] = [k for k, _ in SORTREC]
+    rec["name"] = np.arange(len(SORTREC))      # stands in for the const char* (opaque payload)
+    assert rec.itemsize == 16
+    return rec
+
+
+def test_sortrec_records():
+    """radix_tests.cpp:45-69 (ascending by key) and :121-146 (descending via ~key): stable both ways."""
+    rec = _sortrec_array()
+    for order, expect in ((0, [6, 4, 2, 1, 3, 5, 0, 7]), (1, [0, 7, 1, 3, 5, 2, 4, 6])):
+        src, aux = rec.copy(), np.zeros_like(rec)
+        info = ol.Info()
+        r = ol.oracle().rso_sort_records(ol.ptr(src), ol.ptr(aux), len(rec), 16, 0, ol.U8, order, C.byref(info))
+        res = aux if r else src
+        assert r == 1 and info.ncols == 1                      # one u8 column -> result in aux
+        assert [int(x) for x in res["name"]] == expect
+        if ol.ref() is not None and ol.ref().ref_sizeof_sortrec() == 16:
+            s2, a2 = rec.copy(), np.zeros_like(rec)
+            r2 = ol.ref().ref_sort_sortrec(ol.ptr(s2), ol.ptr(a2), len(rec), order)
+            assert r2 == r and np.array_equal((a2 if r2 else s2)["name"], res["name"])
+
+
+def test_rank_sortrec_u8_index():
+    """radix_tests.cpp:71-105: IdxType = uint8_t, 2N buffer, valid permutation, keys non-decreasing."""
+    rec = _sortrec_array()
+    n = len(rec)
+    ib = np.full(2 * n, 0xA5, dtype=np.uint8)
+    info = ol.Info()
+    r = ol.oracle().rso_sort_rank(ol.ptr(rec), 16, 0, ol.U8, 0, ol.ptr(ib), 1, n, C.byref(info))
+    ranks = ib[n:] if r else ib[:n]
+    assert sorted(int(x) for x in ranks) == list(range(n))
+    assert [int(x) for x in ranks] == [6, 4, 2, 1, 3, 5, 0, 7]
+    if ol.ref() is not None and ol.ref().ref_sizeof_sortrec() == 16:
+        ib2 = np.full(2 * n, 0xA5, dtype=np.uint8)
+        r2 = ol.ref().ref_rank_sortrec_u8idx(ol.ptr(rec), ol.ptr(ib2), n)
+        assert r2 == r and np.array_equal(ib2, ib)
+
+
+def test_listing4_u32_stable_table():
+    """radix_sort_u32.c:100-109 input; its printed table keeps '1st/2nd/3rd 45' and '1st/2nd 4255' in order."""
+    keys = np.array([4255, 45, 45, 45, 1, 2, 0xFFFFFFFF, 4255], dtype=np.uint32)
+    rec = np.empty((8, 2), dtype=np.uint32)
+    rec[:, 0] = keys
+    rec[:, 1] = np.arange(8)
+    src, aux = rec.copy(), np.zeros_like(rec)
+    r = ol.oracle().rso_sort_records(ol.ptr(src), ol.ptr(aux), 8, 8, 0, ol.U32, 0, None)
+    res = aux if r else src
+    assert [int(x) for x in res[:, 0]] == [1, 2, 45, 45, 45, 4255, 4255, 0xFFFFFFFF]
+    assert [int(x) for x in res[:, 1]] == [4, 5, 1, 2, 3, 0, 7, 6]
+
+
+def test_listing5_u64_table():
+    """radix_sort_u64_multipass.c:101-112 keys come out ascending."""
+    keys = np.array([1 << 63, 1 << 52, 1 << 40, 1 << 32, 1 << 48, 1 << 60, 0xFFFFFFFFFFFFFFFF, 4, 4255, 1],
+                    dtype=np.uint64)
+    res, _, info = ol.oracle_sort(keys, ol.U64)
+    assert [int(x) for x in res] == sorted(int(x) for x in keys)
+
+
+def test_listing6_ranks_table():
+    """radix_sort_u32_ranks.c:8-19 keys -> ranks 4,1,2,3,6,7,0,9,5,8."""
+    keys = np.array([4255, 45, 45, 45, 0, 0x800201, 255, 256, 0xFFFFFFFF, 4255], dtype=np.uint32)
+    ranks, half, info, _ = ol.oracle_rank(keys, ol.U32, 4)
+    assert [int(x) for x in ranks] == [4, 1, 2, 3, 6, 7, 0, 9, 5, 8]
+
+
+# ---- observable contract ------------------------------------------------
+
+def test_contract_small_n_and_presorted():
+    lib = ol.oracle()
+    for n in (0, 1):
+        src = np.array([7, 3][:n], dtype=np.uint32)
+        aux = np.full(max(n, 1), 0xA5A5A5A5, dtype=np.uint32)
+        info = ol.Info()
+        assert lib.rso_sort(ol.ptr(src), ol.ptr(aux), n, ol.U32, 0, C.byref(info)) == 0
+        assert info.early_exit == 1 and np.all(aux == 0xA5A5A5A5)
+    # pre-sorted (non-decreasing, with duplicates): src returned, aux untouched (radix_sort.hpp:60-62)
+    src = np.array([1, 1, 2, 5, 5, 900, 70000], dtype=np.uint32)
+    aux = np.full(7, 0xA5A5A5A5, dtype=np.uint32)
+    info = ol.Info()
+    assert lib.rso_sort(ol.ptr(src), ol.ptr(aux), 7, ol.U32, 0, C.byref(info)) == 0
+    assert info.early_exit == 2 and info.n_unsorted == 1 and np.all(aux == 0xA5A5A5A5)
+    # reverse-sorted input is NOT detected: full sort
+    src = np.array([9, 7, 5, 3], dtype=np.uint32)
+    aux = np.zeros(4, dtype=np.uint32)
+    assert lib.rso_sort(ol.ptr(src), ol.ptr(aux), 4, ol.U32, 0, C.byref(info)) == 1  # 1 live column -> aux
+    assert info.early_exit == 0 and info.ncols == 1 and list(aux) == [3, 5, 7, 9]
+    # rank: n==1 writes index 0; n==0 untouched; presorted -> first half iota, second half untouched
+    ib = np.full(2, 0xA5, dtype=np.uint32)
+    assert lib.rso_sort_rank(ol.ptr(np.array([5], dtype=np.uint32)), 4, 0, ol.U32, 0, ol.ptr(ib), 4, 1, None) == 0
+    assert ib[0] == 0 and ib[1] == 0xA5
+    src = np.array([1, 2, 2, 3], dtype=np.uint32)
+    ib = np.full(8, 0xA5, dtype=np.uint32)
+    assert lib.rso_sort_rank(ol.ptr(src), 4, 0, ol.U32, 0, ol.ptr(ib), 4, 4, None) == 0
+    assert list(ib) == [0, 1, 2, 3, 0xA5, 0xA5, 0xA5, 0xA5]
+
+
+@pytest.mark.parametrize("mask,cols,in_aux", [(0x00FFFFFF, [0, 1, 2], 1), (0x0000FFFF, [0, 1], 0),
+                                                 (0x000000FF, [0], 1), (0xFF00FF00, [1, 3], 0)])
+def test_contract_column_skip_and_parity(mask, cols, in_aux):
+    a = ol.splitmix_fill(5000, ol.U32, 77, mask)
+    res, r, info = ol.oracle_sort(a, ol.U32)
+    assert list(info.cols[:info.ncols]) == cols and r == in_aux
+    assert np.array_equal(res, np.sort(a, kind="stable"))
+
+
+def test_histogram_is_loop1():
+    a = ol.splitmix_fill(10000, ol.U32, 5)
+    hist = np.zeros(256 * 8, dtype=np.uint64)
+    nu = C.c_uint64()
+    ol.oracle().rso_histogram(ol.ptr(a), a.size, 4, 0, ol.U32, 0, ol.ptr(hist), C.byref(nu))
+    for j in range(4):
+        assert np.array_equal(hist[256 * j:256 * j + 256], np.bincount((a >> (8 * j)) & 0xFF, minlength=256))
+    assert nu.value == a.size - int(np.sum(a[:-1] <= a[1:]))
+
+
+# ---- randomized differential sweep against the real reference ------------------------------------
+
+@needs_ref
+@pytest.mark.parametrize("dt", range(10), ids=ol.DTYPE_NAMES)
+def test_oracle_vs_reference_sweep(dt):
+    rng = np.random.default_rng(1234 + dt)
+    full = (1 << (8 * ol.DTYPE_SIZE[dt])) - 1
+    for trial in range(40):
+        n = int(rng.choice([0, 1, 2, 3, 17, 255, 256, 257, 1000, 4097, 65535, 65536, 65537, 200000]))
+        mask = full
+        if trial % 3 == 1:   # knock out random byte columns -> column skipping
+            for b in range(ol.DTYPE_SIZE[dt]):
+                if rng.random() < 0.5:
+                    mask &= ~(0xFF << (8 * b))
+        if trial % 3 == 2:   # duplicate-heavy
+            mask &= int(rng.integers(0, full, dtype=np.uint64, endpoint=True))
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        if trial % 7 == 6 and n:
+            a = a[ol.stable_argsort_by_kdf(a, dt, trial & 1)]   # pre-sorted input -> early exit
+        for order in (ol.ASC, ol.DESC):
+            want, want_aux = ol.ref_sort(a, dt, order)
+            got, got_aux, info = ol.oracle_sort(a, dt, order)
+            assert got_aux == want_aux
+            assert np.array_equal(got, want)
+            # the generic record path (rec_size == key size) is the same function
+            src, aux = a.copy(), np.full_like(a, 0xA5)
+            r = ol.oracle().rso_sort_records(ol.ptr(src), ol.ptr(aux), n, ol.DTYPE_SIZE[dt], 0, dt, order, None)
+            assert r == want_aux and np.array_equal(aux if r else src, want)
+
+
+@needs_ref
+def test_oracle_vs_reference_untouched_buffers():
+    """The non-returned buffer holds the previous pass's data; both must match the reference byte for byte."""
+    for mask in (0xFFFFFFFF, 0x00FFFFFF, 0xFF00, 0xFF):
+        a = ol.splitmix_fill(3000, ol.U32, 9, mask)
+        s1, a1 = a.copy(), np.full_like(a, 0xA5)
+        s2, a2 = a.copy(), np.full_like(a, 0xA5)
+        r1 = ol.ref().ref_sort(ol.ptr(s1), ol.ptr(a1), a.size, ol.U32, 0)
+        r2 = ol.oracle().rso_sort(ol.ptr(s2), ol.ptr(a2), a.size, ol.U32, 0, None)
+        assert r1 == r2 and np.array_equal(s1, s2) and np.array_equal(a1, a2)
