@@ -1,0 +1,188 @@
+/*
+ * rsx.h -- C ABI of the MI355X-native LSD radix sort (librsx.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference has
+ * no FFI: its surface is the header-only templates
+ *
+ *     T*       radix_sort(T* src, T* aux, size_t n, KeyFunc&& kf = basic_kdfs::kdf)
+ *                                                           radix_sort.hpp:98-99
+ *     IdxType* radix_sort_rank(const T* src, IdxType* index_buffer, size_t n, KeyFunc&& kf)
+ *                                                           radix_sort_rank.hpp:97-98
+ *     T*       rs_sort_main(src, aux, n, Hist&, kf)         radix_sort.hpp:31-32
+ *
+ * include/radix_sort.hpp, radix_sort_rank.hpp and radix_sort_basic_kdf.hpp in
+ * this directory re-create those templates on top of the functions below
+ * (see INTEGRATION.md).  All entry points use plain pointers and sizes only.
+ *
+ * Conventions
+ *   - Return value: 0 on success, a negative RSX_E* code on failure;
+ *     rsx_last_error() gives the message for the calling thread.  There is no
+ *     CPU fallback: without a usable gfx950 device every sort call fails with
+ *     RSX_ENODEVICE.
+ *   - "Returned pointer" rule (radix_sort.hpp:89,:92): the result is in `src`
+ *     when the number of kept (non-constant) 8-bit key columns is even, in
+ *     `aux` when it is odd; n < 2 and already-sorted inputs return `src` and
+ *     leave `aux` untouched (radix_sort.hpp:37-38,:60-62).  The buffer that is
+ *     not returned has unspecified contents except in those early exits.
+ *   - Order is a stable sort by kdf(key): output element images are bit-exact
+ *     copies of the input's (NaN payloads, -0.0), radix_sort.hpp:85-87.
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Key kinds = the scalar types basic_kdfs::kdf accepts
+ * (radix_sort_basic_kdf.hpp:19-46; radix_experiment.cpp:264-282). */
+typedef enum rsx_dtype {
+	RSX_U8 = 0, RSX_U16 = 1, RSX_U32 = 2, RSX_U64 = 3,
+	RSX_I8 = 4, RSX_I16 = 5, RSX_I32 = 6, RSX_I64 = 7,
+	RSX_F32 = 8, RSX_F64 = 9
+} rsx_dtype;
+
+/* RSX_ASCENDING = basic_kdfs::kdf; RSX_DESCENDING = its bitwise complement,
+ * the reference's descending KDF (README.md:564-574, radix_tests.cpp:111-113,
+ * :175-177).  Equal keys keep input order either way. */
+typedef enum rsx_order { RSX_ASCENDING = 0, RSX_DESCENDING = 1 } rsx_order;
+
+enum {
+	RSX_OK = 0,
+	RSX_EINVAL = -1,     /* bad dtype / size / null pointer                */
+	RSX_ENODEVICE = -2,  /* no usable gfx950 device / HIP runtime failure  */
+	RSX_ENOMEM = -3,     /* device workspace allocation failed             */
+	RSX_EHIP = -4        /* a HIP call failed (see rsx_last_error)         */
+};
+
+/* What the front half of rs_sort_main decided (radix_sort.hpp:48-80). */
+typedef struct rsx_info {
+	uint32_t key_bytes;     /* wc = sizeof(KeyType), radix_sort.hpp:40          */
+	uint32_t ncols;         /* kept columns, radix_sort.hpp:64-70               */
+	uint32_t cols[8];       /* their indices, LSB first                          */
+	uint32_t early_exit;    /* 0 none; 1 n<2 (:37-38); 2 pre-sorted (:60-62)    */
+	uint32_t result_in_aux; /* 1 iff the result is the second buffer / half     */
+} rsx_info;
+
+/* ---- environment ---------------------------------------------------------- */
+
+int         rsx_device_count(void);   /* gfx950 devices visible; 0 if none / no runtime */
+const char *rsx_last_error(void);     /* message of the calling thread's last failure   */
+const char *rsx_version(void);
+size_t      rsx_dtype_size(rsx_dtype dtype);
+/* Bytes of device workspace a sort of n keys of this shape will hold on to. */
+size_t      rsx_workspace_bytes(size_t n, rsx_dtype dtype, size_t payload_bytes);
+/* Release every cached workspace / stream context of the calling process. */
+void        rsx_release(void);
+
+/* ---- radix_sort<T>(src, aux, n) -- radix_sort.hpp:98-115 ------------------ */
+
+/* src/aux may be host pointers (staged over PCIe) or device pointers on the
+ * current device (sorted in place in HBM); both must be of the same kind.
+ * *result receives src or aux.  Blocking. */
+int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
+             void **result, rsx_info *info);
+
+/* Device-resident variant for callers that own a HIP stream (`stream` is a
+ * hipStream_t, NULL = the default stream).  The column plan has to reach the
+ * host to apply the returned-pointer rule, so the call synchronises `stream`
+ * once after the histogram pass; the scatter passes are enqueued and NOT
+ * waited for: the result is valid for work ordered after them on `stream`. */
+int rsx_sort_device(void *d_src, void *d_aux, size_t n, rsx_dtype dtype, rsx_order order,
+                    void *stream, void **result, rsx_info *info);
+
+/* ---- key + payload (struct-of-arrays) ------------------------------------- */
+
+/* Stable sort of (key[i], payload[i]) pairs by kdf(key): the device form of the
+ * reference's radix_sort on {key, payload} records (radix_tests.cpp:41-56 shape,
+ * SURVEY.md 8d cfg 4).  payload_bytes is 4 or 8.  Keys and payloads ping-pong
+ * together; info->result_in_aux tells which pair of buffers holds the result. */
+int rsx_sort_pairs_device(void *d_keys, void *d_keys_aux, void *d_vals, void *d_vals_aux,
+                          size_t n, rsx_dtype dtype, size_t payload_bytes, rsx_order order,
+                          void *stream, rsx_info *info);
+
+/* ---- radix_sort_rank<T,IdxType>(src, index_buffer, n) --------------------- */
+
+/* radix_sort_rank.hpp:97-112 with the pass semantics of Listing 6
+ * (radix_sort_u32_ranks.c:85-107), i.e. a correct stable argsort: see
+ * SURVEY.md section 4 for the header's defect.  index_buffer holds 2n indices of
+ * idx_bytes (1, 2, 4 or 8; n must fit).  *result receives index_buffer (kept
+ * columns even, n<2, pre-sorted) or index_buffer + n (odd).  Pre-sorted input
+ * writes 0..n-1 to the first half and leaves the second untouched
+ * (radix_sort_rank.hpp:52,:55-57); n == 1 writes index_buffer[0] = 0 (:28-32).
+ * Host or device pointers (both of the same kind).  Blocking. */
+int rsx_sort_rank(const void *src, void *index_buffer, size_t n, rsx_dtype dtype,
+                  size_t idx_bytes, rsx_order order, void **result, rsx_info *info);
+
+/* Device-resident variant; idx_bytes is 4 or 8. */
+int rsx_sort_rank_device(const void *d_src, void *d_index_buffer, size_t n, rsx_dtype dtype,
+                         size_t idx_bytes, rsx_order order, void *stream, void **result,
+                         rsx_info *info);
+
+/* ---- records with a host-evaluated key (opaque KeyFunc) -------------------- */
+
+/* radix_sort(src, aux, n, kf) for trivially copyable T and an arbitrary host
+ * KeyFunc (radix_tests.cpp:41-43,:111-113; README.md:562-591): the template
+ * wrapper evaluates kf once per element into `keys` (n unsigned keys of
+ * key_bytes = sizeof(KeyType) in {1,2,4,8}, already KDF-applied); the device
+ * rank-sorts the keys and gathers the rec_bytes-sized records.  Host pointers.
+ * *result receives src or aux by the returned-pointer rule. */
+int rsx_sort_records(void *src, void *aux, size_t n, size_t rec_bytes,
+                     const void *keys, size_t key_bytes, void **result, rsx_info *info);
+
+/* Same derivation for radix_sort_rank with an opaque KeyFunc. */
+int rsx_sort_rank_keys(const void *keys, size_t key_bytes, void *index_buffer, size_t n,
+                       size_t idx_bytes, void **result, rsx_info *info);
+
+/* ---- building blocks exported for the multi-GPU path and the tests --------- */
+
+/* Upfront histogram of every 8-bit KDF column (radix_sort.hpp:48-58):
+ * d_hist receives 256 * key_bytes uint64 counts (device memory), *d_unsorted a
+ * non-zero uint32 iff some kdf(key[i]) > kdf(key[i+1]).  Enqueued on stream. */
+int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order order,
+                         uint64_t *d_hist, uint32_t *d_unsorted, void *stream);
+
+/* One stable partition pass by bucket = lut[top KDF byte] (lut: 256 host bytes,
+ * values < nbuckets <= 256): the MSD split of the multi-GPU sort
+ * (README.md:647-650).  top_hist (host, 256 uint64; may be NULL)
+ * is this shard's histogram of the top KDF byte as rsx_histogram_device
+ * produced it; when NULL it is recomputed.  counts (host, nbuckets uint64)
+ * receives the bucket sizes; bucket b occupies [sum(counts[0..b)), +counts[b])
+ * of d_dst.  Blocking on stream. */
+int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype,
+                         rsx_order order, const uint8_t *lut, uint32_t nbuckets,
+                         const uint64_t *top_hist, uint64_t *counts, void *stream);
+
+/* ---- measurement hooks and input generator (bench.py, tests) ------------------ */
+
+/* Between rsx_profile_begin() and rsx_profile_end() every histogram and scatter
+ * kernel the library launches is bracketed by HIP events recorded on the stream
+ * the kernel is launched on; rsx_profile_end() waits for them and returns the
+ * summed kernel durations.  scatter_bytes = sum over scatter launches of
+ * n * 2 * (key bytes + payload bytes), the algorithmic traffic of one pass
+ * (SURVEY.md 8d); hist_bytes = sum of n * key bytes. */
+typedef struct rsx_profile {
+	double   hist_ms;
+	double   scatter_ms;
+	uint64_t hist_launches;
+	uint64_t scatter_launches;
+	uint64_t hist_bytes;
+	uint64_t scatter_bytes;
+} rsx_profile;
+int rsx_profile_begin(void);
+int rsx_profile_end(rsx_profile *out);
+
+/* d_dst[i] = low elem_bytes bytes of (splitmix64 output number first_index + i
+ * of the stream seeded with `seed`) & mask: the generator of SURVEY.md section 4
+ * and 8d, evaluated counter-based on the device (element i of the serial
+ * generator is finalizer(seed + (i+1) * 0x9E3779B97F4A7C15)). */
+int rsx_fill_splitmix_device(void *d_dst, size_t n, size_t elem_bytes, uint64_t seed,
+                             uint64_t mask, uint64_t first_index, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

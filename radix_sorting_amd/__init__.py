@@ -1,0 +1,230 @@
+"""radix_sorting_amd -- MI355X-native LSD radix sort behind eloj/radix-sorting's surface.
+
+The product is ``librsx.so`` (hand-written HIP for gfx950, C ABI in
+``include/rsx.h``) plus the C++ template headers in ``include/``.  This Python
+package is only the thin host-side doorway used by the tests, ``bench.py`` and
+the multi-GPU driver: it binds the C ABI with ctypes and passes torch tensors'
+``data_ptr()`` / current stream straight through.  PyTorch is plumbing here
+(device memory, streams, ``torch.distributed``); no sorting happens in Python
+and there is no CPU fallback -- a missing library or GPU raises.
+
+Function names and argument meaning follow the reference
+(``radix_sort(src, aux, n, kdf)`` radix_sort.hpp:98-99,
+``radix_sort_rank(src, index_buffer, n, kdf)`` radix_sort_rank.hpp:97-98).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsx.so")
+
+# rsx_dtype (include/rsx.h)
+U8, U16, U32, U64, I8, I16, I32, I64, F32, F64 = range(10)
+DTYPE_SIZE = [1, 2, 4, 8, 1, 2, 4, 8, 4, 8]
+ASCENDING, DESCENDING = 0, 1
+
+
+class RsxError(RuntimeError):
+    pass
+
+
+class Profile(C.Structure):
+    """rsx_profile: HIP-event kernel timings collected between profile_begin() and profile_end()."""
+    _fields_ = [("hist_ms", C.c_double), ("scatter_ms", C.c_double), ("hist_launches", C.c_uint64),
+                ("scatter_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("scatter_bytes", C.c_uint64)]
+
+
+class Info(C.Structure):
+    """rsx_info: what the front half of rs_sort_main decided (radix_sort.hpp:48-80)."""
+    _fields_ = [("key_bytes", C.c_uint32), ("ncols", C.c_uint32), ("cols", C.c_uint32 * 8),
+                ("early_exit", C.c_uint32), ("result_in_aux", C.c_uint32)]
+
+    def kept_columns(self):
+        return [int(self.cols[i]) for i in range(self.ncols)]
+
+
+# every symbol include/rsx.h declares: (name, restype, argtypes)
+_VP, _SZ, _I, _U32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+_PVP, _PINFO = C.POINTER(C.c_void_p), C.POINTER(Info)
+ABI = [
+    ("rsx_device_count", _I, []),
+    ("rsx_last_error", C.c_char_p, []),
+    ("rsx_version", C.c_char_p, []),
+    ("rsx_dtype_size", _SZ, [_I]),
+    ("rsx_workspace_bytes", _SZ, [_SZ, _I, _SZ]),
+    ("rsx_release", None, []),
+    ("rsx_sort", _I, [_VP, _VP, _SZ, _I, _I, _PVP, _PINFO]),
+    ("rsx_sort_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _PVP, _PINFO]),
+    ("rsx_sort_pairs_device", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP, _PINFO]),
+    ("rsx_sort_rank", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _PVP, _PINFO]),
+    ("rsx_sort_rank_device", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _VP, _PVP, _PINFO]),
+    ("rsx_sort_records", _I, [_VP, _VP, _SZ, _SZ, _VP, _SZ, _PVP, _PINFO]),
+    ("rsx_sort_rank_keys", _I, [_VP, _SZ, _VP, _SZ, _SZ, _PVP, _PINFO]),
+    ("rsx_histogram_device", _I, [_VP, _SZ, _I, _I, _VP, _VP, _VP]),
+    ("rsx_partition_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _U32, _VP, _VP, _VP]),
+    ("rsx_profile_begin", _I, []),
+    ("rsx_profile_end", _I, [C.POINTER(Profile)]),
+    ("rsx_fill_splitmix_device", _I, [_VP, _SZ, _SZ, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+]
+
+_lib = None
+
+
+def lib():
+    """The loaded librsx.so.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsxError("%s is missing: build it with `make lib` (hipcc --offload-arch=gfx950); "
+                           "there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (SONAME
+        # libamdhip64.so.7, the same as /opt/rocm's); whichever copy is mapped first serves every
+        # later NEEDED entry of that SONAME, and a second copy cannot see the GPU.  Where torch is
+        # installed it therefore has to be imported before librsx.so pulls in /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        handle = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            f = getattr(handle, name)      # AttributeError here means the ABI and the header diverged
+            f.restype = res
+            f.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RsxError("rsx error %d: %s" % (rc, lib().rsx_last_error().decode()))
+
+
+def device_count():
+    return int(lib().rsx_device_count())
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise RsxError("no gfx950 (MI355X) device visible to HIP; radix_sorting_amd has no CPU path")
+
+
+# ---- torch-facing helpers -------------------------------------------------------------------
+
+def _torch_dtype_code(t):
+    import torch
+    table = {torch.uint8: U8, torch.int8: I8, torch.int16: I16, torch.int32: I32, torch.int64: I64,
+             torch.float32: F32, torch.float64: F64}
+    for name, code in (("uint16", U16), ("uint32", U32), ("uint64", U64)):
+        if hasattr(torch, name):
+            table[getattr(torch, name)] = code
+    if t.dtype not in table:
+        raise RsxError("unsupported tensor dtype %s" % t.dtype)
+    return table[t.dtype]
+
+
+def _stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _check_dev(*tensors):
+    for t in tensors:
+        if not t.is_cuda or not t.is_contiguous():
+            raise RsxError("expected contiguous device tensors")
+
+
+def radix_sort(src, aux, dtype=None, order=ASCENDING, stream=None):
+    """radix_sort(src, aux, n) on device tensors (radix_sort.hpp:98-115).
+
+    Returns (result, info): ``result`` is ``src`` or ``aux`` by the reference's
+    returned-pointer rule.  ``dtype`` overrides the rsx_dtype code, so bit
+    patterns held in an int32/int64 tensor can be sorted as uint32/uint64/float.
+    The scatter passes are only enqueued on ``stream``.
+    """
+    _check_dev(src, aux)
+    code = _torch_dtype_code(src) if dtype is None else dtype
+    if src.element_size() != DTYPE_SIZE[code] or aux.numel() < src.numel() or aux.element_size() != src.element_size():
+        raise RsxError("src/aux do not match the key type")
+    res, info = C.c_void_p(), Info()
+    check(lib().rsx_sort_device(src.data_ptr(), aux.data_ptr(), src.numel(), code, order, _stream_ptr(stream),
+                                C.byref(res), C.byref(info)))
+    return (aux if info.result_in_aux else src), info
+
+
+def radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=None, order=ASCENDING, stream=None):
+    """Stable key+payload sort (struct-of-arrays); returns (keys_result, vals_result, info)."""
+    _check_dev(keys, keys_aux, vals, vals_aux)
+    code = _torch_dtype_code(keys) if dtype is None else dtype
+    if keys.element_size() != DTYPE_SIZE[code] or vals.numel() != keys.numel():
+        raise RsxError("keys/vals do not match")
+    info = Info()
+    check(lib().rsx_sort_pairs_device(keys.data_ptr(), keys_aux.data_ptr(), vals.data_ptr(), vals_aux.data_ptr(),
+                                      keys.numel(), code, vals.element_size(), order, _stream_ptr(stream),
+                                      C.byref(info)))
+    if info.result_in_aux:
+        return keys_aux, vals_aux, info
+    return keys, vals, info
+
+
+def radix_sort_rank(src, index_buffer, dtype=None, order=ASCENDING, stream=None):
+    """radix_sort_rank(src, index_buffer, n) on device tensors (radix_sort_rank.hpp:97-112).
+
+    ``index_buffer`` holds 2n int32/int64 entries; returns (ranks_view, info) where
+    ranks_view is the half of index_buffer the reference would return.
+    """
+    _check_dev(src, index_buffer)
+    code = _torch_dtype_code(src) if dtype is None else dtype
+    n = src.numel()
+    if index_buffer.numel() < 2 * n or index_buffer.element_size() not in (4, 8):
+        raise RsxError("index_buffer must hold 2n 4- or 8-byte entries")
+    res, info = C.c_void_p(), Info()
+    check(lib().rsx_sort_rank_device(src.data_ptr(), index_buffer.data_ptr(), n, code, index_buffer.element_size(),
+                                     order, _stream_ptr(stream), C.byref(res), C.byref(info)))
+    half = index_buffer[n:2 * n] if info.result_in_aux else index_buffer[:n]
+    return half, info
+
+
+def fill_splitmix(t, seed, mask=0xFFFFFFFFFFFFFFFF, first_index=0, stream=None):
+    """Fill a device tensor with the SURVEY.md section 4 / 8d splitmix64 sequence (counter-based on the GPU)."""
+    _check_dev(t)
+    check(lib().rsx_fill_splitmix_device(t.data_ptr(), t.numel(), t.element_size(), seed, mask, first_index,
+                                         _stream_ptr(stream)))
+    return t
+
+
+def profile_begin():
+    check(lib().rsx_profile_begin())
+
+
+def profile_end():
+    p = Profile()
+    check(lib().rsx_profile_end(C.byref(p)))
+    return p
+
+
+# ---- host (numpy) entry points: the C ABI exactly as the C++ template wrapper calls it -----
+
+def radix_sort_host(src, aux, dtype, order=ASCENDING):
+    """rsx_sort on host numpy buffers; returns (result_array, info)."""
+    res, info = C.c_void_p(), Info()
+    check(lib().rsx_sort(src.ctypes.data, aux.ctypes.data, src.size, dtype, order, C.byref(res), C.byref(info)))
+    return (aux if info.result_in_aux else src), info
+
+
+def radix_sort_rank_host(src, index_buffer, dtype, order=ASCENDING):
+    res, info = C.c_void_p(), Info()
+    n = src.size
+    check(lib().rsx_sort_rank(src.ctypes.data, index_buffer.ctypes.data, n, dtype, index_buffer.itemsize, order,
+                              C.byref(res), C.byref(info)))
+    return (index_buffer[n:2 * n] if info.result_in_aux else index_buffer[:n]), info
+
+
+def radix_sort_records_host(src, aux, keys):
+    """rsx_sort_records: records (numpy structured / 2-D array rows) ordered by precomputed unsigned keys."""
+    res, info = C.c_void_p(), Info()
+    n = keys.size
+    rec_bytes = src.nbytes // max(n, 1)
+    check(lib().rsx_sort_records(src.ctypes.data, aux.ctypes.data, n, rec_bytes, keys.ctypes.data, keys.itemsize,
+                                 C.byref(res), C.byref(info)))
+    return (aux if info.result_in_aux else src), info

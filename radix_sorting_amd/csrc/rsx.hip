@@ -1,0 +1,875 @@
+// rsx.hip -- host side of librsx.so: the extern "C" surface declared in
+// include/rsx.h on top of the kernels in rsx_kernels.hpp.
+//
+// The control flow mirrors rs_sort_main (radix_sort.hpp:31-93): histogram +
+// pre-sorted test -> early exit -> column probe -> exclusive scan -> one stable
+// scatter pass per kept column, ping-ponging two buffers -> "returned pointer".
+// There is deliberately no CPU path here: if HIP cannot give us a gfx950
+// device, every entry point fails with RSX_ENODEVICE.
+#include "../../include/rsx.h"
+#include "rsx_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+using namespace rsx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			(void)hipGetLastError();                                                               \
+			return fail(e_ == hipErrorOutOfMemory ? RSX_ENOMEM : RSX_EHIP, "%s failed: %s (%s:%d)", #expr, \
+			            hipGetErrorString(e_), __FILE__, __LINE__);                                \
+		}                                                                                          \
+	} while (0)
+
+#define RSX_TRY(expr)          \
+	do {                       \
+		int rc_ = (expr);      \
+		if (rc_ != RSX_OK)     \
+			return rc_;        \
+	} while (0)
+
+size_t dtype_size(int dtype)
+{
+	switch (dtype) {
+	case RSX_U8: case RSX_I8: return 1;
+	case RSX_U16: case RSX_I16: return 2;
+	case RSX_U32: case RSX_I32: case RSX_F32: return 4;
+	case RSX_U64: case RSX_I64: case RSX_F64: return 8;
+	default: return 0;
+	}
+}
+
+template <typename KT>
+KdfArgs<KT> make_kdf(int dtype, int order)
+{
+	KdfArgs<KT> a;
+	const KT high = (KT)((KT)1 << (sizeof(KT) * 8 - 1));
+	const bool is_signed = dtype == RSX_I8 || dtype == RSX_I16 || dtype == RSX_I32 || dtype == RSX_I64;
+	const bool is_float = dtype == RSX_F32 || dtype == RSX_F64;
+	a.fmask = is_float ? (KT)~(KT)0 : (KT)0;
+	a.sflip = (is_signed || is_float) ? high : (KT)0;
+	a.desc = order == RSX_DESCENDING ? (KT)~(KT)0 : (KT)0;
+	return a;
+}
+
+// ---- a growable device allocation -------------------------------------------
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap)
+			return RSX_OK;
+		if (p) {
+			(void)hipFree(p);
+			p = nullptr;
+			cap = 0;
+		}
+		// grow geometrically-ish so repeated slightly larger sorts do not thrash
+		size_t want = bytes + bytes / 8;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			e = hipMalloc(&p, bytes);
+			want = bytes;
+		}
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			p = nullptr;
+			return fail(RSX_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+		}
+		cap = want;
+		return RSX_OK;
+	}
+	void release()
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+// ---- per (device, stream) context --------------------------------------------
+struct Ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	// fixed small state: [ghist 8*256 u64][unsorted u32 .. pad to 64][Plan 64][lut 256][gbase_lut 256 u64]
+	DevBuf small;
+	DevBuf status;      // [ticket u32, pad to 256 B][tiles * 256 status words]
+	DevBuf keys[2];     // key ping-pong for rank sorts / host staging
+	DevBuf vals[2];     // payload ping-pong for host staging / narrow-index rank
+	DevBuf recs[2];     // record gather staging
+	Plan *host_plan = nullptr;   // pinned
+	u64 *host_hist = nullptr;    // pinned, 256 u64
+
+	u64 *ghist() const { return (u64 *)small.p; }
+	u32 *unsorted() const { return (u32 *)((char *)small.p + 8 * 256 * 8); }
+	Plan *plan() const { return (Plan *)((char *)small.p + 8 * 256 * 8 + 64); }
+	uint8_t *lut() const { return (uint8_t *)((char *)small.p + 8 * 256 * 8 + 128); }
+	u64 *gbase_lut() const { return (u64 *)((char *)small.p + 8 * 256 * 8 + 128 + 256); }
+	static constexpr size_t SMALL_BYTES = 8 * 256 * 8 + 128 + 256 + 256 * 8;
+
+	int init()
+	{
+		RSX_TRY(small.ensure(SMALL_BYTES));
+		if (!host_plan)
+			HIP_TRY(hipHostMalloc((void **)&host_plan, sizeof(Plan), hipHostMallocDefault));
+		if (!host_hist)
+			HIP_TRY(hipHostMalloc((void **)&host_hist, 256 * sizeof(u64), hipHostMallocDefault));
+		return RSX_OK;
+	}
+	void release()
+	{
+		small.release();
+		status.release();
+		for (int i = 0; i < 2; ++i) {
+			keys[i].release();
+			vals[i].release();
+			recs[i].release();
+		}
+		if (host_plan)
+			(void)hipHostFree(host_plan);
+		if (host_hist)
+			(void)hipHostFree(host_hist);
+		host_plan = nullptr;
+		host_hist = nullptr;
+	}
+};
+
+std::mutex g_mu;
+std::map<std::pair<int, void *>, Ctx *> g_ctx;
+
+// ---- optional HIP-event bracketing of the kernels (rsx_profile_begin/end) ------
+struct ProfRec {
+	int kind;   // 0 histogram, 1 scatter
+	hipEvent_t start, stop;
+	u64 bytes;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+	bool on;
+	ProfRec rec;
+	hipStream_t stream;
+	ProfScope(int kind, u64 bytes, hipStream_t s) : on(g_prof_on), stream(s)
+	{
+		if (!on)
+			return;
+		rec.kind = kind;
+		rec.bytes = bytes;
+		if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) {
+			on = false;
+			return;
+		}
+		(void)hipEventRecord(rec.start, stream);
+	}
+	~ProfScope()
+	{
+		if (!on)
+			return;
+		(void)hipEventRecord(rec.stop, stream);
+		g_prof.push_back(rec);
+	}
+};
+int g_devcount = -2;   // -2: not probed
+
+int probe_devices()
+{
+	if (g_devcount != -2)
+		return g_devcount;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		n = 0;
+	}
+	int usable = 0;
+	for (int d = 0; d < n; ++d) {
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+			++usable;
+		else
+			(void)hipGetLastError();
+	}
+	g_devcount = usable;
+	return usable;
+}
+
+int get_ctx(void *stream, Ctx **out)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	if (probe_devices() <= 0)
+		return fail(RSX_ENODEVICE, "no gfx950 (MI355X) device visible to HIP; this library has no CPU path");
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	auto key = std::make_pair(dev, stream);
+	auto it = g_ctx.find(key);
+	if (it == g_ctx.end()) {
+		Ctx *c = new Ctx();
+		c->device = dev;
+		c->stream = (hipStream_t)stream;
+		int rc = c->init();
+		if (rc != RSX_OK) {
+			c->release();
+			delete c;
+			return rc;
+		}
+		it = g_ctx.emplace(key, c).first;
+	}
+	*out = it->second;
+	return RSX_OK;
+}
+
+void info_clear(rsx_info *info, int dtype)
+{
+	if (!info)
+		return;
+	memset(info, 0, sizeof(*info));
+	info->key_bytes = (uint32_t)dtype_size(dtype);
+}
+
+void info_from_plan(rsx_info *info, const Plan &p)
+{
+	if (!info)
+		return;
+	info->ncols = p.ncols;
+	for (u32 i = 0; i < p.ncols && i < 8; ++i)
+		info->cols[i] = p.cols[i];
+}
+
+// ---- phase 1: histogram + plan (radix_sort.hpp:48-80) --------------------------
+template <typename KT>
+int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted)
+{
+	typedef HistCfg<KT> C;
+	const u64 nvec = n / C::VEC + 1;
+	u64 blocks = (nvec + (u64)C::BLOCK * 4 - 1) / ((u64)C::BLOCK * 4);
+	if (blocks > 2048)
+		blocks = 2048;   // 256 CUs x 8: grid-stride the rest
+	if (blocks < 1)
+		blocks = 1;
+	ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
+	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n, d_hist,
+	                   d_unsorted, ka);
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
+template <typename KT>
+int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out)
+{
+	HIP_TRY(hipMemsetAsync(c.small.p, 0, 8 * 256 * 8 + 128, c.stream));
+	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted()));
+	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(1), dim3(64 * sizeof(KT)), 0, c.stream, d_src, (u64)n, c.ghist(),
+	                   c.unsorted(), c.plan(), ka);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
+	HIP_TRY(hipStreamSynchronize(c.stream));
+	*out = *c.host_plan;
+	return RSX_OK;
+}
+
+// ---- phase 2: one scatter pass (radix_sort.hpp:83-90) -----------------------------
+template <typename KT, typename VT>
+int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
+                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut)
+{
+	typedef ScatterCfg<KT, VT> C;
+	const u64 tiles = (n + C::TILE - 1) / C::TILE;
+	const bool wide = n >= (1ull << 30);   // counter width by n, as radix_sort.hpp:102-114 does
+	const size_t st_bytes = 256 + tiles * 256 * (wide ? 8 : 4);
+	RSX_TRY(c.status.ensure(st_bytes));
+	HIP_TRY(hipMemsetAsync(c.status.p, 0, st_bytes, c.stream));
+	u32 *ticket = (u32 *)c.status.p;
+	void *st = (char *)c.status.p + 256;
+	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
+	if (wide)
+		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
+		                   vin, vout, (u64)n, shift, gbase, (u64 *)st, ticket, ka, flags, lut);
+	else
+		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
+		                   vin, vout, (u64)n, shift, gbase, (u32 *)st, ticket, ka, flags, lut);
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
+// ---- keys only -------------------------------------------------------------------
+template <typename KT>
+int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info)
+{
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	Plan plan;
+	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan));
+	info_from_plan(info, plan);
+	if (plan.sorted) {                       // radix_sort.hpp:60-62
+		if (info) {
+			info->early_exit = 2;
+			info->ncols = 0;
+		}
+		*result = src;
+		return RSX_OK;
+	}
+	KT *cur = src, *oth = aux;
+	for (u32 i = 0; i < plan.ncols; ++i) {   // radix_sort.hpp:83-90
+		const u32 col = plan.cols[i];
+		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0, nullptr)));
+		std::swap(cur, oth);
+	}
+	*result = cur;                           // radix_sort.hpp:92
+	if (info)
+		info->result_in_aux = cur == aux;
+	return RSX_OK;
+}
+
+// ---- key + payload -----------------------------------------------------------------
+template <typename KT, typename VT>
+int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
+{
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	Plan plan;
+	RSX_TRY(plan_phase<KT>(c, k0, n, ka, &plan));
+	info_from_plan(info, plan);
+	if (plan.sorted) {
+		if (info) {
+			info->early_exit = 2;
+			info->ncols = 0;
+		}
+		return RSX_OK;
+	}
+	KT *kc = k0, *ko = k1;
+	VT *vc = v0, *vo = v1;
+	for (u32 i = 0; i < plan.ncols; ++i) {
+		const u32 col = plan.cols[i];
+		RSX_TRY((scatter_pass<KT, VT>(c, kc, ko, vc, vo, n, 8 * col, c.ghist() + 256 * col, ka, 0, nullptr)));
+		std::swap(kc, ko);
+		std::swap(vc, vo);
+	}
+	if (info)
+		info->result_in_aux = kc == k1;
+	return RSX_OK;
+}
+
+// ---- rank (stable argsort) ----------------------------------------------------------
+// index halves H0 = ib, H1 = ib + n ping-pong exactly as radix_sort_rank.hpp:77-89;
+// the keys travel with the indices through two workspace
+// buffers instead of being gathered through the index as Listing 6 does.
+template <typename KT, typename IT>
+int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info)
+{
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	Plan plan;
+	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan));
+	info_from_plan(info, plan);
+	if (plan.sorted) {                       // radix_sort_rank.hpp:52,:55-57: first half = iota
+		hipLaunchKernelGGL((rsx_iota_kernel<IT>), dim3(1024), dim3(256), 0, c.stream, ib, (u64)n);
+		HIP_TRY(hipGetLastError());
+		if (info) {
+			info->early_exit = 2;
+			info->ncols = 0;
+		}
+		*result = ib;
+		return RSX_OK;
+	}
+	const u32 P = plan.ncols;
+	if (P > 1) {
+		RSX_TRY(c.keys[0].ensure(n * sizeof(KT)));
+		if (P > 2)
+			RSX_TRY(c.keys[1].ensure(n * sizeof(KT)));
+	}
+	IT *H[2] = {ib, ib + n};
+	for (u32 i = 0; i < P; ++i) {
+		const u32 col = plan.cols[i];
+		const KT *kin = i == 0 ? src : (const KT *)c.keys[(i - 1) & 1].p;
+		KT *kout = (KT *)c.keys[i & 1].p;
+		u32 flags = 0;
+		if (i == 0)
+			flags |= SCATTER_GEN_INDEX;
+		if (i == P - 1)
+			flags |= SCATTER_SKIP_KEYS;
+		RSX_TRY((scatter_pass<KT, IT>(c, kin, kout, H[i & 1], H[(i + 1) & 1], n, 8 * col, c.ghist() + 256 * col, ka, flags,
+		                              nullptr)));
+	}
+	*result = H[P & 1];                      // radix_sort_rank.hpp:91
+	if (info)
+		info->result_in_aux = P & 1;
+	return RSX_OK;
+}
+
+bool is_device_ptr(const void *p)
+{
+	hipPointerAttribute_t attr;
+	hipError_t e = hipPointerGetAttributes(&attr, p);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// dispatch on key width
+#define RSX_DISPATCH_KT(dtype, CALL)                               \
+	switch (dtype_size(dtype)) {                                   \
+	case 1: { typedef uint8_t KT; CALL; } break;                   \
+	case 2: { typedef uint16_t KT; CALL; } break;                  \
+	case 4: { typedef uint32_t KT; CALL; } break;                  \
+	case 8: { typedef u64 KT; CALL; } break;                       \
+	default: return fail(RSX_EINVAL, "unknown dtype %d", (int)(dtype)); \
+	}
+
+}  // namespace
+
+// =================================================================================
+// extern "C" surface
+// =================================================================================
+
+extern "C" {
+
+int rsx_device_count(void)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	return probe_devices();
+}
+
+const char *rsx_last_error(void) { return g_err; }
+const char *rsx_version(void) { return "rsx 0.1 (gfx950)"; }
+size_t rsx_dtype_size(rsx_dtype dtype) { return dtype_size(dtype); }
+
+size_t rsx_workspace_bytes(size_t n, rsx_dtype dtype, size_t payload_bytes)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb)
+		return 0;
+	const size_t elem = kb > payload_bytes ? kb : payload_bytes;
+	const size_t tile = 512 * (elem == 8 ? 8 : 16);
+	const size_t tiles = (n + tile - 1) / tile;
+	return Ctx::SMALL_BYTES + 256 + tiles * 256 * (n >= (1ull << 30) ? 8 : 4);
+}
+
+void rsx_release(void)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	for (auto &kv : g_ctx) {
+		(void)hipSetDevice(kv.first.first);
+		kv.second->release();
+		delete kv.second;
+	}
+	g_ctx.clear();
+}
+
+int rsx_sort_device(void *d_src, void *d_aux, size_t n, rsx_dtype dtype, rsx_order order, void *stream, void **result,
+                    rsx_info *info)
+{
+	info_clear(info, dtype);
+	if (!dtype_size(dtype) || !result || (n && (!d_src || !d_aux)))
+		return fail(RSX_EINVAL, "rsx_sort_device: bad argument");
+	if (n < 2) {                             // radix_sort.hpp:100-101
+		*result = d_src;
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	RSX_DISPATCH_KT(dtype, return sort_keys_device<KT>(*c, (KT *)d_src, (KT *)d_aux, n, dtype, order, result, info));
+	return RSX_OK;
+}
+
+int rsx_sort_pairs_device(void *d_keys, void *d_keys_aux, void *d_vals, void *d_vals_aux, size_t n, rsx_dtype dtype,
+                          size_t payload_bytes, rsx_order order, void *stream, rsx_info *info)
+{
+	info_clear(info, dtype);
+	if (!dtype_size(dtype) || (payload_bytes != 4 && payload_bytes != 8) ||
+	    (n && (!d_keys || !d_keys_aux || !d_vals || !d_vals_aux)))
+		return fail(RSX_EINVAL, "rsx_sort_pairs_device: bad argument");
+	if (n < 2) {
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	if (payload_bytes == 4) {
+		RSX_DISPATCH_KT(dtype, return (sort_pairs_device<KT, u32>(*c, (KT *)d_keys, (KT *)d_keys_aux, (u32 *)d_vals,
+		                                                         (u32 *)d_vals_aux, n, dtype, order, info)));
+	} else {
+		RSX_DISPATCH_KT(dtype, return (sort_pairs_device<KT, u64>(*c, (KT *)d_keys, (KT *)d_keys_aux, (u64 *)d_vals,
+		                                                         (u64 *)d_vals_aux, n, dtype, order, info)));
+	}
+	return RSX_OK;
+}
+
+int rsx_sort_rank_device(const void *d_src, void *d_index_buffer, size_t n, rsx_dtype dtype, size_t idx_bytes,
+                         rsx_order order, void *stream, void **result, rsx_info *info)
+{
+	info_clear(info, dtype);
+	if (!dtype_size(dtype) || (idx_bytes != 4 && idx_bytes != 8) || !result || (n && (!d_src || !d_index_buffer)))
+		return fail(RSX_EINVAL, "rsx_sort_rank_device: bad argument");
+	if (idx_bytes == 4 && n > (1ull << 32))
+		return fail(RSX_EINVAL, "rsx_sort_rank_device: n does not fit a 4-byte index");
+	*result = d_index_buffer;
+	if (n == 0) {                            // radix_sort_rank.hpp:28-32
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	if (n == 1) {
+		HIP_TRY(hipMemsetAsync(d_index_buffer, 0, idx_bytes, c->stream));
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	if (idx_bytes == 4) {
+		RSX_DISPATCH_KT(dtype, return (sort_rank_device<KT, u32>(*c, (const KT *)d_src, (u32 *)d_index_buffer, n, dtype,
+		                                                        order, result, info)));
+	} else {
+		RSX_DISPATCH_KT(dtype, return (sort_rank_device<KT, u64>(*c, (const KT *)d_src, (u64 *)d_index_buffer, n, dtype,
+		                                                        order, result, info)));
+	}
+	return RSX_OK;
+}
+
+int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, void **result, rsx_info *info)
+{
+	info_clear(info, dtype);
+	const size_t kb = dtype_size(dtype);
+	if (!kb || !result || (n && (!src || !aux)))
+		return fail(RSX_EINVAL, "rsx_sort: bad argument");
+	if (n < 2) {                             // radix_sort.hpp:100-101
+		*result = src;
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	Ctx *c;
+	RSX_TRY(get_ctx(nullptr, &c));
+	if (is_device_ptr(src)) {
+		if (!is_device_ptr(aux))
+			return fail(RSX_EINVAL, "rsx_sort: src is a device pointer but aux is not");
+		RSX_TRY(rsx_sort_device(src, aux, n, dtype, order, nullptr, result, info));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		return RSX_OK;
+	}
+	// host buffers: stage over PCIe, sort in HBM, bring the result back into the
+	// buffer the returned-pointer rule names (the other one is left as it was)
+	RSX_TRY(c->keys[0].ensure(n * kb));
+	RSX_TRY(c->keys[1].ensure(n * kb));
+	HIP_TRY(hipMemcpyAsync(c->keys[0].p, src, n * kb, hipMemcpyHostToDevice, c->stream));
+	void *dres = nullptr;
+	rsx_info li;
+	RSX_TRY(rsx_sort_device(c->keys[0].p, c->keys[1].p, n, dtype, order, nullptr, &dres, &li));
+	if (info)
+		*info = li;
+	if (li.early_exit) {
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		*result = src;
+		return RSX_OK;
+	}
+	void *hres = li.result_in_aux ? aux : src;
+	HIP_TRY(hipMemcpyAsync(hres, dres, n * kb, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	*result = hres;
+	return RSX_OK;
+}
+
+int rsx_sort_rank(const void *src, void *index_buffer, size_t n, rsx_dtype dtype, size_t idx_bytes, rsx_order order,
+                  void **result, rsx_info *info)
+{
+	info_clear(info, dtype);
+	const size_t kb = dtype_size(dtype);
+	if (!kb || !result || (idx_bytes != 1 && idx_bytes != 2 && idx_bytes != 4 && idx_bytes != 8) ||
+	    (n && (!src || !index_buffer)))
+		return fail(RSX_EINVAL, "rsx_sort_rank: bad argument");
+	if (idx_bytes < 8 && n > (1ull << (8 * idx_bytes)))
+		return fail(RSX_EINVAL, "rsx_sort_rank: n = %zu does not fit a %zu-byte index", n, idx_bytes);
+	*result = index_buffer;
+	if (n == 0) {
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	Ctx *c;
+	RSX_TRY(get_ctx(nullptr, &c));
+	const bool dev = is_device_ptr(src);
+	if (dev != is_device_ptr(index_buffer))
+		return fail(RSX_EINVAL, "rsx_sort_rank: src and index_buffer must both be host or both be device pointers");
+	if (dev && idx_bytes >= 4) {
+		RSX_TRY(rsx_sort_rank_device(src, index_buffer, n, dtype, idx_bytes, order, nullptr, result, info));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		return RSX_OK;
+	}
+	// staged path: keys in recs[0] (host keys) or in place (device keys); indices computed
+	// as 4- or 8-byte values in vals[0], narrowed into vals[1] when IdxType is 1 or 2 bytes
+	const size_t wide = idx_bytes == 8 ? 8 : 4;
+	const void *dkeys = src;
+	if (!dev) {
+		RSX_TRY(c->recs[0].ensure(n * kb));
+		HIP_TRY(hipMemcpyAsync(c->recs[0].p, src, n * kb, hipMemcpyHostToDevice, c->stream));
+		dkeys = c->recs[0].p;
+	}
+	RSX_TRY(c->vals[0].ensure(2 * n * wide));
+	void *dres = nullptr;
+	rsx_info li;
+	RSX_TRY(rsx_sort_rank_device(dkeys, c->vals[0].p, n, dtype, wide, order, nullptr, &dres, &li));
+	if (info)
+		*info = li;
+	const bool second = dres != c->vals[0].p;
+	char *out = (char *)index_buffer + (second ? n * idx_bytes : 0);
+	const void *from = dres;
+	if (idx_bytes < 4) {
+		RSX_TRY(c->vals[1].ensure(n * idx_bytes));
+		if (idx_bytes == 1)
+			hipLaunchKernelGGL((rsx_convert_kernel<uint8_t, u32>), dim3(256), dim3(256), 0, c->stream, (uint8_t *)c->vals[1].p,
+			                   (const u32 *)dres, (u64)n);
+		else
+			hipLaunchKernelGGL((rsx_convert_kernel<uint16_t, u32>), dim3(256), dim3(256), 0, c->stream,
+			                   (uint16_t *)c->vals[1].p, (const u32 *)dres, (u64)n);
+		HIP_TRY(hipGetLastError());
+		from = c->vals[1].p;
+	}
+	HIP_TRY(hipMemcpyAsync(out, from, n * idx_bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	*result = out;
+	return RSX_OK;
+}
+
+int rsx_sort_rank_keys(const void *keys, size_t key_bytes, void *index_buffer, size_t n, size_t idx_bytes, void **result,
+                       rsx_info *info)
+{
+	rsx_dtype dt;
+	switch (key_bytes) {
+	case 1: dt = RSX_U8; break;
+	case 2: dt = RSX_U16; break;
+	case 4: dt = RSX_U32; break;
+	case 8: dt = RSX_U64; break;
+	default: return fail(RSX_EINVAL, "rsx_sort_rank_keys: key_bytes must be 1, 2, 4 or 8");
+	}
+	return rsx_sort_rank(keys, index_buffer, n, dt, idx_bytes, RSX_ASCENDING, result, info);
+}
+
+int rsx_sort_records(void *src, void *aux, size_t n, size_t rec_bytes, const void *keys, size_t key_bytes, void **result,
+                     rsx_info *info)
+{
+	rsx_dtype dt;
+	switch (key_bytes) {
+	case 1: dt = RSX_U8; break;
+	case 2: dt = RSX_U16; break;
+	case 4: dt = RSX_U32; break;
+	case 8: dt = RSX_U64; break;
+	default: return fail(RSX_EINVAL, "rsx_sort_records: key_bytes must be 1, 2, 4 or 8");
+	}
+	info_clear(info, dt);
+	if (!result || !rec_bytes || (n && (!src || !aux || !keys)))
+		return fail(RSX_EINVAL, "rsx_sort_records: bad argument");
+	*result = src;
+	if (n < 2) {
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	Ctx *c;
+	RSX_TRY(get_ctx(nullptr, &c));
+	const size_t wide = n > (1ull << 32) ? 8 : 4;
+	RSX_TRY(c->keys[0].ensure(n * key_bytes));   // note: rank passes use keys[0]/keys[1] too; the uploaded keys live in recs[1]
+	RSX_TRY(c->recs[1].ensure(n * key_bytes > n * rec_bytes ? n * key_bytes : n * rec_bytes));
+	RSX_TRY(c->vals[0].ensure(2 * n * wide));
+	HIP_TRY(hipMemcpyAsync(c->recs[1].p, keys, n * key_bytes, hipMemcpyHostToDevice, c->stream));
+	void *dres = nullptr;
+	rsx_info li;
+	RSX_TRY(rsx_sort_rank_device(c->recs[1].p, c->vals[0].p, n, dt, wide, RSX_ASCENDING, nullptr, &dres, &li));
+	if (info)
+		*info = li;
+	if (li.early_exit) {                     // pre-sorted by key: records stay where they are
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		return RSX_OK;
+	}
+	// gather the records through the ranks (the keys in recs[1] are no longer needed)
+	RSX_TRY(c->recs[0].ensure(n * rec_bytes));
+	HIP_TRY(hipMemcpyAsync(c->recs[0].p, src, n * rec_bytes, hipMemcpyHostToDevice, c->stream));
+	const uintptr_t al = (uintptr_t)rec_bytes;
+	const unsigned grid = 2048, block = 256;
+#define RSX_GATHER(WORD)                                                                                          \
+	do {                                                                                                          \
+		if (wide == 4)                                                                                            \
+			hipLaunchKernelGGL((rsx_gather_kernel<WORD, u32>), dim3(grid), dim3(block), 0, c->stream,              \
+			                   (WORD *)c->recs[1].p, (const WORD *)c->recs[0].p, (const u32 *)dres, (u64)n,         \
+			                   (u32)(rec_bytes / sizeof(WORD)));                                                  \
+		else                                                                                                      \
+			hipLaunchKernelGGL((rsx_gather_kernel<WORD, u64>), dim3(grid), dim3(block), 0, c->stream,              \
+			                   (WORD *)c->recs[1].p, (const WORD *)c->recs[0].p, (const u64 *)dres, (u64)n,         \
+			                   (u32)(rec_bytes / sizeof(WORD)));                                                  \
+	} while (0)
+	if (al % 16 == 0)
+		RSX_GATHER(uint4);
+	else if (al % 8 == 0)
+		RSX_GATHER(u64);
+	else if (al % 4 == 0)
+		RSX_GATHER(u32);
+	else if (al % 2 == 0)
+		RSX_GATHER(uint16_t);
+	else
+		RSX_GATHER(uint8_t);
+#undef RSX_GATHER
+	HIP_TRY(hipGetLastError());
+	void *hres = li.result_in_aux ? aux : src;
+	HIP_TRY(hipMemcpyAsync(hres, c->recs[1].p, n * rec_bytes, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	*result = hres;
+	return RSX_OK;
+}
+
+int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order order, uint64_t *d_hist,
+                         uint32_t *d_unsorted, void *stream)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb || !d_hist || !d_unsorted || (n && !d_src))
+		return fail(RSX_EINVAL, "rsx_histogram_device: bad argument");
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * kb * sizeof(u64), c->stream));
+	HIP_TRY(hipMemsetAsync(d_unsorted, 0, sizeof(u32), c->stream));
+	if (n == 0)
+		return RSX_OK;
+	RSX_DISPATCH_KT(dtype, return launch_hist<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), (u64 *)d_hist,
+	                                              (u32 *)d_unsorted));
+	return RSX_OK;
+}
+
+int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order, const uint8_t *lut,
+                         uint32_t nbuckets, const uint64_t *top_hist, uint64_t *counts, void *stream)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb || !lut || !counts || nbuckets == 0 || nbuckets > 256 || (n && (!d_src || !d_dst)))
+		return fail(RSX_EINVAL, "rsx_partition_device: bad argument");
+	for (int i = 0; i < 256; ++i)
+		if (lut[i] >= nbuckets)
+			return fail(RSX_EINVAL, "rsx_partition_device: lut[%d] = %u >= nbuckets", i, (unsigned)lut[i]);
+	for (u32 b = 0; b < nbuckets; ++b)
+		counts[b] = 0;
+	if (n == 0)
+		return RSX_OK;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	u64 hist[256];
+	if (top_hist) {
+		memcpy(hist, top_hist, sizeof(hist));
+	} else {
+		HIP_TRY(hipMemsetAsync(c->small.p, 0, 8 * 256 * 8 + 128, c->stream));
+		RSX_DISPATCH_KT(dtype, RSX_TRY(launch_hist<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), c->ghist(),
+		                                              c->unsorted())));
+		HIP_TRY(hipMemcpyAsync(c->host_hist, c->ghist() + 256 * (kb - 1), 256 * sizeof(u64), hipMemcpyDeviceToHost,
+		                       c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		memcpy(hist, c->host_hist, sizeof(hist));
+	}
+	u64 total = 0;
+	for (int i = 0; i < 256; ++i) {
+		counts[lut[i]] += hist[i];
+		total += hist[i];
+	}
+	if (total != n)
+		return fail(RSX_EINVAL, "rsx_partition_device: top_hist sums to %llu, n = %zu", (unsigned long long)total, n);
+	u64 base[256];
+	u64 a = 0;
+	for (u32 b = 0; b < 256; ++b) {
+		base[b] = a;
+		if (b < nbuckets)
+			a += counts[b];
+	}
+	HIP_TRY(hipMemcpyAsync(c->gbase_lut(), base, sizeof(base), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->lut(), lut, 256, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));   // base/lut are stack/host buffers
+	RSX_DISPATCH_KT(dtype, RSX_TRY((scatter_pass<KT, NoVal>(*c, (const KT *)d_src, (KT *)d_dst, nullptr, nullptr, n,
+	                                                       (u32)(8 * (kb - 1)), c->gbase_lut(), make_kdf<KT>(dtype, order),
+	                                                       SCATTER_USE_LUT, c->lut()))));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return RSX_OK;
+}
+
+int rsx_profile_begin(void)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	for (auto &r : g_prof) {
+		(void)hipEventDestroy(r.start);
+		(void)hipEventDestroy(r.stop);
+	}
+	g_prof.clear();
+	g_prof_on = true;
+	return RSX_OK;
+}
+
+int rsx_profile_end(rsx_profile *out)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	g_prof_on = false;
+	if (!out)
+		return fail(RSX_EINVAL, "rsx_profile_end: null output");
+	memset(out, 0, sizeof(*out));
+	for (auto &r : g_prof) {
+		float ms = 0.f;
+		HIP_TRY(hipEventSynchronize(r.stop));
+		HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+		if (r.kind == 0) {
+			out->hist_ms += ms;
+			out->hist_launches += 1;
+			out->hist_bytes += r.bytes;
+		} else {
+			out->scatter_ms += ms;
+			out->scatter_launches += 1;
+			out->scatter_bytes += r.bytes;
+		}
+		(void)hipEventDestroy(r.start);
+		(void)hipEventDestroy(r.stop);
+	}
+	g_prof.clear();
+	return RSX_OK;
+}
+
+int rsx_fill_splitmix_device(void *d_dst, size_t n, size_t elem_bytes, uint64_t seed, uint64_t mask, uint64_t first_index,
+                             void *stream)
+{
+	if (n && !d_dst)
+		return fail(RSX_EINVAL, "rsx_fill_splitmix_device: null destination");
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	if (n == 0)
+		return RSX_OK;
+	const dim3 grid(2048), block(256);
+	switch (elem_bytes) {
+	case 1: hipLaunchKernelGGL((rsx_fill_splitmix_kernel<uint8_t>), grid, block, 0, c->stream, (uint8_t *)d_dst, (u64)n, (u64)seed, (u64)mask, (u64)first_index); break;
+	case 2: hipLaunchKernelGGL((rsx_fill_splitmix_kernel<uint16_t>), grid, block, 0, c->stream, (uint16_t *)d_dst, (u64)n, (u64)seed, (u64)mask, (u64)first_index); break;
+	case 4: hipLaunchKernelGGL((rsx_fill_splitmix_kernel<u32>), grid, block, 0, c->stream, (u32 *)d_dst, (u64)n, (u64)seed, (u64)mask, (u64)first_index); break;
+	case 8: hipLaunchKernelGGL((rsx_fill_splitmix_kernel<u64>), grid, block, 0, c->stream, (u64 *)d_dst, (u64)n, (u64)seed, (u64)mask, (u64)first_index); break;
+	default: return fail(RSX_EINVAL, "rsx_fill_splitmix_device: elem_bytes must be 1, 2, 4 or 8");
+	}
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""Multi-GPU sort: one MSD-digit split, an all-to-all-v bucket exchange, local LSD sorts.
+
+The reference is single-threaded; its README suggests exactly this hybrid for
+parallelism ("one MSB pass then LSB sort the sub-results", README.md:647-650).
+SURVEY.md section 8e is the contract implemented here, one process per GPU:
+
+  1. every rank histograms the top KDF byte of its shard (rsx_histogram_device);
+  2. the 256 counts are summed over ranks (tiny all-reduce) and every rank derives
+     the same splitters: contiguous top-digit ranges holding ~n/G keys each;
+  3. a stable local partition by destination rank (rsx_partition_device: the
+     scatter kernel with bucket = lut[top digit]);
+  4. the G x G count matrix is exchanged, then the buckets themselves, with
+     ``all_to_all_single`` (RCCL all-to-all-v over xGMI; each directed pair of
+     GPUs has its own link);
+  5. each rank LSD-sorts what it received (rsx_sort_device).
+
+Receive order is by source rank and the partition is stable, so with shards held
+in global index order the concatenation of the ranks' results is the stable sort
+of the concatenated input -- bit-identical to the reference run on the whole array.
+
+The device work sits behind a small engine object so that the host logic
+(splitters, count exchange, collectives) can be exercised on CPU with the gloo
+backend in tests (tests/ inject an oracle-backed engine); the product engine is
+HipEngine and it fails loudly without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import (ASCENDING, DTYPE_SIZE, Info, RsxError, _stream_ptr, check, lib, radix_sort)
+
+
+def choose_splitters(top_hist, world):
+    """Map each of the 256 top digits to a destination rank.
+
+    Contiguous, monotone ranges; digit d goes to the rank whose ideal share
+    [r*total/world, (r+1)*total/world) contains the midpoint of d's run.  Every
+    rank computes this from the same all-reduced histogram, so the result is identical everywhere.
+    """
+    h = np.asarray(top_hist, dtype=np.uint64).astype(np.float64)
+    total = float(h.sum())
+    lut = np.zeros(256, dtype=np.uint8)
+    if total == 0 or world == 1:
+        return lut
+    before = np.concatenate([[0.0], np.cumsum(h)[:-1]])
+    mid = before + h / 2.0
+    r = np.floor(mid * world / total).astype(np.int64)
+    r = np.clip(r, 0, world - 1)
+    r = np.maximum.accumulate(r)          # monotone even with empty digits
+    return r.astype(np.uint8)
+
+
+class HipEngine:
+    """Device steps of the distributed sort through librsx.so (the product path)."""
+
+    def __init__(self, dtype, order=ASCENDING):
+        import torch
+        self.torch = torch
+        self.dtype = dtype
+        self.order = order
+        self.kb = DTYPE_SIZE[dtype]
+        self._hist = None
+        self._flag = None
+
+    def top_histogram(self, shard):
+        torch = self.torch
+        if self._hist is None:
+            self._hist = torch.zeros(256 * self.kb, dtype=torch.int64, device=shard.device)
+            self._flag = torch.zeros(1, dtype=torch.int32, device=shard.device)
+        check(lib().rsx_histogram_device(shard.data_ptr(), shard.numel(), self.dtype, self.order,
+                                         self._hist.data_ptr(), self._flag.data_ptr(), _stream_ptr()))
+        return self._hist[256 * (self.kb - 1):].clone()      # counts of the top KDF byte, on device
+
+    def partition(self, shard, out, lut, world, top_hist_host):
+        counts = np.zeros(world, dtype=np.uint64)
+        lut = np.ascontiguousarray(lut, dtype=np.uint8)
+        th = np.ascontiguousarray(top_hist_host, dtype=np.uint64)
+        check(lib().rsx_partition_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order,
+                                         lut.ctypes.data, world, th.ctypes.data, counts.ctypes.data, _stream_ptr()))
+        return counts
+
+    def local_sort(self, keys, aux):
+        res, info = radix_sort(keys, aux, dtype=self.dtype, order=self.order)
+        return res, info
+
+    def empty(self, n, like):
+        return self.torch.empty(n, dtype=like.dtype, device=like.device)
+
+
+def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None):
+    """Sort the concatenation of every rank's ``shard`` (rank order = global index order).
+
+    Returns (sorted_local, stats): rank r ends up with the r-th contiguous slice of
+    the globally sorted sequence (slice sizes follow the splitters, not n/G).
+    ``scratch`` may carry preallocated tensors {"part", "recv", "aux"} (>= capacity) to keep
+    allocation out of a timed region.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = shard.numel()
+    if world == 1:
+        aux = scratch["aux"][:n] if scratch else engine.empty(n, shard)
+        res, info = engine.local_sort(shard, aux)
+        return res, {"sent": 0, "received": n, "local_info": info}
+
+    # 1-2: global histogram of the top digit -> identical splitters on every rank
+    local_hist = engine.top_histogram(shard)
+    global_hist = local_hist.clone()
+    dist.all_reduce(global_hist, group=group)
+    hist_host = torch.stack([local_hist, global_hist]).cpu().numpy().astype(np.uint64)
+    lut = choose_splitters(hist_host[1], world)
+
+    # 3: stable local partition by destination rank
+    part = scratch["part"][:n] if scratch else engine.empty(n, shard)
+    send_counts = engine.partition(shard, part, lut, world, hist_host[0])
+
+    # 4: count matrix, then the buckets (all-to-all-v)
+    sc = torch.tensor(send_counts.astype(np.int64), dtype=torch.int64, device=shard.device)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = rc.cpu().numpy()
+    n_recv = int(recv_counts.sum())
+    if scratch:
+        if n_recv > scratch["recv"].numel():
+            raise RsxError("rank %d receives %d keys, more than the %d-key receive buffer" %
+                           (rank, n_recv, scratch["recv"].numel()))
+        recv = scratch["recv"][:n_recv]
+        aux = scratch["aux"][:n_recv]
+    else:
+        recv = engine.empty(n_recv, shard)
+        aux = engine.empty(n_recv, shard)
+    dist.all_to_all_single(recv, part, output_split_sizes=[int(x) for x in recv_counts],
+                           input_split_sizes=[int(x) for x in send_counts], group=group)
+
+    # 5: local LSD sort of the received bucket range
+    res, info = engine.local_sort(recv, aux)
+    sent = int(send_counts.sum() - send_counts[rank])
+    return res, {"sent": sent, "received": n_recv, "local_info": info, "lut": lut,
+                 "send_counts": send_counts, "recv_counts": recv_counts}

@@ -1,0 +1,319 @@
+"""Parity of the HIP path against the oracle, through the C ABI, on a real MI355X.
+
+Bit-exact bar: output bytes, returned buffer, kept-column list and early exits
+must equal the CPU restatement (itself pinned to the reference in
+tests/test_oracle.py) on the same seeded inputs; the committed golden hashes
+(from the real reference headers) are checked directly as well.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLDEN, "kat_table.json")) as f:
+    KAT = json.load(f)
+
+torch = pytest.importorskip("torch")
+
+# bit patterns travel in same-width signed torch tensors; the rsx dtype code says what they mean
+_CARRIER = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def to_dev(bits):
+    a = np.ascontiguousarray(bits)
+    return torch.from_numpy(a.view(_CARRIER[a.itemsize]).copy()).cuda()
+
+
+def to_bits(t, dt):
+    return t.cpu().numpy().view(ol.NP_BITS[dt])
+
+
+def gpu_sort(bits, dt, order=ol.ASC, fill=0x5A):
+    src = to_dev(bits)
+    aux = torch.full_like(src, int.from_bytes(bytes([fill]) * src.element_size(), "little"))   # every byte = fill
+    res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)
+    torch.cuda.synchronize()
+    return to_bits(res, dt), info, to_bits(src, dt), to_bits(aux, dt)
+
+
+def _id(row):
+    return "%s-n%d-s%d-m%s-o%d" % (row["dtype"], row["n"], row["seed"], row["mask"].lstrip("0") or "0", row.get("order", 0))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    rsa.require_gpu()
+
+
+@pytest.mark.parametrize("row", KAT["scalar"] + KAT["scalar_extra"], ids=_id)
+def test_golden_table(row):
+    """SURVEY.md section 4 known answers (hashes of the real reference's outputs)."""
+    dt = row["dtype_code"]
+    a = ol.splitmix_fill(row["n"], dt, row["seed"], int(row["mask"], 16))
+    if row["n"] == 0:
+        return
+    got, info, _, _ = gpu_sort(a, dt, row["order"])
+    assert "%016x" % ol.fnv1a64(got) == row["fnv_out"]
+    assert info.result_in_aux == row["result_in_aux"]
+
+
+@pytest.mark.parametrize("dt", range(10), ids=ol.DTYPE_NAMES)
+def test_sweep_vs_oracle(dt):
+    rng = np.random.default_rng(4321 + dt)
+    full = (1 << (8 * ol.DTYPE_SIZE[dt])) - 1
+    sizes = [2, 3, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 8191, 8192, 8193, 65535, 65536, 65537,
+             100000, 300001]
+    for trial, n in enumerate(sizes):
+        mask = full
+        if trial % 3 == 1:
+            for b in range(ol.DTYPE_SIZE[dt]):
+                if rng.random() < 0.5:
+                    mask &= ~(0xFF << (8 * b))
+        if trial % 3 == 2:
+            mask &= int(rng.integers(0, full, dtype=np.uint64, endpoint=True))
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        for order in (ol.ASC, ol.DESC):
+            want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+            got, info, _, _ = gpu_sort(a, dt, order)
+            assert info.result_in_aux == want_aux, (n, hex(mask), order)
+            assert info.kept_columns() == list(winfo.cols[:winfo.ncols])
+            assert info.early_exit == winfo.early_exit
+            assert np.array_equal(got, want), (n, hex(mask), order)
+
+
+def test_contract_early_exits_leave_aux_untouched():
+    # pre-sorted (with duplicates) -> src returned, aux byte-for-byte untouched (radix_sort.hpp:60-62)
+    a = np.sort(ol.splitmix_fill(100000, ol.U32, 3, 0xFFFFF))
+    got, info, src_after, aux_after = gpu_sort(a, ol.U32, fill=0x5A)
+    assert info.early_exit == 2 and info.result_in_aux == 0 and info.ncols == 0
+    assert np.array_equal(src_after, a) and np.all(aux_after == 0x5A5A5A5A)
+    # all-equal input is pre-sorted too (appendix A item 3)
+    got, info, _, aux_after = gpu_sort(np.full(70000, 0xDEADBEEF, dtype=np.uint32), ol.U32)
+    assert info.early_exit == 2 and np.all(aux_after == 0x5A5A5A5A)
+    # reverse-sorted input is NOT an early exit
+    got, info, _, _ = gpu_sort(a[::-1].copy(), ol.U32)
+    assert info.early_exit == 0 and np.array_equal(got, a)
+    # a single descent anywhere (also across wave / block / vector boundaries) defeats the early exit
+    for pos in (0, 1, 3, 4, 63, 255, 256, 1023, 1024, 4095, 4096, 50000, 99998):
+        b = a.copy()
+        b[pos], b[pos + 1] = a[-1], a[0]
+        if b[pos] <= b[pos + 1]:
+            continue
+        want, want_aux, winfo = ol.oracle_sort(b, ol.U32)
+        got, info, _, _ = gpu_sort(b, ol.U32)
+        assert info.early_exit == 0 and np.array_equal(got, want) and info.result_in_aux == want_aux, pos
+
+
+@pytest.mark.parametrize("mask,cols,in_aux", [(0x00FFFFFF, [0, 1, 2], 1), (0x0000FFFF, [0, 1], 0),
+                                                 (0x000000FF, [0], 1), (0xFF00FF00, [1, 3], 0)])
+def test_contract_column_skip_and_parity(mask, cols, in_aux):
+    a = ol.splitmix_fill(200000, ol.U32, 77, mask)
+    got, info, src_after, _ = gpu_sort(a, ol.U32)
+    assert info.kept_columns() == cols and info.result_in_aux == in_aux
+    assert np.array_equal(got, np.sort(a, kind="stable"))
+    if len(cols) == 1:
+        assert np.array_equal(src_after, a)   # one kept column: the input buffer is only read
+
+
+def test_unaligned_device_pointers():
+    """Sub-tensors that start off a 16-byte boundary (head/tail path of the histogram kernel)."""
+    for dt in (ol.U8, ol.U16, ol.U32, ol.U64):
+        a = ol.splitmix_fill(50021, dt, 5)
+        for off in (1, 3):
+            src_full = to_dev(np.concatenate([np.zeros(off, a.dtype), a]))
+            aux_full = torch.zeros_like(src_full)
+            res, info = rsa.radix_sort(src_full[off:], aux_full[off:], dtype=dt)
+            torch.cuda.synchronize()
+            want, want_aux, _ = ol.oracle_sort(a, dt)
+            assert info.result_in_aux == want_aux and np.array_equal(to_bits(res, dt), want)
+
+
+def test_float_order_and_test_int_fixture():
+    vals = np.array([128.0, 646464.0, 0.0, -0.0, -0.5, 0.5, -128.0, -np.inf, np.nan, np.inf], dtype=np.float32)
+    got, info, _, _ = gpu_sort(vals.view(np.uint32), ol.F32)
+    assert [int(x) for x in got] == [0xff800000, 0xc3000000, 0xbf000000, 0x80000000, 0x00000000, 0x3f000000,
+                                    0x43000000, 0x491dd400, 0x7f800000, 0x7fc00000]      # README.md:612-623
+    ti = KAT["test_int"]
+    a = np.fromfile(os.path.join(GOLDEN, ti["file"]), dtype=np.uint32)
+    asc, info, _, _ = gpu_sort(a, ol.I32)
+    assert "%016x" % ol.fnv1a64(asc) == ti["fnv_ascending"] and info.result_in_aux == ti["ascending_in_aux"]
+    desc, info, _, _ = gpu_sort(asc, ol.I32, ol.DESC)
+    assert "%016x" % ol.fnv1a64(desc) == ti["fnv_descending"] and info.result_in_aux == ti["descending_in_aux"]
+
+
+def test_skewed_digits():
+    """Degenerate digit distributions: the contention cases of the wave ranking and the look-back."""
+    n = 500000
+    rng = np.random.default_rng(9)
+    cases = [np.full(n, 7, dtype=np.uint32),                                     # (caught by the early exit)
+             np.where(rng.random(n) < 0.99, 0x01010101, 0x02020202).astype(np.uint32),   # two values
+             (rng.integers(0, 4, n) * 0x40404040).astype(np.uint32),             # four values
+             rng.zipf(1.3, n).astype(np.uint32),                                 # Zipf
+             np.arange(n, dtype=np.uint32)[::-1].copy(),                         # strictly descending
+             (np.arange(n, dtype=np.uint32) * 2654435761).astype(np.uint32)]     # multiplicative hash
+    for a in cases:
+        want, want_aux, winfo = ol.oracle_sort(a, ol.U32)
+        got, info, _, _ = gpu_sort(a, ol.U32)
+        assert info.result_in_aux == want_aux and np.array_equal(got, want)
+
+
+# ---- key + payload and rank ----------------------------------------------------------------
+
+def test_pairs_kv_pin():
+    """SURVEY.md section 4 key+payload pin: {f32 key, u32 payload = i}, bits & 0xFFF000FF."""
+    kv = KAT["kv"][0]
+    n = kv["n"]
+    k = ol.splitmix_fill(n, ol.U32, kv["seed"], int(kv["mask"], 16))
+    keys, keys_aux = to_dev(k), torch.zeros(n, dtype=torch.int32, device="cuda")
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    vals_aux = torch.zeros_like(vals)
+    kr, vr, info = rsa.radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=ol.F32)
+    torch.cuda.synchronize()
+    assert info.result_in_aux == kv["result_in_aux"]
+    assert "%016x" % ol.fnv1a64(to_bits(vr, ol.U32)) == kv["fnv_out_payloads"]
+    assert "%016x" % ol.fnv1a64(to_bits(kr, ol.U32)) == kv["fnv_out_keys"]
+
+
+@pytest.mark.parametrize("dt", [ol.U8, ol.U16, ol.U32, ol.U64, ol.I32, ol.F32, ol.F64], ids=lambda d: ol.DTYPE_NAMES[d])
+@pytest.mark.parametrize("vbytes", [4, 8])
+def test_pairs_vs_oracle_records(dt, vbytes):
+    n = 150001
+    k = ol.splitmix_fill(n, dt, 31 + dt, (1 << (8 * ol.DTYPE_SIZE[dt])) - 1 if dt not in (ol.U32, ol.F32) else 0xFFF000FF)
+    vt = torch.int32 if vbytes == 4 else torch.int64
+    keys, keys_aux = to_dev(k), to_dev(np.zeros_like(k))
+    vals = (torch.arange(n, dtype=vt, device="cuda") * 3 + 1)
+    vals_aux = torch.zeros_like(vals)
+    kr, vr, info = rsa.radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=dt)
+    torch.cuda.synchronize()
+    perm = ol.stable_argsort_by_kdf(k, dt)
+    _, want_aux, winfo = ol.oracle_sort(k, dt)
+    assert info.result_in_aux == want_aux
+    assert np.array_equal(to_bits(kr, dt), k[perm])
+    assert np.array_equal(vr.cpu().numpy(), perm.astype(np.int64) * 3 + 1)
+
+
+@pytest.mark.parametrize("row", KAT["rank"], ids=_id)
+def test_rank_golden(row):
+    dt = row["dtype_code"]
+    a = ol.splitmix_fill(row["n"], dt, row["seed"], int(row["mask"], 16))
+    src = to_dev(a)
+    ib = torch.full((2 * a.size,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(src, ib, dtype=dt)
+    torch.cuda.synchronize()
+    assert "%016x" % ol.fnv1a64(to_bits(ranks, ol.U32)) == row["fnv_stable_argsort"]
+    if row["reference_is_correct"]:
+        assert info.result_in_aux == row["reference_result_half"]
+    assert np.array_equal(to_bits(src, dt), a)      # src is const (radix_sort_rank.hpp:97)
+
+
+@pytest.mark.parametrize("dt", range(10), ids=ol.DTYPE_NAMES)
+def test_rank_vs_oracle(dt):
+    rng = np.random.default_rng(77 + dt)
+    full = (1 << (8 * ol.DTYPE_SIZE[dt])) - 1
+    for n, mask, ibytes in ((1, full, 4), (2, full, 4), (777, full, 8), (8192, full & 0xFFFF00FFFFFF00FF, 4),
+                            (100003, full, 4), (100003, full & 0x00FF00FF00FF00FF, 8)):
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        for order in (ol.ASC, ol.DESC):
+            want, whalf, winfo, _ = ol.oracle_rank(a, dt, ibytes, order)
+            it = torch.int32 if ibytes == 4 else torch.int64
+            ib = torch.full((2 * n,), -1, dtype=it, device="cuda")
+            ranks, info = rsa.radix_sort_rank(to_dev(a), ib, dtype=dt, order=order)
+            torch.cuda.synchronize()
+            assert info.result_in_aux == whalf and info.early_exit == winfo.early_exit
+            assert np.array_equal(ranks.cpu().numpy().astype(np.uint64), want.astype(np.uint64)), (n, hex(mask), order)
+
+
+def test_rank_contract_presorted():
+    a = np.sort(ol.splitmix_fill(5000, ol.U32, 1))
+    ib = torch.full((10000,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(to_dev(a), ib, dtype=ol.U32)
+    torch.cuda.synchronize()
+    out = ib.cpu().numpy()
+    assert info.early_exit == 2 and info.result_in_aux == 0
+    assert np.array_equal(out[:5000], np.arange(5000)) and np.all(out[5000:] == -1)   # radix_sort_rank.hpp:52,:55-57
+
+
+# ---- host-pointer entry points (what the C++ template wrapper calls) ----------------------------
+
+def test_host_pointer_sort_and_rank():
+    for dt in (ol.U32, ol.F32, ol.U64, ol.I16, ol.U8):
+        a = ol.splitmix_fill(123457, dt, 50 + dt)
+        want, want_aux, _ = ol.oracle_sort(a, dt)
+        src, aux = a.copy(), np.full_like(a, 0x5A)
+        res, info = rsa.radix_sort_host(src, aux, dt)
+        assert info.result_in_aux == want_aux and np.array_equal(res, want)
+        for ibytes, it in ((4, np.uint32), (8, np.uint64)):
+            ib = np.zeros(2 * a.size, dtype=it)
+            ranks, info = rsa.radix_sort_rank_host(a, ib, dt)
+            wr, whalf, _, _ = ol.oracle_rank(a, dt, ibytes)
+            assert info.result_in_aux == whalf and np.array_equal(ranks, wr)
+    # pre-sorted host input: aux untouched
+    a = np.sort(ol.splitmix_fill(5000, ol.U32, 2))
+    src, aux = a.copy(), np.full_like(a, 0x5A5A5A5A)
+    res, info = rsa.radix_sort_host(src, aux, ol.U32)
+    assert res is src and info.early_exit == 2 and np.all(aux == 0x5A5A5A5A)
+    # narrow IdxType (radix_tests.cpp:75 uses uint8_t)
+    a = ol.splitmix_fill(200, ol.U8, 3)
+    ib = np.full(400, 0xEE, dtype=np.uint8)
+    ranks, info = rsa.radix_sort_rank_host(a, ib, ol.U8)
+    wr, whalf, _, _ = ol.oracle_rank(a, ol.U8, 1)
+    assert info.result_in_aux == whalf and np.array_equal(ranks, wr)
+
+
+def test_records_with_host_keys():
+    """radix_tests.cpp:45-69 / :121-146 shapes: 16-byte records, 1-byte key from an opaque KeyFunc."""
+    recs = np.zeros(8, dtype=np.dtype([("key", np.uint8), ("pad", np.uint8, 7), ("name", np.uint64)]))
+    recs["key"] = [255, 45, 3, 45, 2, 45, 1, 255]
+    recs["name"] = np.arange(8)
+    for keys, expect in ((recs["key"].copy(), [6, 4, 2, 1, 3, 5, 0, 7]),
+                         ((~recs["key"]).astype(np.uint8), [0, 7, 1, 3, 5, 2, 4, 6])):
+        src, aux = recs.copy(), np.zeros_like(recs)
+        res, info = rsa.radix_sort_records_host(src, aux, keys)
+        assert info.result_in_aux == 1 and res is aux
+        assert [int(x) for x in res["name"]] == expect
+    # larger: 24-byte records, u32 keys with duplicates; compare with the oracle's record sort
+    n = 70001
+    k = ol.splitmix_fill(n, ol.U32, 8, 0xFF00FF)
+    rec = np.zeros(n, dtype=np.dtype([("k", np.uint32), ("a", np.uint32), ("b", np.uint64), ("c", np.uint64)]))
+    rec["k"], rec["a"], rec["b"], rec["c"] = k, np.arange(n), np.arange(n) * 7, ~np.arange(n, dtype=np.uint64)
+    src, aux = rec.copy(), np.zeros_like(rec)
+    res, info = rsa.radix_sort_records_host(src, aux, k.copy())
+    s2, a2 = rec.copy(), np.zeros_like(rec)
+    oinfo = ol.Info()
+    r = ol.oracle().rso_sort_records(ol.ptr(s2), ol.ptr(a2), n, 24, 0, ol.U32, 0, C.byref(oinfo))
+    assert info.result_in_aux == r and np.array_equal(res, a2 if r else s2)
+
+
+# ---- BASELINE.json sizes: size-independent properties + full comparison where the oracle is quick enough ----
+
+def test_full_size_2p28_u32_properties():
+    """cfg 2: 2^28 u32 (seed 1).  Sortedness, multiset (histogram of histograms) and checksum invariants,
+    plus bit-exact equality with the oracle on the whole array."""
+    n = 1 << 28
+    a = ol.splitmix_fill(n, ol.U32, 1)
+    src = to_dev(a)
+    aux = torch.empty_like(src)
+    res, info = rsa.radix_sort(src, aux, dtype=ol.U32)
+    torch.cuda.synchronize()
+    assert info.kept_columns() == [0, 1, 2, 3] and info.result_in_aux == 0
+    got = to_bits(res, ol.U32)
+    assert np.all(got[:-1] <= got[1:])
+    assert int(got.astype(np.uint64).sum()) == int(a.astype(np.uint64).sum())
+    assert int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(a))
+    for j in range(4):
+        assert np.array_equal(np.bincount((got >> (8 * j)) & 0xFF, minlength=256),
+                              np.bincount((a >> (8 * j)) & 0xFF, minlength=256))
+    want, want_aux, _ = ol.oracle_sort(a, ol.U32)
+    assert np.array_equal(got, want)
+    # idempotence: sorting the result again is the pre-sorted early exit
+    res2, info2 = rsa.radix_sort(res, aux if res is src else src, dtype=ol.U32)
+    torch.cuda.synchronize()
+    assert info2.early_exit == 2 and res2 is res
