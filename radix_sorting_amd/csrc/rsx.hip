@@ -117,8 +117,10 @@ struct DevBuf {
 struct Ctx {
 	int device = -1;
 	hipStream_t stream = nullptr;
-	// fixed small state: [ghist 8*256 u64][unsorted u32 .. pad to 64][Plan 64][lut 256][gbase_lut 256 u64]
+	// fixed small state: [unsorted u32 | pad 64][Plan 64][kept 8 u32 | pad 64][lut 256][bucket totals 256 u64]
 	DevBuf small;
+	DevBuf hist;        // counts / offsets [nseg][key bytes][256] u64 (see "Segments" in rsx_kernels.hpp)
+	DevBuf bbase;       // MSD split: bucket offsets [nseg][256] u64
 	DevBuf status;      // [ticket u32, pad to 256 B][tiles * 256 status words]
 	DevBuf keys[2];     // key ping-pong for rank sorts / host staging
 	DevBuf vals[2];     // payload ping-pong for host staging / narrow-index rank
@@ -126,12 +128,13 @@ struct Ctx {
 	Plan *host_plan = nullptr;   // pinned
 	u64 *host_hist = nullptr;    // pinned, 256 u64
 
-	u64 *ghist() const { return (u64 *)small.p; }
-	u32 *unsorted() const { return (u32 *)((char *)small.p + 8 * 256 * 8); }
-	Plan *plan() const { return (Plan *)((char *)small.p + 8 * 256 * 8 + 64); }
-	uint8_t *lut() const { return (uint8_t *)((char *)small.p + 8 * 256 * 8 + 128); }
-	u64 *gbase_lut() const { return (u64 *)((char *)small.p + 8 * 256 * 8 + 128 + 256); }
-	static constexpr size_t SMALL_BYTES = 8 * 256 * 8 + 128 + 256 + 256 * 8;
+	u64 *ghist() const { return (u64 *)hist.p; }
+	u32 *unsorted() const { return (u32 *)small.p; }
+	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
+	u32 *kept() const { return (u32 *)((char *)small.p + 128); }
+	uint8_t *lut() const { return (uint8_t *)((char *)small.p + 192); }
+	u64 *bucket_totals() const { return (u64 *)((char *)small.p + 192 + 256); }
+	static constexpr size_t SMALL_BYTES = 192 + 256 + 256 * 8;
 
 	int init()
 	{
@@ -145,6 +148,8 @@ struct Ctx {
 	void release()
 	{
 		small.release();
+		hist.release();
+		bbase.release();
 		status.release();
 		for (int i = 0; i < 2; ++i) {
 			keys[i].release();
@@ -262,31 +267,67 @@ void info_from_plan(rsx_info *info, const Plan &p)
 		info->cols[i] = p.cols[i];
 }
 
+// ---- histogram segment geometry (see "Segments" in rsx_kernels.hpp): the sort uses one segment ----
+struct Geo {
+	u32 nseg;
+	u32 tiles_per_seg;
+	u64 seg_elems;
+	u64 tiles;
+};
+
+Geo one_segment(size_t n)
+{
+	Geo g;
+	g.nseg = 1;
+	g.tiles_per_seg = 1;
+	g.seg_elems = n;
+	g.tiles = 1;
+	return g;
+}
+
+// tiles per super-tile: as many as keeps at least ~2048 super-tiles in flight, at most 8
+u32 choose_tps(size_t n, size_t tile)
+{
+	const u64 tiles = (n + tile - 1) / tile;
+	u64 tps = tiles / 2048;
+	if (tps > 8)
+		tps = 8;
+	if (tps < 1)
+		tps = 1;
+	return (u32)tps;
+}
+
 // ---- phase 1: histogram + plan (radix_sort.hpp:48-80) --------------------------
 template <typename KT>
-int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted)
+int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted, const Geo &g)
 {
 	typedef HistCfg<KT> C;
-	const u64 nvec = n / C::VEC + 1;
-	u64 blocks = (nvec + (u64)C::BLOCK * 4 - 1) / ((u64)C::BLOCK * 4);
-	if (blocks > 2048)
-		blocks = 2048;   // 256 CUs x 8: grid-stride the rest
-	if (blocks < 1)
-		blocks = 1;
+	const u64 per_block = (u64)C::BLOCK * C::U * C::VEC;     // elements one block covers per sweep
+	u64 bps = (g.seg_elems + per_block - 1) / per_block;
+	const u64 cap = 2048 / g.nseg > 0 ? 2048 / g.nseg : 1;    // about 256 CUs x 8 workgroups in all
+	if (bps > cap)
+		bps = cap;
+	if (bps < 1)
+		bps = 1;
 	ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
-	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n, d_hist,
-	                   d_unsorted, ka);
+	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)(g.nseg * bps)), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
+	                   d_hist, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
 
 template <typename KT>
-int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out)
+int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, Plan *out)
 {
-	HIP_TRY(hipMemsetAsync(c.small.p, 0, 8 * 256 * 8 + 128, c.stream));
-	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted()));
-	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(1), dim3(64 * sizeof(KT)), 0, c.stream, d_src, (u64)n, c.ghist(),
-	                   c.unsorted(), c.plan(), ka);
+	const size_t hist_bytes = (size_t)g.nseg * sizeof(KT) * 256 * sizeof(u64);
+	RSX_TRY(c.hist.ensure(hist_bytes));
+	HIP_TRY(hipMemsetAsync(c.hist.p, 0, hist_bytes, c.stream));
+	HIP_TRY(hipMemsetAsync(c.small.p, 0, 192, c.stream));
+	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted(), g));
+	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), g.nseg, ka,
+	                   c.kept());
+	hipLaunchKernelGGL(rsx_plan_finish_kernel, dim3(1), dim3(64), 0, c.stream, (const u32 *)c.kept(), (u32)sizeof(KT),
+	                   (const u32 *)c.unsorted(), c.plan());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
 	HIP_TRY(hipStreamSynchronize(c.stream));
@@ -295,25 +336,27 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out)
 }
 
 // ---- phase 2: one scatter pass (radix_sort.hpp:83-90) -----------------------------
+// gbase[digit]: exclusive offset of the digit for this pass's column
 template <typename KT, typename VT>
 int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
                  KdfArgs<KT> ka, u32 flags, const uint8_t *lut)
 {
 	typedef ScatterCfg<KT, VT> C;
-	const u64 tiles = (n + C::TILE - 1) / C::TILE;
+	const u32 tps = choose_tps(n, C::TILE);
+	const u64 stiles = (n + (u64)tps * C::TILE - 1) / ((u64)tps * C::TILE);
 	const bool wide = n >= (1ull << 30);   // counter width by n, as radix_sort.hpp:102-114 does
-	const size_t st_bytes = 256 + tiles * 256 * (wide ? 8 : 4);
+	const size_t st_bytes = 256 + stiles * 256 * (wide ? 8 : 4);
 	RSX_TRY(c.status.ensure(st_bytes));
 	HIP_TRY(hipMemsetAsync(c.status.p, 0, st_bytes, c.stream));
 	u32 *ticket = (u32 *)c.status.p;
 	void *st = (char *)c.status.p + 256;
 	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
 	if (wide)
-		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
-		                   vin, vout, (u64)n, shift, gbase, (u64 *)st, ticket, ka, flags, lut);
+		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
+		                   vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
 	else
-		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
-		                   vin, vout, (u64)n, shift, gbase, (u32 *)st, ticket, ka, flags, lut);
+		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
+		                   vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
@@ -323,8 +366,9 @@ template <typename KT>
 int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	const Geo g = one_segment(n);
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan));
+	RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));
 	info_from_plan(info, plan);
 	if (plan.sorted) {                       // radix_sort.hpp:60-62
 		if (info) {
@@ -351,8 +395,9 @@ template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	const Geo g = one_segment(n);
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, k0, n, ka, &plan));
+	RSX_TRY(plan_phase<KT>(c, k0, n, ka, g, &plan));
 	info_from_plan(info, plan);
 	if (plan.sorted) {
 		if (info) {
@@ -382,8 +427,9 @@ template <typename KT, typename IT>
 int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	const Geo g = one_segment(n);
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan));
+	RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));
 	info_from_plan(info, plan);
 	if (plan.sorted) {                       // radix_sort_rank.hpp:52,:55-57: first half = iota
 		hipLaunchKernelGGL((rsx_iota_kernel<IT>), dim3(1024), dim3(256), 0, c.stream, ib, (u64)n);
@@ -467,7 +513,7 @@ size_t rsx_workspace_bytes(size_t n, rsx_dtype dtype, size_t payload_bytes)
 	const size_t elem = kb > payload_bytes ? kb : payload_bytes;
 	const size_t tile = 512 * (elem == 8 ? 8 : 16);
 	const size_t tiles = (n + tile - 1) / tile;
-	return Ctx::SMALL_BYTES + 256 + tiles * 256 * (n >= (1ull << 30) ? 8 : 4);
+	return Ctx::SMALL_BYTES + kb * 256 * 8 + 256 + tiles * 256 * (n >= (1ull << 30) ? 8 : 4);
 }
 
 void rsx_release(void)
@@ -756,8 +802,9 @@ int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order
 	HIP_TRY(hipMemsetAsync(d_unsorted, 0, sizeof(u32), c->stream));
 	if (n == 0)
 		return RSX_OK;
+	const Geo g = one_segment(n);
 	RSX_DISPATCH_KT(dtype, return launch_hist<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), (u64 *)d_hist,
-	                                              (u32 *)d_unsorted));
+	                                              (u32 *)d_unsorted, g));
 	return RSX_OK;
 }
 
@@ -776,39 +823,67 @@ int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 		return RSX_OK;
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
-	u64 hist[256];
-	if (top_hist) {
-		memcpy(hist, top_hist, sizeof(hist));
-	} else {
-		HIP_TRY(hipMemsetAsync(c->small.p, 0, 8 * 256 * 8 + 128, c->stream));
-		RSX_DISPATCH_KT(dtype, RSX_TRY(launch_hist<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), c->ghist(),
-		                                              c->unsorted())));
-		HIP_TRY(hipMemcpyAsync(c->host_hist, c->ghist() + 256 * (kb - 1), 256 * sizeof(u64), hipMemcpyDeviceToHost,
-		                       c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		memcpy(hist, c->host_hist, sizeof(hist));
-	}
+	// per-segment histogram of the top KDF byte -> per-(segment, bucket) offsets -> one scatter pass
+	const Geo g = one_segment(n);
+	const size_t hist_bytes = (size_t)g.nseg * kb * 256 * sizeof(u64);
+	RSX_TRY(c->hist.ensure(hist_bytes));
+	RSX_TRY(c->bbase.ensure((size_t)g.nseg * 256 * sizeof(u64)));
+	HIP_TRY(hipMemsetAsync(c->hist.p, 0, hist_bytes, c->stream));
+	HIP_TRY(hipMemsetAsync(c->small.p, 0, 192, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->lut(), lut, 256, hipMemcpyHostToDevice, c->stream));
+	RSX_DISPATCH_KT(dtype, RSX_TRY(launch_hist<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), c->ghist(),
+	                                              c->unsorted(), g)));
+	hipLaunchKernelGGL(rsx_lut_plan_kernel, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->ghist(), g.nseg, (u32)(kb * 256),
+	                   (u32)(256 * (kb - 1)), (const uint8_t *)c->lut(), (u64 *)c->bbase.p, c->bucket_totals());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(c->host_hist, c->bucket_totals(), 256 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));   // also: `lut` (caller's buffer) has been consumed
 	u64 total = 0;
-	for (int i = 0; i < 256; ++i) {
-		counts[lut[i]] += hist[i];
-		total += hist[i];
+	for (u32 b = 0; b < nbuckets; ++b) {
+		counts[b] = c->host_hist[b];
+		total += counts[b];
 	}
 	if (total != n)
-		return fail(RSX_EINVAL, "rsx_partition_device: top_hist sums to %llu, n = %zu", (unsigned long long)total, n);
-	u64 base[256];
-	u64 a = 0;
-	for (u32 b = 0; b < 256; ++b) {
-		base[b] = a;
-		if (b < nbuckets)
-			a += counts[b];
+		return fail(RSX_EHIP, "rsx_partition_device: bucket counts sum to %llu, n = %zu", (unsigned long long)total, n);
+	if (top_hist) {   // cross-check the caller's histogram of the top byte against what the device counted
+		u64 chk[256] = {0};
+		for (int i = 0; i < 256; ++i)
+			chk[lut[i]] += top_hist[i];
+		for (u32 b = 0; b < nbuckets; ++b)
+			if (chk[b] != counts[b])
+				return fail(RSX_EINVAL, "rsx_partition_device: top_hist disagrees with the data for bucket %u", b);
 	}
-	HIP_TRY(hipMemcpyAsync(c->gbase_lut(), base, sizeof(base), hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(hipMemcpyAsync(c->lut(), lut, 256, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));   // base/lut are stack/host buffers
 	RSX_DISPATCH_KT(dtype, RSX_TRY((scatter_pass<KT, NoVal>(*c, (const KT *)d_src, (KT *)d_dst, nullptr, nullptr, n,
-	                                                       (u32)(8 * (kb - 1)), c->gbase_lut(), make_kdf<KT>(dtype, order),
-	                                                       SCATTER_USE_LUT, c->lut()))));
+	                                                       (u32)(8 * (kb - 1)), (const u64 *)c->bbase.p,
+	                                                       make_kdf<KT>(dtype, order), SCATTER_USE_LUT, c->lut()))));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	return RSX_OK;
+}
+
+// Test hook (not in include/rsx.h): runs the histogram + plan kernels exactly as a keys-only sort
+// would and returns the segment geometry and the per-(segment, column, digit) exclusive offsets.
+int rsx_debug_offsets(const void *d_src, size_t n, rsx_dtype dtype, rsx_order order, uint32_t *nseg, uint32_t *tiles_per_seg,
+                      uint64_t *seg_elems, uint64_t *offsets, size_t max_offsets, rsx_info *info)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb || n < 2)
+		return fail(RSX_EINVAL, "rsx_debug_offsets: bad argument");
+	Ctx *c;
+	RSX_TRY(get_ctx(nullptr, &c));
+	info_clear(info, dtype);
+	const Geo g = one_segment(n);
+	Plan plan;
+	RSX_DISPATCH_KT(dtype, RSX_TRY(plan_phase<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), g, &plan)));
+	info_from_plan(info, plan);
+	if (info && plan.sorted)
+		info->early_exit = 2;
+	*nseg = g.nseg;
+	*tiles_per_seg = g.tiles_per_seg;
+	*seg_elems = g.seg_elems;
+	const size_t cnt = (size_t)g.nseg * kb * 256;
+	if (cnt > max_offsets)
+		return fail(RSX_EINVAL, "rsx_debug_offsets: need room for %zu offsets", cnt);
+	HIP_TRY(hipMemcpy(offsets, c->ghist(), cnt * sizeof(u64), hipMemcpyDeviceToHost));
 	return RSX_OK;
 }
 

@@ -9,18 +9,19 @@
 //                       per bin so equal digits do not serialise on one LDS
 //                       address) and merged into HBM with global atomics.
 //   rsx_plan_kernel     column-skip probe (:64-70) + exclusive scan (:72-80):
-//                       one 64-lane wavefront per column, 4 bins per lane,
-//                       scanned through LDS.
+//                       the 256-bin scan of a column is done by one 64-lane
+//                       wavefront through LDS (4 bins per lane).
 //   rsx_scatter_kernel  one scatter pass (:82-90) as a single-read/single-write
 //                       "onesweep": a workgroup takes a tile (ticket order),
-//                       ranks its keys inside each wavefront with 8 ballots +
-//                       mbcnt/popcount, chains the per-digit tile offsets with a
-//                       decoupled look-back over agent-scope status words, stages
-//                       the tile in LDS in output order and writes coalesced runs.
+//                       ranks its keys inside each wavefront through per-wave LDS
+//                       match tables + mbcnt/popcount, chains the per-digit tile
+//                       offsets with a decoupled look-back over agent-scope status
+//                       words, stages the tile in LDS in output order and writes
+//                       coalesced runs.
 //
 // Stability: a wave owns a contiguous slice of the tile, lane l of round r holds
-// element slice + 64 r + l, rounds are ranked in order and lanes by mbcnt, waves
-// and tiles are prefix-summed in memory order -- so equal digits keep their
+// element slice + 64 r + l, rounds are ranked in order and lanes by mbcnt, waves,
+// tiles and segments are prefix-summed in memory order -- so equal digits keep their
 // input order exactly as the reference's in-order traversal with post-increment
 // does.
 #pragma once
@@ -32,11 +33,14 @@ namespace rsx {
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 struct NoVal {};  // "keys only" payload tag
 
 template <typename T> struct val_bytes { static constexpr int value = sizeof(T); };
 template <> struct val_bytes<NoVal> { static constexpr int value = 0; };
+
+#define RSX_COMPILER_FENCE() asm volatile("" ::: "memory")
 
 // ---- key derivation ---------------------------------------------------------
 // radix_sort_basic_kdf.hpp:19-46 folded into three per-launch constants so one
@@ -55,13 +59,19 @@ __device__ __forceinline__ KT kdf_apply(KT raw, const KdfArgs<KT> a)
 	return (KT)(raw ^ ((sign & a.fmask) | a.sflip) ^ a.desc);
 }
 
-__device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 // popcount of the bits of `m` below this lane
 __device__ __forceinline__ u32 mbcnt64(u64 m)
 {
 	return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
+
+// =============================================================================
+// Segments (histogram / plan kernels)
+// =============================================================================
+// The histogram can be kept per contiguous segment of the input: counts[seg][column][256] (u64),
+// turned by the plan kernel into the exclusive offset of (segment, digit).  The sort itself runs
+// with one segment (per-segment counts of the input order are only valid for the first pass);
+// the MSD split of the multi-GPU path uses the same kernels.
 
 // =============================================================================
 // Kernel 1: histogram of all columns + pre-sorted test
@@ -72,6 +82,7 @@ template <typename KT> struct HistCfg {
 	static constexpr int VEC = 16 / sizeof(KT);         // elements per 16-byte lane load
 	static constexpr int R = sizeof(KT) == 8 ? 4 : 8;   // lane-striped copies per bin
 	static constexpr int BLOCK = 256;
+	static constexpr int U = 4;                         // independent 16-byte loads in flight per lane
 };
 
 template <typename KT, int R>
@@ -84,32 +95,41 @@ __device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane)
 	}
 }
 
+// grid = nseg * blocks_per_seg.  With nseg > 1 the host guarantees that src is 16-byte aligned
+// and seg_elems is a multiple of VEC.
 template <typename KT>
 __global__ __launch_bounds__(256) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
-                                                       u32 *__restrict__ unsorted, KdfArgs<KT> ka)
+                                                       u32 *__restrict__ unsorted, KdfArgs<KT> ka, u32 nseg,
+                                                       u32 blocks_per_seg, u64 seg_elems)
 {
 	typedef HistCfg<KT> C;
-	constexpr int WC = C::WC, VEC = C::VEC, R = C::R;
+	constexpr int WC = C::WC, VEC = C::VEC, R = C::R, U = C::U;
 	__shared__ u32 lh[WC * 256 * R];
 	const u32 tid = threadIdx.x;
 	const u32 lane = tid & 63;
+	const u32 seg = blockIdx.x / blocks_per_seg, bis = blockIdx.x % blocks_per_seg;
 	for (u32 i = tid; i < WC * 256 * R; i += C::BLOCK)
 		lh[i] = 0;
 	__syncthreads();
 
-	// elements before the first 16-byte boundary, and after the last full vector
-	const uintptr_t addr = (uintptr_t)src;
-	u64 head = ((16 - (addr & 15)) & 15) / sizeof(KT);
+	// elements before the first 16-byte boundary (single-segment launches only) and after the last full vector
+	u64 head = nseg > 1 ? 0 : ((16 - ((uintptr_t)src & 15)) & 15) / sizeof(KT);
 	if (head > n)
 		head = n;
 	const u64 nvec = (n - head) / VEC;
 	const u64 tail_begin = head + nvec * VEC;
+	const u64 vbeg = nseg > 1 ? (u64)seg * (seg_elems / VEC) : 0;
+	u64 vend = nseg > 1 ? vbeg + seg_elems / VEC : nvec;
+	if (vend > nvec)
+		vend = nvec;
 	bool descent = false;
 
-	if (blockIdx.x == 0) {
-		// scalar fringe: < 2*VEC elements in total
-		for (u64 i = tid; i < head + (n - tail_begin); i += C::BLOCK) {
-			const u64 e = i < head ? i : tail_begin + (i - head);
+	if (bis == 0 && (seg == 0 || seg == nseg - 1)) {
+		// scalar fringe (< 2*VEC elements): the head belongs to segment 0, the tail to the last segment
+		const u64 nhead = seg == 0 ? head : 0;
+		const u64 ntail = seg == nseg - 1 ? n - tail_begin : 0;
+		for (u64 i = tid; i < nhead + ntail; i += C::BLOCK) {
+			const u64 e = i < nhead ? i : tail_begin + (i - nhead);
 			const KT k = kdf_apply(src[e], ka);
 			if (e + 1 < n && k > kdf_apply(src[e + 1], ka))
 				descent = true;
@@ -119,20 +139,19 @@ __global__ __launch_bounds__(256) void rsx_hist_kernel(const KT *__restrict__ sr
 
 	typedef KT vec_t __attribute__((ext_vector_type(VEC)));
 	const vec_t *vsrc = (const vec_t *)(src + head);
-	constexpr int U = 4;   // independent 16-byte loads in flight per lane
-	const u64 stride = (u64)gridDim.x * (C::BLOCK * U);
-	for (u64 v0 = (u64)blockIdx.x * (C::BLOCK * U) + tid; v0 < nvec; v0 += stride) {
+	const u64 stride = (u64)blocks_per_seg * (C::BLOCK * U);
+	for (u64 v0 = vbeg + (u64)bis * (C::BLOCK * U) + tid; v0 < vend; v0 += stride) {
 		vec_t raw[U];
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const u64 v = v0 + (u64)u * C::BLOCK;
-			if (v < nvec)
+			if (v < vend)
 				raw[u] = vsrc[v];
 		}
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const u64 v = v0 + (u64)u * C::BLOCK;
-			if (v >= nvec)
+			if (v >= vend)
 				break;
 			KT k[VEC];
 #pragma unroll
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(256) void rsx_hist_kernel(const KT *__restrict__ sr
 				nxt = (KT)__shfl_down((u32)k[0], 1);
 			}
 			const u64 next_elem = head + (v + 1) * VEC;
-			const bool edge = lane == 63 || v + 1 >= nvec;  // the next lane is idle or holds another row
+			const bool edge = lane == 63 || v + 1 >= vend;  // the next lane is idle or holds another row
 			if (edge)
 				nxt = next_elem < n ? kdf_apply(src[next_elem], ka) : k[VEC - 1];
 			descent |= k[VEC - 1] > nxt;
@@ -189,78 +208,131 @@ __global__ __launch_bounds__(256) void rsx_hist_kernel(const KT *__restrict__ sr
 		atomicOr(unsorted, 1u);
 
 	__syncthreads();
+	u64 *gh = ghist + (u64)seg * (WC * 256);
 	for (u32 i = tid; i < WC * 256; i += C::BLOCK) {
 		u32 s = 0;
 #pragma unroll
 		for (int r = 0; r < R; ++r)
 			s += lh[i * R + r];
 		if (s)
-			atomicAdd(&ghist[i], (u64)s);
+			atomicAdd(&gh[i], (u64)s);
 	}
 }
 
 // =============================================================================
-// Kernel 2: column-skip probe + exclusive scan (one wavefront per column)
+// Kernel 2: column-skip probe + exclusive scan
 // =============================================================================
 
-struct Plan {            // 64 bytes, copied to the host after this kernel
+struct Plan {            // 64 bytes, copied to the host after the plan kernels
 	u32 ncols;           // kept columns (radix_sort.hpp:64-70)
 	u32 sorted;          // 1: pre-sorted early exit (radix_sort.hpp:60-62)
 	u32 cols[8];
 	u32 pad[6];
 };
 
-// Launched with one workgroup of WC wavefronts.  ghist holds counts on entry and
-// exclusive offsets on exit, like the reference's histogram array.
-template <typename KT>
-__global__ __launch_bounds__(64 * sizeof(KT)) void rsx_plan_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
-                                                                  const u32 *__restrict__ unsorted, Plan *__restrict__ plan,
-                                                                  KdfArgs<KT> ka)
+// Exclusive scan of 256 u64 values held in LDS, by ONE wavefront (lanes 0..63 of the caller):
+// 4 bins per lane, lane totals combined with a Hillis-Steele pass through LDS.
+__device__ __forceinline__ void wave_scan_256(u64 *vals, u64 *lsum, u32 lane)
 {
-	constexpr int WC = sizeof(KT);
-	__shared__ u64 lsum[WC][64];
-	__shared__ u32 kept[WC];
-	const u32 lane = threadIdx.x & 63, col = threadIdx.x >> 6;
-
-	const KT key0 = kdf_apply(src[0], ka);                        // radix_sort.hpp:65
-	const u32 d0 = (u32)(key0 >> (8 * col)) & 0xFFu;
-	u64 *h = ghist + 256 * col;
-	if (lane == 0)
-		kept[col] = h[d0] != n;                                   // radix_sort.hpp:67
-
-	// single-wavefront scan of 256 bins: 4 bins per lane, lane totals through LDS
 	u64 c[4];
 #pragma unroll
 	for (int i = 0; i < 4; ++i)
-		c[i] = h[4 * lane + i];
+		c[i] = vals[4 * lane + i];
 	const u64 mine = c[0] + c[1] + c[2] + c[3];
 	u64 incl = mine;
-	lsum[col][lane] = incl;
-	__syncthreads();
+	lsum[lane] = incl;
 #pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {                       // Hillis-Steele inside one wave
-		const u64 add = lane >= (u32)off ? lsum[col][lane - off] : 0;
-		__syncthreads();
+	for (int off = 1; off < 64; off <<= 1) {   // DS operations of one wave execute in issue order
+		RSX_COMPILER_FENCE();
+		const u64 add = lane >= (u32)off ? lsum[lane - off] : 0;
+		RSX_COMPILER_FENCE();
 		incl += add;
-		lsum[col][lane] = incl;
-		__syncthreads();
+		lsum[lane] = incl;
 	}
-	u64 a = incl - mine;                                           // radix_sort.hpp:74-79
+	u64 a = incl - mine;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		h[4 * lane + i] = a;
+		vals[4 * lane + i] = a;
 		a += c[i];
 	}
+}
 
+// One workgroup (256 threads, thread = digit) per column.  ghist[seg][col][256] holds counts on
+// entry; on exit the exclusive offset of (segment, digit): every key with a smaller digit, plus the
+// keys with the same digit in earlier segments -- the reference's exclusive scan
+// (radix_sort.hpp:72-80) refined by segment.  kept[col] answers the column-skip probe (:64-70).
+template <typename KT>
+__global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
+                                                       u32 nseg, KdfArgs<KT> ka, u32 *__restrict__ kept)
+{
+	constexpr int WC = sizeof(KT);
+	__shared__ u64 tot[256];
+	__shared__ u64 lsum[64];
+	const u32 d = threadIdx.x, col = blockIdx.x;
+	u64 *h = ghist + 256 * col + d;
+	const u64 seg_stride = (u64)WC * 256;
+
+	u64 total = 0;
+	for (u32 s = 0; s < nseg; ++s)
+		total += h[s * seg_stride];
+	const KT key0 = kdf_apply(src[0], ka);                         // radix_sort.hpp:65
+	if (d == ((u32)(key0 >> (8 * col)) & 0xFFu))
+		kept[col] = total != n;                                    // radix_sort.hpp:67
+	tot[d] = total;
 	__syncthreads();
+	if (d < 64)
+		wave_scan_256(tot, lsum, d);                               // radix_sort.hpp:74-79
+	__syncthreads();
+	u64 running = tot[d];
+	for (u32 s = 0; s < nseg; ++s) {
+		const u64 t = h[s * seg_stride];
+		h[s * seg_stride] = running;
+		running += t;
+	}
+}
+
+__global__ void rsx_plan_finish_kernel(const u32 *__restrict__ kept, u32 wc, const u32 *__restrict__ unsorted,
+                                       Plan *__restrict__ plan)
+{
 	if (threadIdx.x == 0) {
 		u32 nc = 0;
-		for (int i = 0; i < WC; ++i)
+		for (u32 i = 0; i < wc; ++i)
 			if (kept[i])
-				plan->cols[nc++] = i;
+				plan->cols[nc++] = i;                              // LSB first, radix_sort.hpp:66-69
 		plan->ncols = nc;
-		plan->sorted = *unsorted == 0;
+		plan->sorted = *unsorted == 0;                             // radix_sort.hpp:60
 	}
+}
+
+// Bucket offsets for the MSD split: bucket = lut[digit of column `col`].  cnt[seg][col][256]
+// (counts) -> bbase[seg][256] exclusive offsets of (segment, bucket), totals[256] bucket sizes.
+__global__ __launch_bounds__(256) void rsx_lut_plan_kernel(const u64 *__restrict__ cnt, u32 nseg, u32 seg_stride,
+                                                           u32 col_ofs, const uint8_t *__restrict__ lut,
+                                                           u64 *__restrict__ bbase, u64 *__restrict__ totals)
+{
+	__shared__ u64 bucket[256];
+	__shared__ u64 lsum[64];
+	const u32 t = threadIdx.x;
+	const u32 my_bucket = lut[t];
+	u64 running = 0;   // thread t as bucket: keys of bucket t in earlier segments
+	for (u32 s = 0; s < nseg; ++s) {
+		bucket[t] = 0;
+		__syncthreads();
+		atomicAdd(&bucket[my_bucket], cnt[(u64)s * seg_stride + col_ofs + t]);
+		__syncthreads();
+		bbase[(u64)s * 256 + t] = running;
+		running += bucket[t];
+		__syncthreads();
+	}
+	totals[t] = running;
+	bucket[t] = running;
+	__syncthreads();
+	if (t < 64)
+		wave_scan_256(bucket, lsum, t);
+	__syncthreads();
+	const u64 base = bucket[t];
+	for (u32 s = 0; s < nseg; ++s)
+		bbase[(u64)s * 256 + t] += base;
 }
 
 // =============================================================================
@@ -284,47 +356,84 @@ enum : u32 {
 	SCATTER_USE_LUT = 4      // bucket = lut[digit] (MSD split for the multi-GPU sort)
 };
 
-// Lanes holding the same 8-bit digit as this lane (valid lanes only).
-__device__ __forceinline__ u64 match_digit(u32 d, bool valid)
-{
-	u64 m = __ballot(valid);
-#pragma unroll
-	for (int b = 0; b < 8; ++b) {
-		const bool bit = (d >> b) & 1u;
-		const u64 bal = __ballot(bit);
-		m &= bit ? bal : ~bal;
-	}
-	return m;
-}
+// Tile shape: NWAVES wavefronts per workgroup, KPT keys per lane => NWAVES*64*KPT keys per tile.
+template <int NWAVES_, int KPT_, int LB_ = 8, int OCC_ = 2> struct TileShape {
+	static constexpr int NWAVES = NWAVES_;
+	static constexpr int KPT = KPT_;
+	static constexpr int LB = LB_;     // predecessors' status words fetched per look-back round trip
+	static constexpr int OCC = OCC_;   // workgroups per CU the register allocation is bounded for
+};
+template <typename KT, typename VT> struct DefaultShape
+	: TileShape<8, ((sizeof(KT) > (size_t)val_bytes<VT>::value ? sizeof(KT) : (size_t)val_bytes<VT>::value) == 8 ? 8 : 16)> {};
 
-template <typename KT, typename VT> struct ScatterCfg {
-	static constexpr int NWAVES = 8;
+template <typename KT, typename VT, typename SH = DefaultShape<KT, VT>> struct ScatterCfg {
+	static constexpr int NWAVES = SH::NWAVES;
 	static constexpr int BLOCK = NWAVES * 64;
 	static constexpr int ELEM = sizeof(KT) > (size_t)val_bytes<VT>::value ? sizeof(KT) : val_bytes<VT>::value;
-	static constexpr int KPT = ELEM == 8 ? 8 : 16;       // keys per lane: 32 KiB of staging either way
+	static constexpr int KPT = SH::KPT;
 	static constexpr int TILE = BLOCK * KPT;
+	static constexpr int CHUNK = 16 / ELEM;   // consecutive staged elements one lane writes out together
+	static constexpr int HR = 4;              // lane-striped copies of the super-tile histogram
+	// the per-wave match tables (256 slots x 16 B) live in the staging area until ranking is done
+	static constexpr int TABLE_BYTES = NWAVES * 256 * 16;
+	static constexpr int STAGE_BYTES = TILE * ELEM > TABLE_BYTES ? TILE * ELEM : TABLE_BYTES;
+	static_assert(NWAVES >= 4, "256 digit threads are needed");
+	static_assert(TILE <= 65536, "ranks are packed in 16 bits");
+	static_assert(KPT % CHUNK == 0, "whole chunks per lane");
 };
 
-template <typename KT, typename VT> struct ScatterSmem {
-	typedef ScatterCfg<KT, VT> C;
-	__attribute__((aligned(16))) unsigned char stage_raw[C::TILE * C::ELEM];
-	u32 whist[C::NWAVES][256];   // per-wave digit counters, later per-wave bases
-	u64 delta[256];              // global offset of a digit's run minus its tile-local offset
+// One slot per digit and wave: the lanes of the current round that hold the digit (64-bit
+// mask) and how many keys of earlier rounds held it.
+struct MatchSlot { u32 mask_lo, mask_hi, count, pad; };
+
+template <typename KT, typename VT, typename ST, typename SH> struct ScatterSmem {
+	typedef ScatterCfg<KT, VT, SH> C;
+	__attribute__((aligned(16))) unsigned char stage_raw[C::STAGE_BYTES];
+	u32 wbase[C::NWAVES][256];   // tile-local start of (wave, digit)'s run; first the super-tile histogram
+	ST delta[256];               // global offset of a digit's run minus its tile-local offset
 	u32 wsum[4];
-	u32 tile;
+	u32 ticket;
 };
 
-template <typename KT, typename VT, typename ST, bool FULL>
-__device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT> &sm, const KT *__restrict__ kin, KT *__restrict__ kout,
-                                             const VT *__restrict__ vin, VT *__restrict__ vout, const u32 tile,
-                                             const u64 tile_base, const u32 tile_count, const u32 shift,
-                                             const u64 *__restrict__ gbase, ST *status, const KdfArgs<KT> ka,
-                                             const u32 flags, const uint8_t *__restrict__ lut)
+template <typename KT>
+__device__ __forceinline__ u32 digit_of(KT raw, const KdfArgs<KT> ka, u32 shift, u32 flags, const uint8_t *__restrict__ lut)
 {
-	typedef ScatterCfg<KT, VT> C;
-	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT;
+	u32 d = (u32)(kdf_apply(raw, ka) >> shift) & 0xFFu;
+	if (flags & SCATTER_USE_LUT)
+		d = lut[d];
+	return d;
+}
+
+// 16-byte (or 8-byte) store to an address that is only element-aligned.
+template <typename T, int E>
+__device__ __forceinline__ void store_chunk(T *dst, const T (&v)[E])
+{
+	typedef T vec_t __attribute__((ext_vector_type(E)));
+	typedef vec_t uvec_t __attribute__((aligned(sizeof(T))));
+	vec_t x;
+#pragma unroll
+	for (int e = 0; e < E; ++e)
+		x[e] = v[e];
+	*(uvec_t *)dst = x;
+}
+
+#define RSX_STAMP(k)                                                    \
+	do {                                                                \
+		if (TL && threadIdx.x == 0)                                     \
+			tl[(u64)tile * 16 + (k)] = __builtin_readcyclecounter();    \
+	} while (0)
+
+// One tile of a super-tile: rank, lay out, stage, write out.  `running` (digit threads) is the
+// global offset at which this tile's run of digit tid starts; it is advanced by the tile's count.
+template <typename KT, typename VT, typename ST, typename SH, bool FULL, bool TL>
+__device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, const KT *__restrict__ kin, KT *__restrict__ kout,
+                                             const VT *__restrict__ vin, VT *__restrict__ vout, const u32 tile,
+                                             const u64 tile_base, const u32 tile_count, const u32 shift, u64 &running,
+                                             const KdfArgs<KT> ka, const u32 flags, const uint8_t *__restrict__ lut, u64 *tl)
+{
+	typedef ScatterCfg<KT, VT, SH> C;
+	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, CHUNK = C::CHUNK;
 	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
-	typedef StatusBits<ST> SB;
 	KT *stage_k = (KT *)sm.stage_raw;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
@@ -350,38 +459,62 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT> &sm, const KT *
 			}
 		}
 	}
+	// zero this wave's match table (4 KiB = 4 x 16 B per lane); the caller's barrier separates this
+	// from the previous tile's reads of the staging area
+	{
+		u32x4 *t = (u32x4 *)sm.stage_raw + wid * 256 + lane;
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			t[i * 64] = u32x4{0u, 0u, 0u, 0u};
+	}
+	if (TL) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		RSX_STAMP(2);
+	}
 
-	// ---- rank inside the wave, rounds in memory order
-	u32 rk[KPT];   // bits 0..15 rank, bits 16..23 digit
-	u32 *wh = sm.whist[wid];
+	// ---- rank inside the wave, rounds in memory order.
+	// Match through LDS: every lane ORs its lane bit into its digit's slot, reads the slot back
+	// (= the lanes of this round with the same digit, and the count of earlier rounds), and the
+	// highest of those lanes clears the mask and bumps the count.  DS operations of one wave
+	// execute in issue order, so the read sees every lane's OR (and this wave's zeroing above), and
+	// the next round's OR sees the cleared mask.
+	MatchSlot *tab = (MatchSlot *)sm.stage_raw + wid * 256;
+	const u32 lanebit = 1u << (lane & 31);
+	const u32 half = lane >> 5;
+	u32 rk[KPT];   // bits 0..15 rank inside the wave, bits 16..23 digit
 #pragma unroll
 	for (int r = 0; r < KPT; ++r) {
 		const bool valid = FULL || (wofs + r * 64 < tile_count);
-		u32 d = (u32)(kdf_apply(key[r], ka) >> shift) & 0xFFu;
-		if (flags & SCATTER_USE_LUT)
-			d = lut[d];
-		const u64 m = match_digit(d, valid);
-		const u32 cnt = (u32)__popcll(m);
-		const u32 below = mbcnt64(m);
-		const u32 prev = wh[d];
-		if (valid && below == cnt - 1)
-			wh[d] = prev + cnt;
-		rk[r] = (prev + below) | (d << 16);
+		const u32 d = digit_of(key[r], ka, shift, flags, lut);
+		rk[r] = d << 16;
+		if (valid) {
+			u32 *slot = &tab[d].mask_lo;
+			__hip_atomic_fetch_or(slot + half, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			RSX_COMPILER_FENCE();
+			const u32x4 s = *(const u32x4 *)slot;
+			RSX_COMPILER_FENCE();
+			const u32 cnt = __popc(s.x) + __popc(s.y);
+			const u32 below = __builtin_amdgcn_mbcnt_hi(s.y, __builtin_amdgcn_mbcnt_lo(s.x, 0u));
+			if (below == cnt - 1)
+				*(u32x4 *)slot = u32x4{0u, 0u, s.z + cnt, 0u};
+			RSX_COMPILER_FENCE();
+			rk[r] |= s.z + below;
+		}
 	}
+	RSX_STAMP(3);
 	__syncthreads();
+	RSX_STAMP(4);
 
-	// ---- digit thread d: prefix over waves, publish the tile aggregate, prefix over digits
+	// ---- digit thread d: counts per wave -> tile-local layout and this tile's global offsets
+	u32 wcnt[NWAVES];
 	u32 tile_cnt = 0, incl = 0;
-	ST *my_status = status + (u64)tile * 256 + tid;
 	if (tid < 256) {
+		const MatchSlot *t0 = (const MatchSlot *)sm.stage_raw + tid;
 #pragma unroll
 		for (int w = 0; w < NWAVES; ++w) {
-			const u32 t = sm.whist[w][tid];
-			sm.whist[w][tid] = tile_cnt;
-			tile_cnt += t;
+			wcnt[w] = t0[w * 256].count;
+			tile_cnt += wcnt[w];
 		}
-		const ST word = ((ST)(tile == 0 ? ST_PREFIX : ST_AGGREGATE) << SB::SHIFT) | (ST)tile_cnt;
-		__hip_atomic_store(my_status, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		incl = tile_cnt;
 #pragma unroll
 		for (int off = 1; off < 64; off <<= 1) {
@@ -392,66 +525,75 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT> &sm, const KT *
 		if (lane == 63)
 			sm.wsum[wid] = incl;
 	}
-	__syncthreads();
-	u32 tbase = 0;
+	__syncthreads();   // every table read is done: the staging area may be overwritten from here on
+	RSX_STAMP(6);
 	if (tid < 256) {
+		u32 tbase = 0;
 		for (u32 w = 0; w < wid; ++w)
 			tbase += sm.wsum[w];
 		tbase += incl - tile_cnt;   // tile-local start of digit tid's run
+		u32 acc = tbase;
 #pragma unroll
-		for (int w = 0; w < NWAVES; ++w)
-			sm.whist[w][tid] += tbase;
+		for (int w = 0; w < NWAVES; ++w) {
+			sm.wbase[w][tid] = acc;
+			acc += wcnt[w];
+		}
+		sm.delta[tid] = (ST)(running - tbase);   // modulo 2^32 when ST is 32-bit (n < 2^30 then)
+		running += tile_cnt;
 	}
 	__syncthreads();
+	RSX_STAMP(7);
 
 	// ---- stage keys in output order
+	const u32 *wb = sm.wbase[wid];
 #pragma unroll
 	for (int r = 0; r < KPT; ++r) {
 		const bool valid = FULL || (wofs + r * 64 < tile_count);
-		const u32 d = rk[r] >> 16;
-		const u32 pos = wh[d] + (rk[r] & 0xFFFFu);
+		const u32 pos = wb[rk[r] >> 16] + (rk[r] & 0xFFFFu);
 		rk[r] = pos;
 		if (valid)
 			stage_k[pos] = key[r];
 	}
-
-	// ---- decoupled look-back over the predecessors' status words (digit thread d)
-	if (tid < 256) {
-		u64 excl = 0;
-		if (tile != 0) {
-			const ST *p = my_status - 256;
-			for (;;) {
-				const ST w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const u32 f = (u32)(w >> SB::SHIFT);
-				if (f == ST_EMPTY) {
-					__builtin_amdgcn_s_sleep(1);
-					continue;
-				}
-				excl += (u64)(w & SB::VALMASK);
-				if (f == ST_PREFIX)
-					break;
-				p -= 256;
-			}
-			const ST word = ((ST)ST_PREFIX << SB::SHIFT) | (ST)(excl + tile_cnt);
-			__hip_atomic_store(my_status, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		sm.delta[tid] = gbase[tid] + excl - tbase;
-	}
+	RSX_STAMP(8);
 	__syncthreads();
+	RSX_STAMP(9);
 
-	// ---- write out: consecutive staged elements of one digit go to consecutive addresses
-	u32 dig[KPT];
+	// ---- write out.  The staged tile is sorted by digit, and consecutive staged elements of one digit
+	// go to consecutive addresses: a lane takes CHUNK consecutive elements and, when they share a digit
+	// (first == last), stores them with one wide store; chunks straddling a run boundary go element-wise.
+	u32 pk[KPT / CHUNK];   // the chunk's digits, one byte each (CHUNK <= 4 whenever there is a payload)
 #pragma unroll
-	for (int k = 0; k < KPT; ++k) {
-		const u32 i = tid + k * BLOCK;
-		if (FULL || i < tile_count) {
-			const KT kv = stage_k[i];
-			u32 d = (u32)(kdf_apply(kv, ka) >> shift) & 0xFFu;
-			if (flags & SCATTER_USE_LUT)
-				d = lut[d];
-			dig[k] = d;
-			if (!(flags & SCATTER_SKIP_KEYS))
-				kout[sm.delta[d] + i] = kv;
+	for (int j = 0; j < KPT / CHUNK; ++j) {
+		const u32 i0 = CHUNK * (tid + j * BLOCK);
+		KT kv[CHUNK];
+		u32 d[CHUNK];
+		{
+			typedef KT kvec_t __attribute__((ext_vector_type(CHUNK)));
+			const kvec_t x = *(const kvec_t *)(stage_k + i0);
+#pragma unroll
+			for (int e = 0; e < CHUNK; ++e)
+				kv[e] = x[e];
+		}
+#pragma unroll
+		for (int e = 0; e < CHUNK; ++e)
+			d[e] = digit_of(kv[e], ka, shift, flags, lut);
+		if constexpr (HAS_VAL) {
+			u32 p = 0;
+#pragma unroll
+			for (int e = 0; e < CHUNK; ++e)
+				p |= d[e] << (8 * e);
+			pk[j] = p;
+		}
+		if (!(flags & SCATTER_SKIP_KEYS)) {
+			const bool whole = FULL || i0 + CHUNK <= tile_count;
+			if (sizeof(KT) >= 4 && whole && d[0] == d[CHUNK - 1]) {
+				store_chunk<KT, CHUNK>(kout + (ST)(sm.delta[d[0]] + i0), kv);
+			} else {
+#pragma unroll
+				for (int e = 0; e < CHUNK; ++e)
+					if (FULL || i0 + e < tile_count)
+						kout[(ST)(sm.delta[d[e]] + i0 + e)] = kv[e];
+			}
 		}
 	}
 	if constexpr (HAS_VAL) {
@@ -465,38 +607,154 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT> &sm, const KT *
 		}
 		__syncthreads();
 #pragma unroll
-		for (int k = 0; k < KPT; ++k) {
-			const u32 i = tid + k * BLOCK;
-			if (FULL || i < tile_count)
-				vout[sm.delta[dig[k]] + i] = stage_v[i];
+		for (int j = 0; j < KPT / CHUNK; ++j) {
+			const u32 i0 = CHUNK * (tid + j * BLOCK);
+			VT vv[CHUNK];
+			{
+				typedef VT vvec_t __attribute__((ext_vector_type(CHUNK)));
+				const vvec_t x = *(const vvec_t *)(stage_v + i0);
+#pragma unroll
+				for (int e = 0; e < CHUNK; ++e)
+					vv[e] = x[e];
+			}
+			const u32 d0 = pk[j] & 0xFFu, dl = (pk[j] >> (8 * (CHUNK - 1))) & 0xFFu;
+			const bool whole = FULL || i0 + CHUNK <= tile_count;
+			if (whole && d0 == dl) {
+				store_chunk<VT, CHUNK>(vout + (ST)(sm.delta[d0] + i0), vv);
+			} else {
+#pragma unroll
+				for (int e = 0; e < CHUNK; ++e)
+					if (FULL || i0 + e < tile_count)
+						vout[(ST)(sm.delta[(pk[j] >> (8 * e)) & 0xFFu] + i0 + e)] = vv[e];
+			}
 		}
+	}
+	if (TL) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		RSX_STAMP(10);
 	}
 }
 
-template <typename KT, typename VT, typename ST>
-__global__ __launch_bounds__(512) void rsx_scatter_kernel(const KT *__restrict__ kin, KT *__restrict__ kout,
-                                                          const VT *__restrict__ vin, VT *__restrict__ vout, u64 n,
-                                                          u32 shift, const u64 *__restrict__ gbase, ST *status,
-                                                          u32 *ticket, KdfArgs<KT> ka, u32 flags,
-                                                          const uint8_t *__restrict__ lut)
+// A workgroup takes a SUPER-TILE of `tps` consecutive tiles (one ticket, one status row, one
+// look-back) and then scatters its tiles one after the other.  Chaining tile by tile does not scale
+// on this chip: a status word takes about 1.3 us to travel under load, during which dozens of tiles
+// reach their look-back, so every tile would have to read dozens of predecessors.  With a super-tile
+// the chain advances tps times slower and its latency is paid once per tps tiles.
+//   phase A  count the super-tile's digits (one extra read of its keys; the second read, in phase B,
+//            comes out of L2 / Infinity Cache), publish the aggregate, look back, publish the prefix;
+//   phase B  rank / stage / write each tile with offsets carried from tile to tile in registers.
+// grid = number of super-tiles.  gbase[digit] is the exclusive offset of the digit for this pass.
+template <typename KT, typename VT, typename ST, typename SH = DefaultShape<KT, VT>, bool TL = false>
+__global__ __launch_bounds__(SH::NWAVES * 64, (SH::NWAVES * SH::OCC + 3) / 4) void rsx_scatter_kernel(
+	const KT *__restrict__ kin, KT *__restrict__ kout, const VT *__restrict__ vin, VT *__restrict__ vout, u64 n, u32 shift,
+	const u64 *__restrict__ gbase, u32 tps, ST *status, u32 *ticket, KdfArgs<KT> ka, u32 flags,
+	const uint8_t *__restrict__ lut, u64 *tl)
 {
-	typedef ScatterCfg<KT, VT> C;
-	__shared__ ScatterSmem<KT, VT> sm;
-	const u32 tid = threadIdx.x;
+	typedef ScatterCfg<KT, VT, SH> C;
+	typedef StatusBits<ST> SB;
+	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, HR = C::HR;
+	__shared__ ScatterSmem<KT, VT, ST, SH> sm;
+	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const u64 t_start = TL ? __builtin_readcyclecounter() : 0;
 	if (tid == 0)
-		sm.tile = atomicAdd(ticket, 1u);   // tiles are handed out in start order => look-back cannot deadlock
-	for (u32 i = tid; i < C::NWAVES * 256; i += C::BLOCK)
-		(&sm.whist[0][0])[i] = 0;
+		sm.ticket = atomicAdd(ticket, 1u);   // super-tiles are handed out in start order => look-back cannot deadlock
+	u32 *hist = &sm.wbase[0][0];             // [256][HR] while phase A runs
+	for (u32 i = tid; i < 256 * HR; i += BLOCK)
+		hist[i] = 0;
 	__syncthreads();
-	const u32 tile = sm.tile;
-	const u64 tile_base = (u64)tile * C::TILE;
-	const u32 tile_count = (n - tile_base) < (u64)C::TILE ? (u32)(n - tile_base) : (u32)C::TILE;
-	if (tile_count == (u32)C::TILE)
-		scatter_tile<KT, VT, ST, true>(sm, kin, kout, vin, vout, tile, tile_base, tile_count, shift, gbase, status, ka,
-		                               flags, lut);
-	else
-		scatter_tile<KT, VT, ST, false>(sm, kin, kout, vin, vout, tile, tile_base, tile_count, shift, gbase, status, ka,
-		                                flags, lut);
+	const u32 stile = sm.ticket;
+	const u64 first_tile = (u64)stile * tps;
+	const u64 beg = first_tile * C::TILE;
+	u64 end = beg + (u64)tps * C::TILE;
+	if (end > n)
+		end = n;
+
+	// ---- phase A: digit counts of the whole super-tile
+	for (u64 base = beg; base < end; base += C::TILE) {
+		const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
+		const u32 wofs = wid * (64 * KPT) + lane;
+		KT key[KPT];
+#pragma unroll
+		for (int r = 0; r < KPT; ++r) {
+			const u32 o = wofs + r * 64;
+			key[r] = o < cnt ? kin[base + o] : (KT)0;
+		}
+#pragma unroll
+		for (int r = 0; r < KPT; ++r) {
+			const u32 o = wofs + r * 64;
+			if (o < cnt)
+				atomicAdd(&hist[digit_of(key[r], ka, shift, flags, lut) * HR + (lane & (HR - 1))], 1u);
+		}
+	}
+	__syncthreads();
+
+	// ---- digit thread d: publish the aggregate, look back along the chain of super-tiles, publish the prefix
+	u64 running = 0;
+	if (tid < 256) {
+		u32 st_cnt = 0;
+#pragma unroll
+		for (int r = 0; r < HR; ++r)
+			st_cnt += hist[tid * HR + r];
+		ST *my_status = status + (u64)stile * 256 + tid;
+		const ST word = ((ST)(stile == 0 ? ST_PREFIX : ST_AGGREGATE) << SB::SHIFT) | (ST)st_cnt;
+		__hip_atomic_store(my_status, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		u64 excl = 0;
+		u32 depth = 0;
+		if (stile != 0) {
+			// LB predecessors are fetched per round trip (independent loads), then consumed in order:
+			// aggregates are summed until the first inclusive prefix; an empty word ends the batch.
+			constexpr int LB = SH::LB;
+			long back = (long)stile - 1;   // nearest predecessor not consumed yet
+			const ST *col = status + tid;
+			for (;;) {
+				ST w[LB];
+#pragma unroll
+				for (int j = 0; j < LB; ++j) {
+					const long t = back - j > 0 ? back - j : 0;   // super-tile 0 always holds a prefix: safe filler
+					w[j] = __hip_atomic_load(col + (u64)t * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				bool done = false;
+				int used = 0;
+#pragma unroll
+				for (int j = 0; j < LB; ++j) {
+					const u32 f = (u32)(w[j] >> SB::SHIFT);
+					if (!done && used == j && f != ST_EMPTY) {
+						excl += (u64)(w[j] & SB::VALMASK);
+						++used;
+						++depth;
+						done = f == ST_PREFIX;
+					}
+				}
+				if (done)
+					break;
+				back -= used;
+				if (used == 0)
+					__builtin_amdgcn_s_sleep(1);
+			}
+			const ST pword = ((ST)ST_PREFIX << SB::SHIFT) | (ST)(excl + st_cnt);
+			__hip_atomic_store(my_status, pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		running = gbase[tid] + excl;
+		if (TL && tid == 0) {
+			tl[first_tile * 16 + 0] = t_start;
+			tl[first_tile * 16 + 1] = __builtin_readcyclecounter();
+			tl[first_tile * 16 + 12] = depth;
+		}
+	}
+	__syncthreads();   // the histogram (aliasing wbase) has been consumed
+
+	// ---- phase B: the tiles, in order
+	for (u64 base = beg; base < end; base += C::TILE) {
+		const u32 tile = (u32)(base / C::TILE);
+		const u32 tile_count = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
+		if (tile_count == (u32)C::TILE)
+			scatter_tile<KT, VT, ST, SH, true, TL>(sm, kin, kout, vin, vout, tile, base, tile_count, shift, running, ka, flags,
+			                                       lut, tl);
+		else
+			scatter_tile<KT, VT, ST, SH, false, TL>(sm, kin, kout, vin, vout, tile, base, tile_count, shift, running, ka, flags,
+			                                        lut, tl);
+		__syncthreads();   // staging reads done before the next tile's tables are zeroed
+	}
 }
 
 // =============================================================================
