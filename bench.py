@@ -196,7 +196,7 @@ def main():
                 "parallelism": "1 gpu" if world == 1 else "msd%d" % world, "output_sorted": ok,
             },
             "roofline": {
-                "kernel": "rsx_scatter_kernel<u32,NoVal,u32>",
+                "kernel": "rsx_scatter2_kernel<u32,NoVal,u32>",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_per_launch(),

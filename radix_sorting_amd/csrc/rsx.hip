@@ -8,11 +8,13 @@
 // device, every entry point fails with RSX_ENODEVICE.
 #include "../../include/rsx.h"
 #include "rsx_kernels.hpp"
+#include "rsx_scatter2.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -128,6 +130,8 @@ struct Ctx {
 	Plan *host_plan = nullptr;   // pinned
 	u64 *host_hist = nullptr;    // pinned, 256 u64
 
+	bool fast = false;           // rsx_scatter2_kernel allowed on this device (LDS atomic order verified)
+
 	u64 *ghist() const { return (u64 *)hist.p; }
 	u32 *unsorted() const { return (u32 *)small.p; }
 	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
@@ -167,6 +171,7 @@ struct Ctx {
 
 std::mutex g_mu;
 std::map<std::pair<int, void *>, Ctx *> g_ctx;
+std::map<int, int> g_lds_order_ok;   // device -> result of lds_order_selfcheck (1 ok, 0 not)
 
 // ---- optional HIP-event bracketing of the kernels (rsx_profile_begin/end) ------
 struct ProfRec {
@@ -225,6 +230,32 @@ int probe_devices()
 	return usable;
 }
 
+// rsx_scatter2_kernel ranks keys with returning LDS atomics and needs them to resolve same-address lanes
+// in lane order.  gfx950 does, but that is an observed property, not a documented one: verify it once
+// per device (about a millisecond) and otherwise stay on the table-based ranking of rsx_scatter_kernel.
+int lds_order_selfcheck(int dev)
+{
+	auto it = g_lds_order_ok.find(dev);
+	if (it != g_lds_order_ok.end())
+		return it->second;
+	int ok = 0;
+	const char *force = getenv("RSX_FORCE_TABLE_RANK");
+	u64 *d_bad = nullptr;
+	if (!(force && force[0] == '1') && hipMalloc((void **)&d_bad, sizeof(u64)) == hipSuccess) {
+		u64 bad = ~0ull;
+		if (hipMemset(d_bad, 0, sizeof(u64)) == hipSuccess) {
+			hipLaunchKernelGGL(rsx_lds_order_check_kernel, dim3(1024), dim3(512), 0, 0, d_bad, 0x9E3779B9u, 512);
+			if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+			    hipMemcpy(&bad, d_bad, sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess)
+				ok = bad == 0;
+		}
+		(void)hipFree(d_bad);
+	}
+	(void)hipGetLastError();
+	g_lds_order_ok[dev] = ok;
+	return ok;
+}
+
 int get_ctx(void *stream, Ctx **out)
 {
 	std::lock_guard<std::mutex> lock(g_mu);
@@ -238,6 +269,7 @@ int get_ctx(void *stream, Ctx **out)
 		Ctx *c = new Ctx();
 		c->device = dev;
 		c->stream = (hipStream_t)stream;
+		c->fast = lds_order_selfcheck(dev) != 0;
 		int rc = c->init();
 		if (rc != RSX_OK) {
 			c->release();
@@ -341,9 +373,16 @@ template <typename KT, typename VT>
 int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
                  KdfArgs<KT> ka, u32 flags, const uint8_t *lut)
 {
-	typedef ScatterCfg<KT, VT> C;
-	const u32 tps = choose_tps(n, C::TILE);
-	const u64 stiles = (n + (u64)tps * C::TILE - 1) / ((u64)tps * C::TILE);
+	typedef ScatterCfg<KT, VT> C1;   // table-ranked fallback (rsx_kernels.hpp)
+	typedef Sc2Cfg<KT, VT> C2;       // count-first kernel (rsx_scatter2.hpp)
+	const size_t tile = c.fast ? (size_t)C2::TILE : (size_t)C1::TILE;
+	const u64 tiles = (n + tile - 1) / tile;
+	u32 tps;
+	if (c.fast)
+		tps = tiles >= 1024 ? (u32)C2::TPS : 1u;
+	else
+		tps = choose_tps(n, tile);
+	const u64 stiles = (tiles + tps - 1) / tps;
 	const bool wide = n >= (1ull << 30);   // counter width by n, as radix_sort.hpp:102-114 does
 	const size_t st_bytes = 256 + stiles * 256 * (wide ? 8 : 4);
 	RSX_TRY(c.status.ensure(st_bytes));
@@ -351,12 +390,22 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 	u32 *ticket = (u32 *)c.status.p;
 	void *st = (char *)c.status.p + 256;
 	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
-	if (wide)
-		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
-		                   vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-	else
-		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, c.stream, kin, kout,
-		                   vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+	const dim3 grid((unsigned)stiles);
+	if (c.fast) {
+		if (wide)
+			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
+			                   shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		else
+			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
+			                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+	} else {
+		if (wide)
+			hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
+			                   shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		else
+			hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
+			                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+	}
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }

@@ -353,18 +353,32 @@ enum : u32 { ST_EMPTY = 0, ST_AGGREGATE = 1, ST_PREFIX = 2 };
 enum : u32 {
 	SCATTER_GEN_INDEX = 1,   // payload of element i is i (first rank pass, radix_sort_rank.hpp:52)
 	SCATTER_SKIP_KEYS = 2,   // do not write keys (last rank pass: only the indices are wanted)
-	SCATTER_USE_LUT = 4      // bucket = lut[digit] (MSD split for the multi-GPU sort)
+	SCATTER_USE_LUT = 4,     // bucket = lut[digit] (MSD split for the multi-GPU sort)
+	SCATTER_DBG_LINEAR = 64, // probe only: write the staged tile back to its own position (no scatter)
+	SCATTER_DBG_NOSTORE = 128, // probe only: skip the global stores
+	SCATTER_DBG_NOLOADB = 256  // probe only: phase B fabricates keys instead of re-reading them
 };
 
 // Tile shape: NWAVES wavefronts per workgroup, KPT keys per lane => NWAVES*64*KPT keys per tile.
-template <int NWAVES_, int KPT_, int LB_ = 8, int OCC_ = 2> struct TileShape {
+// RANK_: how keys are ranked inside a wavefront
+//   RANK_ATOMIC  one returning LDS atomic add per key on the wave's digit counter.  Relies on the LDS
+//                handing out the return values of one wave-instruction's same-address lanes in increasing
+//                lane order.  That is how gfx950 behaves (tools/ubench/lds_atomic_order.hip: 1.2e10 lane
+//                checks, no exception) but it is not documented, so the host verifies it on the device
+//                it runs on before selecting this mode (rsx.hip, lds_order_selfcheck).
+//   RANK_TABLE   match through per-wave LDS tables (lane masks): no assumption beyond in-order DS issue.
+enum { RANK_TABLE = 0, RANK_ATOMIC = 1 };
+
+template <int NWAVES_, int KPT_, int LB_ = 8, int OCC_ = 2, int RANK_ = RANK_ATOMIC> struct TileShape {
+	static constexpr int RANK = RANK_;
 	static constexpr int NWAVES = NWAVES_;
 	static constexpr int KPT = KPT_;
 	static constexpr int LB = LB_;     // predecessors' status words fetched per look-back round trip
 	static constexpr int OCC = OCC_;   // workgroups per CU the register allocation is bounded for
 };
-template <typename KT, typename VT> struct DefaultShape
-	: TileShape<8, ((sizeof(KT) > (size_t)val_bytes<VT>::value ? sizeof(KT) : (size_t)val_bytes<VT>::value) == 8 ? 8 : 16)> {};
+template <typename KT, typename VT, int RANK = RANK_TABLE> struct DefaultShape
+	: TileShape<8, ((sizeof(KT) > (size_t)val_bytes<VT>::value ? sizeof(KT) : (size_t)val_bytes<VT>::value) == 8 ? 8 : 16), 8, 2,
+	            RANK> {};
 
 template <typename KT, typename VT, typename SH = DefaultShape<KT, VT>> struct ScatterCfg {
 	static constexpr int NWAVES = SH::NWAVES;
@@ -374,22 +388,25 @@ template <typename KT, typename VT, typename SH = DefaultShape<KT, VT>> struct S
 	static constexpr int TILE = BLOCK * KPT;
 	static constexpr int CHUNK = 16 / ELEM;   // consecutive staged elements one lane writes out together
 	static constexpr int HR = 4;              // lane-striped copies of the super-tile histogram
-	// the per-wave match tables (256 slots x 16 B) live in the staging area until ranking is done
-	static constexpr int TABLE_BYTES = NWAVES * 256 * 16;
+	// RANK_TABLE: the per-wave match tables (256 slots x 16 B) live in the staging area until ranking is done
+	static constexpr int TABLE_BYTES = SH::RANK == RANK_TABLE ? NWAVES * 256 * 16 : 0;
 	static constexpr int STAGE_BYTES = TILE * ELEM > TABLE_BYTES ? TILE * ELEM : TABLE_BYTES;
 	static_assert(NWAVES >= 4, "256 digit threads are needed");
-	static_assert(TILE <= 65536, "ranks are packed in 16 bits");
-	static_assert(KPT % CHUNK == 0, "whole chunks per lane");
+	static_assert(TILE <= 65536, "tile-local positions are packed in 16 bits");
+	static_assert(KPT % CHUNK == 0 && KPT % 2 == 0, "whole chunks / rank pairs per lane");
+	static_assert(NWAVES * 128 >= 256 * HR, "the super-tile histogram borrows the counter array");
 };
 
-// One slot per digit and wave: the lanes of the current round that hold the digit (64-bit
-// mask) and how many keys of earlier rounds held it.
+// One slot per digit and wave (RANK_TABLE): the lanes of the current round that hold the digit
+// (64-bit mask) and how many keys of earlier rounds held it.
 struct MatchSlot { u32 mask_lo, mask_hi, count, pad; };
 
 template <typename KT, typename VT, typename ST, typename SH> struct ScatterSmem {
 	typedef ScatterCfg<KT, VT, SH> C;
 	__attribute__((aligned(16))) unsigned char stage_raw[C::STAGE_BYTES];
-	u32 wbase[C::NWAVES][256];   // tile-local start of (wave, digit)'s run; first the super-tile histogram
+	// 16-bit cell per (wave, digit), two digits per word: the wave's digit counter while ranking, then
+	// the tile-local start of (wave, digit)'s run.  Phase A borrows it for the super-tile histogram.
+	u32 wcell[C::NWAVES][128];
 	ST delta[256];               // global offset of a digit's run minus its tile-local offset
 	u32 wsum[4];
 	u32 ticket;
@@ -436,84 +453,98 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
 	KT *stage_k = (KT *)sm.stage_raw;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	unsigned short *cell16 = (unsigned short *)&sm.wcell[0][0];   // [NWAVES][256] 16-bit cells
 
 	// ---- load: wave w owns [tile_base + w*64*KPT, +64*KPT), lane l of round r the element 64 r + l of it
 	const u32 wofs = wid * (64 * KPT) + lane;
 	KT key[KPT];
-	VT val[KPT];
 #pragma unroll
 	for (int r = 0; r < KPT; ++r) {
 		const u32 o = wofs + r * 64;
 		key[r] = (FULL || o < tile_count) ? kin[tile_base + o] : (KT)0;
 	}
-	if constexpr (HAS_VAL) {
-		if (flags & SCATTER_GEN_INDEX) {
+
+	u32 rkp[KPT / 2];   // 16 bits per key: rank inside the wave, later the tile-local position
 #pragma unroll
-			for (int r = 0; r < KPT; ++r)
-				val[r] = (VT)(tile_base + wofs + r * 64);
-		} else {
+	for (int i = 0; i < KPT / 2; ++i)
+		rkp[i] = 0;
+	if constexpr (SH::RANK == RANK_ATOMIC) {
+		// ---- rank inside the wave: one returning LDS atomic per key on the wave's own digit counters
+		// (16-bit cells, two per word), rounds in memory order, lanes of a round in lane order (see
+		// RANK_ATOMIC above).  The rounds do not wait for one another: DS operations of a wave are
+		// executed in issue order.
+		u32 *wc = sm.wcell[wid];
 #pragma unroll
-			for (int r = 0; r < KPT; ++r) {
-				const u32 o = wofs + r * 64;
-				val[r] = (FULL || o < tile_count) ? vin[tile_base + o] : (VT)0;
+		for (int i = 0; i < 2; ++i)
+			wc[lane + 64 * i] = 0;   // the caller's barrier separates this from the previous tile's reads
+		if (TL) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			RSX_STAMP(2);
+		}
+#pragma unroll
+		for (int r = 0; r < KPT; ++r) {
+			const bool valid = FULL || (wofs + r * 64 < tile_count);
+			const u32 d = digit_of(key[r], ka, shift, flags, lut);
+			if (valid) {
+				const u32 sh = (d & 1u) * 16u;
+				const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				rkp[r >> 1] |= ((old >> sh) & 0xFFFFu) << (16 * (r & 1));
 			}
 		}
-	}
-	// zero this wave's match table (4 KiB = 4 x 16 B per lane); the caller's barrier separates this
-	// from the previous tile's reads of the staging area
-	{
-		u32x4 *t = (u32x4 *)sm.stage_raw + wid * 256 + lane;
+	} else {
+		// zero this wave's match table (4 KiB = 4 x 16 B per lane); the caller's barrier separates this
+		// from the previous tile's reads of the staging area
+		{
+			u32x4 *t = (u32x4 *)sm.stage_raw + wid * 256 + lane;
 #pragma unroll
-		for (int i = 0; i < 4; ++i)
-			t[i * 64] = u32x4{0u, 0u, 0u, 0u};
-	}
-	if (TL) {
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		RSX_STAMP(2);
-	}
-
-	// ---- rank inside the wave, rounds in memory order.
-	// Match through LDS: every lane ORs its lane bit into its digit's slot, reads the slot back
-	// (= the lanes of this round with the same digit, and the count of earlier rounds), and the
-	// highest of those lanes clears the mask and bumps the count.  DS operations of one wave
-	// execute in issue order, so the read sees every lane's OR (and this wave's zeroing above), and
-	// the next round's OR sees the cleared mask.
-	MatchSlot *tab = (MatchSlot *)sm.stage_raw + wid * 256;
-	const u32 lanebit = 1u << (lane & 31);
-	const u32 half = lane >> 5;
-	u32 rk[KPT];   // bits 0..15 rank inside the wave, bits 16..23 digit
+			for (int i = 0; i < 4; ++i)
+				t[i * 64] = u32x4{0u, 0u, 0u, 0u};
+		}
+		if (TL) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			RSX_STAMP(2);
+		}
+		// ---- rank inside the wave, rounds in memory order.
+		// Match through LDS: every lane ORs its lane bit into its digit's slot, reads the slot back
+		// (= the lanes of this round with the same digit, and the count of earlier rounds), and the
+		// highest of those lanes clears the mask and bumps the count.  DS operations of one wave
+		// execute in issue order, so the read sees every lane's OR (and this wave's zeroing above), and
+		// the next round's OR sees the cleared mask.
+		MatchSlot *tab = (MatchSlot *)sm.stage_raw + wid * 256;
+		const u32 lanebit = 1u << (lane & 31);
+		const u32 half = lane >> 5;
 #pragma unroll
-	for (int r = 0; r < KPT; ++r) {
-		const bool valid = FULL || (wofs + r * 64 < tile_count);
-		const u32 d = digit_of(key[r], ka, shift, flags, lut);
-		rk[r] = d << 16;
-		if (valid) {
-			u32 *slot = &tab[d].mask_lo;
-			__hip_atomic_fetch_or(slot + half, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			RSX_COMPILER_FENCE();
-			const u32x4 s = *(const u32x4 *)slot;
-			RSX_COMPILER_FENCE();
-			const u32 cnt = __popc(s.x) + __popc(s.y);
-			const u32 below = __builtin_amdgcn_mbcnt_hi(s.y, __builtin_amdgcn_mbcnt_lo(s.x, 0u));
-			if (below == cnt - 1)
-				*(u32x4 *)slot = u32x4{0u, 0u, s.z + cnt, 0u};
-			RSX_COMPILER_FENCE();
-			rk[r] |= s.z + below;
+		for (int r = 0; r < KPT; ++r) {
+			const bool valid = FULL || (wofs + r * 64 < tile_count);
+			const u32 d = digit_of(key[r], ka, shift, flags, lut);
+			if (valid) {
+				u32 *slot = &tab[d].mask_lo;
+				__hip_atomic_fetch_or(slot + half, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				RSX_COMPILER_FENCE();
+				const u32x4 s = *(const u32x4 *)slot;
+				RSX_COMPILER_FENCE();
+				const u32 cnt = __popc(s.x) + __popc(s.y);
+				const u32 below = __builtin_amdgcn_mbcnt_hi(s.y, __builtin_amdgcn_mbcnt_lo(s.x, 0u));
+				if (below == cnt - 1)
+					*(u32x4 *)slot = u32x4{0u, 0u, s.z + cnt, 0u};
+				RSX_COMPILER_FENCE();
+				rkp[r >> 1] |= (s.z + below) << (16 * (r & 1));
+			}
 		}
 	}
 	RSX_STAMP(3);
 	__syncthreads();
 	RSX_STAMP(4);
 
-	// ---- digit thread d: counts per wave -> tile-local layout and this tile's global offsets
-	u32 wcnt[NWAVES];
+	// ---- digit thread d: tile count -> tile-local layout and this tile's global offsets
 	u32 tile_cnt = 0, incl = 0;
 	if (tid < 256) {
-		const MatchSlot *t0 = (const MatchSlot *)sm.stage_raw + tid;
 #pragma unroll
 		for (int w = 0; w < NWAVES; ++w) {
-			wcnt[w] = t0[w * 256].count;
-			tile_cnt += wcnt[w];
+			if constexpr (SH::RANK == RANK_ATOMIC)
+				tile_cnt += cell16[w * 256 + tid];
+			else
+				tile_cnt += ((const MatchSlot *)sm.stage_raw + tid)[w * 256].count;
 		}
 		incl = tile_cnt;
 #pragma unroll
@@ -525,7 +556,7 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 		if (lane == 63)
 			sm.wsum[wid] = incl;
 	}
-	__syncthreads();   // every table read is done: the staging area may be overwritten from here on
+	__syncthreads();
 	RSX_STAMP(6);
 	if (tid < 256) {
 		u32 tbase = 0;
@@ -534,23 +565,32 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 		tbase += incl - tile_cnt;   // tile-local start of digit tid's run
 		u32 acc = tbase;
 #pragma unroll
-		for (int w = 0; w < NWAVES; ++w) {
-			sm.wbase[w][tid] = acc;
-			acc += wcnt[w];
+		for (int w = 0; w < NWAVES; ++w) {   // counts -> starts, in place (RANK_TABLE: from the tables)
+			u32 c;
+			if constexpr (SH::RANK == RANK_ATOMIC)
+				c = cell16[w * 256 + tid];
+			else
+				c = ((const MatchSlot *)sm.stage_raw + tid)[w * 256].count;
+			cell16[w * 256 + tid] = (unsigned short)acc;
+			acc += c;
 		}
 		sm.delta[tid] = (ST)(running - tbase);   // modulo 2^32 when ST is 32-bit (n < 2^30 then)
+		if (TL && (flags & SCATTER_DBG_LINEAR))
+			sm.delta[tid] = (ST)tile_base;
 		running += tile_cnt;
 	}
-	__syncthreads();
+	__syncthreads();   // RANK_TABLE: every table read is done, the staging area may be overwritten
 	RSX_STAMP(7);
 
 	// ---- stage keys in output order
-	const u32 *wb = sm.wbase[wid];
+	const unsigned short *wb = cell16 + wid * 256;
 #pragma unroll
 	for (int r = 0; r < KPT; ++r) {
 		const bool valid = FULL || (wofs + r * 64 < tile_count);
-		const u32 pos = wb[rk[r] >> 16] + (rk[r] & 0xFFFFu);
-		rk[r] = pos;
+		const u32 d = digit_of(key[r], ka, shift, flags, lut);
+		const u32 pos = (u32)wb[d] + ((rkp[r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
+		if constexpr (HAS_VAL)
+			rkp[r >> 1] = (rkp[r >> 1] & ~(0xFFFFu << (16 * (r & 1)))) | (pos << (16 * (r & 1)));
 		if (valid)
 			stage_k[pos] = key[r];
 	}
@@ -561,9 +601,11 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 	// ---- write out.  The staged tile is sorted by digit, and consecutive staged elements of one digit
 	// go to consecutive addresses: a lane takes CHUNK consecutive elements and, when they share a digit
 	// (first == last), stores them with one wide store; chunks straddling a run boundary go element-wise.
-	u32 pk[KPT / CHUNK];   // the chunk's digits, one byte each (CHUNK <= 4 whenever there is a payload)
+	u32 pk[HAS_VAL ? KPT / CHUNK : 1];   // the chunk's digits, one byte each (CHUNK <= 4 whenever there is a payload)
 #pragma unroll
 	for (int j = 0; j < KPT / CHUNK; ++j) {
+		if (j % 4 == 0)
+			__builtin_amdgcn_sched_barrier(0);   // keep at most four chunks' registers alive at a time
 		const u32 i0 = CHUNK * (tid + j * BLOCK);
 		KT kv[CHUNK];
 		u32 d[CHUNK];
@@ -584,7 +626,7 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 				p |= d[e] << (8 * e);
 			pk[j] = p;
 		}
-		if (!(flags & SCATTER_SKIP_KEYS)) {
+		if (!(flags & SCATTER_SKIP_KEYS) && !(TL && (flags & SCATTER_DBG_NOSTORE))) {
 			const bool whole = FULL || i0 + CHUNK <= tile_count;
 			if (sizeof(KT) >= 4 && whole && d[0] == d[CHUNK - 1]) {
 				store_chunk<KT, CHUNK>(kout + (ST)(sm.delta[d[0]] + i0), kv);
@@ -597,13 +639,26 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 		}
 	}
 	if constexpr (HAS_VAL) {
+		// payloads: same positions, through the same staging area
 		VT *stage_v = (VT *)sm.stage_raw;
+		VT val[KPT];
+		if (flags & SCATTER_GEN_INDEX) {
+#pragma unroll
+			for (int r = 0; r < KPT; ++r)
+				val[r] = (VT)(tile_base + wofs + r * 64);
+		} else {
+#pragma unroll
+			for (int r = 0; r < KPT; ++r) {
+				const u32 o = wofs + r * 64;
+				val[r] = (FULL || o < tile_count) ? vin[tile_base + o] : (VT)0;
+			}
+		}
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < KPT; ++r) {
 			const bool valid = FULL || (wofs + r * 64 < tile_count);
 			if (valid)
-				stage_v[rk[r]] = val[r];
+				stage_v[(rkp[r >> 1] >> (16 * (r & 1))) & 0xFFFFu] = val[r];
 		}
 		__syncthreads();
 #pragma unroll
@@ -658,38 +713,46 @@ __global__ __launch_bounds__(SH::NWAVES * 64, (SH::NWAVES * SH::OCC + 3) / 4) vo
 	const u64 t_start = TL ? __builtin_readcyclecounter() : 0;
 	if (tid == 0)
 		sm.ticket = atomicAdd(ticket, 1u);   // super-tiles are handed out in start order => look-back cannot deadlock
-	u32 *hist = &sm.wbase[0][0];             // [256][HR] while phase A runs
+	u32 *hist = &sm.wcell[0][0];             // [256][HR] while phase A runs
 	for (u32 i = tid; i < 256 * HR; i += BLOCK)
 		hist[i] = 0;
 	__syncthreads();
-	const u32 stile = sm.ticket;
+	const u32 stile = __builtin_amdgcn_readfirstlane(sm.ticket);   // wave-uniform: addresses below stay scalar
 	const u64 first_tile = (u64)stile * tps;
 	const u64 beg = first_tile * C::TILE;
 	u64 end = beg + (u64)tps * C::TILE;
 	if (end > n)
 		end = n;
 
-	// ---- phase A: digit counts of the whole super-tile
-	for (u64 base = beg; base < end; base += C::TILE) {
-		const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
+	// ---- phase A: digit counts of the whole super-tile (order does not matter here)
+	{
+		constexpr int PA = KPT < 16 ? KPT : 16;   // loads in flight per lane
 		const u32 wofs = wid * (64 * KPT) + lane;
-		KT key[KPT];
+		for (u64 base = beg; base < end; base += C::TILE) {
+			const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
+#pragma unroll 1
+			for (int r0 = 0; r0 < KPT; r0 += PA) {
+				KT cur[PA];
 #pragma unroll
-		for (int r = 0; r < KPT; ++r) {
-			const u32 o = wofs + r * 64;
-			key[r] = o < cnt ? kin[base + o] : (KT)0;
-		}
+				for (int r = 0; r < PA; ++r) {
+					const u32 o = wofs + (r0 + r) * 64;
+					cur[r] = o < cnt ? kin[base + o] : (KT)0;
+				}
 #pragma unroll
-		for (int r = 0; r < KPT; ++r) {
-			const u32 o = wofs + r * 64;
-			if (o < cnt)
-				atomicAdd(&hist[digit_of(key[r], ka, shift, flags, lut) * HR + (lane & (HR - 1))], 1u);
+				for (int r = 0; r < PA; ++r) {
+					const u32 o = wofs + (r0 + r) * 64;
+					if (o < cnt)
+						atomicAdd(&hist[digit_of(cur[r], ka, shift, flags, lut) * HR + (lane & (HR - 1))], 1u);
+				}
+			}
 		}
 	}
 	__syncthreads();
 
 	// ---- digit thread d: publish the aggregate, look back along the chain of super-tiles, publish the prefix
 	u64 running = 0;
+	if (TL && tid == 0)
+		tl[first_tile * 16 + 13] = __builtin_readcyclecounter();
 	if (tid < 256) {
 		u32 st_cnt = 0;
 #pragma unroll
@@ -741,7 +804,7 @@ __global__ __launch_bounds__(SH::NWAVES * 64, (SH::NWAVES * SH::OCC + 3) / 4) vo
 			tl[first_tile * 16 + 12] = depth;
 		}
 	}
-	__syncthreads();   // the histogram (aliasing wbase) has been consumed
+	__syncthreads();   // the histogram (aliasing wcell) has been consumed
 
 	// ---- phase B: the tiles, in order
 	for (u64 base = beg; base < end; base += C::TILE) {
@@ -753,8 +816,57 @@ __global__ __launch_bounds__(SH::NWAVES * 64, (SH::NWAVES * SH::OCC + 3) / 4) vo
 		else
 			scatter_tile<KT, VT, ST, SH, false, TL>(sm, kin, kout, vin, vout, tile, base, tile_count, shift, running, ka, flags,
 			                                        lut, tl);
-		__syncthreads();   // staging reads done before the next tile's tables are zeroed
+		__syncthreads();   // staging reads done before the next tile's counters / tables are reset
 	}
+}
+
+// =============================================================================
+// Self-check for RANK_ATOMIC / rsx_scatter2_kernel
+// =============================================================================
+// Do returning LDS atomics hand out their return values in increasing lane order when several lanes of
+// one wave-instruction hit the same address, and in issue order across instructions?  Every wave runs
+// rounds of `old = atomicAdd(&cnt[d], 1)` on digits with heavy collisions and compares `old` with the
+// rank obtained independently from ballots (the 8-ballot match).  *bad counts the disagreements.
+__global__ __launch_bounds__(512) void rsx_lds_order_check_kernel(u64 *bad, u32 seed, int rounds)
+{
+	__shared__ u32 cnt[8][256];
+	__shared__ u32 ref[8][256];
+	const u32 tid = threadIdx.x, wid = tid >> 6;
+	for (u32 i = tid; i < 8 * 256; i += 512) {
+		(&cnt[0][0])[i] = 0;
+		(&ref[0][0])[i] = 0;
+	}
+	__syncthreads();
+	u32 x = seed ^ (blockIdx.x * 2654435761u) ^ (tid * 40503u);
+	u64 nbad = 0;
+	for (int r = 0; r < rounds; ++r) {
+		x = x * 1664525u + 1013904223u;
+		u32 d;
+		switch ((blockIdx.x + r / 64) & 3) {
+		case 0: d = (x >> 13) & 0xFF; break;                                  // uniform
+		case 1: d = (x >> 13) & 1; break;                                     // two digits
+		case 2: d = ((x >> 13) & 7) * 32; break;                              // eight addresses on one bank
+		default: d = ((x >> 9) % 3 == 0) ? 200 : ((x >> 13) & 0xFF); break;   // one hot digit + uniform
+		}
+		const u32 old = __hip_atomic_fetch_add(&cnt[wid][d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		u64 m = ~0ull;
+#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			const bool bit = (d >> b) & 1u;
+			const u64 bal = __ballot(bit);
+			m &= bit ? bal : ~bal;
+		}
+		const u32 below = mbcnt64(m);
+		const u32 prev = ref[wid][d];
+		RSX_COMPILER_FENCE();
+		if (below == (u32)__popcll(m) - 1)
+			ref[wid][d] = prev + (u32)__popcll(m);
+		RSX_COMPILER_FENCE();
+		if (old != prev + below)
+			++nbad;
+	}
+	if (nbad)
+		atomicAdd(bad, nbad);
 }
 
 // =============================================================================

@@ -1,0 +1,405 @@
+// rsx_scatter2.hpp -- the "count first" scatter pass (default), gfx950.
+//
+// Same job as rsx_scatter_kernel (rsx_kernels.hpp): one stable scatter pass of the reference's
+// loop at radix_sort.hpp:82-90.  What is different is the order of work inside a workgroup:
+//
+//   phase A  the workgroup takes a super-tile of up to TPS tiles and COUNTS first: one streaming
+//            read of its keys (from HBM) fills, for every tile, a 16-bit cell per (wave, digit).
+//            From the cells come the super-tile's digit totals (published, chained by decoupled
+//            look-back exactly as in rsx_scatter_kernel) and, by prefix sums over waves and digits,
+//            the tile-local start of every (wave, digit) run, which is written back into the cells.
+//   phase B  per tile, a second read of the keys (now out of L2 / Infinity Cache): one returning
+//            LDS atomic add on the (wave, digit) cell hands each key its final tile-local position
+//            and the key is staged there at once -- no rank registers, no rank/stage barrier, and
+//            the register footprint does not grow with the tile.  Then the staged tile is written
+//            out in wide chunks.
+//
+// Why tiles are as large as LDS allows (32 Ki four-byte keys = 128 KiB of staging, one workgroup
+// of 16 waves per CU): on MI355X the memory side retires one write request per touched 256-byte
+// block, so a scattered write is only efficient when each digit's run is long.  With 256 digits a
+// 32 Ki-key tile gives 512-byte runs (tools/ubench/store_runs.hip: 128-byte runs 2.2 TB/s, 512-byte
+// runs 3.0 TB/s, 1 KiB 3.8 TB/s, unaligned).
+//
+// Stability rests on the returning LDS atomic: lanes of one wave-instruction that hit the same cell
+// must receive their return values in increasing lane order, and successive instructions of a wave
+// in issue order.  gfx950 does that (tools/ubench/lds_atomic_order.hip) but it is not a documented
+// guarantee, so the host checks it on the device before it selects this kernel (rsx.hip).
+#pragma once
+
+#include "rsx_kernels.hpp"
+
+namespace rsx {
+
+template <typename KT, typename VT, int NWAVES_ = 16, int TPS_ = 2, int LB_ = 8, bool CELL16_ = true> struct Sc2Cfg {
+	static constexpr bool CELL16 = CELL16_;           // 16-bit cells packed two per word, or one 32-bit cell per digit
+	static constexpr int NWAVES = NWAVES_;
+	static constexpr int BLOCK = NWAVES * 64;
+	static constexpr int ELEM = sizeof(KT) > (size_t)val_bytes<VT>::value ? sizeof(KT) : val_bytes<VT>::value;
+	static constexpr int KPT = ELEM == 8 ? 16 : 32;    // keys per lane: 128 KiB of staging at 16 waves
+	static constexpr int TILE = BLOCK * KPT;
+	static constexpr int TPS = TPS_;                   // tiles per super-tile (at most)
+	static constexpr int LB = LB_;                     // status words fetched per look-back round trip
+	static constexpr int SB = 8;                       // keys per lane in flight in the streaming loops
+	static constexpr int CHUNK = 16 / ELEM;            // consecutive staged elements one lane writes out together
+	static constexpr int STAGE_BYTES = TILE * ELEM;
+	static_assert(NWAVES >= 4, "256 digit threads are needed");
+	static_assert(TILE <= 32768, "tile-local positions live in 16-bit cells, two per word");
+	static_assert(KPT % (2 * SB) == 0 && KPT % CHUNK == 0 && KPT % 2 == 0, "whole batch pairs / chunks per lane");
+};
+
+template <typename KT, typename VT, typename ST, typename C> struct Sc2Smem {
+	__attribute__((aligned(16))) unsigned char stage_raw[C::STAGE_BYTES];
+	u32 cell[C::TPS][C::NWAVES][C::CELL16 ? 128 : 256];   // cell per (tile, wave, digit): count, then run start / cursor
+	ST delta[C::TPS][256];              // global offset of a digit's run minus its tile-local offset
+	u32 wsum[C::TPS][4];
+	u32 ticket;
+};
+
+template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bool TL = false>
+__global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__restrict__ kin, KT *__restrict__ kout,
+                                                                 const VT *__restrict__ vin, VT *__restrict__ vout, u64 n,
+                                                                 u32 shift, const u64 *__restrict__ gbase, u32 tps, ST *status,
+                                                                 u32 *ticket, KdfArgs<KT> ka, u32 flags,
+                                                                 const uint8_t *__restrict__ lut, u64 *tl)
+{
+	typedef StatusBits<ST> SB_;
+	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, TPS = C::TPS, SB = C::SB, CHUNK = C::CHUNK;
+	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
+	__shared__ Sc2Smem<KT, VT, ST, C> sm;
+	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const u64 t_start = TL ? __builtin_readcyclecounter() : 0;
+
+	if (tid == 0)
+		sm.ticket = atomicAdd(ticket, 1u);   // super-tiles are handed out in start order => look-back cannot deadlock
+	constexpr int CW = C::CELL16 ? 128 : 256;   // words per (tile, wave)
+	for (u32 i = tid; i < TPS * NWAVES * CW; i += BLOCK)
+		(&sm.cell[0][0][0])[i] = 0;
+	__syncthreads();
+	const u32 stile = __builtin_amdgcn_readfirstlane(sm.ticket);
+	const u64 beg = (u64)stile * tps * C::TILE;
+	u64 end = beg + (u64)tps * C::TILE;
+	if (end > n)
+		end = n;
+	const u32 wofs = wid * (64 * KPT) + lane;   // wave w owns [w*64*KPT, +64*KPT) of a tile; round r: element 64 r + lane
+
+	// ---- phase A: count, per tile and wave.  Order inside a wave's slice does not matter here, so the
+	// slice is streamed with 16-byte loads (when the keys are 16-byte aligned), all of them in flight.
+	constexpr int VEC = 16 / sizeof(KT);
+	const bool vec_ok = (((uintptr_t)kin) & 15) == 0;
+#pragma unroll
+	for (int t = 0; t < TPS; ++t) {
+		const u64 base = beg + (u64)t * C::TILE;
+		if (t < (int)tps && base < end) {
+			const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
+			u32 *wc = sm.cell[t][wid];
+			if (vec_ok && cnt == (u32)C::TILE) {
+				typedef KT vec_t __attribute__((ext_vector_type(VEC)));
+				constexpr int NV = KPT / VEC;   // 16-byte loads per lane
+				const vec_t *vp = (const vec_t *)(kin + base + (u64)wid * (64 * KPT)) + lane;
+				vec_t v[NV];
+#pragma unroll
+				for (int i = 0; i < NV; ++i)
+					v[i] = vp[i * 64];
+#pragma unroll
+				for (int i = 0; i < NV; ++i) {
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) {
+						const u32 d = digit_of((KT)v[i][e], ka, shift, flags, lut);
+						if constexpr (C::CELL16)
+							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
+						else
+							atomicAdd(&wc[d], 1u);
+					}
+				}
+			} else {
+#pragma unroll 1
+				for (int r0 = 0; r0 < KPT; r0 += SB) {
+					KT cur[SB];
+#pragma unroll
+					for (int r = 0; r < SB; ++r) {
+						const u32 o = wofs + (r0 + r) * 64;
+						cur[r] = o < cnt ? kin[base + o] : (KT)0;
+					}
+#pragma unroll
+					for (int r = 0; r < SB; ++r) {
+						const u32 o = wofs + (r0 + r) * 64;
+						if (o < cnt) {
+							const u32 d = digit_of(cur[r], ka, shift, flags, lut);
+							if constexpr (C::CELL16)
+								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
+							else
+								atomicAdd(&wc[d], 1u);
+						}
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (TL && tid == 0)
+		tl[(u64)stile * 16 + 1] = __builtin_readcyclecounter();
+
+	// ---- digit thread d: totals, chain (publish aggregate / look back / publish prefix), tile layouts
+	unsigned short *cell16 = (unsigned short *)&sm.cell[0][0][0];   // [TPS][NWAVES][256]
+	u32 tc[TPS], incl[TPS];
+	u64 excl = 0;
+	if (tid < 256) {
+		u32 st_cnt = 0;
+#pragma unroll
+		for (int t = 0; t < TPS; ++t) {
+			u32 c = 0;
+#pragma unroll
+			for (int w = 0; w < NWAVES; ++w)
+				c += C::CELL16 ? (u32)cell16[(t * NWAVES + w) * 256 + tid] : sm.cell[t][w][tid & (CW - 1)];
+			tc[t] = c;
+			st_cnt += c;
+		}
+		ST *my_status = status + (u64)stile * 256 + tid;
+		const ST word = ((ST)(stile == 0 ? ST_PREFIX : ST_AGGREGATE) << SB_::SHIFT) | (ST)st_cnt;
+		__hip_atomic_store(my_status, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		u32 depth = 0;
+		if (stile != 0) {
+			// LB predecessors are fetched per round trip (independent loads), then consumed in order:
+			// aggregates are summed until the first inclusive prefix; an empty word ends the batch.
+			constexpr int LB = C::LB;
+			long back = (long)stile - 1;   // nearest predecessor not consumed yet
+			const ST *col = status + tid;
+			for (;;) {
+				ST w[LB];
+#pragma unroll
+				for (int j = 0; j < LB; ++j) {
+					const long p = back - j > 0 ? back - j : 0;   // super-tile 0 always holds a prefix: safe filler
+					w[j] = __hip_atomic_load(col + (u64)p * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				bool done = false;
+				int used = 0;
+#pragma unroll
+				for (int j = 0; j < LB; ++j) {
+					const u32 f = (u32)(w[j] >> SB_::SHIFT);
+					if (!done && used == j && f != ST_EMPTY) {
+						excl += (u64)(w[j] & SB_::VALMASK);
+						++used;
+						++depth;
+						done = f == ST_PREFIX;
+					}
+				}
+				if (done)
+					break;
+				back -= used;
+				if (used == 0)
+					__builtin_amdgcn_s_sleep(1);
+			}
+			const ST pword = ((ST)ST_PREFIX << SB_::SHIFT) | (ST)(excl + st_cnt);
+			__hip_atomic_store(my_status, pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (TL && tid == 0) {
+			tl[(u64)stile * 16 + 0] = t_start;
+			tl[(u64)stile * 16 + 2] = __builtin_readcyclecounter();
+			tl[(u64)stile * 16 + 12] = depth;
+		}
+		// prefix over digits, per tile (wave scan now, wave totals through LDS)
+#pragma unroll
+		for (int t = 0; t < TPS; ++t) {
+			u32 x = tc[t];
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const u32 y = __shfl_up(x, off);
+				if (lane >= (u32)off)
+					x += y;
+			}
+			incl[t] = x;
+			if (lane == 63)
+				sm.wsum[t][wid] = x;
+		}
+	}
+	__syncthreads();
+	if (tid < 256) {
+		u64 running = gbase[tid] + excl;
+#pragma unroll
+		for (int t = 0; t < TPS; ++t) {
+			u32 tbase = incl[t] - tc[t];
+			for (u32 w = 0; w < wid; ++w)
+				tbase += sm.wsum[t][w];
+			u32 acc = tbase;   // counts -> run starts, in place
+#pragma unroll
+			for (int w = 0; w < NWAVES; ++w) {
+				u32 c;
+				if constexpr (C::CELL16) {
+					c = cell16[(t * NWAVES + w) * 256 + tid];
+					cell16[(t * NWAVES + w) * 256 + tid] = (unsigned short)acc;
+				} else {
+					c = sm.cell[t][w][tid & (CW - 1)];
+					sm.cell[t][w][tid & (CW - 1)] = acc;
+				}
+				acc += c;
+			}
+			sm.delta[t][tid] = (ST)(running - tbase);   // modulo 2^32 when ST is 32-bit (n < 2^30 then)
+			running += tc[t];
+		}
+	}
+	__syncthreads();
+	if (TL && tid == 0)
+		tl[(u64)stile * 16 + 3] = __builtin_readcyclecounter();
+
+	// ---- phase B: the tiles, in order
+	KT *stage_k = (KT *)sm.stage_raw;
+#pragma unroll
+	for (int t = 0; t < TPS; ++t) {
+		const u64 base = beg + (u64)t * C::TILE;
+		if (!(t < (int)tps && base < end))
+			break;
+		const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
+		const bool full = cnt == (u32)C::TILE;
+		u32 *wc = sm.cell[t][wid];
+		const ST *delta = sm.delta[t];
+
+		// rank + stage: the returning atomic on the (wave, digit) cursor is the key's tile-local position.
+		// Rounds are issued in memory order; lanes of a round come back in lane order (see the header).
+		u32 posp[HAS_VAL ? KPT / 2 : 1];
+		if constexpr (HAS_VAL) {
+#pragma unroll
+			for (int i = 0; i < KPT / 2; ++i)
+				posp[i] = 0;
+		}
+		auto load_batch = [&](KT (&dst)[SB], const int r0) {
+#pragma unroll
+			for (int r = 0; r < SB; ++r) {
+				const u32 o = wofs + (r0 + r) * 64;
+				if (TL && (flags & SCATTER_DBG_NOLOADB))
+					dst[r] = (KT)((o ^ (u32)base) * 2654435761u);
+				else
+					dst[r] = (full || o < cnt) ? kin[base + o] : (KT)0;
+			}
+		};
+		auto stage_batch = [&](const KT (&cur)[SB], const int r0) {
+#pragma unroll
+			for (int r = 0; r < SB; ++r) {
+				const u32 o = wofs + (r0 + r) * 64;
+				if (full || o < cnt) {
+					const u32 d = digit_of(cur[r], ka, shift, flags, lut);
+					u32 pos;
+					if constexpr (C::CELL16) {
+						const u32 sh = (d & 1u) * 16u;
+						const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						pos = (old >> sh) & 0xFFFFu;
+					} else {
+						pos = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+					stage_k[pos] = cur[r];
+					if constexpr (HAS_VAL)
+						posp[(r0 + r) >> 1] |= pos << (16 * ((r0 + r) & 1));
+				}
+			}
+		};
+		// two batches of loads are in flight while one is ranked and staged
+		{
+			KT b0[SB], b1[SB];
+			load_batch(b0, 0);
+#pragma unroll
+			for (int r0 = 0; r0 < KPT; r0 += 2 * SB) {
+				load_batch(b1, r0 + SB);
+				stage_batch(b0, r0);
+				if (r0 + 2 * SB < KPT)
+					load_batch(b0, r0 + 2 * SB);
+				stage_batch(b1, r0 + SB);
+			}
+		}
+		__syncthreads();
+		if (TL && tid == 0)
+			tl[(u64)stile * 16 + 4 + 2 * t] = __builtin_readcyclecounter();
+
+		// write out.  The staged tile is sorted by digit and consecutive staged elements of one digit go to
+		// consecutive addresses: a lane takes CHUNK consecutive elements and, when they share a digit
+		// (first == last), stores them with one wide store; chunks straddling a run boundary go element-wise.
+		u32 pk[HAS_VAL ? KPT / CHUNK : 1];
+#pragma unroll
+		for (int j = 0; j < KPT / CHUNK; ++j) {
+			if (j % 4 == 0)
+				__builtin_amdgcn_sched_barrier(0);   // keep a few chunks' registers alive at a time
+			const u32 i0 = CHUNK * (tid + j * BLOCK);
+			KT kv[CHUNK];
+			u32 d[CHUNK];
+			{
+				typedef KT kvec_t __attribute__((ext_vector_type(CHUNK)));
+				const kvec_t x = *(const kvec_t *)(stage_k + i0);
+#pragma unroll
+				for (int e = 0; e < CHUNK; ++e)
+					kv[e] = x[e];
+			}
+#pragma unroll
+			for (int e = 0; e < CHUNK; ++e)
+				d[e] = digit_of(kv[e], ka, shift, flags, lut);
+			if constexpr (HAS_VAL) {
+				u32 p = 0;
+#pragma unroll
+				for (int e = 0; e < CHUNK; ++e)
+					p |= d[e] << (8 * e);
+				pk[j] = p;
+			}
+			if (!(flags & SCATTER_SKIP_KEYS) && !(TL && (flags & SCATTER_DBG_NOSTORE))) {
+				const bool whole = full || i0 + CHUNK <= cnt;
+				if (sizeof(KT) >= 4 && whole && d[0] == d[CHUNK - 1]) {
+					store_chunk<KT, CHUNK>(kout + (ST)(delta[d[0]] + i0), kv);
+				} else {
+#pragma unroll
+					for (int e = 0; e < CHUNK; ++e)
+						if (full || i0 + e < cnt)
+							kout[(ST)(delta[d[e]] + i0 + e)] = kv[e];
+				}
+			}
+		}
+		if constexpr (HAS_VAL) {
+			// payloads: same positions, through the same staging area
+			VT *stage_v = (VT *)sm.stage_raw;
+			__syncthreads();
+#pragma unroll
+			for (int r0 = 0; r0 < KPT; r0 += SB) {
+				VT val[SB];
+#pragma unroll
+				for (int r = 0; r < SB; ++r) {
+					const u32 o = wofs + (r0 + r) * 64;
+					if (flags & SCATTER_GEN_INDEX)
+						val[r] = (VT)(base + o);
+					else
+						val[r] = (full || o < cnt) ? vin[base + o] : (VT)0;
+				}
+#pragma unroll
+				for (int r = 0; r < SB; ++r) {
+					const u32 o = wofs + (r0 + r) * 64;
+					if (full || o < cnt)
+						stage_v[(posp[(r0 + r) >> 1] >> (16 * ((r0 + r) & 1))) & 0xFFFFu] = val[r];
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int j = 0; j < KPT / CHUNK; ++j) {
+				if (j % 4 == 0)
+					__builtin_amdgcn_sched_barrier(0);
+				const u32 i0 = CHUNK * (tid + j * BLOCK);
+				VT vv[CHUNK];
+				{
+					typedef VT vvec_t __attribute__((ext_vector_type(CHUNK)));
+					const vvec_t x = *(const vvec_t *)(stage_v + i0);
+#pragma unroll
+					for (int e = 0; e < CHUNK; ++e)
+						vv[e] = x[e];
+				}
+				const u32 d0 = pk[j] & 0xFFu, dl = (pk[j] >> (8 * (CHUNK - 1))) & 0xFFu;
+				const bool whole = full || i0 + CHUNK <= cnt;
+				if (whole && d0 == dl) {
+					store_chunk<VT, CHUNK>(vout + (ST)(delta[d0] + i0), vv);
+				} else {
+#pragma unroll
+					for (int e = 0; e < CHUNK; ++e)
+						if (full || i0 + e < cnt)
+							vout[(ST)(delta[(pk[j] >> (8 * e)) & 0xFFu] + i0 + e)] = vv[e];
+				}
+			}
+		}
+		__syncthreads();   // staging reads done before the next tile is staged
+		if (TL && tid == 0)
+			tl[(u64)stile * 16 + 5 + 2 * t] = __builtin_readcyclecounter();
+	}
+}
+
+}  // namespace rsx

@@ -1,6 +1,6 @@
 // scatter_probe: tuning harness for rsx_scatter_kernel (tile shapes, phase timeline).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc tools/ubench/scatter_probe.hip -o tools/ubench/scatter_probe.bin
-#include "rsx_kernels.hpp"
+#include "rsx_scatter2.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -26,12 +26,16 @@ static void *d_status;
 static u64 *d_tl;
 static size_t n;
 
+static u32 g_tps = 8;
+static u32 g_flags = 0;
+
 template <typename SH, bool TL>
 float run_once(u32 shift, bool timeline_dump)
 {
 	typedef ScatterCfg<u32, NoVal, SH> C;
-	const u64 tiles = ((n + C::TILE - 1) / C::TILE + SH::SEGS - 1) / SH::SEGS * SH::SEGS;
-	const size_t st_bytes = 256 + tiles * 256 * 4;
+	const u64 tiles = (n + C::TILE - 1) / C::TILE;
+	const u64 stiles = (tiles + g_tps - 1) / g_tps;
+	const size_t st_bytes = 256 + stiles * 256 * 4;
 	CK(hipMemsetAsync(d_status, 0, st_bytes, 0));
 	if (TL)
 		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
@@ -40,9 +44,9 @@ float run_once(u32 shift, bool timeline_dump)
 	CK(hipEventCreate(&e1));
 	KdfArgs<u32> ka{0, 0, 0};
 	CK(hipEventRecord(e0, 0));
-	hipLaunchKernelGGL((rsx_scatter_kernel<u32, NoVal, u32, SH, TL>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, 0, d_in, d_out,
-	                   (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8),
-	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, 0u, (const uint8_t *)nullptr, d_tl);
+	hipLaunchKernelGGL((rsx_scatter_kernel<u32, NoVal, u32, SH, TL>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in, d_out,
+	                   (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8), g_tps,
+	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, (const uint8_t *)nullptr, d_tl);
 	CK(hipGetLastError());
 	CK(hipEventRecord(e1, 0));
 	CK(hipEventSynchronize(e1));
@@ -51,36 +55,108 @@ float run_once(u32 shift, bool timeline_dump)
 	if (TL && timeline_dump) {
 		std::vector<u64> tl(tiles * 16);
 		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
-		const char *names[] = {"ticket+zero", "load wait", "rank", "sync1", "agg+lookback(d0)", "scan+sync2", "bases+sync3", "stage",
-		                       "sync4", "writeout"};
-		double sum[10] = {0};
-		double depth = 0, maxdepth = 0;
-		u64 tmin = ~0ull, tmax = 0;
+		// stamps per tile: 2 loaded, 3 ranked, 4 sync1, 6 counts+sync2, 7 bases+sync3, 8 staged, 9 sync4, 10 written
+		// per super-tile (row of its first tile): 0 start, 1 phase A + look-back done, 12 depth
+		const int seq[] = {2, 3, 4, 6, 7, 8, 9, 10};
+		const char *names[] = {"rank", "sync1", "counts+sync2", "bases+sync3", "stage", "sync4", "writeout"};
+		double sum[7] = {0}, lookb = 0, phaseA = 0, depth = 0, maxdepth = 0, loadw = 0, span = 0;
+		u64 nst = 0;
 		for (u64 t = 0; t < tiles; ++t) {
 			const u64 *r = &tl[t * 16];
-			for (int k = 0; k < 10; ++k)
-				sum[k] += (double)(r[k + 1] - r[k]);
-			depth += r[12];
-			maxdepth = std::max(maxdepth, (double)r[12]);
-			tmin = std::min(tmin, r[0]);
-			tmax = std::max(tmax, r[10]);
+			for (int k = 0; k < 7; ++k)
+				sum[k] += (double)(r[seq[k + 1]] - r[seq[k]]);
+			if (t % g_tps == 0) {
+				phaseA += (double)(r[13] - r[0]);
+				lookb += (double)(r[1] - r[13]);
+				depth += r[12];
+				maxdepth = std::max(maxdepth, (double)r[12]);
+				loadw += (double)(r[2] - r[1]);
+				const u64 last = std::min(tiles - 1, t + g_tps - 1);
+				span += (double)(tl[last * 16 + 10] - r[0]);
+				++nst;
+			} else {
+				loadw += (double)(r[2] - tl[(t - 1) * 16 + 10]);
+			}
 		}
-		double total = 0;
-		for (int k = 0; k < 10; ++k)
-			total += sum[k];
-		printf("  timeline (avg s_memtime ticks per tile; kernel span %llu ticks, %.3f ms => %.1f MHz tick):\n",
-		       (unsigned long long)(tmax - tmin), ms, (tmax - tmin) / (ms * 1e3));
-		for (int k = 0; k < 10; ++k)
-			printf("    %-20s %9.0f  (%4.1f%%)\n", names[k], sum[k] / tiles, 100.0 * sum[k] / total);
-		printf("    total per tile       %9.0f ; look-back depth (digit 0): avg %.2f max %.0f\n", total / tiles, depth / tiles, maxdepth);
+		printf("  per super-tile: phase A %9.0f ticks, look-back %9.0f ticks, depth avg %.2f max %.0f, lifetime %9.0f ticks\n",
+		       phaseA / nst, lookb / nst, depth / nst, maxdepth, span / nst);
+		printf("  per tile: load wait %7.0f", loadw / tiles);
+		for (int k = 0; k < 7; ++k)
+			printf(" | %s %6.0f", names[k], sum[k] / tiles);
+		printf("\n");
 	}
 	return ms;
 }
 
+template <typename C, bool TL>
+float run2_once(u32 shift, bool dump, u32 tps)
+{
+	const u64 tiles = (n + C::TILE - 1) / C::TILE;
+	const u64 stiles = (tiles + tps - 1) / tps;
+	CK(hipMemsetAsync(d_status, 0, 256 + stiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, stiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, TL>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in, d_out,
+	                   (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8), tps,
+	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, (const uint8_t *)nullptr, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	if (TL && dump) {
+		std::vector<u64> tl(stiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, stiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lb = 0, lay = 0, st[4] = {0}, wo[4] = {0}, depth = 0, life = 0;
+		for (u64 s = 0; s < stiles; ++s) {
+			const u64 *r = &tl[s * 16];
+			a += (double)(r[1] - r[0]);
+			lb += (double)(r[2] - r[1]);
+			lay += (double)(r[3] - r[2]);
+			u64 prev = r[3];
+			for (u32 t = 0; t < tps && t < 4; ++t) {
+				st[t] += (double)(r[4 + 2 * t] - prev);
+				wo[t] += (double)(r[5 + 2 * t] - r[4 + 2 * t]);
+				prev = r[5 + 2 * t];
+			}
+			life += (double)(prev - r[0]);
+			depth += r[12];
+		}
+		printf("  per super-tile: phase A %8.0f | chain %7.0f (depth %.1f) | layout %6.0f |", a / stiles, lb / stiles, depth / stiles,
+		       lay / stiles);
+		for (u32 t = 0; t < tps && t < 4; ++t)
+			printf(" stage%u %7.0f write%u %7.0f |", t, st[t] / stiles, t, wo[t] / stiles);
+		printf(" lifetime %8.0f\n", life / stiles);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench2(const char *name, u32 tps)
+{
+	run2_once<C, false>(0, false, tps);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run2_once<C, false>(8 * (i % 4), false, tps);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-12s tps %u tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, tps, C::TILE,
+	       sizeof(Sc2Smem<u32, NoVal, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run2_once<C, true>(0, true, tps);
+}
+
 template <typename SH>
-void bench(const char *name)
+void bench(const char *name, u32 tps)
 {
 	typedef ScatterCfg<u32, NoVal, SH> C;
+	g_tps = tps;
 	run_once<SH, false>(0, false);
 	float best = 1e9, sum = 0;
 	const int reps = 5;
@@ -89,7 +165,7 @@ void bench(const char *name)
 		best = std::min(best, ms);
 		sum += ms;
 	}
-	printf("%-10s tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
+	printf("%-10s tps %u tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, tps, C::TILE,
 	       sizeof(ScatterSmem<u32, NoVal, u32, SH>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
 	run_once<SH, true>(0, true);
 }
@@ -109,15 +185,26 @@ int main(int argc, char **argv)
 	CK(hipMemset(d_hist, 0, 8 * 256 * 8));
 	CK(hipMemset(d_flag, 0, 64));
 	KdfArgs<u32> ka{0, 0, 0};
-	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, d_hist, d_flag, ka);
-	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(1), dim3(256), 0, 0, d_in, (u64)n, d_hist, d_flag, d_plan, ka);
+	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, d_hist, d_flag, ka, 1u, 2048u, (u64)n);
+	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, 1u, ka, d_flag + 8);
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
-	bench<TileShape<8, 16, 8, 2, 1>>("8x16 s1");
-	bench<TileShape<8, 16, 8, 2, 8>>("8x16 s8");
-	bench<TileShape<8, 16, 8, 2, 32>>("8x16 s32");
-	bench<TileShape<8, 16, 8, 2, 128>>("8x16 s128");
-	bench<TileShape<8, 16, 4, 2, 128>>("8x16 s128 lb4");
-	bench<TileShape<8, 16, 8, 2, 512>>("8x16 s512");
+	bench2<Sc2Cfg<u32, NoVal, 16, 2>>("v2 16w tps2", 2);
+	g_flags = SCATTER_DBG_NOLOADB;
+	printf("-- v2 16w tps2, no phase-B loads: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
+	g_flags = SCATTER_DBG_NOLOADB | SCATTER_DBG_NOSTORE;
+	printf("-- v2 16w tps2, no phase-B loads, no stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
+	g_flags = 0;
+	// correctness of v2: digits of the output must be non-decreasing and the multiset preserved (checked via sum)
+	{
+		typedef Sc2Cfg<u32, NoVal, 16, 2> C;
+		run2_once<C, false>(0, false, 2);
+		std::vector<u32> out(1 << 20), in(1 << 20);
+		CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+		size_t bad = 0;
+		for (size_t i = 1; i < out.size(); ++i)
+			bad += (out[i - 1] & 0xFF) > (out[i] & 0xFF);
+		printf("v2 check: digit order violations in the first 2^20 outputs: %zu\n", bad);
+	}
 	return 0;
 }
