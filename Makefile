@@ -6,18 +6,25 @@ ARCH    ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 CSRC     = radix_sorting_amd/csrc
 
-all: lib oracle
+all: lib oracle cpp
 
 lib: radix_sorting_amd/librsx.so
 
-radix_sorting_amd/librsx.so: $(CSRC)/rsx.hip $(CSRC)/rsx_kernels.hpp include/rsx.h
+radix_sorting_amd/librsx.so: $(CSRC)/rsx.hip $(CSRC)/rsx_kernels.hpp $(CSRC)/rsx_scatter2.hpp include/rsx.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/rsx.hip -o $@
 
-oracle:
+oracle: lib
 	$(MAKE) -C oracle
 
+# C++ check of the template surface in include/ (needs a GPU to run: tests/test_gpu_cpp.py)
+cpp: tests/cpp/dropin_check
+
+tests/cpp/dropin_check: tests/cpp/dropin_check.cpp include/radix_sort.hpp include/radix_sort_rank.hpp include/radix_sort_basic_kdf.hpp include/rsx.h radix_sorting_amd/librsx.so
+	g++ -std=gnu++17 -O2 -Wall -Iinclude tests/cpp/dropin_check.cpp -Lradix_sorting_amd -lrsx \
+	-Wl,-rpath,'$$ORIGIN/../../radix_sorting_amd' -Wl,-rpath-link,/opt/rocm/lib -o $@
+
 clean:
-	rm -f radix_sorting_amd/librsx.so
+	rm -f radix_sorting_amd/librsx.so tests/cpp/dropin_check
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle cpp clean

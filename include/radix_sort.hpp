@@ -1,0 +1,119 @@
+// radix_sort.hpp -- drop-in for the reference's header of the same name, backed by librsx.so (MI355X).
+//
+// Same template surface (reference radix_sort.hpp:98-99 and :31-32):
+//
+//     T* radix_sort(T* src, T* aux, size_t n, KeyFunc&& kf = basic_kdfs::kdf)
+//     T* rs_sort_main(T* src, T* aux, size_t n, Hist& histogram, KeyFunc&& kf = basic_kdfs::kdf)
+//
+// and the same observable contract: stable order by kf(element), n < 2 and
+// pre-sorted inputs return src with aux untouched, otherwise the result is in src when the number of
+// non-constant 8-bit key columns is even and in aux when it is odd; callers use the returned pointer.
+//
+// Where the work happens
+//   * T a scalar and kf the default basic_kdfs::kdf (or rsx_kdf::descending<T>): rsx_sort() -- the
+//     keys are sorted on the GPU with the key derivation done in the kernels.
+//   * any other callable (radix_tests.cpp:41-43,:111-113,:175-177 shapes): kf is evaluated once per
+//     element on the host into an array of KeyType, the GPU rank-sorts those keys and gathers the
+//     (trivially copyable) elements: rsx_sort_records().
+// There is no CPU sorting path: without a usable MI355X the call throws std::runtime_error, where the
+// reference "cannot fail".  The buffer that is not returned has unspecified contents (the reference
+// leaves the previous pass's data there).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "radix_sort_basic_kdf.hpp"
+#include "rsx.h"
+
+#ifndef RESTRICT
+#define RESTRICT __restrict__
+#endif
+
+namespace rsx_kdf {
+// Tagged descending KDF: the complement of basic_kdfs::kdf (README.md:564-574), recognised by the
+// wrapper so that descending scalar sorts also stay on the device.
+template <typename T> struct descending {
+	auto operator()(const T &v) const { return static_cast<decltype(basic_kdfs::kdf<T>(v))>(~basic_kdfs::kdf<T>(v)); }
+};
+}  // namespace rsx_kdf
+
+namespace rsx_detail {
+
+template <typename T> constexpr rsx_dtype dtype_of()
+{
+	if constexpr (std::is_same_v<T, float>) return RSX_F32;
+	else if constexpr (std::is_same_v<T, double>) return RSX_F64;
+	else if constexpr (std::is_signed_v<T>)
+		return sizeof(T) == 1 ? RSX_I8 : sizeof(T) == 2 ? RSX_I16 : sizeof(T) == 4 ? RSX_I32 : RSX_I64;
+	else
+		return sizeof(T) == 1 ? RSX_U8 : sizeof(T) == 2 ? RSX_U16 : sizeof(T) == 4 ? RSX_U32 : RSX_U64;
+}
+
+// Is KeyFunc the default basic_kdfs::kdf<T> / the tagged descending KDF?  (Specialised on "T is a key
+// scalar" so that basic_kdfs::kdf<T> is never named for record types.)
+template <typename T, typename KeyFunc, bool = basic_kdfs::detail::is_key_scalar_v<T>> struct kdf_kind {
+	static constexpr bool is_default = false, is_descending = false;
+};
+template <typename T, typename KeyFunc> struct kdf_kind<T, KeyFunc, true> {
+	using F = std::remove_cv_t<std::remove_reference_t<KeyFunc>>;
+	static constexpr bool is_default = std::is_same_v<F, decltype(basic_kdfs::kdf<T>)>;
+	static constexpr bool is_descending = std::is_same_v<F, rsx_kdf::descending<T>>;
+};
+template <typename T, typename KeyFunc> constexpr bool is_default_kdf_v = kdf_kind<T, KeyFunc>::is_default;
+template <typename T, typename KeyFunc> constexpr bool is_descending_kdf_v = kdf_kind<T, KeyFunc>::is_descending;
+
+[[noreturn]] inline void fail(const char *what, int rc)
+{
+	throw std::runtime_error(std::string(what) + ": rsx error " + std::to_string(rc) + ": " + rsx_last_error());
+}
+
+template <typename T, typename KeyFunc>
+T *sort_dispatch(T *src, T *aux, size_t n, KeyFunc &&kf)
+{
+	using KeyType = std::remove_cv_t<std::remove_reference_t<std::invoke_result_t<KeyFunc &, const T &>>>;
+	static_assert(sizeof(KeyType) <= 8, "KeyType must be 64-bits or less");        // reference radix_sort.hpp:34
+	static_assert(std::is_unsigned_v<KeyType>, "KeyType must be unsigned");         // reference radix_sort.hpp:35
+	if (n < 2)
+		return src;                                                                // reference radix_sort.hpp:37-38
+	void *result = nullptr;
+	int rc;
+	if constexpr (is_default_kdf_v<T, KeyFunc>) {
+		rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_ASCENDING, &result, nullptr);
+	} else if constexpr (is_descending_kdf_v<T, KeyFunc>) {
+		rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_DESCENDING, &result, nullptr);
+	} else {
+		static_assert(std::is_trivially_copyable_v<T>, "the GPU path moves elements as raw bytes");
+		std::vector<KeyType> keys(n);
+		for (size_t i = 0; i < n; ++i)
+			keys[i] = kf(src[i]);
+		rc = rsx_sort_records(src, aux, n, sizeof(T), keys.data(), sizeof(KeyType), &result, nullptr);
+	}
+	if (rc != RSX_OK)
+		fail("radix_sort", rc);
+	return static_cast<T *>(result);
+}
+
+}  // namespace rsx_detail
+
+// `passes` is kept for source compatibility; the number of 8-bit columns follows from KeyType.
+template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>),
+          int passes = sizeof(std::invoke_result_t<KeyFunc &, const T &>)>
+T *radix_sort(T *RESTRICT src, T *RESTRICT aux, size_t n, KeyFunc &&kf = basic_kdfs::kdf<T>)
+{
+	return rsx_detail::sort_dispatch<T>(src, aux, n, kf);
+}
+
+// The reference lets the caller supply the histogram storage (any container with value_type and
+// operator[], radix_sort.hpp:28-33).  The device keeps its own counters; `histogram` is accepted for
+// compatibility and left untouched.
+template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>), typename Hist>
+T *rs_sort_main(T *RESTRICT src, T *RESTRICT aux, size_t n, Hist &histogram, KeyFunc &&kf = basic_kdfs::kdf<T>)
+{
+	(void)histogram;
+	return rsx_detail::sort_dispatch<T>(src, aux, n, kf);
+}

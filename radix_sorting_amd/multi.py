@@ -132,8 +132,11 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     else:
         recv = engine.empty(n_recv, shard)
         aux = engine.empty(n_recv, shard)
-    dist.all_to_all_single(recv, part, output_split_sizes=[int(x) for x in recv_counts],
-                           input_split_sizes=[int(x) for x in send_counts], group=group)
+    # the exchange moves opaque bytes: every key width then works on every backend (gloo has no int16)
+    es = shard.element_size()
+    dist.all_to_all_single(recv.view(torch.uint8), part.view(torch.uint8),
+                           output_split_sizes=[int(x) * es for x in recv_counts],
+                           input_split_sizes=[int(x) * es for x in send_counts], group=group)
 
     # 5: local LSD sort of the received bucket range
     res, info = engine.local_sort(recv, aux)

@@ -1,0 +1,192 @@
+// dropin_check.cpp -- exercises the C++ template surface in include/ (radix_sort.hpp,
+// radix_sort_rank.hpp, radix_sort_basic_kdf.hpp) the way the reference's own callers do
+// (radix_tests.cpp:45-207 shapes, radix_experiment.cpp:205), but checks exact results: stable order,
+// returned-pointer parity, untouched aux on the early exits.  Needs a GPU; run by tests/test_gpu_cpp.py.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#include "radix_sort.hpp"
+#include "radix_sort_rank.hpp"
+
+static int failures = 0;
+#define CHECK(cond)                                                         \
+	do {                                                                    \
+		if (!(cond)) {                                                      \
+			printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);        \
+			++failures;                                                     \
+		}                                                                   \
+	} while (0)
+
+struct sortrec {
+	uint8_t key;
+	const char *name;
+};
+static const sortrec source_arr[] = {{255, "1st 255"}, {45, "1st 45"}, {3, "3"},  {45, "2nd 45"},
+                                     {2, "2"},         {45, "3rd 45"}, {1, "1"}, {255, "2nd 255"}};
+
+template <typename T>
+static void check_scalar(size_t n, uint64_t mask, unsigned seed)
+{
+	std::mt19937_64 rng(seed);
+	std::vector<T> src(n), aux(n, T()), want(n);
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t bits = rng() & mask;
+		std::memcpy(&src[i], &bits, sizeof(T));
+	}
+	want = src;
+	std::stable_sort(want.begin(), want.end(), [](const T &a, const T &b) { return basic_kdfs::kdf(a) < basic_kdfs::kdf(b); });
+	// number of non-constant key bytes decides the returned buffer (radix_sort.hpp:64-70,:89-92)
+	int cols = 0;
+	bool presorted = true;
+	for (size_t i = 1; i < n; ++i)
+		presorted &= basic_kdfs::kdf(src[i - 1]) <= basic_kdfs::kdf(src[i]);
+	for (size_t b = 0; b < sizeof(T); ++b) {
+		bool varies = false;
+		for (size_t i = 1; i < n && !varies; ++i)
+			varies = ((basic_kdfs::kdf(src[i]) >> (8 * b)) & 0xFF) != ((basic_kdfs::kdf(src[0]) >> (8 * b)) & 0xFF);
+		cols += varies;
+	}
+	T *res = radix_sort(src.data(), aux.data(), n);
+	CHECK(std::memcmp(res, want.data(), n * sizeof(T)) == 0);
+	if (n < 2 || presorted)
+		CHECK(res == src.data());
+	else
+		CHECK(res == ((cols & 1) ? aux.data() : src.data()));
+	// descending tag: complemented KDF, equal keys keep input order
+	std::vector<T> s2(n), a2(n);
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t bits = rng() & mask;
+		std::memcpy(&s2[i], &bits, sizeof(T));
+	}
+	std::vector<T> w2 = s2;
+	std::stable_sort(w2.begin(), w2.end(), [](const T &a, const T &b) { return basic_kdfs::kdf(a) > basic_kdfs::kdf(b); });
+	T *r2 = radix_sort(s2.data(), a2.data(), n, rsx_kdf::descending<T>());
+	CHECK(std::memcmp(r2, w2.data(), n * sizeof(T)) == 0);
+	// ranks of the (unsorted) second array: stable argsort, returned half by column parity
+	if (n < (1u << 20)) {
+		std::vector<T> orig(n);
+		std::vector<uint32_t> ib(2 * n + 2, 0xEEEEEEEEu), wr(n);
+		std::mt19937_64 rng2(seed + 1000);
+		for (size_t i = 0; i < n; ++i) {
+			uint64_t bits = rng2() & mask;
+			std::memcpy(&orig[i], &bits, sizeof(T));
+		}
+		std::iota(wr.begin(), wr.end(), 0u);
+		std::stable_sort(wr.begin(), wr.end(), [&](uint32_t a, uint32_t b) { return basic_kdfs::kdf(orig[a]) < basic_kdfs::kdf(orig[b]); });
+		uint32_t *ranks = radix_sort_rank(orig.data(), ib.data(), n);
+		CHECK(ranks == ib.data() || ranks == ib.data() + n);
+		CHECK(n == 0 || std::memcmp(ranks, wr.data(), n * 4) == 0);
+		if (n == 0)
+			CHECK(ib[0] == 0xEEEEEEEEu);
+		if (n == 1)
+			CHECK(ib[0] == 0 && ib[1] == 0xEEEEEEEEu);
+	}
+}
+
+int main()
+{
+	// radix_tests.cpp:45-69: records ordered by a 1-byte key (one column -> result in aux), stable
+	{
+		const size_t N = sizeof(source_arr) / sizeof(source_arr[0]);
+		std::vector<sortrec> src(source_arr, source_arr + N), aux(N);
+		auto kdf_sortrec = [](const sortrec &e) -> uint8_t { return e.key; };
+		sortrec *res = radix_sort(src.data(), aux.data(), N, kdf_sortrec);
+		const char *expect[] = {"1", "2", "3", "1st 45", "2nd 45", "3rd 45", "1st 255", "2nd 255"};
+		CHECK(res == aux.data());
+		for (size_t i = 0; i < N; ++i)
+			CHECK(std::strcmp(res[i].name, expect[i]) == 0);
+	}
+	// radix_tests.cpp:121-146: pointers to records, descending via ~key
+	{
+		const size_t N = sizeof(source_arr) / sizeof(source_arr[0]);
+		std::vector<const sortrec *> src(N), aux(N);
+		for (size_t i = 0; i < N; ++i)
+			src[i] = &source_arr[i];
+		auto kdf_rev = [](const sortrec *e) -> uint8_t { return ~e->key; };
+		const sortrec **res = radix_sort(src.data(), aux.data(), N, kdf_rev);
+		const char *expect[] = {"1st 255", "2nd 255", "1st 45", "2nd 45", "3rd 45", "3", "2", "1"};
+		for (size_t i = 0; i < N; ++i)
+			CHECK(std::strcmp(res[i]->name, expect[i]) == 0);
+	}
+	// radix_tests.cpp:156-173 + README.md:612-623: float order including -0.0, infinities, NaN
+	{
+		float src[] = {128.0f, 646464.0f, 0.0f, -0.0f, -0.5f, 0.5f, -128.0f, -INFINITY, NAN, INFINITY};
+		const size_t N = sizeof(src) / sizeof(src[0]);
+		float aux[N];
+		float *res = radix_sort(src, aux, N);
+		const uint32_t expect[] = {0xff800000, 0xc3000000, 0xbf000000, 0x80000000, 0x00000000,
+		                           0x3f000000, 0x43000000, 0x491dd400, 0x7f800000, 0x7fc00000};
+		for (size_t i = 0; i < N; ++i) {
+			uint32_t u;
+			std::memcpy(&u, res + i, 4);
+			CHECK(u == expect[i]);
+		}
+	}
+	// radix_tests.cpp:179-207: 50 000 ints ascending, then re-sorted descending with ~(e ^ 1<<31)
+	{
+		std::default_random_engine generator;
+		std::normal_distribution<double> distribution(0.0, 1.0e9);
+		const size_t N = 50000;
+		std::vector<int> buf(2 * N);
+		int *src = buf.data(), *aux = src + N;   // both halves of one allocation (radix_tests.cpp:184-185)
+		for (size_t i = 0; i < N; ++i)
+			src[i] = (int)std::max(-2.0e9, std::min(2.0e9, distribution(generator)));
+		int *res = radix_sort(src, aux, N);
+		CHECK(std::is_sorted(res, res + N));
+		auto kdf_int_reverse = [](const int &e) -> unsigned int { return ~((unsigned)e ^ (1u << 31)); };
+		res = radix_sort(res, res == src ? aux : src, N, kdf_int_reverse);
+		CHECK(std::is_sorted(res, res + N, std::greater<int>()));
+	}
+	// radix_tests.cpp:71-105: rank sort of the records with IdxType = uint8_t
+	{
+		const size_t N = sizeof(source_arr) / sizeof(source_arr[0]);
+		std::vector<uint8_t> ib(2 * N, 0xEE);
+		auto kdf_sortrec = [](const sortrec &e) -> uint8_t { return e.key; };
+		uint8_t *ranks = radix_sort_rank(source_arr, ib.data(), N, kdf_sortrec);
+		const uint8_t expect[] = {6, 4, 2, 1, 3, 5, 0, 7};
+		CHECK(ranks == ib.data() + N);
+		for (size_t i = 0; i < N; ++i)
+			CHECK(ranks[i] == expect[i]);
+	}
+	// scalars of every width: exact stable order and returned-pointer parity, with skipped columns
+	check_scalar<uint32_t>(100003, 0xFFFFFFFFull, 1);
+	check_scalar<uint32_t>(100003, 0x00FFFFFFull, 2);
+	check_scalar<uint32_t>(70000, 0x0000FF00ull, 3);
+	check_scalar<uint64_t>(65537, 0x000000FFFFFFFFFFull, 4);
+	check_scalar<int64_t>(50000, ~0ull, 5);
+	check_scalar<int32_t>(4097, ~0ull, 6);
+	check_scalar<uint16_t>(30000, 0xFFFFull, 7);
+	check_scalar<uint8_t>(30000, 0xFFull, 8);
+	check_scalar<int8_t>(255, 0xFFull, 9);
+	check_scalar<float>(100000, 0xFFFFFFFFull, 10);
+	check_scalar<double>(100000, ~0ull, 11);
+	check_scalar<uint32_t>(1, ~0ull, 12);
+	check_scalar<uint32_t>(0, ~0ull, 13);
+	// float ranks against std::stable_sort
+	{
+		const size_t n = 200000;
+		std::mt19937 rng(99);
+		std::vector<float> keys(n);
+		for (auto &k : keys) {
+			uint32_t b = rng() & 0xFFF000FFu;
+			std::memcpy(&k, &b, 4);
+		}
+		std::vector<uint32_t> ib(2 * n), want(n);
+		std::iota(want.begin(), want.end(), 0u);
+		std::stable_sort(want.begin(), want.end(), [&](uint32_t a, uint32_t b) { return basic_kdfs::kdf(keys[a]) < basic_kdfs::kdf(keys[b]); });
+		uint32_t *ranks = radix_sort_rank(keys.data(), ib.data(), n);
+		CHECK(std::memcmp(ranks, want.data(), n * 4) == 0);
+	}
+	if (failures) {
+		printf("dropin_check: %d failures\n", failures);
+		return 1;
+	}
+	printf("dropin_check OK\n");
+	return 0;
+}

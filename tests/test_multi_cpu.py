@@ -1,0 +1,114 @@
+"""Host logic of the multi-GPU sort (radix_sorting_amd/multi.py) on CPU: world_size-2 and -3 gloo runs.
+
+The device steps are injected: an oracle-backed engine (numpy + the C restatement) stands in for
+HipEngine, so what is exercised here is the splitter choice, the count exchange, the all-to-all-v
+plumbing and the ordering argument (concatenated rank outputs == stable sort of concatenated input).
+The HIP engine itself is covered by tests/test_gpu_multi.py on the GPU box.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from radix_sorting_amd import multi
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist          # noqa: E402
+import torch.multiprocessing as mp        # noqa: E402
+
+
+class OracleEngine:
+    """CPU stand-in for multi.HipEngine (tests only): same interface, numpy / oracle arithmetic."""
+
+    def __init__(self, dtype, order=0):
+        self.dtype, self.order = dtype, order
+
+    def _bits(self, t):
+        return t.numpy().view(ol.NP_BITS[self.dtype])
+
+    def top_histogram(self, shard):
+        k = ol.kdf_keys(self._bits(shard), self.dtype, self.order)
+        top = (k >> ol.NP_BITS[self.dtype](8 * (ol.DTYPE_SIZE[self.dtype] - 1))).astype(np.int64)
+        return torch.from_numpy(np.bincount(top, minlength=256).astype(np.int64))
+
+    def partition(self, shard, out, lut, world, top_hist_host):
+        bits = self._bits(shard)
+        k = ol.kdf_keys(bits, self.dtype, self.order)
+        top = (k >> ol.NP_BITS[self.dtype](8 * (ol.DTYPE_SIZE[self.dtype] - 1))).astype(np.int64)
+        dest = np.asarray(lut)[top]
+        perm = np.argsort(dest, kind="stable")
+        out.numpy().view(bits.dtype)[:bits.size] = bits[perm]
+        return np.bincount(dest, minlength=world).astype(np.uint64)
+
+    def local_sort(self, keys, aux):
+        res, in_aux, info = ol.oracle_sort(self._bits(keys), self.dtype, self.order)
+        target = aux if in_aux else keys
+        target.numpy().view(res.dtype)[:res.size] = res
+        return target[:res.size], info
+
+    def empty(self, n, like):
+        return torch.empty(n, dtype=like.dtype)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        carrier = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[ol.DTYPE_SIZE[dtype]]
+        n = n_per_rank[rank]
+        first = sum(n_per_rank[:rank])
+        whole = ol.splitmix_fill(sum(n_per_rank), dtype, seed, mask)
+        shard = torch.from_numpy(whole[first:first + n].view(carrier).copy())
+        res, stats = multi.distributed_sort(shard, OracleEngine(dtype, order))
+        np.save(os.path.join(outdir, "out%d.npy" % rank), res.numpy().view(ol.NP_BITS[dtype]).copy())
+        np.save(os.path.join(outdir, "recv%d.npy" % rank), np.asarray(stats.get("recv_counts", [n])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dtype,order,mask", [
+    (2, ol.U32, 0, 0xFFFFFFFF),
+    (2, ol.F32, 1, 0xFFFFFFFF),
+    (3, ol.U32, 0, 0x00FFFFFF),       # constant top byte: every key lands on one rank
+    (2, ol.I64, 0, 0xFFFFFFFFFFFFFFFF),
+    (3, ol.U16, 0, 0xFFFF),
+])
+def test_distributed_sort_matches_single_sort(tmp_path, world, dtype, order, mask):
+    n_per_rank = [40000 + 137 * r for r in range(world)]      # ragged shards
+    seed = 91
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dtype, order, n_per_rank, mask, seed, str(tmp_path)), nprocs=world, join=True)
+    whole = ol.splitmix_fill(sum(n_per_rank), dtype, seed, mask)
+    want, _, _ = ol.oracle_sort(whole, dtype, order)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
+    assert got.size == want.size
+    assert np.array_equal(got, want)          # bit-identical to sorting the whole array on one rank
+    sizes = [np.load(os.path.join(str(tmp_path), "out%d.npy" % r)).size for r in range(world)]
+    if mask == 0xFFFFFFFF and dtype == ol.U32:
+        assert max(sizes) < 1.2 * sum(sizes) / world      # uniform keys -> balanced splitters
+
+
+def test_choose_splitters_properties():
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        for hist in (rng.integers(0, 1000, 256), np.r_[np.zeros(255, np.int64), [5000]],
+                     np.r_[[10 ** 9], rng.integers(0, 10, 255)], np.zeros(256, np.int64)):
+            lut = multi.choose_splitters(hist.astype(np.uint64), world)
+            assert lut.dtype == np.uint8 and lut.shape == (256,)
+            assert np.all(np.diff(lut.astype(np.int64)) >= 0)         # contiguous, monotone digit ranges
+            assert lut.max() < world
+    # uniform histogram -> equal shares
+    lut = multi.choose_splitters(np.full(256, 100, dtype=np.uint64), 8)
+    assert np.array_equal(np.bincount(lut, minlength=8), np.full(8, 32))
