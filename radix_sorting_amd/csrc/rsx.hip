@@ -392,12 +392,26 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
 	const dim3 grid((unsigned)stiles);
 	if (c.fast) {
-		if (wide)
-			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
-			                   shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-		else
-			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
-			                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic
+		const bool plain = val_bytes<VT>::value == 0 && ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0 && !(flags & SCATTER_USE_LUT);
+		if constexpr (val_bytes<VT>::value == 0) {
+			if (plain) {
+				if (wide)
+					hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
+					                   kout, vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+				else
+					hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
+					                   kout, vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+			}
+		}
+		if (!plain) {
+			if (wide)
+				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
+				                   (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+			else
+				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
+				                   (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		}
 	} else {
 		if (wide)
 			hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,

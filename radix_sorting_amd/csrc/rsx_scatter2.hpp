@@ -55,7 +55,20 @@ template <typename KT, typename VT, typename ST, typename C> struct Sc2Smem {
 	u32 ticket;
 };
 
-template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bool TL = false>
+// DIG_PLAIN: the key is its own KDF (unsigned, ascending) and there is no bucket table: the digit is one
+// bit-field extract.  DIG_GENERIC: kdf_apply + optional lut, as in rsx_scatter_kernel.
+enum { DIG_GENERIC = 0, DIG_PLAIN = 1 };
+
+template <int DIG, typename KT>
+__device__ __forceinline__ u32 digit2(KT raw, const KdfArgs<KT> ka, u32 shift, u32 flags, const uint8_t *__restrict__ lut)
+{
+	if constexpr (DIG == DIG_PLAIN)
+		return (u32)(raw >> shift) & 0xFFu;
+	else
+		return digit_of(raw, ka, shift, flags, lut);
+}
+
+template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bool TL = false, int DIG = DIG_GENERIC>
 __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__restrict__ kin, KT *__restrict__ kout,
                                                                  const VT *__restrict__ vin, VT *__restrict__ vout, u64 n,
                                                                  u32 shift, const u64 *__restrict__ gbase, u32 tps, ST *status,
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				for (int i = 0; i < NV; ++i) {
 #pragma unroll
 					for (int e = 0; e < VEC; ++e) {
-						const u32 d = digit_of((KT)v[i][e], ka, shift, flags, lut);
+						const u32 d = digit2<DIG>((KT)v[i][e], ka, shift, flags, lut);
 						if constexpr (C::CELL16)
 							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 						else
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					for (int r = 0; r < SB; ++r) {
 						const u32 o = wofs + (r0 + r) * 64;
 						if (o < cnt) {
-							const u32 d = digit_of(cur[r], ka, shift, flags, lut);
+							const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
 							if constexpr (C::CELL16)
 								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 							else
@@ -243,13 +256,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 
 	// ---- phase B: the tiles, in order
 	KT *stage_k = (KT *)sm.stage_raw;
-#pragma unroll
-	for (int t = 0; t < TPS; ++t) {
-		const u64 base = beg + (u64)t * C::TILE;
-		if (!(t < (int)tps && base < end))
-			break;
-		const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
-		const bool full = cnt == (u32)C::TILE;
+	auto do_tile = [&](auto full_c, const int t, const u64 base, const u32 cnt) {
+		constexpr bool full = decltype(full_c)::value;   // a whole tile: no bounds checks
 		u32 *wc = sm.cell[t][wid];
 		const ST *delta = sm.delta[t];
 
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			for (int r = 0; r < SB; ++r) {
 				const u32 o = wofs + (r0 + r) * 64;
 				if (full || o < cnt) {
-					const u32 d = digit_of(cur[r], ka, shift, flags, lut);
+					const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
 					u32 pos;
 					if constexpr (C::CELL16) {
 						const u32 sh = (d & 1u) * 16u;
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			}
 #pragma unroll
 			for (int e = 0; e < CHUNK; ++e)
-				d[e] = digit_of(kv[e], ka, shift, flags, lut);
+				d[e] = digit2<DIG>(kv[e], ka, shift, flags, lut);
 			if constexpr (HAS_VAL) {
 				u32 p = 0;
 #pragma unroll
@@ -351,6 +359,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		if constexpr (HAS_VAL) {
 			// payloads: same positions, through the same staging area
 			VT *stage_v = (VT *)sm.stage_raw;
+			const bool gen_index = (flags & SCATTER_GEN_INDEX) != 0;
 			__syncthreads();
 #pragma unroll
 			for (int r0 = 0; r0 < KPT; r0 += SB) {
@@ -358,10 +367,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 #pragma unroll
 				for (int r = 0; r < SB; ++r) {
 					const u32 o = wofs + (r0 + r) * 64;
-					if (flags & SCATTER_GEN_INDEX)
-						val[r] = (VT)(base + o);
-					else
-						val[r] = (full || o < cnt) ? vin[base + o] : (VT)0;
+					val[r] = gen_index ? (VT)(base + o) : ((full || o < cnt) ? vin[base + o] : (VT)0);
 				}
 #pragma unroll
 				for (int r = 0; r < SB; ++r) {
@@ -399,6 +405,17 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		__syncthreads();   // staging reads done before the next tile is staged
 		if (TL && tid == 0)
 			tl[(u64)stile * 16 + 5 + 2 * t] = __builtin_readcyclecounter();
+	};
+#pragma unroll
+	for (int t = 0; t < TPS; ++t) {
+		const u64 base = beg + (u64)t * C::TILE;
+		if (!(t < (int)tps && base < end))
+			break;
+		const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
+		if (cnt == (u32)C::TILE)
+			do_tile(std::true_type{}, t, base, cnt);
+		else
+			do_tile(std::false_type{}, t, base, cnt);
 	}
 }
 
