@@ -379,7 +379,7 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 	const u64 tiles = (n + tile - 1) / tile;
 	u32 tps;
 	if (c.fast)
-		tps = tiles >= 1024 ? (u32)C2::TPS : 1u;
+		tps = (u32)C2::TPS;   // 1: a 32 Ki-key tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
 	else
 		tps = choose_tps(n, tile);
 	const u64 stiles = (tiles + tps - 1) / tps;

@@ -30,7 +30,7 @@
 
 namespace rsx {
 
-template <typename KT, typename VT, int NWAVES_ = 16, int TPS_ = 2, int LB_ = 8, bool CELL16_ = true> struct Sc2Cfg {
+template <typename KT, typename VT, int NWAVES_ = 16, int TPS_ = 1, int LB_ = 8, bool CELL16_ = false> struct Sc2Cfg {
 	static constexpr bool CELL16 = CELL16_;           // 16-bit cells packed two per word, or one 32-bit cell per digit
 	static constexpr int NWAVES = NWAVES_;
 	static constexpr int BLOCK = NWAVES * 64;
@@ -280,22 +280,31 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			}
 		};
 		auto stage_batch = [&](const KT (&cur)[SB], const int r0) {
+			// all the batch's atomics are issued before the first position is needed: the returning
+			// atomics of a wave pipeline in the LDS; only then the keys are stored at their positions
+			u32 pos[SB];
+#pragma unroll
+			for (int r = 0; r < SB; ++r) {
+				const u32 o = wofs + (r0 + r) * 64;
+				pos[r] = 0;
+				if (full || o < cnt) {
+					const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
+					if constexpr (C::CELL16) {
+						const u32 sh = (d & 1u) * 16u;
+						const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						pos[r] = (old >> sh) & 0xFFFFu;
+					} else {
+						pos[r] = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+				}
+			}
 #pragma unroll
 			for (int r = 0; r < SB; ++r) {
 				const u32 o = wofs + (r0 + r) * 64;
 				if (full || o < cnt) {
-					const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
-					u32 pos;
-					if constexpr (C::CELL16) {
-						const u32 sh = (d & 1u) * 16u;
-						const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						pos = (old >> sh) & 0xFFFFu;
-					} else {
-						pos = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					}
-					stage_k[pos] = cur[r];
+					stage_k[pos[r]] = cur[r];
 					if constexpr (HAS_VAL)
-						posp[(r0 + r) >> 1] |= pos << (16 * ((r0 + r) & 1));
+						posp[(r0 + r) >> 1] |= pos[r] << (16 * ((r0 + r) & 1));
 				}
 			}
 		};

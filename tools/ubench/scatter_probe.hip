@@ -101,7 +101,7 @@ float run2_once(u32 shift, bool dump, u32 tps)
 	CK(hipEventCreate(&e1));
 	KdfArgs<u32> ka{0, 0, 0};
 	CK(hipEventRecord(e0, 0));
-	hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, TL>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in, d_out,
+	hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, TL, DIG_PLAIN>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in, d_out,
 	                   (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8), tps,
 	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, (const uint8_t *)nullptr, d_tl);
 	CK(hipGetLastError());
@@ -190,11 +190,13 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal, 16, 2>>("v2 16w tps2", 2);
-	g_flags = SCATTER_DBG_NOLOADB;
-	printf("-- v2 16w tps2, no phase-B loads: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("-- no stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
 	g_flags = SCATTER_DBG_NOLOADB | SCATTER_DBG_NOSTORE;
-	printf("-- v2 16w tps2, no phase-B loads, no stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
+	printf("-- no phase-B loads, no stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
 	g_flags = 0;
+	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, false>>("v2 16w c32 tps1", 1);
+	bench2<Sc2Cfg<u32, NoVal, 8, 2>>("v2 8w tps2", 2);
 	// correctness of v2: digits of the output must be non-decreasing and the multiset preserved (checked via sum)
 	{
 		typedef Sc2Cfg<u32, NoVal, 16, 2> C;
