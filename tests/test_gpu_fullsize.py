@@ -1,0 +1,124 @@
+"""BASELINE.json's full-size configurations (2^28 elements) on one MI355X.
+
+cfg 2 (2^28 u32) is in tests/test_gpu_parity.py with a full oracle comparison.  Here: cfg 3 (2^28 u64 with skipped
+columns, uniform and Zipf-like) and cfg 4 (2^28 f32 keys + u32 payload = stable ranks).  At this size the checks are
+the size-independent properties the domain offers -- sortedness by KDF, stability, permutation checksums, the
+returned-buffer rule, idempotence -- computed on the GPU with torch; one u64 case is also compared with the oracle.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N = 1 << 28
+SIGN64 = -(1 << 63)
+SIGN32 = -(1 << 31)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    rsa.require_gpu()
+
+
+def _sorted_unsigned64(t):
+    f = t ^ SIGN64                      # unsigned order == signed order with the top bit flipped
+    return bool((f[1:] >= f[:-1]).all().item())
+
+
+def _checksums(t):
+    return int(t.sum().item()), int((t * (t >> 7)).sum().item())   # order-independent wrap-around sums
+
+
+@pytest.mark.parametrize("mask,cols,in_aux", [(0xFFFFFFFFFFFFFFFF, 8, 0), (0x000000FFFFFFFFFF, 5, 1), (0x00000000FFFFFFFF, 4, 0)])
+def test_cfg3_u64_column_skipping(mask, cols, in_aux):
+    src = torch.empty(N, dtype=torch.int64, device="cuda")
+    aux = torch.empty_like(src)
+    rsa.fill_splitmix(src, seed=3, mask=mask)
+    before = _checksums(src)
+    res, info = rsa.radix_sort(src, aux, dtype=rsa.U64)
+    torch.cuda.synchronize()
+    assert info.ncols == cols and info.result_in_aux == in_aux          # SURVEY.md 8d cfg 3, appendix A item 5
+    assert _sorted_unsigned64(res)
+    assert _checksums(res) == before
+    if cols == 5:   # one case bit for bit against the oracle (about half a minute of host time)
+        a = ol.splitmix_fill(N, ol.U64, 3, mask)
+        want, want_aux, _ = ol.oracle_sort(a, ol.U64)
+        assert want_aux == in_aux
+        assert np.array_equal(res.cpu().numpy().view(np.uint64), want)
+    other = src if res is aux else aux
+    res2, info2 = rsa.radix_sort(res, other, dtype=rsa.U64)              # idempotence: the pre-sorted early exit
+    torch.cuda.synchronize()
+    assert info2.early_exit == 2 and res2 is res
+
+
+def test_cfg3_u64_zipf_like():
+    """SURVEY.md 8d cfg 3 (iv): key = 2^(b-1) + low bits, b = 1 + (r >> 58) % 40 -- heavy duplicates, skewed high digits, P = 5."""
+    r = torch.empty(N, dtype=torch.int64, device="cuda")
+    rsa.fill_splitmix(r, seed=33)
+    b = 1 + (((r >> 58) & 63) % 40)
+    one = torch.ones_like(r)
+    keys = (one << (b - 1)) + (r & ((one << (b - 1)) - 1))
+    del r, b, one
+    before = _checksums(keys)
+    aux = torch.empty_like(keys)
+    res, info = rsa.radix_sort(keys, aux, dtype=rsa.U64)
+    torch.cuda.synchronize()
+    assert info.ncols == 5 and info.result_in_aux == 1
+    assert _sorted_unsigned64(res) and _checksums(res) == before
+
+
+@pytest.mark.parametrize("variant", ["random_bits", "uniform_pm1", "duplicate_heavy"])
+def test_cfg4_f32_keys_u32_ranks(variant):
+    """radix_sort_rank on 2^28 float keys: output = stable ranks in the half the column parity dictates."""
+    bits = torch.empty(N, dtype=torch.int32, device="cuda")
+    if variant == "random_bits":          # NaNs, infinities, denormals
+        rsa.fill_splitmix(bits, seed=6)
+    elif variant == "duplicate_heavy":    # SURVEY.md 8d cfg 4 (iii): stability observable
+        rsa.fill_splitmix(bits, seed=12, mask=0xFFF000FF)
+    else:                                 # (ii): (int24 - 2^23) * 2^-23, exact on every platform
+        r = torch.empty(N, dtype=torch.int64, device="cuda")
+        rsa.fill_splitmix(r, seed=7)
+        f = (((r >> 40) & 0xFFFFFF) - (1 << 23)).to(torch.float32) * (2.0 ** -23)
+        bits = f.view(torch.int32).contiguous()
+        del r, f
+    ib = torch.full((2 * N,), -1, dtype=torch.int32, device="cuda")
+    keep = bits.clone()
+    ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert torch.equal(bits, keep)                                       # src is const (radix_sort_rank.hpp:97)
+    assert info.result_in_aux == (info.ncols & 1)                        # radix_sort_rank.hpp:88,:91
+    r64 = ranks.to(torch.int64)
+    # a permutation: every index once
+    seen = torch.zeros(N, dtype=torch.int8, device="cuda")
+    seen[r64] = 1
+    assert int(seen.sum().item()) == N
+    del seen
+    # keys in rank order are non-decreasing by KDF, and equal KDF keys keep input order (stability)
+    g = bits[r64]
+    kdf = torch.where(g < 0, ~g, g ^ SIGN32) ^ SIGN32                    # float KDF, then to signed-comparable
+    ok_order = kdf[1:] >= kdf[:-1]
+    assert bool(ok_order.all().item())
+    same = kdf[1:] == kdf[:-1]
+    assert bool((r64[1:][same] > r64[:-1][same]).all().item())
+    if variant == "duplicate_heavy":
+        assert int(same.sum().item()) > N // 2
+
+
+def test_cfg4_pairs_f32_u32_payload():
+    """The same configuration through the key+payload entry point (keys and payloads both move)."""
+    keys = torch.empty(N, dtype=torch.int32, device="cuda")
+    rsa.fill_splitmix(keys, seed=12, mask=0xFFF000FF)
+    vals = torch.arange(N, dtype=torch.int32, device="cuda")
+    ka, va = torch.empty_like(keys), torch.empty_like(vals)
+    orig = keys.clone()
+    kr, vr, info = rsa.radix_sort_pairs(keys, ka, vals, va, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert torch.equal(orig[vr.to(torch.int64)], kr)                     # payload still belongs to its key
+    kdf = torch.where(kr < 0, ~kr, kr ^ SIGN32) ^ SIGN32
+    assert bool((kdf[1:] >= kdf[:-1]).all().item())
+    same = kdf[1:] == kdf[:-1]
+    assert bool((vr[1:][same] > vr[:-1][same]).all().item())            # stable
