@@ -1,0 +1,54 @@
+"""Times BASELINE.json's other single-GPU configurations (cfg 3: 2^28 u64 with column skipping; cfg 4: 2^28 f32 keys +
+u32 ranks / payload) the way bench.py times cfg 2: fresh unsorted device-resident batches, whole sorts, wall clock over K steps."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import radix_sorting_amd as rsa
+
+N, K, W = 1 << 28, 8, 2
+rsa.require_gpu()
+out = []
+
+def timed(name, make, run, bytes_per_key):
+    batches = [make(i) for i in range(K + W)]
+    for i in range(W):
+        run(batches[i])
+    torch.cuda.synchronize()
+    rsa.profile_begin()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        info = run(batches[i])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    p = rsa.profile_end()
+    row = {"config": name, "ms_per_sort": dt * 1e3, "Gkeys_per_s": N / dt / 1e9, "kept_columns": info.ncols,
+           "algorithmic_bytes_per_key": bytes_per_key(info.ncols), "algorithmic_GBps": N * bytes_per_key(info.ncols) / dt / 1e9,
+           "scatter_ms_per_launch": p.scatter_ms / max(p.scatter_launches, 1),
+           "scatter_GBps": p.scatter_bytes / max(p.scatter_ms, 1e-9) / 1e6, "hist_ms": p.hist_ms / K}
+    out.append(row)
+    print(json.dumps(row), flush=True)
+    del batches
+    torch.cuda.empty_cache()
+
+aux64 = torch.empty(N, dtype=torch.int64, device="cuda")
+def mk64(mask):
+    def f(i):
+        t = torch.empty(N, dtype=torch.int64, device="cuda"); rsa.fill_splitmix(t, seed=3 + i, mask=mask); return t
+    return f
+def run64(t):
+    return rsa.radix_sort(t, aux64, dtype=rsa.U64)[1]
+for name, mask in (("cfg3 u64 uniform (P=8)", 0xFFFFFFFFFFFFFFFF), ("cfg3 u64 & 0xFFFFFFFFFF (P=5)", 0xFFFFFFFFFF), ("cfg3 u64 & 0xFFFFFFFF (P=4)", 0xFFFFFFFF)):
+    timed(name, mk64(mask), run64, lambda P: (1 + 2 * P) * 8)
+del aux64
+ib = torch.empty(2 * N, dtype=torch.int32, device="cuda")
+def mk32(mask):
+    def f(i):
+        t = torch.empty(N, dtype=torch.int32, device="cuda"); rsa.fill_splitmix(t, seed=6 + i, mask=mask); return t
+    return f
+def runrank(t):
+    return rsa.radix_sort_rank(t, ib, dtype=rsa.F32)[1]
+timed("cfg4 f32 random bits -> u32 ranks", mk32(0xFFFFFFFF), runrank, lambda P: 4 + P * 2 * 8)
+timed("cfg4 f32 & 0xFFF000FF -> u32 ranks", mk32(0xFFF000FF), runrank, lambda P: 4 + P * 2 * 8)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
