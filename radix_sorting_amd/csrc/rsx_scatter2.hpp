@@ -78,6 +78,10 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	typedef StatusBits<ST> SB_;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, TPS = C::TPS, SB = C::SB, CHUNK = C::CHUNK;
 	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
+	// One tile per super-tile: the tile's keys stay in registers between the count and the staging, so they
+	// are read from memory once.  (With more tiles per super-tile they are re-read out of L2 / Infinity Cache.)
+	constexpr bool KEEP = TPS == 1 && !HAS_VAL;   // (with a payload the registers are needed for the positions)
+	KT keep[KEEP ? KPT : 1];
 	__shared__ Sc2Smem<KT, VT, ST, C> sm;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const u64 t_start = TL ? __builtin_readcyclecounter() : 0;
@@ -113,11 +117,51 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 #pragma unroll
 				for (int i = 0; i < NV; ++i)
 					v[i] = vp[i * 64];
+				if constexpr (KEEP) {
+					// 16-byte loads give lane l the elements 4(64 i + l) .. +3; ranking wants round r = element 64 r + l.
+					// Transpose through the wave's own slice of the (still unused) staging area: linear write, strided
+					// read.  DS operations of one wave execute in issue order, so no barrier is needed.
+					KT *scratch = (KT *)sm.stage_raw + (u32)wid * (64 * KPT);
 #pragma unroll
-				for (int i = 0; i < NV; ++i) {
+					for (int i = 0; i < NV; ++i)
+						*((vec_t *)scratch + i * 64 + lane) = v[i];
+					RSX_COMPILER_FENCE();
 #pragma unroll
-					for (int e = 0; e < VEC; ++e) {
-						const u32 d = digit2<DIG>((KT)v[i][e], ka, shift, flags, lut);
+					for (int r = 0; r < KPT; ++r)
+						keep[r] = scratch[r * 64 + lane];
+					RSX_COMPILER_FENCE();
+#pragma unroll
+					for (int r = 0; r < KPT; ++r) {
+						const u32 d = digit2<DIG>(keep[r], ka, shift, flags, lut);
+						if constexpr (C::CELL16)
+							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
+						else
+							atomicAdd(&wc[d], 1u);
+					}
+				} else {
+#pragma unroll
+					for (int i = 0; i < NV; ++i) {
+#pragma unroll
+						for (int e = 0; e < VEC; ++e) {
+							const u32 d = digit2<DIG>((KT)v[i][e], ka, shift, flags, lut);
+							if constexpr (C::CELL16)
+								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
+							else
+								atomicAdd(&wc[d], 1u);
+						}
+					}
+				}
+			} else if constexpr (KEEP) {
+#pragma unroll
+				for (int r = 0; r < KPT; ++r) {
+					const u32 o = wofs + r * 64;
+					keep[r] = o < cnt ? kin[base + o] : (KT)0;
+				}
+#pragma unroll
+				for (int r = 0; r < KPT; ++r) {
+					const u32 o = wofs + r * 64;
+					if (o < cnt) {
+						const u32 d = digit2<DIG>(keep[r], ka, shift, flags, lut);
 						if constexpr (C::CELL16)
 							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 						else
@@ -308,8 +352,17 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				}
 			}
 		};
-		// two batches of loads are in flight while one is ranked and staged
-		{
+		if constexpr (KEEP) {
+#pragma unroll
+			for (int r0 = 0; r0 < KPT; r0 += SB) {
+				KT cur[SB];
+#pragma unroll
+				for (int r = 0; r < SB; ++r)
+					cur[r] = keep[r0 + r];
+				stage_batch(cur, r0);
+			}
+		} else {
+			// two batches of loads are in flight while one is ranked and staged
 			KT b0[SB], b1[SB];
 			load_batch(b0, 0);
 #pragma unroll
