@@ -1,6 +1,7 @@
 // scatter_probe: tuning harness for rsx_scatter_kernel (tile shapes, phase timeline).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc tools/ubench/scatter_probe.hip -o tools/ubench/scatter_probe.bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc -I tools/ubench tools/ubench/scatter_probe.hip -o tools/ubench/scatter_probe.bin
 #include "rsx_scatter2.hpp"
+#include "rsx_scatter3_experimental.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -136,6 +137,77 @@ float run2_once(u32 shift, bool dump, u32 tps)
 	return ms;
 }
 
+template <typename C, bool TL>
+float run3_once(u32 shift, bool dump, u32 grid)
+{
+	const u64 tiles = (n + C::TILE - 1) / C::TILE;
+	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter3_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, d_out, (u64)n, shift,
+	                   d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags,
+	                   (const uint8_t *)nullptr, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	if (TL && dump) {
+		std::vector<u64> tl(tiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, st = 0, depth = 0, life = 0;
+		u64 cntd = 0;
+		for (u64 s = 0; s < tiles; ++s) {
+			const u64 *r = &tl[s * 16];
+			if (r[0] == 0 || r[4] == 0)
+				continue;
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			st += (double)(r[4] - r[2]);
+			life += (double)(r[4] - r[0]);
+			depth += r[12];
+			++cntd;
+		}
+		if (tiles > 4400) {
+			// how 256 consecutive tiles (one per CU) lie in time: spread of each stamp, relative to the first tile's F start
+			for (int k = 9; k <= 10; ++k) {
+				std::vector<double> ts;
+				for (u64 s2 = 4096; s2 < 4096 + 256; ++s2)
+					ts.push_back(((double)tl[s2 * 16 + k] - (double)tl[4096 * 16 + 9]) * 24.0);   // 100 MHz ticks -> ~2.4 GHz cycles
+				std::sort(ts.begin(), ts.end());
+				printf("    %s of tiles 4096..4351 (cycles after tile 4096's barrier #1): min %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f\n",
+				       k == 9 ? "barrier #1" : "barrier #4", ts[0], ts[25], ts[128], ts[230], ts[255]);
+			}
+			printf("    barrier #1 of tile 4352 (next round): %8.0f\n", ((double)tl[4352 * 16 + 9] - (double)tl[4096 * 16 + 9]) * 24.0);
+		}
+		printf("  per tile: F (write-out of the previous + refill + count) %8.0f | layout %6.0f | chain %7.0f (depth %.1f) | stage(incl chain) %7.0f | lifetime %8.0f\n",
+		       a / cntd, lay / cntd, ch / cntd, depth / cntd, st / cntd, life / cntd);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench3(const char *name, u32 grid)
+{
+	run3_once<C, false>(0, false, grid);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run3_once<C, false>(8 * (i % 4), false, grid);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-12s grid %u tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, grid, C::TILE,
+	       sizeof(Sc3Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run3_once<C, true>(0, true, grid);
+}
+
 template <typename C>
 void bench2(const char *name, u32 tps)
 {
@@ -189,18 +261,29 @@ int main(int argc, char **argv)
 	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, 1u, ka, d_flag + 8);
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
-	bench2<Sc2Cfg<u32, NoVal, 16, 2>>("v2 16w tps2", 2);
-	g_flags = SCATTER_DBG_NOSTORE;
-	printf("-- no stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
-	g_flags = SCATTER_DBG_NOLOADB | SCATTER_DBG_NOSTORE;
-	printf("-- no phase-B loads, no stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal, 16, 2>, true>(0, true, 2));
+	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	bench3<Sc3Cfg<u32>>("v3 default", 256);
+		g_flags = SCATTER_DBG_NOSTORE;
+	printf("-- v3 no stores: %.3f ms\n", run3_once<Sc3Cfg<u32>, true>(0, true, 256));
 	g_flags = 0;
-	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, false>>("v2 16w c32 tps1", 1);
-	bench2<Sc2Cfg<u32, NoVal, 8, 2>>("v2 8w tps2", 2);
+	bench3<Sc3Cfg<u32, 16, 8, 0>>("v3 nostagger", 256);
+	bench3<Sc3Cfg<u32, 16, 8, 60000>>("v3 stag60k", 256);
+	bench3<Sc3Cfg<u32, 16, 4>>("v3 lb4", 256);
+	bench3<Sc3Cfg<u32, 16, 16>>("v3 lb16", 256);
+	{
+		typedef Sc3Cfg<u32> C;
+		run3_once<C, false>(0, false, 256);
+		std::vector<u32> out(1 << 20);
+		CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+		size_t bad = 0;
+		for (size_t i = 1; i < out.size(); ++i)
+			bad += (out[i - 1] & 0xFF) > (out[i] & 0xFF);
+		printf("v3 check: digit order violations in the first 2^20 outputs: %zu\n", bad);
+	}
 	// correctness of v2: digits of the output must be non-decreasing and the multiset preserved (checked via sum)
 	{
-		typedef Sc2Cfg<u32, NoVal, 16, 2> C;
-		run2_once<C, false>(0, false, 2);
+		typedef Sc2Cfg<u32, NoVal> C;
+		run2_once<C, false>(0, false, 1);
 		std::vector<u32> out(1 << 20), in(1 << 20);
 		CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
 		size_t bad = 0;

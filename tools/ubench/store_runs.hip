@@ -61,12 +61,110 @@ __global__ __launch_bounds__(512) void k(u32 *out, u64 stream_stride_elems, u32 
 	}
 }
 
+// XCD-affine variant: workgroup b (on XCD b % 8) takes its tiles from XCD b % 8's own counter; the s-th ticket of XCD x
+// is tile (s / K) * 8K + x * K + s % K: blocks of K consecutive tiles stay on one XCD (one L2).
+__global__ __launch_bounds__(512) void kx(u32 *out, u64 stream_stride_elems, u32 run_elems, u32 ntiles, u32 misalign, u32 *ticket,
+                                          u32 K)
+{
+	__shared__ u32 s_t;
+	const u32 tid = threadIdx.x, x = blockIdx.x & 7;
+	for (;;) {
+		if (tid == 0)
+			s_t = atomicAdd(ticket + x * 32, 1u);
+		__syncthreads();
+		const u32 s = s_t;
+		__syncthreads();
+		const u32 t = (s / K) * 8 * K + x * K + s % K;
+		if (t >= ntiles)
+			return;
+		const u32 tile_elems = 256 * run_elems;
+		for (u32 i0 = tid * 4; i0 < tile_elems; i0 += 512 * 4) {
+			const u32 r = i0 / run_elems, o = i0 % run_elems;
+			u32 *dst = out + (u64)r * stream_stride_elems + misalign * (r & 3) + (u64)t * run_elems + o;
+			*(uu32x4 *)dst = u32x4{i0, t, r, o};
+		}
+	}
+}
+
 int main()
 {
 	const u64 total_elems = 1ull << 28;
 	u32 *d, *d_ticket;
 	hipMalloc(&d, total_elems * 4 + (1 << 20));
-	hipMalloc(&d_ticket, 4);
+	hipMalloc(&d_ticket, 1024);
+	printf("-- working-set size: misaligned 512-B runs into a region of W bytes, rewritten until 4 GiB are stored (does the Infinity Cache absorb the partial writes?)\n");
+	for (u64 wlog : {24ull, 25ull, 26ull, 27ull, 28ull, 30ull}) {
+		const u64 welems = (1ull << wlog) / 4;
+		const u32 run_elems = 128;
+		const u32 ntiles = (u32)(welems / (256ull * run_elems));
+		const u64 stride = welems / 256;
+		const int reps = (int)((1ull << 32) / (1ull << wlog));
+		for (u32 m : {0u, 1u}) {
+			hipEvent_t e0, e1;
+			(void)hipEventCreate(&e0);
+			(void)hipEventCreate(&e1);
+			(void)hipMemset(d_ticket, 0, 1024);
+			hipLaunchKernelGGL(k, dim3(512), dim3(512), 0, 0, d, stride, run_elems, ntiles, m, d_ticket);
+			(void)hipDeviceSynchronize();
+			float tot = 0;
+			for (int rep = 0; rep < reps; ++rep) {
+				(void)hipMemset(d_ticket, 0, 1024);
+				(void)hipEventRecord(e0);
+				hipLaunchKernelGGL(k, dim3(512), dim3(512), 0, 0, d, stride, run_elems, ntiles, m, d_ticket);
+				(void)hipEventRecord(e1);
+				(void)hipEventSynchronize(e1);
+				float ms;
+				(void)hipEventElapsedTime(&ms, e0, e1);
+				tot += ms;
+			}
+			printf("W = 2^%llu B shift %u: %.0f GB/s\n", wlog, m, (double)reps * welems * 4.0 / (tot * 1e-3) / 1e9);
+		}
+	}
+	printf("-- stream r shifted by m * (r & 3) elements: which misalignment costs?\n");
+	for (u32 m : {0u, 1u, 2u, 4u, 8u, 16u, 32u}) {
+		const u32 run_bytes = 512, run_elems = run_bytes / 4;
+		const u32 ntiles = (u32)(total_elems / (256ull * run_elems));
+		const u64 stride = total_elems / 256;
+		float best = 1e9;
+		for (int rep = 0; rep < 3; ++rep) {
+			(void)hipMemset(d_ticket, 0, 1024);
+			hipEvent_t e0, e1;
+			(void)hipEventCreate(&e0);
+			(void)hipEventCreate(&e1);
+			(void)hipEventRecord(e0);
+			hipLaunchKernelGGL(k, dim3(512), dim3(512), 0, 0, d, stride, run_elems, ntiles, m, d_ticket);
+			(void)hipEventRecord(e1);
+			(void)hipEventSynchronize(e1);
+			float ms;
+			(void)hipEventElapsedTime(&ms, e0, e1);
+			best = std::min(best, ms);
+		}
+		printf("run 512 B shift %2u elements: %.3f ms  %.0f GB/s\n", m, best, total_elems * 4.0 / (best * 1e-3) / 1e9);
+	}
+	return 0;
+	printf("-- XCD-affine tile blocks (misaligned streams)\n");
+	for (u32 run_bytes : {128u, 256u, 512u, 1024u}) {
+		for (u32 K : {1u, 4u, 32u, 128u}) {
+			const u32 run_elems = run_bytes / 4;
+			const u32 ntiles = (u32)(total_elems / (256ull * run_elems));
+			const u64 stride = total_elems / 256;
+			float best = 1e9;
+			for (int rep = 0; rep < 3; ++rep) {
+				hipMemset(d_ticket, 0, 1024);
+				hipEvent_t e0, e1;
+				hipEventCreate(&e0);
+				hipEventCreate(&e1);
+				hipEventRecord(e0);
+				hipLaunchKernelGGL(kx, dim3(512), dim3(512), 0, 0, d, stride, run_elems, ntiles, 1u, d_ticket, K);
+				hipEventRecord(e1);
+				hipEventSynchronize(e1);
+				float ms;
+				hipEventElapsedTime(&ms, e0, e1);
+				best = std::min(best, ms);
+			}
+			printf("run %5u B  K %3u: %.3f ms  %.0f GB/s\n", run_bytes, K, best, total_elems * 4.0 / (best * 1e-3) / 1e9);
+		}
+	}
 	for (u32 misalign : {0u, 1u}) {
 		for (u32 run_bytes : {32u, 64u, 128u, 256u, 512u, 1024u, 4096u}) {
 			const u32 run_elems = run_bytes / 4;
