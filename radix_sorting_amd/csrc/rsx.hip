@@ -336,7 +336,7 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 	typedef HistCfg<KT> C;
 	const u64 per_block = (u64)C::BLOCK * C::U * C::VEC;     // elements one block covers per sweep
 	u64 bps = (g.seg_elems + per_block - 1) / per_block;
-	const u64 cap = 2048 / g.nseg > 0 ? 2048 / g.nseg : 1;    // about 256 CUs x 8 workgroups in all
+	const u64 cap = 512 / g.nseg > 0 ? 512 / g.nseg : 1;      // 256 CUs x 2 workgroups of 1024 threads in all
 	if (bps > cap)
 		bps = cap;
 	if (bps < 1)

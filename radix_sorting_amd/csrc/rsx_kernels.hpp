@@ -77,12 +77,15 @@ __device__ __forceinline__ u32 mbcnt64(u64 m)
 // Kernel 1: histogram of all columns + pre-sorted test
 // =============================================================================
 
-template <typename KT> struct HistCfg {
+// Measured on MI355X, 2^28 u32 (tools/ubench/hist_probe.hip): the kernel is bound by the LDS atomics (four per key,
+// about ten cycles per wave-instruction and CU), so what matters is a full CU (32 waves = two workgroups of 1024) and
+// few workgroups (each ends with one global atomic per bin): 0.26 ms against 0.35 ms for 2048 workgroups of 256.
+template <typename KT, int BLOCK_ = 1024, int U_ = 4, int R_ = (sizeof(KT) == 8 ? 8 : 16)> struct HistCfg {
 	static constexpr int WC = sizeof(KT);               // columns
 	static constexpr int VEC = 16 / sizeof(KT);         // elements per 16-byte lane load
-	static constexpr int R = sizeof(KT) == 8 ? 4 : 8;   // lane-striped copies per bin
-	static constexpr int BLOCK = 256;
-	static constexpr int U = 4;                         // independent 16-byte loads in flight per lane
+	static constexpr int R = R_;                        // lane-striped copies per bin
+	static constexpr int BLOCK = BLOCK_;
+	static constexpr int U = U_;                        // independent 16-byte loads in flight per lane
 };
 
 template <typename KT, int R>
@@ -97,12 +100,11 @@ __device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane)
 
 // grid = nseg * blocks_per_seg.  With nseg > 1 the host guarantees that src is 16-byte aligned
 // and seg_elems is a multiple of VEC.
-template <typename KT>
-__global__ __launch_bounds__(256) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
-                                                       u32 *__restrict__ unsorted, KdfArgs<KT> ka, u32 nseg,
-                                                       u32 blocks_per_seg, u64 seg_elems)
+template <typename KT, typename C = HistCfg<KT>>
+__global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
+                                                            u32 *__restrict__ unsorted, KdfArgs<KT> ka, u32 nseg,
+                                                            u32 blocks_per_seg, u64 seg_elems)
 {
-	typedef HistCfg<KT> C;
 	constexpr int WC = C::WC, VEC = C::VEC, R = C::R, U = C::U;
 	__shared__ u32 lh[WC * 256 * R];
 	const u32 tid = threadIdx.x;
