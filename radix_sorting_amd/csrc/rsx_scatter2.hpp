@@ -80,7 +80,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
 	// One tile per super-tile: the tile's keys stay in registers between the count and the staging, so they
 	// are read from memory once.  (With more tiles per super-tile they are re-read out of L2 / Infinity Cache.)
-	constexpr bool KEEP = TPS == 1 && !HAS_VAL;   // (with a payload the registers are needed for the positions)
+	constexpr bool KEEP = TPS == 1;
 	KT keep[KEEP ? KPT : 1];
 	__shared__ Sc2Smem<KT, VT, ST, C> sm;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -98,6 +98,18 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	if (end > n)
 		end = n;
 	const u32 wofs = wid * (64 * KPT) + lane;   // wave w owns [w*64*KPT, +64*KPT) of a tile; round r: element 64 r + lane
+	// Element `base + wofs + 64 r` of an array: a uniform (scalar) address for (base, r) plus ONE 32-bit lane offset,
+	// instead of a 64-bit address per round kept in registers (or spilled) across the tile.
+	auto elem = [&](const auto *arr, const u64 base, const int r, const u32 wo) {
+		typedef std::remove_cv_t<std::remove_pointer_t<decltype(arr)>> T;
+		return *(const T *)((const char *)(arr + base + (u64)r * 64) + wo * (u32)sizeof(T));
+	};
+	// A partial tile (the last one) works on an opaque copy of wofs: what it derives from it (32 bounds tests, ...) is
+	// then computed there and not hoisted in front of the branch, where every tile would pay for it with registers.
+	auto opaque = [](u32 x) {
+		asm volatile("" : "+v"(x));
+		return x;
+	};
 
 	// ---- phase A: count, per tile and wave.  Order inside a wave's slice does not matter here, so the
 	// slice is streamed with 16-byte loads (when the keys are 16-byte aligned), all of them in flight.
@@ -152,14 +164,15 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					}
 				}
 			} else if constexpr (KEEP) {
+				const u32 wo = opaque(wofs);
 #pragma unroll
 				for (int r = 0; r < KPT; ++r) {
-					const u32 o = wofs + r * 64;
-					keep[r] = o < cnt ? kin[base + o] : (KT)0;
+					const u32 o = wo + r * 64;
+					keep[r] = o < cnt ? elem(kin, base, r, wo) : (KT)0;
 				}
 #pragma unroll
 				for (int r = 0; r < KPT; ++r) {
-					const u32 o = wofs + r * 64;
+					const u32 o = wo + r * 64;
 					if (o < cnt) {
 						const u32 d = digit2<DIG>(keep[r], ka, shift, flags, lut);
 						if constexpr (C::CELL16)
@@ -169,17 +182,18 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					}
 				}
 			} else {
+				const u32 wo = opaque(wofs);
 #pragma unroll 1
 				for (int r0 = 0; r0 < KPT; r0 += SB) {
 					KT cur[SB];
 #pragma unroll
 					for (int r = 0; r < SB; ++r) {
-						const u32 o = wofs + (r0 + r) * 64;
-						cur[r] = o < cnt ? kin[base + o] : (KT)0;
+						const u32 o = wo + (r0 + r) * 64;
+						cur[r] = o < cnt ? elem(kin, base, r0 + r, wo) : (KT)0;
 					}
 #pragma unroll
 					for (int r = 0; r < SB; ++r) {
-						const u32 o = wofs + (r0 + r) * 64;
+						const u32 o = wo + (r0 + r) * 64;
 						if (o < cnt) {
 							const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
 							if constexpr (C::CELL16)
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	KT *stage_k = (KT *)sm.stage_raw;
 	auto do_tile = [&](auto full_c, const int t, const u64 base, const u32 cnt) {
 		constexpr bool full = decltype(full_c)::value;   // a whole tile: no bounds checks
+		const u32 wo = full ? wofs : opaque(wofs);
 		u32 *wc = sm.cell[t][wid];
 		const ST *delta = sm.delta[t];
 
@@ -316,11 +331,11 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		auto load_batch = [&](KT (&dst)[SB], const int r0) {
 #pragma unroll
 			for (int r = 0; r < SB; ++r) {
-				const u32 o = wofs + (r0 + r) * 64;
+				const u32 o = wo + (r0 + r) * 64;
 				if (TL && (flags & SCATTER_DBG_NOLOADB))
 					dst[r] = (KT)((o ^ (u32)base) * 2654435761u);
 				else
-					dst[r] = (full || o < cnt) ? kin[base + o] : (KT)0;
+					dst[r] = (full || o < cnt) ? elem(kin, base, r0 + r, wo) : (KT)0;
 			}
 		};
 		auto stage_batch = [&](const KT (&cur)[SB], const int r0) {
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			u32 pos[SB];
 #pragma unroll
 			for (int r = 0; r < SB; ++r) {
-				const u32 o = wofs + (r0 + r) * 64;
+				const u32 o = wo + (r0 + r) * 64;
 				pos[r] = 0;
 				if (full || o < cnt) {
 					const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			}
 #pragma unroll
 			for (int r = 0; r < SB; ++r) {
-				const u32 o = wofs + (r0 + r) * 64;
+				const u32 o = wo + (r0 + r) * 64;
 				if (full || o < cnt) {
 					stage_k[pos[r]] = cur[r];
 					if constexpr (HAS_VAL)
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		for (int j = 0; j < KPT / CHUNK; ++j) {
 			if (j % 4 == 0)
 				__builtin_amdgcn_sched_barrier(0);   // keep a few chunks' registers alive at a time
-			const u32 i0 = CHUNK * (tid + j * BLOCK);
+			const u32 i0 = opaque(CHUNK * tid) + CHUNK * j * BLOCK;   // (recomputed: kept across the tile, the indices cost registers)
 			KT kv[CHUNK];
 			u32 d[CHUNK];
 			{
@@ -428,12 +443,12 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				VT val[SB];
 #pragma unroll
 				for (int r = 0; r < SB; ++r) {
-					const u32 o = wofs + (r0 + r) * 64;
-					val[r] = gen_index ? (VT)(base + o) : ((full || o < cnt) ? vin[base + o] : (VT)0);
+					const u32 o = wo + (r0 + r) * 64;
+					val[r] = gen_index ? (VT)(base + o) : ((full || o < cnt) ? elem(vin, base, r0 + r, wo) : (VT)0);
 				}
 #pragma unroll
 				for (int r = 0; r < SB; ++r) {
-					const u32 o = wofs + (r0 + r) * 64;
+					const u32 o = wo + (r0 + r) * 64;
 					if (full || o < cnt)
 						stage_v[(posp[(r0 + r) >> 1] >> (16 * ((r0 + r) & 1))) & 0xFFFFu] = val[r];
 				}
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			for (int j = 0; j < KPT / CHUNK; ++j) {
 				if (j % 4 == 0)
 					__builtin_amdgcn_sched_barrier(0);
-				const u32 i0 = CHUNK * (tid + j * BLOCK);
+				const u32 i0 = opaque(CHUNK * tid) + CHUNK * j * BLOCK;   // (recomputed: kept across the tile, the indices cost registers)
 				VT vv[CHUNK];
 				{
 					typedef VT vvec_t __attribute__((ext_vector_type(CHUNK)));
