@@ -210,38 +210,87 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	if (TL && tid == 0)
 		tl[(u64)stile * 16 + 1] = __builtin_readcyclecounter();
 
-	// ---- digit thread d: totals, chain (publish aggregate / look back / publish prefix), tile layouts
+	// ---- digit thread d: totals, publish the aggregate, START the look-back, tile layouts; the chain is
+	// resolved (and the prefix published) after the layout, while waves 4.. are already staging their keys.
 	unsigned short *cell16 = (unsigned short *)&sm.cell[0][0][0];   // [TPS][NWAVES][256]
-	u32 tc[TPS], incl[TPS];
-	u64 excl = 0;
+	constexpr int LB = C::LB;
+	u32 tc[TPS], incl[TPS], tb[TPS];
+	ST w[LB];
+	u32 st_cnt = 0;
+	int back = (int)stile - 1;   // nearest predecessor not consumed yet
+	ST *my_status = status + (stile * 256u + tid);   // (32-bit element offsets from the uniform base)
+	// LB predecessors are fetched per round trip (independent loads) and consumed in order
+	auto look = [&]() {
+		const u32 t = opaque(tid);   // (or the compiler keeps LB loop-invariant offsets in registers)
+#pragma unroll
+		for (int j = 0; j < LB; ++j) {
+			const int p = back - j > 0 ? back - j : 0;   // super-tile 0 always holds a prefix: safe filler
+			w[j] = __hip_atomic_load(status + ((u32)p * 256u + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	};
 	if (tid < 256) {
-		u32 st_cnt = 0;
 #pragma unroll
 		for (int t = 0; t < TPS; ++t) {
 			u32 c = 0;
 #pragma unroll
-			for (int w = 0; w < NWAVES; ++w)
-				c += C::CELL16 ? (u32)cell16[(t * NWAVES + w) * 256 + tid] : sm.cell[t][w][tid & (CW - 1)];
+			for (int k = 0; k < NWAVES; ++k)
+				c += C::CELL16 ? (u32)cell16[(t * NWAVES + k) * 256 + tid] : sm.cell[t][k][tid & (CW - 1)];
 			tc[t] = c;
 			st_cnt += c;
 		}
-		ST *my_status = status + (u64)stile * 256 + tid;
 		const ST word = ((ST)(stile == 0 ? ST_PREFIX : ST_AGGREGATE) << SB_::SHIFT) | (ST)st_cnt;
 		__hip_atomic_store(my_status, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (stile != 0)
+			look();
+		// prefix over digits, per tile (wave scan now, wave totals through LDS)
+#pragma unroll
+		for (int t = 0; t < TPS; ++t) {
+			u32 x = tc[t];
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const u32 y = __shfl_up(x, off);
+				if (lane >= (u32)off)
+					x += y;
+			}
+			incl[t] = x;
+			if (lane == 63)
+				sm.wsum[t][opaque(wid)] = x;
+		}
+	}
+	__syncthreads();
+	if (tid < 256) {
+#pragma unroll
+		for (int t = 0; t < TPS; ++t) {
+			u32 tbase = incl[t] - tc[t];
+			for (u32 k = 0; k < wid; ++k)
+				tbase += sm.wsum[t][k];
+			tb[t] = tbase;
+			u32 acc = tbase;   // counts -> run starts, in place
+#pragma unroll
+			for (int k = 0; k < NWAVES; ++k) {
+				u32 c;
+				if constexpr (C::CELL16) {
+					c = cell16[(t * NWAVES + k) * 256 + tid];
+					cell16[(t * NWAVES + k) * 256 + tid] = (unsigned short)acc;
+				} else {
+					c = sm.cell[t][k][tid & (CW - 1)];
+					sm.cell[t][k][tid & (CW - 1)] = acc;
+				}
+				acc += c;
+			}
+		}
+	}
+	__syncthreads();
+	if (TL && tid == 0) {
+		tl[(u64)stile * 16 + 0] = t_start;
+		tl[(u64)stile * 16 + 2] = __builtin_readcyclecounter();
+	}
+	if (tid < 256) {
+		// the chain: aggregates are summed until the first inclusive prefix; an empty word ends the batch
+		u64 excl = 0;
 		u32 depth = 0;
 		if (stile != 0) {
-			// LB predecessors are fetched per round trip (independent loads), then consumed in order:
-			// aggregates are summed until the first inclusive prefix; an empty word ends the batch.
-			constexpr int LB = C::LB;
-			long back = (long)stile - 1;   // nearest predecessor not consumed yet
-			const ST *col = status + tid;
 			for (;;) {
-				ST w[LB];
-#pragma unroll
-				for (int j = 0; j < LB; ++j) {
-					const long p = back - j > 0 ? back - j : 0;   // super-tile 0 always holds a prefix: safe filler
-					w[j] = __hip_atomic_load(col + (u64)p * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
 				bool done = false;
 				int used = 0;
 #pragma unroll
@@ -259,58 +308,22 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				back -= used;
 				if (used == 0)
 					__builtin_amdgcn_s_sleep(1);
+				look();
 			}
 			const ST pword = ((ST)ST_PREFIX << SB_::SHIFT) | (ST)(excl + st_cnt);
 			__hip_atomic_store(my_status, pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		if (TL && tid == 0) {
-			tl[(u64)stile * 16 + 0] = t_start;
-			tl[(u64)stile * 16 + 2] = __builtin_readcyclecounter();
-			tl[(u64)stile * 16 + 12] = depth;
-		}
-		// prefix over digits, per tile (wave scan now, wave totals through LDS)
-#pragma unroll
-		for (int t = 0; t < TPS; ++t) {
-			u32 x = tc[t];
-#pragma unroll
-			for (int off = 1; off < 64; off <<= 1) {
-				const u32 y = __shfl_up(x, off);
-				if (lane >= (u32)off)
-					x += y;
-			}
-			incl[t] = x;
-			if (lane == 63)
-				sm.wsum[t][wid] = x;
-		}
-	}
-	__syncthreads();
-	if (tid < 256) {
 		u64 running = gbase[tid] + excl;
 #pragma unroll
 		for (int t = 0; t < TPS; ++t) {
-			u32 tbase = incl[t] - tc[t];
-			for (u32 w = 0; w < wid; ++w)
-				tbase += sm.wsum[t][w];
-			u32 acc = tbase;   // counts -> run starts, in place
-#pragma unroll
-			for (int w = 0; w < NWAVES; ++w) {
-				u32 c;
-				if constexpr (C::CELL16) {
-					c = cell16[(t * NWAVES + w) * 256 + tid];
-					cell16[(t * NWAVES + w) * 256 + tid] = (unsigned short)acc;
-				} else {
-					c = sm.cell[t][w][tid & (CW - 1)];
-					sm.cell[t][w][tid & (CW - 1)] = acc;
-				}
-				acc += c;
-			}
-			sm.delta[t][tid] = (ST)(running - tbase);   // modulo 2^32 when ST is 32-bit (n < 2^30 then)
+			sm.delta[t][tid] = (ST)(running - tb[t]);   // modulo 2^32 when ST is 32-bit (n < 2^30 then)
 			running += tc[t];
 		}
+		if (TL && tid == 0) {
+			tl[(u64)stile * 16 + 3] = __builtin_readcyclecounter();
+			tl[(u64)stile * 16 + 12] = depth;
+		}
 	}
-	__syncthreads();
-	if (TL && tid == 0)
-		tl[(u64)stile * 16 + 3] = __builtin_readcyclecounter();
 
 	// ---- phase B: the tiles, in order
 	KT *stage_k = (KT *)sm.stage_raw;

@@ -117,9 +117,9 @@ float run2_once(u32 shift, bool dump, u32 tps)
 		for (u64 s = 0; s < stiles; ++s) {
 			const u64 *r = &tl[s * 16];
 			a += (double)(r[1] - r[0]);
-			lb += (double)(r[2] - r[1]);
-			lay += (double)(r[3] - r[2]);
-			u64 prev = r[3];
+			lay += (double)(r[2] - r[1]);
+			lb += (double)(r[3] - r[2]);
+			u64 prev = r[2];   // staging starts after the layout; the digit threads resolve the chain first
 			for (u32 t = 0; t < tps && t < 4; ++t) {
 				st[t] += (double)(r[4 + 2 * t] - prev);
 				wo[t] += (double)(r[5 + 2 * t] - r[4 + 2 * t]);
@@ -128,8 +128,8 @@ float run2_once(u32 shift, bool dump, u32 tps)
 			life += (double)(prev - r[0]);
 			depth += r[12];
 		}
-		printf("  per super-tile: phase A %8.0f | chain %7.0f (depth %.1f) | layout %6.0f |", a / stiles, lb / stiles, depth / stiles,
-		       lay / stiles);
+		printf("  per super-tile: phase A %8.0f | layout %6.0f | chain %7.0f (depth %.1f) inside |", a / stiles, lay / stiles, lb / stiles,
+		       depth / stiles);
 		for (u32 t = 0; t < tps && t < 4; ++t)
 			printf(" stage%u %7.0f write%u %7.0f |", t, st[t] / stiles, t, wo[t] / stiles);
 		printf(" lifetime %8.0f\n", life / stiles);
@@ -257,7 +257,7 @@ int main(int argc, char **argv)
 	CK(hipMemset(d_hist, 0, 8 * 256 * 8));
 	CK(hipMemset(d_flag, 0, 64));
 	KdfArgs<u32> ka{0, 0, 0};
-	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, d_hist, d_flag, ka, 1u, 2048u, (u64)n);
+	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(512), dim3(HistCfg<u32>::BLOCK), 0, 0, d_in, (u64)n, d_hist, d_flag, ka, 1u, 512u, (u64)n);
 	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, 1u, ka, d_flag + 8);
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
