@@ -133,22 +133,25 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					// 16-byte loads give lane l the elements 4(64 i + l) .. +3; ranking wants round r = element 64 r + l.
 					// Transpose through the wave's own slice of the (still unused) staging area: linear write, strided
 					// read.  DS operations of one wave execute in issue order, so no barrier is needed.
+					// Vector i holds the rounds VEC i .. VEC i + VEC - 1: they are read back and counted as soon as it has
+					// arrived, while the later vectors are still on their way.
 					KT *scratch = (KT *)sm.stage_raw + (u32)wid * (64 * KPT);
 #pragma unroll
-					for (int i = 0; i < NV; ++i)
+					for (int i = 0; i < NV; ++i) {
 						*((vec_t *)scratch + i * 64 + lane) = v[i];
-					RSX_COMPILER_FENCE();
+						RSX_COMPILER_FENCE();
 #pragma unroll
-					for (int r = 0; r < KPT; ++r)
-						keep[r] = scratch[r * 64 + lane];
-					RSX_COMPILER_FENCE();
+						for (int r = i * VEC; r < (i + 1) * VEC; ++r)
+							keep[r] = scratch[r * 64 + lane];
 #pragma unroll
-					for (int r = 0; r < KPT; ++r) {
-						const u32 d = digit2<DIG>(keep[r], ka, shift, flags, lut);
-						if constexpr (C::CELL16)
-							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
-						else
-							atomicAdd(&wc[d], 1u);
+						for (int r = i * VEC; r < (i + 1) * VEC; ++r) {
+							const u32 d = digit2<DIG>(keep[r], ka, shift, flags, lut);
+							if constexpr (C::CELL16)
+								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
+							else
+								atomicAdd(&wc[d], 1u);
+						}
+						RSX_COMPILER_FENCE();
 					}
 				} else {
 #pragma unroll
