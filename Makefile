@@ -6,7 +6,7 @@ ARCH    ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 CSRC     = radix_sorting_amd/csrc
 
-all: lib oracle cpp
+all: lib oracle cpp cli
 
 lib: radix_sorting_amd/librsx.so
 
@@ -23,8 +23,19 @@ tests/cpp/dropin_check: tests/cpp/dropin_check.cpp include/radix_sort.hpp includ
 	g++ -std=gnu++17 -O2 -Wall -Iinclude tests/cpp/dropin_check.cpp -Lradix_sorting_amd -lrsx \
 	-Wl,-rpath,'$$ORIGIN/../../radix_sorting_amd' -Wl,-rpath-link,/opt/rocm/lib -o $@
 
+# counterparts of the reference's `radix` and `radix_bench` commands on this repo's headers (tools/radix.cpp, tools/radix_bench.cpp)
+cli: tools/radix tools/radix_bench
+
+tools/radix: tools/radix.cpp include/radix_sort.hpp include/radix_sort_basic_kdf.hpp include/rsx.h radix_sorting_amd/librsx.so
+	g++ -std=gnu++17 -O2 -Wall -Iinclude tools/radix.cpp -Lradix_sorting_amd -lrsx \
+	-Wl,-rpath,'$$ORIGIN/../radix_sorting_amd' -Wl,-rpath-link,/opt/rocm/lib -o $@
+
+tools/radix_bench: tools/radix_bench.cpp include/radix_sort.hpp include/radix_sort_rank.hpp include/radix_sort_basic_kdf.hpp include/rsx.h radix_sorting_amd/librsx.so
+	g++ -std=gnu++17 -O2 -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/radix_bench.cpp -Lradix_sorting_amd -lrsx \
+	-L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../radix_sorting_amd' -Wl,-rpath,/opt/rocm/lib -o $@
+
 clean:
-	rm -f radix_sorting_amd/librsx.so tests/cpp/dropin_check
+	rm -f radix_sorting_amd/librsx.so tests/cpp/dropin_check tools/radix tools/radix_bench
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle cpp clean
+.PHONY: all lib oracle cpp cli clean

@@ -37,3 +37,42 @@ def test_reference_tests_run_unmodified_on_our_headers():
     for line in ("Sorting struct sortrec... OK", "Sorting struct sortrec** (reverse)... OK", "Sorting float[]... OK",
                  "Rank sorting struct sortrec... OK"):
         assert line in out.stdout
+
+
+def _cli(name):
+    exe = os.path.join(ROOT, "tools", name)
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "cli"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("ktype,mask,where", [("uint32_t", None, "source"), ("uint32_t", "00FFFFFF", "auxilary"),
+                                               ("uint64_t", "FFFFFFFFFF", "auxilary"), ("float", None, "source"),
+                                               ("int32_t", None, "source"), ("double", None, "source"), ("uint8_t", None, "auxilary")])
+def test_radix_cli_counterpart(tmp_path, ktype, mask, where):
+    """tools/radix prints the reference's lines (radix_experiment.cpp:241-285) and sorts correctly."""
+    args = [_cli("radix"), "1000000", "0", "0", ktype] + ([mask] if mask else [])
+    out = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=tmp_path)   # no key file there: generated
+    assert out.returncode == 0, out.stdout + out.stderr
+    n = {"uint8_t": 1000000, "uint64_t": 1000000, "double": 1000000}.get(ktype, 1000000)
+    for needle in ("src='40M_32bit_keys.dat', entries=1000000, use_mmap=0, use_huge=0, type='%s'" % ktype,
+                   "Sorting %d entries..." % n, "Verifying sort... Forward sorted OK.", "[...]",
+                   "Sorted %d entries in " % n, "Result in the %s buffer" % where):
+        assert needle in out.stdout, (needle, out.stdout)
+    if mask:
+        assert "Applying value mask to input." in out.stdout
+    dump = [l for l in out.stdout.splitlines() if len(l) > 10 and l[8] == ":" and l[:8].isdigit()]
+    assert len(dump) == 20 and dump[0].startswith("00000000: ") and dump[-1].startswith("%08d: " % (n - 1))
+
+
+def test_radix_bench_counterpart(tmp_path):
+    """tools/radix_bench prints the reference's row names and columns for the sizes 1 .. 4*10^7."""
+    out = subprocess.run([_cli("radix_bench"), "--min-time", "0.05", "--filter", "radix_sort", "--device"], capture_output=True,
+                         text=True, timeout=900, cwd=tmp_path)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l.split() for l in out.stdout.splitlines() if l.startswith("FSu32/")]
+    names = [r[0] for r in rows]
+    for kind in ("radix_sort", "radix_sort_rank", "radix_sort_device"):
+        for n in (1, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 40000000):
+            assert "FSu32/%s/%d" % (kind, n) in names
+    assert "KeyRate" in out.stdout and "bytes_per_second" in out.stdout
