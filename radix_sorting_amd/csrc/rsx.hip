@@ -122,6 +122,7 @@ struct Ctx {
 	// fixed small state: [unsorted u32 | pad 64][Plan 64][kept 8 u32 | pad 64][lut 256][bucket totals 256 u64]
 	DevBuf small;
 	DevBuf hist;        // counts / offsets [nseg][key bytes][256] u64 (see "Segments" in rsx_kernels.hpp)
+	DevBuf hpart;       // the histogram kernel's per-workgroup rows [workgroups][key bytes][256] u32
 	DevBuf bbase;       // MSD split: bucket offsets [nseg][256] u64
 	DevBuf status;      // [ticket u32, pad to 256 B][tiles * 256 status words]
 	DevBuf keys[2];     // key ping-pong for rank sorts / host staging
@@ -153,6 +154,7 @@ struct Ctx {
 	{
 		small.release();
 		hist.release();
+		hpart.release();
 		bbase.release();
 		status.release();
 		for (int i = 0; i < 2; ++i) {
@@ -341,9 +343,13 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 		bps = cap;
 	if (bps < 1)
 		bps = 1;
+	const u32 cols256 = (u32)sizeof(KT) * 256;
+	RSX_TRY(c.hpart.ensure((size_t)g.nseg * bps * cols256 * sizeof(u32)));
 	ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
 	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)(g.nseg * bps)), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
-	                   d_hist, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems);
+	                   (u32 *)c.hpart.p, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems);
+	hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)(g.nseg * sizeof(KT)), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
+	                   (const u32 *)c.hpart.p, d_hist, (u32)bps, cols256);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }

@@ -78,9 +78,10 @@ __device__ __forceinline__ u32 mbcnt64(u64 m)
 // =============================================================================
 
 // Measured on MI355X, 2^28 u32 (tools/ubench/hist_probe.hip): the kernel is bound by the LDS atomics (four per key,
-// about ten cycles per wave-instruction and CU), so what matters is a full CU (32 waves = two workgroups of 1024) and
-// few workgroups (each ends with one global atomic per bin): 0.26 ms against 0.35 ms for 2048 workgroups of 256.
-template <typename KT, int BLOCK_ = 1024, int U_ = 4, int R_ = (sizeof(KT) == 8 ? 8 : 16)> struct HistCfg {
+// about ten cycles per wave-instruction and CU), so what matters is a full CU (32 waves = two workgroups of 1024), few
+// workgroups, and no more than two or three 16-byte loads in flight per lane (0.23-0.27 ms; four: 0.32; 2048
+// workgroups of 256: 0.36).
+template <typename KT, int BLOCK_ = 1024, int U_ = 2, int R_ = (sizeof(KT) == 8 ? 8 : 16)> struct HistCfg {
 	static constexpr int WC = sizeof(KT);               // columns
 	static constexpr int VEC = 16 / sizeof(KT);         // elements per 16-byte lane load
 	static constexpr int R = R_;                        // lane-striped copies per bin
@@ -101,17 +102,20 @@ __device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane)
 // grid = nseg * blocks_per_seg.  With nseg > 1 the host guarantees that src is 16-byte aligned
 // and seg_elems is a multiple of VEC.
 template <typename KT, typename C = HistCfg<KT>>
-__global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
+__global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u32 *__restrict__ partial,
                                                             u32 *__restrict__ unsorted, KdfArgs<KT> ka, u32 nseg,
                                                             u32 blocks_per_seg, u64 seg_elems)
 {
 	constexpr int WC = C::WC, VEC = C::VEC, R = C::R, U = C::U;
 	__shared__ u32 lh[WC * 256 * R];
+	__shared__ u32 s_descent;
 	const u32 tid = threadIdx.x;
 	const u32 lane = tid & 63;
 	const u32 seg = blockIdx.x / blocks_per_seg, bis = blockIdx.x % blocks_per_seg;
 	for (u32 i = tid; i < WC * 256 * R; i += C::BLOCK)
 		lh[i] = 0;
+	if (tid == 0)
+		s_descent = 0;
 	__syncthreads();
 
 	// elements before the first 16-byte boundary (single-segment launches only) and after the last full vector
@@ -206,19 +210,40 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict
 		}
 	}
 
+	// One flag for the whole array: on unsorted input every wave has seen a descent, and 8192 atomics on one address
+	// serialise to about 80 us however small n is.  So: one vote per workgroup, and only while the flag is still clear.
 	if (__any(descent) && mbcnt64(__ballot(1)) == 0)
-		atomicOr(unsorted, 1u);
+		s_descent = 1;
 
+	// The workgroup's counts go to its own row of `partial` (plain stores; rsx_hist_reduce_kernel adds the rows up).
 	__syncthreads();
-	u64 *gh = ghist + (u64)seg * (WC * 256);
+	if (tid == 0 && s_descent && __hip_atomic_load(unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+		atomicOr(unsorted, 1u);
+	u32 *row = partial + (u64)blockIdx.x * (WC * 256);
 	for (u32 i = tid; i < WC * 256; i += C::BLOCK) {
 		u32 s = 0;
 #pragma unroll
 		for (int r = 0; r < R; ++r)
 			s += lh[i * R + r];
-		if (s)
-			atomicAdd(&gh[i], (u64)s);
+		row[i] = s;
 	}
+}
+
+// counts[seg][i] += sum over the segment's workgroups of partial[row][i].  grid = (nseg * cols256 / 256, HIST_REDUCE_SPLIT):
+// blockIdx.y takes every HIST_REDUCE_SPLIT-th row, all its loads in flight at once, and adds its share with one global
+// atomic per bin (32 per address instead of one per histogram workgroup); `ghist` is zeroed by the caller.
+constexpr u32 HIST_REDUCE_SPLIT = 32;
+__global__ __launch_bounds__(256) void rsx_hist_reduce_kernel(const u32 *__restrict__ partial, u64 *__restrict__ ghist,
+                                                              u32 blocks_per_seg, u32 cols256)
+{
+	const u32 per_seg = cols256 / 256, seg = blockIdx.x / per_seg, i = (blockIdx.x % per_seg) * 256 + threadIdx.x;
+	const u32 *p = partial + (u64)seg * blocks_per_seg * cols256 + i;
+	u64 s = 0;
+#pragma unroll 16
+	for (u32 b = blockIdx.y; b < blocks_per_seg; b += HIST_REDUCE_SPLIT)
+		s += p[(u64)b * cols256];
+	if (s)
+		atomicAdd(&ghist[(u64)seg * cols256 + i], s);
 }
 
 // =============================================================================

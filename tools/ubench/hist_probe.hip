@@ -19,6 +19,7 @@ using namespace rsx;
 
 static u32 *d_in;
 static u64 *d_hist;
+static u32 *d_part;
 static u32 *d_flag;
 static size_t n;
 
@@ -32,7 +33,8 @@ template <typename C> void bench(const char *name, unsigned grid)
 		CK(hipEventCreate(&e0));
 		CK(hipEventCreate(&e1));
 		CK(hipEventRecord(e0, 0));
-		hipLaunchKernelGGL((rsx_hist_kernel<u32, C>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, (u64)n, d_hist, d_flag, ka, 1u, grid, (u64)n);
+		hipLaunchKernelGGL((rsx_hist_kernel<u32, C>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, (u64)n, d_part, d_flag, ka, 1u, grid, (u64)n);
+		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3(4, HIST_REDUCE_SPLIT), dim3(256), 0, 0, (const u32 *)d_part, d_hist, grid, 1024u);
 		CK(hipGetLastError());
 		CK(hipEventRecord(e1, 0));
 		CK(hipEventSynchronize(e1));
@@ -58,22 +60,22 @@ int main(int argc, char **argv)
 	CK(hipMalloc(&d_in, n * 4));
 	CK(hipMalloc(&d_hist, 8 * 256 * 8));
 	CK(hipMalloc(&d_flag, 64));
+	CK(hipMalloc(&d_part, 4096 * 1024 * 4));
 	hipLaunchKernelGGL((rsx_fill_splitmix_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, 1ull, ~0ull, 0ull);
 	CK(hipMemset(d_flag, 0, 64));
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
-	bench<HistCfg<u32>>("default", 2048);
-	bench<HistCfg<u32>>("default", 1280);
-	bench<HistCfg<u32>>("default", 512);
-	bench<HistCfg<u32, 256, 8>>("U8", 1280);
-	bench<HistCfg<u32, 512, 4>>("block 512", 1024);
-	bench<HistCfg<u32, 512, 4>>("block 512", 512);
-	bench<HistCfg<u32, 1024, 4>>("block 1024", 512);
-	bench<HistCfg<u32, 1024, 4>>("block 1024", 256);
-	bench<HistCfg<u32, 1024, 2>>("block 1024 U2", 512);
-	bench<HistCfg<u32, 1024, 4, 4>>("block 1024 R4", 512);
-	bench<HistCfg<u32, 1024, 4, 16>>("block 1024 R16", 512);
-	bench<HistCfg<u32, 256, 4, 4>>("R4", 2048);
-	bench<HistCfg<u32, 256, 4, 16>>("R16", 512);
+	for (int rep = 0; rep < 2; ++rep) {
+		bench<HistCfg<u32, 1024, 1>>("block 1024 U1", 512);
+		bench<HistCfg<u32, 1024, 2>>("block 1024 U2", 512);
+		bench<HistCfg<u32, 1024, 3>>("block 1024 U3", 512);
+		bench<HistCfg<u32, 1024, 4>>("block 1024 U4", 512);
+		bench<HistCfg<u32, 1024, 8>>("block 1024 U8", 512);
+		bench<HistCfg<u32, 1024, 2, 8>>("block 1024 U2 R8", 512);
+		bench<HistCfg<u32, 1024, 2>>("block 1024 U2", 256);
+		bench<HistCfg<u32, 1024, 2>>("block 1024 U2", 1024);
+		bench<HistCfg<u32, 512, 2>>("block 512 U2", 1024);
+		bench<HistCfg<u32, 256, 2, 8>>("block 256 U2 R8", 2048);
+	}
 	return 0;
 }

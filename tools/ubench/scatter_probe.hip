@@ -257,7 +257,10 @@ int main(int argc, char **argv)
 	CK(hipMemset(d_hist, 0, 8 * 256 * 8));
 	CK(hipMemset(d_flag, 0, 64));
 	KdfArgs<u32> ka{0, 0, 0};
-	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(512), dim3(HistCfg<u32>::BLOCK), 0, 0, d_in, (u64)n, d_hist, d_flag, ka, 1u, 512u, (u64)n);
+	u32 *d_part;
+	CK(hipMalloc(&d_part, 512 * 1024 * 4));
+	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(512), dim3(HistCfg<u32>::BLOCK), 0, 0, d_in, (u64)n, d_part, d_flag, ka, 1u, 512u, (u64)n);
+	hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3(4, HIST_REDUCE_SPLIT), dim3(256), 0, 0, (const u32 *)d_part, d_hist, 512u, 1024u);
 	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, 1u, ka, d_flag + 8);
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
