@@ -9,6 +9,7 @@
 #include "../../include/rsx.h"
 #include "rsx_kernels.hpp"
 #include "rsx_scatter2.hpp"
+#include "rsx_small.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -435,6 +436,22 @@ template <typename KT>
 int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	if (c.fast && n * sizeof(KT) <= SMALL_SORT_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
+		// the whole sort in one workgroup and one launch (rsx_small.hpp)
+		ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
+		hipLaunchKernelGGL((rsx_small_sort_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, src, aux, (u32)n, ka, c.plan());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
+		HIP_TRY(hipStreamSynchronize(c.stream));
+		const Plan p = *c.host_plan;
+		info_from_plan(info, p);
+		if (info && p.sorted)
+			info->early_exit = 2;
+		*result = (p.ncols & 1) ? aux : src;     // radix_sort.hpp:92 (sorted input: no column, src)
+		if (info)
+			info->result_in_aux = *result == aux;
+		return RSX_OK;
+	}
 	const Geo g = one_segment(n);
 	Plan plan;
 	RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));

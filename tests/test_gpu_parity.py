@@ -89,6 +89,36 @@ def test_sweep_vs_oracle(dt):
             assert np.array_equal(got, want), (n, hex(mask), order)
 
 
+@pytest.mark.parametrize("dt", range(10), ids=ol.DTYPE_NAMES)
+def test_small_sort_boundaries_and_general_path_at_small_n(dt, monkeypatch):
+    """n * sizeof(key) <= 64 KiB takes the one-workgroup kernel (csrc/rsx_small.hpp): its size limits and wave-slice
+    boundaries; and the same inputs through the general kernels (RSX_NO_SMALL_SORT=1), which they would otherwise never see."""
+    rng = np.random.default_rng(99 + dt)
+    size = ol.DTYPE_SIZE[dt]
+    cap = 65536 // size
+    full = (1 << (8 * size)) - 1
+    sizes = sorted({2, 15, 16, 17, 1023, 1024, 1025, 1087, 1088, 1089, cap // 2 - 1, cap // 2, cap // 2 + 1, cap - 64, cap - 1, cap,
+                    cap + 1})
+    for trial, n in enumerate(sizes):
+        mask = full if trial % 2 == 0 else full & ~(0xFF << (8 * int(rng.integers(0, size))))
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        if trial % 5 == 4:
+            a = np.sort(a.view(ol.NP_BITS[dt]))[::-1].copy()      # descending bit patterns: heavy digit skew per wave slice
+        for order in (ol.ASC, ol.DESC):
+            want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+            for general in (False, True):
+                if general:
+                    monkeypatch.setenv("RSX_NO_SMALL_SORT", "1")
+                else:
+                    monkeypatch.delenv("RSX_NO_SMALL_SORT", raising=False)
+                got, info, _, _ = gpu_sort(a, dt, order)
+                assert info.result_in_aux == want_aux, (n, hex(mask), order, general)
+                assert info.kept_columns() == list(winfo.cols[:winfo.ncols]), (n, hex(mask), order, general)
+                assert info.early_exit == winfo.early_exit
+                assert np.array_equal(got, want), (n, hex(mask), order, general)
+    monkeypatch.delenv("RSX_NO_SMALL_SORT", raising=False)
+
+
 def test_contract_early_exits_leave_aux_untouched():
     # pre-sorted (with duplicates) -> src returned, aux byte-for-byte untouched (radix_sort.hpp:60-62)
     a = np.sort(ol.splitmix_fill(100000, ol.U32, 3, 0xFFFFF))
