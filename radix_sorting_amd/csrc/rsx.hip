@@ -376,19 +376,63 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, 
 
 // ---- phase 2: one scatter pass (radix_sort.hpp:83-90) -----------------------------
 // gbase[digit]: exclusive offset of the digit for this pass's column
+template <typename KT, typename VT, typename C2>
+int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
+                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut)
+{
+	const u64 tiles = (n + C2::TILE - 1) / C2::TILE;
+	const u32 tps = (u32)C2::TPS;   // 1: a tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
+	const bool wide = n >= (1ull << 30);   // counter width by n, as radix_sort.hpp:102-114 does
+	const size_t st_bytes = 256 + tiles * 256 * (wide ? 8 : 4);
+	RSX_TRY(c.status.ensure(st_bytes));
+	HIP_TRY(hipMemsetAsync(c.status.p, 0, st_bytes, c.stream));
+	u32 *ticket = (u32 *)c.status.p;
+	void *st = (char *)c.status.p + 256;
+	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
+	const dim3 grid((unsigned)tiles);
+	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic
+	const bool plain = val_bytes<VT>::value == 0 && ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0 && !(flags & SCATTER_USE_LUT);
+	if constexpr (val_bytes<VT>::value == 0) {
+		if (plain) {
+			if (wide)
+				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
+				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+			else
+				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
+				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		}
+	}
+	if (!plain) {
+		if (wide)
+			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
+			                   (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		else
+			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
+			                   (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+	}
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
 template <typename KT, typename VT>
 int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
                  KdfArgs<KT> ka, u32 flags, const uint8_t *lut)
 {
+	if (c.fast) {
+		typedef Sc2Cfg<KT, VT> C2;   // count-first kernel (rsx_scatter2.hpp), 32 Ki-key tiles
+		typedef Sc2SmallCfg<KT, VT> Small;
+		if constexpr (Small::AVAILABLE) {
+			// default tiles for fewer than about a third of the CUs: quarter tiles, so that more of the chip works (10^6 keys:
+			// 31 -> 123 tiles, 108 -> 91 us per sort; at 10^7 keys, 305 default tiles, quarter tiles are slower: 204 against 178 us)
+			if (n < (size_t)96 * C2::TILE && !getenv("RSX_NO_SMALL_TILES"))
+				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut);
+		}
+		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut);
+	}
 	typedef ScatterCfg<KT, VT> C1;   // table-ranked fallback (rsx_kernels.hpp)
-	typedef Sc2Cfg<KT, VT> C2;       // count-first kernel (rsx_scatter2.hpp)
-	const size_t tile = c.fast ? (size_t)C2::TILE : (size_t)C1::TILE;
+	const size_t tile = (size_t)C1::TILE;
 	const u64 tiles = (n + tile - 1) / tile;
-	u32 tps;
-	if (c.fast)
-		tps = (u32)C2::TPS;   // 1: a 32 Ki-key tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
-	else
-		tps = choose_tps(n, tile);
+	const u32 tps = choose_tps(n, tile);
 	const u64 stiles = (tiles + tps - 1) / tps;
 	const bool wide = n >= (1ull << 30);   // counter width by n, as radix_sort.hpp:102-114 does
 	const size_t st_bytes = 256 + stiles * 256 * (wide ? 8 : 4);
@@ -398,35 +442,12 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 	void *st = (char *)c.status.p + 256;
 	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
 	const dim3 grid((unsigned)stiles);
-	if (c.fast) {
-		// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic
-		const bool plain = val_bytes<VT>::value == 0 && ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0 && !(flags & SCATTER_USE_LUT);
-		if constexpr (val_bytes<VT>::value == 0) {
-			if (plain) {
-				if (wide)
-					hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
-					                   kout, vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-				else
-					hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
-					                   kout, vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-			}
-		}
-		if (!plain) {
-			if (wide)
-				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
-				                   (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-			else
-				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
-				                   (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-		}
-	} else {
-		if (wide)
-			hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
-			                   shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-		else
-			hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
-			                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
-	}
+	if (wide)
+		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
+		                   shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+	else
+		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
+		                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }

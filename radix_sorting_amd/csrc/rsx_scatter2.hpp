@@ -30,21 +30,30 @@
 
 namespace rsx {
 
-template <typename KT, typename VT, int NWAVES_ = 16, int TPS_ = 1, int LB_ = 8, bool CELL16_ = false> struct Sc2Cfg {
+// KPT_ = 0: the default tile (as large as LDS allows).  Arrays of up to a few million keys take a quarter of it
+// (Sc2SmallCfg): with default tiles most CUs would have nothing to do, and the output is cache-resident there anyway,
+// so short runs cost nothing.
+template <typename KT, typename VT, int NWAVES_ = 16, int TPS_ = 1, int LB_ = 8, bool CELL16_ = false, int KPT_ = 0> struct Sc2Cfg {
 	static constexpr bool CELL16 = CELL16_;           // 16-bit cells packed two per word, or one 32-bit cell per digit
 	static constexpr int NWAVES = NWAVES_;
 	static constexpr int BLOCK = NWAVES * 64;
 	static constexpr int ELEM = sizeof(KT) > (size_t)val_bytes<VT>::value ? sizeof(KT) : val_bytes<VT>::value;
-	static constexpr int KPT = ELEM == 8 ? 16 : 32;    // keys per lane: 128 KiB of staging at 16 waves
+	static constexpr int KPT = KPT_ ? KPT_ : (ELEM == 8 ? 16 : 32);   // keys per lane: 128 KiB of staging at 16 waves
 	static constexpr int TILE = BLOCK * KPT;
 	static constexpr int TPS = TPS_;                   // tiles per super-tile (at most)
 	static constexpr int LB = LB_;                     // status words fetched per look-back round trip
-	static constexpr int SB = 8;                       // keys per lane in flight in the streaming loops
+	static constexpr int SB = KPT >= 16 ? 8 : KPT / 2;  // keys per lane in flight in the streaming loops
 	static constexpr int CHUNK = 16 / ELEM;            // consecutive staged elements one lane writes out together
 	static constexpr int STAGE_BYTES = TILE * ELEM;
 	static_assert(NWAVES >= 4, "256 digit threads are needed");
 	static_assert(TILE <= 32768, "tile-local positions live in 16-bit cells, two per word");
 	static_assert(KPT % (2 * SB) == 0 && KPT % CHUNK == 0 && KPT % 2 == 0, "whole batch pairs / chunks per lane");
+};
+
+template <typename KT, typename VT> struct Sc2SmallCfg {
+	static constexpr int ELEM = sizeof(KT) > (size_t)val_bytes<VT>::value ? sizeof(KT) : val_bytes<VT>::value;
+	static constexpr bool AVAILABLE = sizeof(KT) >= 4;   // (narrower keys: one 16-byte load would exceed the lane's keys)
+	typedef Sc2Cfg<KT, VT, 16, 1, 8, false, AVAILABLE ? (ELEM == 8 ? 4 : 8) : 0> type;
 };
 
 template <typename KT, typename VT, typename ST, typename C> struct Sc2Smem {
