@@ -12,6 +12,8 @@
 // Where the work happens
 //   * T a scalar and kf the default basic_kdfs::kdf (or rsx_kdf::descending<T>): rsx_sort() -- the
 //     keys are sorted on the GPU with the key derivation done in the kernels.
+//   * rsx_kdf::by_member<&T::field[, descending]> on records: rsx_sort_records_tagged() -- key extraction, rank
+//     sort and the gather of the records on the GPU.
 //   * any other callable (radix_tests.cpp:41-43,:111-113,:175-177 shapes): kf is evaluated once per
 //     element on the host into an array of KeyType, the GPU rank-sorts those keys and gathers the
 //     (trivially copyable) elements: rsx_sort_records().
@@ -40,6 +42,26 @@ namespace rsx_kdf {
 template <typename T> struct descending {
 	auto operator()(const T &v) const { return static_cast<decltype(basic_kdfs::kdf<T>(v))>(~basic_kdfs::kdf<T>(v)); }
 };
+
+// Tagged member KDF: "order the records by this scalar field", i.e. [](const T &e) { return kdf(e.field); } (the
+// shapes of radix_tests.cpp:41-43,:111-113; with Descending, README.md:564-574) written as data.  It is an ordinary
+// KeyFunc -- calling it gives basic_kdfs::kdf of the field, or its complement -- and the wrapper recognises it: key
+// extraction, stable rank sort and the gather of the records then all run on the device (rsx_sort_records_tagged)
+// instead of evaluating a lambda once per element on the host.
+//     radix_sort(src, aux, n, rsx_kdf::by_member<&sortrec::key>{});
+//     radix_sort(src, aux, n, rsx_kdf::by_member<&sortrec::score, true>{});      // descending
+template <auto Member, bool Descending = false> struct by_member;
+template <typename T, typename F, F T::*Member, bool Descending> struct by_member<Member, Descending> {
+	using record_type = T;
+	using field_type = F;
+	static constexpr bool descending = Descending;
+	auto operator()(const T &e) const
+	{
+		using K = decltype(basic_kdfs::kdf<F>(e.*Member));
+		return Descending ? static_cast<K>(~basic_kdfs::kdf<F>(e.*Member)) : basic_kdfs::kdf<F>(e.*Member);
+	}
+	static size_t offset(const T &e) { return (size_t)(reinterpret_cast<const char *>(&(e.*Member)) - reinterpret_cast<const char *>(&e)); }
+};
 }  // namespace rsx_kdf
 
 namespace rsx_detail {
@@ -67,6 +89,10 @@ template <typename T, typename KeyFunc> struct kdf_kind<T, KeyFunc, true> {
 template <typename T, typename KeyFunc> constexpr bool is_default_kdf_v = kdf_kind<T, KeyFunc>::is_default;
 template <typename T, typename KeyFunc> constexpr bool is_descending_kdf_v = kdf_kind<T, KeyFunc>::is_descending;
 
+template <typename KeyFunc> struct is_member_kdf : std::false_type {};
+template <auto M, bool D> struct is_member_kdf<rsx_kdf::by_member<M, D>> : std::true_type {};
+template <typename KeyFunc> constexpr bool is_member_kdf_v = is_member_kdf<std::remove_cv_t<std::remove_reference_t<KeyFunc>>>::value;
+
 [[noreturn]] inline void fail(const char *what, int rc)
 {
 	throw std::runtime_error(std::string(what) + ": rsx error " + std::to_string(rc) + ": " + rsx_last_error());
@@ -86,6 +112,12 @@ T *sort_dispatch(T *src, T *aux, size_t n, KeyFunc &&kf)
 		rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_ASCENDING, &result, nullptr);
 	} else if constexpr (is_descending_kdf_v<T, KeyFunc>) {
 		rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_DESCENDING, &result, nullptr);
+	} else if constexpr (is_member_kdf_v<KeyFunc>) {
+		using MK = std::remove_cv_t<std::remove_reference_t<KeyFunc>>;
+		static_assert(std::is_trivially_copyable_v<T>, "the GPU path moves elements as raw bytes");
+		static_assert(std::is_same_v<typename MK::record_type, T>, "by_member names a field of another type");
+		rc = rsx_sort_records_tagged(src, aux, n, sizeof(T), MK::offset(src[0]), dtype_of<typename MK::field_type>(),
+		                             MK::descending ? RSX_DESCENDING : RSX_ASCENDING, &result, nullptr);
 	} else {
 		static_assert(std::is_trivially_copyable_v<T>, "the GPU path moves elements as raw bytes");
 		std::vector<KeyType> keys(n);

@@ -133,6 +133,24 @@ int rsx_sort_rank_device(const void *d_src, void *d_index_buffer, size_t n, rsx_
 int rsx_sort_records(void *src, void *aux, size_t n, size_t rec_bytes,
                      const void *keys, size_t key_bytes, void **result, rsx_info *info);
 
+/* ---- records with a declared key (tagged KeyFunc) ----------------------------- */
+
+/* radix_sort(src, aux, n, kf) where kf is "the scalar field at byte key_offset
+ * of the element, default KDF of its type, ascending or complemented": the shapes
+ * of radix_tests.cpp:41-43,:45-69,:111-113 and README.md:562-591 written as data
+ * instead of code (include/radix_sort.hpp: rsx_kdf::by_member<&T::field>).
+ * Key extraction, stable rank sort and the gather of the rec_bytes-sized records
+ * all run on the device.  *result receives src or aux by the returned-pointer rule
+ * (radix_sort.hpp:89,:92); pre-sorted input returns src with aux untouched. */
+int rsx_sort_records_tagged(void *src, void *aux, size_t n, size_t rec_bytes, size_t key_offset,
+                            rsx_dtype key_dtype, rsx_order order, void **result, rsx_info *info);
+
+/* Device-pointer form: records resident in HBM, work enqueued on `stream`
+ * (one synchronisation inside, as rsx_sort_device). */
+int rsx_sort_records_tagged_device(void *d_src, void *d_aux, size_t n, size_t rec_bytes,
+                                   size_t key_offset, rsx_dtype key_dtype, rsx_order order,
+                                   void *stream, void **result, rsx_info *info);
+
 /* Same derivation for radix_sort_rank with an opaque KeyFunc. */
 int rsx_sort_rank_keys(const void *keys, size_t key_bytes, void *index_buffer, size_t n,
                        size_t idx_bytes, void **result, rsx_info *info);

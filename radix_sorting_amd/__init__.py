@@ -59,6 +59,8 @@ ABI = [
     ("rsx_sort_rank", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _PVP, _PINFO]),
     ("rsx_sort_rank_device", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _VP, _PVP, _PINFO]),
     ("rsx_sort_records", _I, [_VP, _VP, _SZ, _SZ, _VP, _SZ, _PVP, _PINFO]),
+    ("rsx_sort_records_tagged", _I, [_VP, _VP, _SZ, _SZ, _SZ, _I, _I, _PVP, _PINFO]),
+    ("rsx_sort_records_tagged_device", _I, [_VP, _VP, _SZ, _SZ, _SZ, _I, _I, _VP, _PVP, _PINFO]),
     ("rsx_sort_rank_keys", _I, [_VP, _SZ, _VP, _SZ, _SZ, _PVP, _PINFO]),
     ("rsx_histogram_device", _I, [_VP, _SZ, _I, _I, _VP, _VP, _VP]),
     ("rsx_partition_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _U32, _VP, _VP, _VP]),
@@ -218,6 +220,26 @@ def radix_sort_rank_host(src, index_buffer, dtype, order=ASCENDING):
     check(lib().rsx_sort_rank(src.ctypes.data, index_buffer.ctypes.data, n, dtype, index_buffer.itemsize, order,
                               C.byref(res), C.byref(info)))
     return (index_buffer[n:2 * n] if info.result_in_aux else index_buffer[:n]), info
+
+
+def radix_sort_records_tagged_host(src, aux, key_offset, key_dtype, order=ASCENDING):
+    """rsx_sort_records_tagged: numpy records (structured array or 2-D rows) ordered by the scalar field at key_offset."""
+    res, info = C.c_void_p(), Info()
+    n = len(src)
+    rec_bytes = src.nbytes // max(n, 1)
+    check(lib().rsx_sort_records_tagged(src.ctypes.data, aux.ctypes.data, n, rec_bytes, key_offset, key_dtype, order,
+                                        C.byref(res), C.byref(info)))
+    return (aux if info.result_in_aux else src), info
+
+
+def radix_sort_records_tagged(src, aux, rec_bytes, key_offset, key_dtype, order=ASCENDING, stream=None):
+    """rsx_sort_records_tagged_device on torch uint8 tensors holding n records of rec_bytes each."""
+    require_gpu()
+    res, info = C.c_void_p(), Info()
+    n = src.numel() * src.element_size() // rec_bytes
+    check(lib().rsx_sort_records_tagged_device(src.data_ptr(), aux.data_ptr(), n, rec_bytes, key_offset, key_dtype, order,
+                                               _stream_ptr(stream), C.byref(res), C.byref(info)))
+    return (aux if res.value == aux.data_ptr() else src), info
 
 
 def radix_sort_records_host(src, aux, keys):

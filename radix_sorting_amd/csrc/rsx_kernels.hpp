@@ -932,6 +932,29 @@ __global__ void rsx_convert_kernel(DT *dst, const ST_ *src, u64 n)
 		dst[i] = (DT)src[i];
 }
 
+// keys[i] = the KT at byte key_off of record i (records rec_bytes apart; any alignment: assembled from bytes unless
+// both the stride and the offset are multiples of sizeof(KT))
+template <typename KT>
+__global__ void rsx_extract_key_kernel(KT *__restrict__ keys, const unsigned char *__restrict__ recs, u64 n, u32 rec_bytes,
+                                       u32 key_off)
+{
+	const bool aligned = rec_bytes % sizeof(KT) == 0 && key_off % sizeof(KT) == 0 && ((uintptr_t)recs % sizeof(KT)) == 0;
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const unsigned char *p = recs + i * rec_bytes + key_off;
+		KT k;
+		if (aligned) {
+			k = *(const KT *)p;
+		} else {
+			k = 0;
+#pragma unroll
+			for (int b = 0; b < (int)sizeof(KT); ++b)
+				k |= (KT)p[b] << (8 * b);
+		}
+		keys[i] = k;
+	}
+}
+
 // dst record i = src record idx[i]; records are rec_bytes wide, moved in WORD units
 template <typename WORD, typename IT>
 __global__ void rsx_gather_kernel(WORD *__restrict__ dst, const WORD *__restrict__ src, const IT *__restrict__ idx,

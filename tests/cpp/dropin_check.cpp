@@ -183,6 +183,75 @@ int main()
 		uint32_t *ranks = radix_sort_rank(keys.data(), ib.data(), n);
 		CHECK(std::memcmp(ranks, want.data(), n * 4) == 0);
 	}
+	// records ordered by a declared member (rsx_kdf::by_member): device extraction + rank + gather, against
+	// std::stable_sort; field types, descending, odd record sizes, the returned-pointer rule
+	{
+		struct Rec16 { uint8_t name[7]; uint8_t pad; float score; uint32_t id; };      // 16 bytes, float key at offset 8
+		struct Rec12 { uint16_t tag; int16_t key; uint64_t payload; } __attribute__((packed));   // 12 bytes, unaligned payload
+		struct Rec24 { uint64_t a; double key; uint32_t b; uint32_t c; };
+		const size_t n = 150001;
+		std::mt19937_64 rng(2024);
+		{
+			std::vector<Rec16> src(n), aux(n), want;
+			for (size_t i = 0; i < n; ++i) {
+				uint32_t bits = (uint32_t)rng() & 0xFFF000FFu;
+				std::memcpy(&src[i].score, &bits, 4);
+				src[i].id = (uint32_t)i;
+				std::memset(src[i].name, (int)(i & 0x7F), 7);
+				src[i].pad = 0;
+			}
+			want = src;
+			std::stable_sort(want.begin(), want.end(), [](const Rec16 &x, const Rec16 &y) { return basic_kdfs::kdf(x.score) < basic_kdfs::kdf(y.score); });
+			Rec16 *r = radix_sort(src.data(), aux.data(), n, rsx_kdf::by_member<&Rec16::score>{});
+			CHECK(std::memcmp(r, want.data(), n * sizeof(Rec16)) == 0);
+			// descending by the same field: equal keys keep forward input order (README.md:564-574)
+			std::vector<Rec16> src2(n), aux2(n);
+			for (size_t i = 0; i < n; ++i)
+				src2[i] = want[n - 1 - i], src2[i].id = (uint32_t)i;
+			auto want2 = src2;
+			std::stable_sort(want2.begin(), want2.end(), [](const Rec16 &x, const Rec16 &y) { return basic_kdfs::kdf(x.score) > basic_kdfs::kdf(y.score); });
+			Rec16 *r2 = radix_sort(src2.data(), aux2.data(), n, rsx_kdf::by_member<&Rec16::score, true>{});
+			CHECK(std::memcmp(r2, want2.data(), n * sizeof(Rec16)) == 0);
+		}
+		{
+			std::vector<Rec12> src(n), aux(n), want;
+			for (size_t i = 0; i < n; ++i) {
+				src[i].tag = (uint16_t)i;
+				src[i].key = (int16_t)(rng() & 0xFFFF);
+				src[i].payload = rng();
+			}
+			want = src;
+			std::stable_sort(want.begin(), want.end(), [](const Rec12 &x, const Rec12 &y) { return x.key < y.key; });
+			Rec12 *r = radix_sort(src.data(), aux.data(), n, rsx_kdf::by_member<&Rec12::key>{});
+			CHECK(r == src.data());               // int16: two kept columns -> source buffer
+			CHECK(std::memcmp(r, want.data(), n * sizeof(Rec12)) == 0);
+		}
+		{
+			std::vector<Rec24> src(n), aux(n), want;
+			for (size_t i = 0; i < n; ++i) {
+				src[i].a = rng();
+				uint64_t bits = rng() & 0x7FFFFFFFFFFFFF00ull;     // positive, low byte constant: 7 kept columns -> auxiliary buffer
+				std::memcpy(&src[i].key, &bits, 8);
+				src[i].b = (uint32_t)i;
+				src[i].c = ~(uint32_t)i;
+			}
+			want = src;
+			std::stable_sort(want.begin(), want.end(), [](const Rec24 &x, const Rec24 &y) { return basic_kdfs::kdf(x.key) < basic_kdfs::kdf(y.key); });
+			Rec24 *r = radix_sort(src.data(), aux.data(), n, rsx_kdf::by_member<&Rec24::key>{});
+			CHECK(r == aux.data());
+			CHECK(std::memcmp(r, want.data(), n * sizeof(Rec24)) == 0);
+			// already sorted by the key: source returned, auxiliary buffer untouched
+			std::vector<Rec24> aux2(n);
+			std::memset(aux2.data(), 0x5A, n * sizeof(Rec24));
+			auto sorted = want;
+			Rec24 *r3 = radix_sort(sorted.data(), aux2.data(), n, rsx_kdf::by_member<&Rec24::key>{});
+			CHECK(r3 == sorted.data());
+			bool untouched = true;
+			for (size_t i = 0; i < n * sizeof(Rec24); ++i)
+				untouched &= reinterpret_cast<unsigned char *>(aux2.data())[i] == 0x5A;
+			CHECK(untouched);
+		}
+	}
 	if (failures) {
 		printf("dropin_check: %d failures\n", failures);
 		return 1;

@@ -119,6 +119,21 @@ def test_small_sort_boundaries_and_general_path_at_small_n(dt, monkeypatch):
     monkeypatch.delenv("RSX_NO_SMALL_SORT", raising=False)
 
 
+@pytest.mark.parametrize("dt", [ol.U32, ol.I64, ol.F32, ol.F64], ids=lambda d: ol.DTYPE_NAMES[d])
+def test_default_tiles_at_medium_sizes(dt, monkeypatch):
+    """Arrays below 96 default tiles take quarter tiles; RSX_NO_SMALL_TILES=1 sends the same inputs through the 32 Ki-key
+    tiles (one partial tile, a few tiles, tile boundary +-1)."""
+    monkeypatch.setenv("RSX_NO_SMALL_TILES", "1")
+    rng = np.random.default_rng(7 + dt)
+    tile = 32768 if ol.DTYPE_SIZE[dt] == 4 else 16384
+    for n in (tile - 1, tile, tile + 1, 3 * tile + 17, 300001):
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), (1 << (8 * ol.DTYPE_SIZE[dt])) - 1)
+        for order in (ol.ASC, ol.DESC):
+            want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+            got, info, _, _ = gpu_sort(a, dt, order)
+            assert info.result_in_aux == want_aux and np.array_equal(got, want), (n, order)
+
+
 def test_contract_early_exits_leave_aux_untouched():
     # pre-sorted (with duplicates) -> src returned, aux byte-for-byte untouched (radix_sort.hpp:60-62)
     a = np.sort(ol.splitmix_fill(100000, ol.U32, 3, 0xFFFFF))
@@ -320,6 +335,43 @@ def test_records_with_host_keys():
     oinfo = ol.Info()
     r = ol.oracle().rso_sort_records(ol.ptr(s2), ol.ptr(a2), n, 24, 0, ol.U32, 0, C.byref(oinfo))
     assert info.result_in_aux == r and np.array_equal(res, a2 if r else s2)
+
+
+@pytest.mark.parametrize("layout", ["f32@8of16", "i16@2of12", "f64@8of24", "u8@0of16", "u64@3of19"])
+@pytest.mark.parametrize("order", [ol.ASC, ol.DESC])
+def test_records_with_declared_key(layout, order):
+    """rsx_sort_records_tagged[_device]: the key is a scalar field at a byte offset of the record; extraction,
+    rank sort and gather on the device.  Bit-exact against the oracle's record sort, host and device pointers."""
+    spec = {"f32@8of16": (ol.F32, 8, 16, 0xFFF000FF), "i16@2of12": (ol.I16, 2, 12, 0xFFFF), "f64@8of24": (ol.F64, 8, 24, ~0xFF),
+            "u8@0of16": (ol.U8, 0, 16, 0xFF), "u64@3of19": (ol.U64, 3, 19, 0x0000FFFFFFFF00FF)}[layout]
+    dt, off, rb, mask = spec
+    kb = ol.DTYPE_SIZE[dt]
+    for n in (2, 1000, 70001, 300007):
+        rng = np.random.default_rng(n + off)
+        rec = rng.integers(0, 256, size=(n, rb), dtype=np.uint8)
+        keys = ol.splitmix_fill(n, dt, n + 5, mask & ((1 << (8 * kb)) - 1))
+        rec[:, off:off + kb] = keys.view(np.uint8).reshape(n, kb)
+        s2, a2 = rec.copy(), np.full_like(rec, 0x5A)
+        oinfo = ol.Info()
+        r = ol.oracle().rso_sort_records(ol.ptr(s2), ol.ptr(a2), n, rb, off, dt, order, C.byref(oinfo))
+        want = a2 if r else s2
+        # host pointers
+        src, aux = rec.copy(), np.full_like(rec, 0x5A)
+        res, info = rsa.radix_sort_records_tagged_host(src, aux, off, dt, order)
+        assert info.result_in_aux == r and np.array_equal(res, want), (layout, n, "host")
+        assert info.kept_columns() == list(oinfo.cols[:oinfo.ncols])
+        # device pointers
+        dsrc = torch.from_numpy(rec.copy().reshape(-1)).cuda()
+        daux = torch.full_like(dsrc, 0x5A)
+        dres, dinfo = rsa.radix_sort_records_tagged(dsrc, daux, rb, off, dt, order)
+        torch.cuda.synchronize()
+        assert dinfo.result_in_aux == r and (dres is daux) == bool(r)
+        assert np.array_equal(dres.cpu().numpy().reshape(n, rb), want), (layout, n, "device")
+    # pre-sorted by the key: source returned, auxiliary buffer untouched
+    srt = want.copy()
+    aux = np.full_like(srt, 0x5A)
+    res, info = rsa.radix_sort_records_tagged_host(srt, aux, off, dt, order)
+    assert res is srt and info.early_exit == 2 and (aux == 0x5A).all()
 
 
 # ---- BASELINE.json sizes: size-independent properties + full comparison where the oracle is quick enough ----
