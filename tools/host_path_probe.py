@@ -1,0 +1,25 @@
+import os, sys, time
+ROOT = "/root/repo"
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as ol, radix_sorting_amd as rsa
+n = 1 << 28
+a = ol.splitmix_fill(n, ol.U32, 1)
+aux = np.zeros_like(a)
+rsa.radix_sort_host(a[:1 << 20].copy(), aux[:1 << 20], rsa.U32)
+src = a.copy()
+for rep in range(4):
+    np.copyto(src, a)
+    t0 = time.perf_counter()
+    res, info = rsa.radix_sort_host(src, aux, rsa.U32)
+    dt = time.perf_counter() - t0
+    print("reused buffers: %.1f ms" % (dt * 1e3))
+for rep in range(3):
+    src2 = a.copy()
+    t0 = time.perf_counter()
+    res, info = rsa.radix_sort_host(src2, aux, rsa.U32)
+    dt = time.perf_counter() - t0
+    print("fresh src: %.1f ms" % (dt * 1e3))
+    del src2
+# already-sorted input: early exit, only H2D
+t0 = time.perf_counter(); res, info = rsa.radix_sort_host(res, aux, rsa.U32); print("sorted input (H2D + hist only): %.1f ms, exit %d" % ((time.perf_counter() - t0) * 1e3, info.early_exit))
