@@ -122,3 +122,24 @@ def test_cfg4_pairs_f32_u32_payload():
     assert bool((kdf[1:] >= kdf[:-1]).all().item())
     same = kdf[1:] == kdf[:-1]
     assert bool((vr[1:][same] > vr[:-1][same]).all().item())            # stable
+
+
+@pytest.mark.parametrize("dt,tdt", [(rsa.U8, "uint8"), (rsa.I16, "int16")], ids=["u8", "i16"])
+def test_counter_width_above_2p30(dt, tdt):
+    """n >= 2^30 switches the chain's status words (and the digit offsets) to 64 bits, as radix_sort.hpp:102-114 widens its
+    counters.  2^30 + 12345 narrow keys (1 and 2 kept columns): sortedness and the multiset (256 / 65536-bin counts)."""
+    n = (1 << 30) + 12345
+    tt = getattr(torch, tdt)
+    src = torch.empty(n, dtype=tt, device="cuda")
+    aux = torch.empty_like(src)
+    rsa.fill_splitmix(src, seed=77)
+    bins = 256 if dt == rsa.U8 else 65536
+    as_index = (src.to(torch.int32) + (0 if dt == rsa.U8 else 32768))
+    before = torch.bincount(as_index, minlength=bins)
+    del as_index
+    res, info = rsa.radix_sort(src, aux, dtype=dt)
+    torch.cuda.synchronize()
+    assert info.ncols == (1 if dt == rsa.U8 else 2) and info.result_in_aux == (1 if dt == rsa.U8 else 0)
+    assert bool((res[1:] >= res[:-1]).all().item())
+    as_index = (res.to(torch.int32) + (0 if dt == rsa.U8 else 32768))
+    assert torch.equal(torch.bincount(as_index, minlength=bins), before)
