@@ -131,6 +131,7 @@ struct Ctx {
 	DevBuf recs[2];     // record gather staging
 	DevBuf tkeys;       // keys extracted from records (rsx_sort_records_tagged*)
 	Plan *host_plan = nullptr;   // pinned
+	hipEvent_t plan_ev = nullptr;   // recorded behind the plan's copy to the host
 	u64 *host_hist = nullptr;    // pinned, 256 u64
 
 	bool fast = false;           // rsx_scatter2_kernel allowed on this device (LDS atomic order verified)
@@ -165,6 +166,9 @@ struct Ctx {
 			recs[i].release();
 		}
 		tkeys.release();
+		if (plan_ev)
+			(void)hipEventDestroy(plan_ev);
+		plan_ev = nullptr;
 		if (host_plan)
 			(void)hipHostFree(host_plan);
 		if (host_hist)
@@ -371,7 +375,20 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, 
 	                   (const u32 *)c.unsorted(), c.plan());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
+	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
+		if (!c.plan_ev)
+			HIP_TRY(hipEventCreateWithFlags(&c.plan_ev, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(c.plan_ev, c.stream));
+		return RSX_OK;
+	}
 	HIP_TRY(hipStreamSynchronize(c.stream));
+	*out = *c.host_plan;
+	return RSX_OK;
+}
+
+int plan_wait(Ctx &c, Plan *out)
+{
+	HIP_TRY(hipEventSynchronize(c.plan_ev));
 	*out = *c.host_plan;
 	return RSX_OK;
 }
@@ -380,7 +397,7 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, 
 // gbase[digit]: exclusive offset of the digit for this pass's column
 template <typename KT, typename VT, typename C2>
 int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut)
+                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan)
 {
 	const u64 tiles = (n + C2::TILE - 1) / C2::TILE;
 	const u32 tps = (u32)C2::TPS;   // 1: a tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
@@ -398,19 +415,19 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 		if (plain) {
 			if (wide)
 				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
-				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
 			else
 				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
-				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
 		}
 	}
 	if (!plain) {
 		if (wide)
 			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
-			                   (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+			                   (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
 		else
 			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
-			                   (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+			                   (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
 	}
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
@@ -418,8 +435,10 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 
 template <typename KT, typename VT>
 int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut)
+                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan = nullptr)
 {
+	if (dplan && !c.fast)
+		return fail(RSX_EINVAL, "speculative pass without the fast kernel");
 	if (c.fast) {
 		typedef Sc2Cfg<KT, VT> C2;   // count-first kernel (rsx_scatter2.hpp), 32 Ki-key tiles
 		typedef Sc2SmallCfg<KT, VT> Small;
@@ -427,9 +446,9 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 			// default tiles for fewer than about a third of the CUs: quarter tiles, so that more of the chip works (10^6 keys:
 			// 31 -> 123 tiles, 108 -> 91 us per sort; at 10^7 keys, 305 default tiles, quarter tiles are slower: 204 against 178 us)
 			if (n < (size_t)96 * C2::TILE && !getenv("RSX_NO_SMALL_TILES"))
-				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut);
+				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan);
 		}
-		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut);
+		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan);
 	}
 	typedef ScatterCfg<KT, VT> C1;   // table-ranked fallback (rsx_kernels.hpp)
 	const size_t tile = (size_t)C1::TILE;
@@ -477,7 +496,16 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	}
 	const Geo g = one_segment(n);
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));
+	// The first pass is enqueued before the host knows the plan (it reads the device's copy and does nothing on
+	// sorted input): the host's wait for the plan, 20-25 us of idle GPU otherwise, hides behind it.
+	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION");
+	if (spec) {
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, nullptr));
+		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan())));
+		RSX_TRY(plan_wait(c, &plan));
+	} else {
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));
+	}
 	info_from_plan(info, plan);
 	if (plan.sorted) {                       // radix_sort.hpp:60-62
 		if (info) {
@@ -488,7 +516,9 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 		return RSX_OK;
 	}
 	KT *cur = src, *oth = aux;
-	for (u32 i = 0; i < plan.ncols; ++i) {   // radix_sort.hpp:83-90
+	if (spec)
+		std::swap(cur, oth);                 // pass 0 is on its way
+	for (u32 i = spec ? 1 : 0; i < plan.ncols; ++i) {   // radix_sort.hpp:83-90
 		const u32 col = plan.cols[i];
 		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0, nullptr)));
 		std::swap(cur, oth);

@@ -82,10 +82,21 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  const VT *__restrict__ vin, VT *__restrict__ vout, u64 n,
                                                                  u32 shift, const u64 *__restrict__ gbase, u32 tps, ST *status,
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags,
-                                                                 const uint8_t *__restrict__ lut, u64 *tl)
+                                                                 const uint8_t *__restrict__ lut, u64 *tl,
+                                                                 const Plan *__restrict__ dplan = nullptr)
 {
 	typedef StatusBits<ST> SB_;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, TPS = C::TPS, SB = C::SB, CHUNK = C::CHUNK;
+	// Speculative first pass: launched before the host has seen the plan, so that the host's wait for the plan is hidden
+	// behind it.  The pass finds its column in the device-side plan and does nothing if the input is sorted
+	// (radix_sort.hpp:60-62: `aux` must stay untouched then).  `gbase` is the histogram's column 0 in this case.
+	if (dplan) {
+		if (dplan->sorted || dplan->ncols == 0)
+			return;
+		const u32 col = dplan->cols[0];
+		shift = 8 * col;
+		gbase += 256 * col;
+	}
 	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
 	// One tile per super-tile: the tile's keys stay in registers between the count and the staging, so they
 	// are read from memory once.  (With more tiles per super-tile they are re-read out of L2 / Infinity Cache.)
