@@ -265,6 +265,10 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 16>>("v2 16Ki x2/CU", 1);
+	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 0>>("v2 cell16", 1);
+	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, false, 16>>("v2 16Ki cell32", 1);
+	bench2<Sc2Cfg<u32, NoVal, 8, 1, 8, true, 0>>("v2 8 waves", 1);
 	bench3<Sc3Cfg<u32>>("v3 default", 256);
 		g_flags = SCATTER_DBG_NOSTORE;
 	printf("-- v3 no stores: %.3f ms\n", run3_once<Sc3Cfg<u32>, true>(0, true, 256));
