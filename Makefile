@@ -21,7 +21,7 @@ cpp: tests/cpp/dropin_check
 
 tests/cpp/dropin_check: tests/cpp/dropin_check.cpp include/radix_sort.hpp include/radix_sort_rank.hpp include/radix_sort_basic_kdf.hpp include/rsx.h radix_sorting_amd/librsx.so
 	g++ -std=gnu++17 -O2 -Wall -Iinclude tests/cpp/dropin_check.cpp -Lradix_sorting_amd -lrsx \
-	-Wl,-rpath,'$$ORIGIN/../../radix_sorting_amd' -Wl,-rpath-link,/opt/rocm/lib -o $@
+	-Wl,-rpath,'$$ORIGIN/../../radix_sorting_amd' -Wl,-rpath-link,/opt/rocm/lib -pthread -o $@
 
 # counterparts of the reference's `radix` and `radix_bench` commands on this repo's headers (tools/radix.cpp, tools/radix_bench.cpp)
 cli: tools/radix tools/radix_bench

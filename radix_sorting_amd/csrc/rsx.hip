@@ -135,6 +135,9 @@ struct Ctx {
 	u64 *host_hist = nullptr;    // pinned, 256 u64
 
 	bool fast = false;           // rsx_scatter2_kernel allowed on this device (LDS atomic order verified)
+	// The reference is re-entrant (concurrent calls on disjoint buffers are safe); here calls that share a context
+	// (same device and stream) share its workspace, so every entry point holds this for its duration.
+	std::recursive_mutex mu;
 
 	u64 *ghist() const { return (u64 *)hist.p; }
 	u32 *unsorted() const { return (u32 *)small.p; }
@@ -190,6 +193,7 @@ struct ProfRec {
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
 
 struct ProfScope {
 	bool on;
@@ -212,6 +216,7 @@ struct ProfScope {
 		if (!on)
 			return;
 		(void)hipEventRecord(rec.stop, stream);
+		std::lock_guard<std::mutex> lock(g_prof_mu);
 		g_prof.push_back(rec);
 	}
 };
@@ -680,6 +685,7 @@ int rsx_sort_device(void *d_src, void *d_aux, size_t n, rsx_dtype dtype, rsx_ord
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	RSX_DISPATCH_KT(dtype, return sort_keys_device<KT>(*c, (KT *)d_src, (KT *)d_aux, n, dtype, order, result, info));
 	return RSX_OK;
 }
@@ -698,6 +704,7 @@ int rsx_sort_pairs_device(void *d_keys, void *d_keys_aux, void *d_vals, void *d_
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	if (payload_bytes == 4) {
 		RSX_DISPATCH_KT(dtype, return (sort_pairs_device<KT, u32>(*c, (KT *)d_keys, (KT *)d_keys_aux, (u32 *)d_vals,
 		                                                         (u32 *)d_vals_aux, n, dtype, order, info)));
@@ -724,6 +731,7 @@ int rsx_sort_rank_device(const void *d_src, void *d_index_buffer, size_t n, rsx_
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	if (n == 1) {
 		HIP_TRY(hipMemsetAsync(d_index_buffer, 0, idx_bytes, c->stream));
 		if (info)
@@ -754,6 +762,7 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, v
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(nullptr, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	if (is_device_ptr(src)) {
 		if (!is_device_ptr(aux))
 			return fail(RSX_EINVAL, "rsx_sort: src is a device pointer but aux is not");
@@ -801,6 +810,7 @@ int rsx_sort_rank(const void *src, void *index_buffer, size_t n, rsx_dtype dtype
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(nullptr, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	const bool dev = is_device_ptr(src);
 	if (dev != is_device_ptr(index_buffer))
 		return fail(RSX_EINVAL, "rsx_sort_rank: src and index_buffer must both be host or both be device pointers");
@@ -880,6 +890,7 @@ int rsx_sort_records(void *src, void *aux, size_t n, size_t rec_bytes, const voi
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(nullptr, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	const size_t wide = n > (1ull << 32) ? 8 : 4;
 	RSX_TRY(c->keys[0].ensure(n * key_bytes));   // note: rank passes use keys[0]/keys[1] too; the uploaded keys live in recs[1]
 	RSX_TRY(c->recs[1].ensure(n * key_bytes > n * rec_bytes ? n * key_bytes : n * rec_bytes));
@@ -1004,6 +1015,7 @@ int rsx_sort_records_tagged_device(void *d_src, void *d_aux, size_t n, size_t re
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	rsx_info li;
 	RSX_TRY(records_tagged_core(*c, d_src, d_aux, n, rec_bytes, key_offset, key_dtype, order, &li));
 	if (info)
@@ -1030,6 +1042,7 @@ int rsx_sort_records_tagged(void *src, void *aux, size_t n, size_t rec_bytes, si
 	}
 	Ctx *c;
 	RSX_TRY(get_ctx(nullptr, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	RSX_TRY(c->recs[0].ensure(n * rec_bytes));
 	RSX_TRY(c->recs[1].ensure(n * rec_bytes));
 	HIP_TRY(hipMemcpyAsync(c->recs[0].p, src, n * rec_bytes, hipMemcpyHostToDevice, c->stream));
@@ -1054,6 +1067,7 @@ int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order
 		return fail(RSX_EINVAL, "rsx_histogram_device: bad argument");
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * kb * sizeof(u64), c->stream));
 	HIP_TRY(hipMemsetAsync(d_unsorted, 0, sizeof(u32), c->stream));
 	if (n == 0)
@@ -1079,6 +1093,7 @@ int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 		return RSX_OK;
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	// per-segment histogram of the top KDF byte -> per-(segment, bucket) offsets -> one scatter pass
 	const Geo g = one_segment(n);
 	const size_t hist_bytes = (size_t)g.nseg * kb * 256 * sizeof(u64);
@@ -1126,6 +1141,7 @@ int rsx_debug_offsets(const void *d_src, size_t n, rsx_dtype dtype, rsx_order or
 		return fail(RSX_EINVAL, "rsx_debug_offsets: bad argument");
 	Ctx *c;
 	RSX_TRY(get_ctx(nullptr, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	info_clear(info, dtype);
 	const Geo g = one_segment(n);
 	Plan plan;
@@ -1189,6 +1205,7 @@ int rsx_fill_splitmix_device(void *d_dst, size_t n, size_t elem_bytes, uint64_t 
 		return fail(RSX_EINVAL, "rsx_fill_splitmix_device: null destination");
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	if (n == 0)
 		return RSX_OK;
 	const dim3 grid(2048), block(256);

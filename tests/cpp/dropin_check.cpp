@@ -9,6 +9,7 @@
 #include <cstring>
 #include <numeric>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "radix_sort.hpp"
@@ -251,6 +252,49 @@ int main()
 				untouched &= reinterpret_cast<unsigned char *>(aux2.data())[i] == 0x5A;
 			CHECK(untouched);
 		}
+	}
+	// The reference is re-entrant: concurrent calls on disjoint buffers are safe.  Six host threads, different types and
+	// sizes, several sorts each, all on the default stream's context.
+	{
+		std::vector<std::thread> th;
+		std::vector<int> bad(6, 0);
+		for (int t = 0; t < 6; ++t)
+			th.emplace_back([t, &bad] {
+				std::mt19937_64 rng(1000 + t);
+				for (int rep = 0; rep < 6; ++rep) {
+					const size_t n = 1000 + (size_t)(rng() % 400000);
+					if (t % 3 == 0) {
+						std::vector<uint32_t> a(n), b(n);
+						for (auto &x : a)
+							x = (uint32_t)rng();
+						auto want = a;
+						std::sort(want.begin(), want.end());
+						uint32_t *r = radix_sort(a.data(), b.data(), n);
+						bad[t] += std::memcmp(r, want.data(), n * 4) != 0;
+					} else if (t % 3 == 1) {
+						std::vector<double> a(n), b(n);
+						for (auto &x : a)
+							x = (double)(int64_t)rng() * 1e-3;
+						auto want = a;
+						std::sort(want.begin(), want.end());
+						double *r = radix_sort(a.data(), b.data(), n);
+						bad[t] += std::memcmp(r, want.data(), n * 8) != 0;
+					} else {
+						std::vector<int16_t> a(n);
+						std::vector<uint32_t> ib(2 * n), want(n);
+						for (auto &x : a)
+							x = (int16_t)rng();
+						std::iota(want.begin(), want.end(), 0u);
+						std::stable_sort(want.begin(), want.end(), [&](uint32_t x, uint32_t y) { return a[x] < a[y]; });
+						uint32_t *r = radix_sort_rank(a.data(), ib.data(), n);
+						bad[t] += std::memcmp(r, want.data(), n * 4) != 0;
+					}
+				}
+			});
+		for (auto &x : th)
+			x.join();
+		for (int t = 0; t < 6; ++t)
+			CHECK(bad[t] == 0);
 	}
 	if (failures) {
 		printf("dropin_check: %d failures\n", failures);
