@@ -539,6 +539,21 @@ template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	if (c.fast && n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
+		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
+		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, VT, false>), dim3(1), dim3(1024), 0, c.stream, (const KT *)k0, k1, v0, v1,
+		                   (u32)n, ka, c.plan());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
+		HIP_TRY(hipStreamSynchronize(c.stream));
+		const Plan p = *c.host_plan;
+		info_from_plan(info, p);
+		if (info) {
+			info->early_exit = p.sorted ? 2 : 0;
+			info->result_in_aux = p.ncols & 1;
+		}
+		return RSX_OK;
+	}
 	const Geo g = one_segment(n);
 	Plan plan;
 	RSX_TRY(plan_phase<KT>(c, k0, n, ka, g, &plan));
@@ -571,6 +586,22 @@ template <typename KT, typename IT>
 int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
+		ProfScope prof(1, (u64)n * (sizeof(KT) + 2 * sizeof(IT)), c.stream);
+		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, IT, true>), dim3(1), dim3(1024), 0, c.stream, src, (KT *)nullptr, ib, ib + n,
+		                   (u32)n, ka, c.plan());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
+		HIP_TRY(hipStreamSynchronize(c.stream));
+		const Plan p = *c.host_plan;
+		info_from_plan(info, p);
+		if (info) {
+			info->early_exit = p.sorted ? 2 : 0;
+			info->result_in_aux = p.ncols & 1;
+		}
+		*result = (p.ncols & 1) ? ib + n : ib;   // radix_sort_rank.hpp:91 (sorted: first half = iota)
+		return RSX_OK;
+	}
 	const Geo g = one_segment(n);
 	Plan plan;
 	RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));

@@ -245,6 +245,45 @@ def test_pairs_vs_oracle_records(dt, vbytes):
     assert np.array_equal(vr.cpu().numpy(), perm.astype(np.int64) * 3 + 1)
 
 
+@pytest.mark.parametrize("dt", [ol.U8, ol.I16, ol.U32, ol.F32, ol.U64, ol.F64], ids=lambda d: ol.DTYPE_NAMES[d])
+@pytest.mark.parametrize("vbytes", [4, 8])
+def test_small_pairs_and_rank_boundaries(dt, vbytes, monkeypatch):
+    """Pairs and ranks that fit LDS twice (2 * n * (key + payload bytes) <= 128 KiB) take the one-workgroup kernel
+    (csrc/rsx_small.hpp): its limits, both orders, and the same inputs through the general kernels."""
+    kb = ol.DTYPE_SIZE[dt]
+    cap = 131072 // (2 * (kb + vbytes))
+    full = (1 << (8 * kb)) - 1
+    vt = torch.int32 if vbytes == 4 else torch.int64
+    rng = np.random.default_rng(5 + dt + vbytes)
+    for trial, n in enumerate(sorted({2, 3, 64, 65, 1025, cap // 2 + 1, cap - 1, cap, cap + 1})):
+        mask = full if trial % 2 else full & ~(0xFF << (8 * int(rng.integers(0, kb))))
+        k = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        for order in (ol.ASC, ol.DESC):
+            perm = ol.stable_argsort_by_kdf(k, dt, order)
+            _, want_aux, winfo = ol.oracle_sort(k, dt, order)
+            rwant, rhalf, rinfo, _ = ol.oracle_rank(k, dt, vbytes, order)
+            for general in (False, True):
+                if general:
+                    monkeypatch.setenv("RSX_NO_SMALL_SORT", "1")
+                else:
+                    monkeypatch.delenv("RSX_NO_SMALL_SORT", raising=False)
+                keys, keys_aux = to_dev(k), to_dev(np.zeros_like(k))
+                vals = torch.arange(n, dtype=vt, device="cuda") * 5 + 2
+                vals_aux = torch.zeros_like(vals)
+                kr, vr, info = rsa.radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=dt, order=order)
+                torch.cuda.synchronize()
+                assert info.result_in_aux == want_aux and info.early_exit == winfo.early_exit, (n, order, general)
+                if not winfo.early_exit:
+                    assert np.array_equal(to_bits(kr, dt), k[perm]), (n, order, general)
+                    assert np.array_equal(vr.cpu().numpy(), perm.astype(np.int64) * 5 + 2), (n, order, general)
+                ib = torch.full((2 * n,), -1, dtype=vt, device="cuda")
+                ranks, rinf = rsa.radix_sort_rank(to_dev(k), ib, dtype=dt, order=order)
+                torch.cuda.synchronize()
+                assert rinf.result_in_aux == rhalf and rinf.early_exit == rinfo.early_exit, (n, order, general)
+                assert np.array_equal(ranks.cpu().numpy().astype(np.uint64), rwant.astype(np.uint64)), (n, order, general)
+    monkeypatch.delenv("RSX_NO_SMALL_SORT", raising=False)
+
+
 @pytest.mark.parametrize("row", KAT["rank"], ids=_id)
 def test_rank_golden(row):
     dt = row["dtype_code"]
