@@ -1,29 +1,28 @@
-// rsx_kernels.hpp -- CDNA4 (gfx950) kernels of the LSD radix sort.
+// rsx_kernels.hpp -- CDNA4 (gfx950) kernels of the LSD radix sort: everything but the default scatter pass.
 //
-// Three kernels replace the three loops of the reference's rs_sort_main
-// (radix_sort.hpp:31-93):
+// The three loops of the reference's rs_sort_main (radix_sort.hpp:31-93) become
 //
-//   rsx_hist_kernel     loop 1 (:48-58): every 8-bit column's histogram in ONE
-//                       read of the keys + the pre-sorted test.  Histograms are
-//                       privatised in LDS per workgroup (R lane-striped copies
-//                       per bin so equal digits do not serialise on one LDS
-//                       address) and merged into HBM with global atomics.
-//   rsx_plan_kernel     column-skip probe (:64-70) + exclusive scan (:72-80):
-//                       the 256-bin scan of a column is done by one 64-lane
-//                       wavefront through LDS (4 bins per lane).
-//   rsx_scatter_kernel  one scatter pass (:82-90) as a single-read/single-write
-//                       "onesweep": a workgroup takes a tile (ticket order),
-//                       ranks its keys inside each wavefront through per-wave LDS
-//                       match tables + mbcnt/popcount, chains the per-digit tile
-//                       offsets with a decoupled look-back over agent-scope status
-//                       words, stages the tile in LDS in output order and writes
-//                       coalesced runs.
+//   rsx_hist_kernel       loop 1 (:48-58): every 8-bit column's histogram in ONE read of the keys + the pre-sorted
+//   + rsx_hist_reduce_    test.  Histograms are privatised in LDS per workgroup (R lane-striped copies per bin so
+//     kernel              that equal digits do not serialise on one LDS address); each workgroup writes its counts to
+//                         its own row and a split reduce adds the rows up.
+//   rsx_plan_kernel       column-skip probe (:64-70) + exclusive scan (:72-80): the 256-bin scan of a column is done
+//   + rsx_plan_finish_    by one 64-lane wavefront through LDS (4 bins per lane).
+//     kernel
+//   rsx_scatter2_kernel   one scatter pass (:82-90), the default: rsx_scatter2.hpp.
+//   rsx_scatter_kernel    the same pass without relying on the lane order of returning LDS atomics (the fallback when
+//                         the device self-check fails): a workgroup takes a tile (ticket order), ranks its keys inside
+//                         each wavefront through per-wave LDS match tables + mbcnt/popcount, chains the per-digit tile
+//                         offsets with a decoupled look-back over agent-scope status words, stages the tile in LDS in
+//                         output order and writes coalesced runs.
+//   rsx_small_sort_kernel, rsx_small_pairs_kernel   the whole sort in one workgroup for small arrays: rsx_small.hpp.
 //
-// Stability: a wave owns a contiguous slice of the tile, lane l of round r holds
-// element slice + 64 r + l, rounds are ranked in order and lanes by mbcnt, waves,
-// tiles and segments are prefix-summed in memory order -- so equal digits keep their
-// input order exactly as the reference's in-order traversal with post-increment
-// does.
+// Also here: the key derivation (kdf_apply), the status-word format of the look-back chain, and the small helper
+// kernels (fill, iota, convert, key extraction, record gather).
+//
+// Stability: a wave owns a contiguous slice of the tile, lane l of round r holds element slice + 64 r + l, rounds
+// are ranked in order and lanes in lane order, waves and tiles are prefix-summed in memory order -- so equal digits
+// keep their input order exactly as the reference's in-order traversal with post-increment does.
 #pragma once
 
 #include <hip/hip_runtime.h>
