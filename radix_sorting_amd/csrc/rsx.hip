@@ -367,12 +367,21 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 }
 
 template <typename KT>
-int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, Plan *out)
+int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, Plan *out, size_t status_total = 0)
 {
 	const size_t hist_bytes = (size_t)g.nseg * sizeof(KT) * 256 * sizeof(u64);
 	RSX_TRY(c.hist.ensure(hist_bytes));
-	HIP_TRY(hipMemsetAsync(c.hist.p, 0, hist_bytes, c.stream));
-	HIP_TRY(hipMemsetAsync(c.small.p, 0, 192, c.stream));
+	if (status_total) {
+		// flags, histogram and the status words of every pass of this sort in one launch
+		RSX_TRY(c.status.ensure(status_total));
+		const u64 total16 = (192 + hist_bytes + status_total) / 16;
+		const unsigned blocks = (unsigned)std::min<u64>((total16 + 255) / 256, 2048);
+		hipLaunchKernelGGL(rsx_zero3_kernel, dim3(blocks), dim3(256), 0, c.stream, (u32x4 *)c.small.p, (u64)(192 / 16),
+		                   (u32x4 *)c.hist.p, (u64)(hist_bytes / 16), (u32x4 *)c.status.p, (u64)(status_total / 16));
+	} else {
+		HIP_TRY(hipMemsetAsync(c.hist.p, 0, hist_bytes, c.stream));
+		HIP_TRY(hipMemsetAsync(c.small.p, 0, 192, c.stream));
+	}
 	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted(), g));
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), g.nseg, ka,
 	                   c.kept());
@@ -402,16 +411,22 @@ int plan_wait(Ctx &c, Plan *out)
 // gbase[digit]: exclusive offset of the digit for this pass's column
 template <typename KT, typename VT, typename C2>
 int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan)
+                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan, int region)
 {
 	const u64 tiles = (n + C2::TILE - 1) / C2::TILE;
 	const u32 tps = (u32)C2::TPS;   // 1: a tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
 	const bool wide = n >= (1ull << 30);   // counter width by n, as radix_sort.hpp:102-114 does
 	const size_t st_bytes = 256 + tiles * 256 * (wide ? 8 : 4);
-	RSX_TRY(c.status.ensure(st_bytes));
-	HIP_TRY(hipMemsetAsync(c.status.p, 0, st_bytes, c.stream));
-	u32 *ticket = (u32 *)c.status.p;
-	void *st = (char *)c.status.p + 256;
+	char *base = (char *)c.status.p;
+	if (region < 0) {   // own region, zeroed here
+		RSX_TRY(c.status.ensure(st_bytes));
+		HIP_TRY(hipMemsetAsync(c.status.p, 0, st_bytes, c.stream));
+		base = (char *)c.status.p;
+	} else {            // region `region` of a buffer the caller has sized (status_bytes) and zeroed (plan_phase)
+		base += (size_t)region * st_bytes;
+	}
+	u32 *ticket = (u32 *)base;
+	void *st = base + 256;
 	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
 	const dim3 grid((unsigned)tiles);
 	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic
@@ -438,22 +453,37 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 	return RSX_OK;
 }
 
+// quarter tiles? (default tiles for fewer than about a third of the CUs: 10^6 keys: 31 -> 123 tiles, 108 -> 91 us per sort;
+// at 10^7 keys, 305 default tiles, quarter tiles are slower: 204 against 178 us)
+template <typename KT, typename VT> bool use_small_tiles(size_t n)
+{
+	if constexpr (Sc2SmallCfg<KT, VT>::AVAILABLE)
+		return n < (size_t)96 * Sc2Cfg<KT, VT>::TILE && !getenv("RSX_NO_SMALL_TILES");
+	return false;
+}
+
+// bytes of status words (ticket included) one pass of the fast kernel takes for n elements
+template <typename KT, typename VT> size_t status_bytes(size_t n)
+{
+	const size_t tile = use_small_tiles<KT, VT>(n) ? (size_t)Sc2SmallCfg<KT, VT>::type::TILE : (size_t)Sc2Cfg<KT, VT>::TILE;
+	return 256 + (n + tile - 1) / tile * 256 * (n >= (1ull << 30) ? 8 : 4);
+}
+
 template <typename KT, typename VT>
 int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan = nullptr)
+                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan = nullptr, int region = -1)
 {
-	if (dplan && !c.fast)
-		return fail(RSX_EINVAL, "speculative pass without the fast kernel");
+	if ((dplan || region >= 0) && !c.fast)
+		return fail(RSX_EINVAL, "speculative pass / status regions without the fast kernel");
 	if (c.fast) {
 		typedef Sc2Cfg<KT, VT> C2;   // count-first kernel (rsx_scatter2.hpp), 32 Ki-key tiles
 		typedef Sc2SmallCfg<KT, VT> Small;
 		if constexpr (Small::AVAILABLE) {
-			// default tiles for fewer than about a third of the CUs: quarter tiles, so that more of the chip works (10^6 keys:
-			// 31 -> 123 tiles, 108 -> 91 us per sort; at 10^7 keys, 305 default tiles, quarter tiles are slower: 204 against 178 us)
-			if (n < (size_t)96 * C2::TILE && !getenv("RSX_NO_SMALL_TILES"))
-				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan);
+			if (use_small_tiles<KT, VT>(n))
+				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan,
+				                                                     region);
 		}
-		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan);
+		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan, region);
 	}
 	typedef ScatterCfg<KT, VT> C1;   // table-ranked fallback (rsx_kernels.hpp)
 	const size_t tile = (size_t)C1::TILE;
@@ -504,12 +534,14 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	// The first pass is enqueued before the host knows the plan (it reads the device's copy and does nothing on
 	// sorted input): the host's wait for the plan, 20-25 us of idle GPU otherwise, hides behind it.
 	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION");
+	// with the fast kernel every pass has its own region of status words, all zeroed together with the histogram
+	const size_t status_total = c.fast ? status_bytes<KT, NoVal>(n) * sizeof(KT) : 0;
 	if (spec) {
-		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, nullptr));
-		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan())));
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, nullptr, status_total));
+		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), 0)));
 		RSX_TRY(plan_wait(c, &plan));
 	} else {
-		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan, status_total));
 	}
 	info_from_plan(info, plan);
 	if (plan.sorted) {                       // radix_sort.hpp:60-62
@@ -525,7 +557,8 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 		std::swap(cur, oth);                 // pass 0 is on its way
 	for (u32 i = spec ? 1 : 0; i < plan.ncols; ++i) {   // radix_sort.hpp:83-90
 		const u32 col = plan.cols[i];
-		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0, nullptr)));
+		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0, nullptr, nullptr,
+		                                 c.fast ? (int)i : -1)));
 		std::swap(cur, oth);
 	}
 	*result = cur;                           // radix_sort.hpp:92

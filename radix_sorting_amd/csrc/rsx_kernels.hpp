@@ -931,6 +931,20 @@ __global__ void rsx_convert_kernel(DT *dst, const ST_ *src, u64 n)
 		dst[i] = (DT)src[i];
 }
 
+// Zeroes up to three regions (16-byte granules) in one launch: the flags, the histogram and the status words of all the
+// passes of a sort.  (Each hipMemsetAsync is a launch of its own; at 10^5 keys six of them were a third of the sort.)
+__global__ __launch_bounds__(256) void rsx_zero3_kernel(u32x4 *a, u64 na, u32x4 *b, u64 nb, u32x4 *c, u64 nc)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u32x4 z = {0u, 0u, 0u, 0u};
+	for (u64 i = t; i < na; i += stride)
+		a[i] = z;
+	for (u64 i = t; i < nb; i += stride)
+		b[i] = z;
+	for (u64 i = t; i < nc; i += stride)
+		c[i] = z;
+}
+
 // keys[i] = the KT at byte key_off of record i (records rec_bytes apart; any alignment: assembled from bytes unless
 // both the stride and the offset are multiples of sizeof(KT))
 template <typename KT>
