@@ -130,7 +130,8 @@ struct Ctx {
 	DevBuf vals[2];     // payload ping-pong for host staging / narrow-index rank
 	DevBuf recs[2];     // record gather staging
 	DevBuf tkeys;       // keys extracted from records (rsx_sort_records_tagged*)
-	Plan *host_plan = nullptr;   // pinned
+	Plan *host_plan = nullptr;   // pinned, written by the kernels themselves (dev_host_plan: its device address)
+	Plan *dev_host_plan = nullptr;
 	hipEvent_t plan_ev = nullptr;   // recorded behind the plan's copy to the host
 	u64 *host_hist = nullptr;    // pinned, 256 u64
 
@@ -151,7 +152,10 @@ struct Ctx {
 	{
 		RSX_TRY(small.ensure(SMALL_BYTES));
 		if (!host_plan)
-			HIP_TRY(hipHostMalloc((void **)&host_plan, sizeof(Plan), hipHostMallocDefault));
+		{
+			HIP_TRY(hipHostMalloc((void **)&host_plan, sizeof(Plan), hipHostMallocMapped));
+			HIP_TRY(hipHostGetDevicePointer((void **)&dev_host_plan, host_plan, 0));
+		}
 		if (!host_hist)
 			HIP_TRY(hipHostMalloc((void **)&host_hist, 256 * sizeof(u64), hipHostMallocDefault));
 		return RSX_OK;
@@ -386,9 +390,8 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, 
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), g.nseg, ka,
 	                   c.kept());
 	hipLaunchKernelGGL(rsx_plan_finish_kernel, dim3(1), dim3(64), 0, c.stream, (const u32 *)c.kept(), (u32)sizeof(KT),
-	                   (const u32 *)c.unsorted(), c.plan());
+	                   (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
 	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
 		if (!c.plan_ev)
 			HIP_TRY(hipEventCreateWithFlags(&c.plan_ev, hipEventDisableTiming));
@@ -516,9 +519,8 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	if (c.fast && n * sizeof(KT) <= SMALL_SORT_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
 		// the whole sort in one workgroup and one launch (rsx_small.hpp)
 		ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
-		hipLaunchKernelGGL((rsx_small_sort_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, src, aux, (u32)n, ka, c.plan());
+		hipLaunchKernelGGL((rsx_small_sort_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, src, aux, (u32)n, ka, c.dev_host_plan);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
 		HIP_TRY(hipStreamSynchronize(c.stream));
 		const Plan p = *c.host_plan;
 		info_from_plan(info, p);
@@ -575,9 +577,8 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 	if (c.fast && n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
 		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, VT, false>), dim3(1), dim3(1024), 0, c.stream, (const KT *)k0, k1, v0, v1,
-		                   (u32)n, ka, c.plan());
+		                   (u32)n, ka, c.dev_host_plan);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
 		HIP_TRY(hipStreamSynchronize(c.stream));
 		const Plan p = *c.host_plan;
 		info_from_plan(info, p);
@@ -622,9 +623,8 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
 		ProfScope prof(1, (u64)n * (sizeof(KT) + 2 * sizeof(IT)), c.stream);
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, IT, true>), dim3(1), dim3(1024), 0, c.stream, src, (KT *)nullptr, ib, ib + n,
-		                   (u32)n, ka, c.plan());
+		                   (u32)n, ka, c.dev_host_plan);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(c.host_plan, c.plan(), sizeof(Plan), hipMemcpyDeviceToHost, c.stream));
 		HIP_TRY(hipStreamSynchronize(c.stream));
 		const Plan p = *c.host_plan;
 		info_from_plan(info, p);

@@ -317,16 +317,26 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 	}
 }
 
+// `host_plan`: the same 64 bytes in pinned, device-visible host memory -- the host reads the plan there once this kernel
+// has completed, without a copy of its own (one launch less per sort).
 __global__ void rsx_plan_finish_kernel(const u32 *__restrict__ kept, u32 wc, const u32 *__restrict__ unsorted,
-                                       Plan *__restrict__ plan)
+                                       Plan *__restrict__ plan, Plan *__restrict__ host_plan)
 {
 	if (threadIdx.x == 0) {
+		Plan p;
+		for (u32 i = 0; i < 8; ++i)
+			p.cols[i] = 0;
 		u32 nc = 0;
 		for (u32 i = 0; i < wc; ++i)
 			if (kept[i])
-				plan->cols[nc++] = i;                              // LSB first, radix_sort.hpp:66-69
-		plan->ncols = nc;
-		plan->sorted = *unsorted == 0;                             // radix_sort.hpp:60
+				p.cols[nc++] = i;                                  // LSB first, radix_sort.hpp:66-69
+		p.ncols = nc;
+		p.sorted = *unsorted == 0;                                 // radix_sort.hpp:60
+		plan->ncols = host_plan->ncols = p.ncols;
+		plan->sorted = host_plan->sorted = p.sorted;
+		for (u32 i = 0; i < 8; ++i)
+			plan->cols[i] = host_plan->cols[i] = p.cols[i];
+		__threadfence_system();
 	}
 }
 

@@ -18,7 +18,7 @@ constexpr u32 SMALL_SORT_BYTES = 65536;   // per LDS buffer
 
 template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_small_sort_kernel(KT *__restrict__ src, KT *__restrict__ aux, u32 n, KdfArgs<KT> ka,
-                                                              Plan *__restrict__ plan_out)
+                                                              Plan *__restrict__ plan_out)   // pinned host memory
 {
 	constexpr int WC = sizeof(KT), NW = 16, BLOCK = 1024;
 	constexpr u32 CAP = SMALL_SORT_BYTES / sizeof(KT);
