@@ -40,6 +40,12 @@ def run64(t):
     return rsa.radix_sort(t, aux64, dtype=rsa.U64)[1]
 for name, mask in (("cfg3 u64 uniform (P=8)", 0xFFFFFFFFFFFFFFFF), ("cfg3 u64 & 0xFFFFFFFFFF (P=5)", 0xFFFFFFFFFF), ("cfg3 u64 & 0xFFFFFFFF (P=4)", 0xFFFFFFFF)):
     timed(name, mk64(mask), run64, lambda P: (1 + 2 * P) * 8)
+def mk_zipf(i):   # SURVEY.md 8d cfg 3 (iv): key = 2^(b-1) + low bits, b = 1 + (r >> 58) % 40
+    r = torch.empty(N, dtype=torch.int64, device="cuda"); rsa.fill_splitmix(r, seed=33 + i)
+    b = 1 + (((r >> 58) & 63) % 40)
+    one = torch.ones_like(r)
+    return ((one << (b - 1)) + (r & ((one << (b - 1)) - 1))).contiguous()
+timed("cfg3 u64 Zipf-like (P=5)", mk_zipf, run64, lambda P: (1 + 2 * P) * 8)
 del aux64
 ib = torch.empty(2 * N, dtype=torch.int32, device="cuda")
 def mk32(mask):
@@ -50,5 +56,10 @@ def runrank(t):
     return rsa.radix_sort_rank(t, ib, dtype=rsa.F32)[1]
 timed("cfg4 f32 random bits -> u32 ranks", mk32(0xFFFFFFFF), runrank, lambda P: 4 + P * 2 * 8)
 timed("cfg4 f32 & 0xFFF000FF -> u32 ranks", mk32(0xFFF000FF), runrank, lambda P: 4 + P * 2 * 8)
+def mk_pm1(i):    # SURVEY.md 8d cfg 4 (ii): (int24 - 2^23) * 2^-23, uniform in [-1, 1): clustered exponents
+    r = torch.empty(N, dtype=torch.int64, device="cuda"); rsa.fill_splitmix(r, seed=7 + i)
+    f = (((r >> 40) & 0xFFFFFF) - (1 << 23)).to(torch.float32) * (2.0 ** -23)
+    return f.view(torch.int32).contiguous()
+timed("cfg4 f32 uniform [-1,1) -> u32 ranks", mk_pm1, runrank, lambda P: 4 + P * 2 * 8)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
