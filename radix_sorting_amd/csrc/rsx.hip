@@ -432,26 +432,45 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 	void *st = base + 256;
 	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
 	const dim3 grid((unsigned)tiles);
-	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic
+	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic;
+	// columns with a hot digit (Plan::hot) take the instantiation that tests every round for a wave-uniform digit
 	const bool plain = val_bytes<VT>::value == 0 && ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0 && !(flags & SCATTER_USE_LUT);
+	const bool hot = (flags & SCATTER_HOT) != 0;
+	flags &= ~(u32)SCATTER_HOT;
+#define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
+	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, \
+	                   vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan)
+	bool launched = false;
 	if constexpr (val_bytes<VT>::value == 0) {
 		if (plain) {
-			if (wide)
-				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
-				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
-			else
-				hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_PLAIN>), grid, dim3(C2::BLOCK), 0, c.stream, kin,
-				                   kout, vin, vout, (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
+			launched = true;
+			if (wide) {
+				if (hot)
+					RSX_LAUNCH2(u64, DIG_PLAIN, true);
+				else
+					RSX_LAUNCH2(u64, DIG_PLAIN, false);
+			} else {
+				if (hot)
+					RSX_LAUNCH2(u32, DIG_PLAIN, true);
+				else
+					RSX_LAUNCH2(u32, DIG_PLAIN, false);
+			}
 		}
 	}
-	if (!plain) {
-		if (wide)
-			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u64, C2>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
-			                   (u64)n, shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
-		else
-			hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, vout,
-			                   (u64)n, shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan);
+	if (!launched) {
+		if (wide) {
+			if (hot)
+				RSX_LAUNCH2(u64, DIG_GENERIC, true);
+			else
+				RSX_LAUNCH2(u64, DIG_GENERIC, false);
+		} else {
+			if (hot)
+				RSX_LAUNCH2(u32, DIG_GENERIC, true);
+			else
+				RSX_LAUNCH2(u32, DIG_GENERIC, false);
+		}
 	}
+#undef RSX_LAUNCH2
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
@@ -489,6 +508,7 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan, region);
 	}
 	typedef ScatterCfg<KT, VT> C1;   // table-ranked fallback (rsx_kernels.hpp)
+	flags &= ~(u32)SCATTER_HOT;      // (its match tables do not care how many lanes share a digit)
 	const size_t tile = (size_t)C1::TILE;
 	const u64 tiles = (n + tile - 1) / tile;
 	const u32 tps = choose_tps(n, tile);
@@ -559,8 +579,8 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 		std::swap(cur, oth);                 // pass 0 is on its way
 	for (u32 i = spec ? 1 : 0; i < plan.ncols; ++i) {   // radix_sort.hpp:83-90
 		const u32 col = plan.cols[i];
-		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0, nullptr, nullptr,
-		                                 c.fast ? (int)i : -1)));
+		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka,
+		                                 (plan.hot >> col & 1) ? SCATTER_HOT : 0, nullptr, nullptr, c.fast ? (int)i : -1)));
 		std::swap(cur, oth);
 	}
 	*result = cur;                           // radix_sort.hpp:92
@@ -603,7 +623,8 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 	VT *vc = v0, *vo = v1;
 	for (u32 i = 0; i < plan.ncols; ++i) {
 		const u32 col = plan.cols[i];
-		RSX_TRY((scatter_pass<KT, VT>(c, kc, ko, vc, vo, n, 8 * col, c.ghist() + 256 * col, ka, 0, nullptr)));
+		RSX_TRY((scatter_pass<KT, VT>(c, kc, ko, vc, vo, n, 8 * col, c.ghist() + 256 * col, ka, (plan.hot >> col & 1) ? SCATTER_HOT : 0,
+		                              nullptr)));
 		std::swap(kc, ko);
 		std::swap(vc, vo);
 	}
@@ -660,7 +681,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		const u32 col = plan.cols[i];
 		const KT *kin = i == 0 ? src : (const KT *)c.keys[(i - 1) & 1].p;
 		KT *kout = (KT *)c.keys[i & 1].p;
-		u32 flags = 0;
+		u32 flags = (plan.hot >> col & 1) ? SCATTER_HOT : 0;
 		if (i == 0)
 			flags |= SCATTER_GEN_INDEX;
 		if (i == P - 1)

@@ -253,7 +253,8 @@ struct Plan {            // 64 bytes, copied to the host after the plan kernels
 	u32 ncols;           // kept columns (radix_sort.hpp:64-70)
 	u32 sorted;          // 1: pre-sorted early exit (radix_sort.hpp:60-62)
 	u32 cols[8];
-	u32 pad[6];
+	u32 hot;             // bit c: one digit of column c holds an eighth of the keys or more
+	u32 pad[5];
 };
 
 // Exclusive scan of 256 u64 values held in LDS, by ONE wavefront (lanes 0..63 of the caller):
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 	const KT key0 = kdf_apply(src[0], ka);                         // radix_sort.hpp:65
 	if (d == ((u32)(key0 >> (8 * col)) & 0xFFu))
 		kept[col] = total != n;                                    // radix_sort.hpp:67
+	if (total >= n / 8 + 1)
+		kept[8 + col] = 1;                                         // a hot digit (see Plan::hot)
 	tot[d] = total;
 	__syncthreads();
 	if (d < 64)
@@ -332,8 +335,12 @@ __global__ void rsx_plan_finish_kernel(const u32 *__restrict__ kept, u32 wc, con
 				p.cols[nc++] = i;                                  // LSB first, radix_sort.hpp:66-69
 		p.ncols = nc;
 		p.sorted = *unsorted == 0;                                 // radix_sort.hpp:60
+		p.hot = 0;
+		for (u32 i = 0; i < wc; ++i)
+			p.hot |= (kept[8 + i] ? 1u : 0u) << i;
 		plan->ncols = host_plan->ncols = p.ncols;
 		plan->sorted = host_plan->sorted = p.sorted;
+		plan->hot = host_plan->hot = p.hot;
 		for (u32 i = 0; i < 8; ++i)
 			plan->cols[i] = host_plan->cols[i] = p.cols[i];
 		__threadfence_system();
@@ -390,6 +397,7 @@ enum : u32 {
 	SCATTER_GEN_INDEX = 1,   // payload of element i is i (first rank pass, radix_sort_rank.hpp:52)
 	SCATTER_SKIP_KEYS = 2,   // do not write keys (last rank pass: only the indices are wanted)
 	SCATTER_USE_LUT = 4,     // bucket = lut[digit] (MSD split for the multi-GPU sort)
+	SCATTER_HOT = 16,        // host side only: one digit holds an eighth of the keys or more -> the HOT kernels (rsx_scatter2.hpp)
 	SCATTER_DBG_LINEAR = 64, // probe only: write the staged tile back to its own position (no scatter)
 	SCATTER_DBG_NOSTORE = 128, // probe only: skip the global stores
 	SCATTER_DBG_NOLOADB = 256  // probe only: phase B fabricates keys instead of re-reading them
