@@ -739,10 +739,13 @@ size_t rsx_workspace_bytes(size_t n, rsx_dtype dtype, size_t payload_bytes)
 	const size_t kb = dtype_size(dtype);
 	if (!kb)
 		return 0;
+	// upper bound over the kernels' shapes: quarter tiles (8 Ki elements, 4 Ki with an 8-byte element), a region of status
+	// words per pass, the histogram kernel's rows (at most 512 workgroups)
 	const size_t elem = kb > payload_bytes ? kb : payload_bytes;
-	const size_t tile = 512 * (elem == 8 ? 8 : 16);
+	const size_t tile = elem == 8 ? 4096 : 8192;
 	const size_t tiles = (n + tile - 1) / tile;
-	return Ctx::SMALL_BYTES + kb * 256 * 8 + 256 + tiles * 256 * (n >= (1ull << 30) ? 8 : 4);
+	const size_t status = (256 + tiles * 256 * (n >= (1ull << 30) ? 8 : 4)) * kb;
+	return Ctx::SMALL_BYTES + kb * 256 * 8 + status + (size_t)512 * kb * 256 * 4;
 }
 
 void rsx_release(void)
