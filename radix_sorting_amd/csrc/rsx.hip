@@ -434,42 +434,40 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 	const dim3 grid((unsigned)tiles);
 	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic;
 	// columns with a hot digit (Plan::hot) take the instantiation that tests every round for a wave-uniform digit
-	const bool plain = val_bytes<VT>::value == 0 && ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0 && !(flags & SCATTER_USE_LUT);
+	const bool integer = val_bytes<VT>::value == 0 && ka.fmask == 0 && !(flags & SCATTER_USE_LUT);
+	const bool plain = integer && ka.sflip == 0 && ka.desc == 0;
 	const bool hot = (flags & SCATTER_HOT) != 0;
 	flags &= ~(u32)SCATTER_HOT;
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, \
 	                   vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan)
+#define RSX_LAUNCH2_ST(DIGV)                 \
+	do {                                     \
+		if (wide) {                          \
+			if (hot)                         \
+				RSX_LAUNCH2(u64, DIGV, true);  \
+			else                             \
+				RSX_LAUNCH2(u64, DIGV, false); \
+		} else {                             \
+			if (hot)                         \
+				RSX_LAUNCH2(u32, DIGV, true);  \
+			else                             \
+				RSX_LAUNCH2(u32, DIGV, false); \
+		}                                    \
+	} while (0)
 	bool launched = false;
 	if constexpr (val_bytes<VT>::value == 0) {
 		if (plain) {
 			launched = true;
-			if (wide) {
-				if (hot)
-					RSX_LAUNCH2(u64, DIG_PLAIN, true);
-				else
-					RSX_LAUNCH2(u64, DIG_PLAIN, false);
-			} else {
-				if (hot)
-					RSX_LAUNCH2(u32, DIG_PLAIN, true);
-				else
-					RSX_LAUNCH2(u32, DIG_PLAIN, false);
-			}
+			RSX_LAUNCH2_ST(DIG_PLAIN);
+		} else if (integer) {   // signed and / or descending integers: plain digit XOR a per-pass constant
+			launched = true;
+			RSX_LAUNCH2_ST(DIG_XOR);
 		}
 	}
-	if (!launched) {
-		if (wide) {
-			if (hot)
-				RSX_LAUNCH2(u64, DIG_GENERIC, true);
-			else
-				RSX_LAUNCH2(u64, DIG_GENERIC, false);
-		} else {
-			if (hot)
-				RSX_LAUNCH2(u32, DIG_GENERIC, true);
-			else
-				RSX_LAUNCH2(u32, DIG_GENERIC, false);
-		}
-	}
+	if (!launched)
+		RSX_LAUNCH2_ST(DIG_GENERIC);
+#undef RSX_LAUNCH2_ST
 #undef RSX_LAUNCH2
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;

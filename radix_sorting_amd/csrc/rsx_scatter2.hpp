@@ -66,13 +66,17 @@ template <typename KT, typename VT, typename ST, typename C> struct Sc2Smem {
 
 // DIG_PLAIN: the key is its own KDF (unsigned, ascending) and there is no bucket table: the digit is one
 // bit-field extract.  DIG_GENERIC: kdf_apply + optional lut, as in rsx_scatter_kernel.
-enum { DIG_GENERIC = 0, DIG_PLAIN = 1 };
+// DIG_XOR: integer keys of either sign and order (no float mask, no bucket table): the KDF only complements fixed bits,
+// so the digit is the plain bit field XOR one per-pass constant (0x80 on a signed key's top byte, 0xFF when descending).
+enum { DIG_GENERIC = 0, DIG_PLAIN = 1, DIG_XOR = 2 };
 
 template <int DIG, typename KT>
 __device__ __forceinline__ u32 digit2(KT raw, const KdfArgs<KT> ka, u32 shift, u32 flags, const uint8_t *__restrict__ lut)
 {
 	if constexpr (DIG == DIG_PLAIN)
 		return (u32)(raw >> shift) & 0xFFu;
+	else if constexpr (DIG == DIG_XOR)
+		return ((u32)(raw >> shift) & 0xFFu) ^ ((u32)((ka.sflip ^ ka.desc) >> shift) & 0xFFu);   // (the constant is scalar arithmetic)
 	else
 		return digit_of(raw, ka, shift, flags, lut);
 }
