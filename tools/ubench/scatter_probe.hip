@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc -I tools/ubench tools/ubench/scatter_probe.hip -o tools/ubench/scatter_probe.bin
 #include "rsx_scatter2.hpp"
 #include "rsx_scatter3_experimental.hpp"
+#include "rsx_scatter4_experimental.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -137,6 +138,67 @@ float run2_once(u32 shift, bool dump, u32 tps)
 	return ms;
 }
 
+template <bool TL>
+float run4_once(u32 shift, bool dump)
+{
+	const u64 tiles = n / Sc4Cfg::TILE;
+	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter4_kernel<TL>), dim3((unsigned)tiles), dim3(1024), 0, 0, d_in, d_out, (u64)n, shift,
+	                   d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, g_flags, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	if (TL && dump) {
+		std::vector<u64> tl(tiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, s0 = 0, w0 = 0, s1 = 0, w1 = 0, depth = 0;
+		for (u64 s = 0; s < tiles; ++s) {
+			const u64 *r = &tl[s * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			s0 += (double)(r[4] - r[2]);
+			w0 += (double)(r[5] - r[4]);
+			s1 += (double)(r[6] - r[5]);
+			w1 += (double)(r[7] - r[6]);
+			depth += r[12];
+		}
+		printf("  per 64 Ki-key tile: phase A %7.0f | layout %6.0f | chain %6.0f (depth %.1f) inside | stage0 %6.0f write0 %6.0f | stage1 %6.0f write1 %6.0f | lifetime %7.0f\n",
+		       a / tiles, lay / tiles, ch / tiles, depth / tiles, s0 / tiles, w0 / tiles, s1 / tiles, w1 / tiles,
+		       (a + lay + s0 + w0 + s1 + w1) / tiles);
+	}
+	return ms;
+}
+
+static void bench4()
+{
+	run4_once<false>(0, false);
+	float best = 1e9, sum = 0;
+	for (int i = 0; i < 5; ++i) {
+		float ms = run4_once<false>(8 * (i % 4), false);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("v4 64Ki tiles, 2 windows, lds %zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", sizeof(Sc4Smem), sum / 5, best,
+	       n * 8.0 / (best * 1e-3) / 1e9);
+	run4_once<true>(0, true);
+	run4_once<false>(0, false);
+	std::vector<u32> out(1 << 20);
+	CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+	size_t bad = 0;
+	for (size_t i = 1; i < out.size(); ++i)
+		bad += (out[i - 1] & 0xFF) > (out[i] & 0xFF);
+	printf("v4 check: digit order violations in the first 2^20 outputs: %zu\n", bad);
+}
+
 template <typename C, bool TL>
 float run3_once(u32 shift, bool dump, u32 grid)
 {
@@ -265,6 +327,7 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	bench4();
 	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 16>>("v2 16Ki x2/CU", 1);
 	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 0>>("v2 cell16", 1);
 	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, false, 16>>("v2 16Ki cell32", 1);
