@@ -173,26 +173,20 @@ int main(int argc, char *argv[])
 		return 3;
 	}
 	const size_t e = entries > 0 ? (size_t)entries : 0;
-	try {
-		if (!strcmp(ktype, "uint8_t"))
-			return run<uint8_t>(e, mask);
-		if (!strcmp(ktype, "uint16_t"))
-			return run<uint16_t>(e, mask);
-		if (!strcmp(ktype, "uint32_t"))
-			return run<uint32_t>(e, mask);
-		if (!strcmp(ktype, "uint64_t"))
-			return run<uint64_t>(e, mask);
-		if (!strcmp(ktype, "int32_t"))
-			return run<int32_t>(e, mask);
-		if (!strcmp(ktype, "int64_t"))
-			return run<int64_t>(e, mask);
-		if (!strcmp(ktype, "float"))
-			return run<float>(e, mask);
-		if (!strcmp(ktype, "double"))
-			return run<double>(e, mask);
-	} catch (const std::exception &ex) {
-		printf("Error: %s\n", ex.what());
-		return 4;
+	static const struct {
+		const char *name;
+		int (*sort)(size_t, uint64_t);
+	} types[] = {{"uint8_t", run<uint8_t>}, {"uint16_t", run<uint16_t>}, {"uint32_t", run<uint32_t>}, {"uint64_t", run<uint64_t>},
+	             {"int32_t", run<int32_t>},  {"int64_t", run<int64_t>},   {"float", run<float>},       {"double", run<double>}};
+	for (const auto &t : types) {
+		if (strcmp(ktype, t.name) != 0)
+			continue;
+		try {
+			return t.sort(e, mask);
+		} catch (const std::exception &ex) {
+			printf("Error: %s\n", ex.what());
+			return 4;
+		}
 	}
 	printf("Error: unknown key type, '%s'.\n", ktype);
 	return 100;
