@@ -86,6 +86,18 @@ void        rsx_release(void);
 int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
              void **result, rsx_info *info);
 
+/* The same sort without any host synchronisation: every pass is scheduled on the
+ * device (each finds its column, its buffers and "nothing to do" in the plan the
+ * histogram kernels left in device memory), and the result always ends in d_buf --
+ * when the number of kept columns is odd (radix_sort.hpp:89,:92 would return aux) a
+ * last kernel copies it back.  d_scratch is the auxiliary buffer (n elements; its
+ * contents afterwards are unspecified, untouched if the input was sorted).  Nothing
+ * is returned but the status of the enqueue: the call can be captured into a HIP
+ * graph (after one uncaptured call of the same size has sized the workspace) and
+ * replayed on new contents of d_buf.  Keys only. */
+int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
+                           void *stream);
+
 /* Device-resident variant for callers that own a HIP stream (`stream` is a
  * hipStream_t, NULL = the default stream).  The column plan has to reach the
  * host to apply the returned-pointer rule, so the call synchronises `stream`

@@ -54,6 +54,7 @@ ABI = [
     ("rsx_workspace_bytes", _SZ, [_SZ, _I, _SZ]),
     ("rsx_release", None, []),
     ("rsx_sort", _I, [_VP, _VP, _SZ, _I, _I, _PVP, _PINFO]),
+    ("rsx_sort_inplace_async", _I, [_VP, _VP, _SZ, _I, _I, _VP]),
     ("rsx_sort_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _PVP, _PINFO]),
     ("rsx_sort_pairs_device", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP, _PINFO]),
     ("rsx_sort_rank", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _PVP, _PINFO]),
@@ -152,6 +153,16 @@ def radix_sort(src, aux, dtype=None, order=ASCENDING, stream=None):
     check(lib().rsx_sort_device(src.data_ptr(), aux.data_ptr(), src.numel(), code, order, _stream_ptr(stream),
                                 C.byref(res), C.byref(info)))
     return (aux if info.result_in_aux else src), info
+
+
+def radix_sort_inplace_async(buf, scratch, dtype=None, order=ASCENDING, stream=None):
+    """rsx_sort_inplace_async: no host synchronisation, the sorted keys always end in ``buf`` (graph-capturable)."""
+    _check_dev(buf, scratch)
+    code = _torch_dtype_code(buf) if dtype is None else dtype
+    if buf.element_size() != DTYPE_SIZE[code] or scratch.numel() < buf.numel():
+        raise RsxError("buf/scratch do not match")
+    check(lib().rsx_sort_inplace_async(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream)))
+    return buf
 
 
 def radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=None, order=ASCENDING, stream=None):

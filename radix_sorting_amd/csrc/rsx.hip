@@ -414,7 +414,7 @@ int plan_wait(Ctx &c, Plan *out)
 // gbase[digit]: exclusive offset of the digit for this pass's column
 template <typename KT, typename VT, typename C2>
 int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan, int region)
+                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan, int region, u32 pass_index)
 {
 	const u64 tiles = (n + C2::TILE - 1) / C2::TILE;
 	const u32 tps = (u32)C2::TPS;   // 1: a tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
@@ -440,7 +440,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 	flags &= ~(u32)SCATTER_HOT;
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, \
-	                   vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan)
+	                   vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan, pass_index)
 #define RSX_LAUNCH2_ST(DIGV)                 \
 	do {                                     \
 		if (wide) {                          \
@@ -491,7 +491,7 @@ template <typename KT, typename VT> size_t status_bytes(size_t n)
 
 template <typename KT, typename VT>
 int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan = nullptr, int region = -1)
+                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan = nullptr, int region = -1, u32 pass_index = 0)
 {
 	if ((dplan || region >= 0) && !c.fast)
 		return fail(RSX_EINVAL, "speculative pass / status regions without the fast kernel");
@@ -501,9 +501,9 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 		if constexpr (Small::AVAILABLE) {
 			if (use_small_tiles<KT, VT>(n))
 				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan,
-				                                                     region);
+				                                                     region, pass_index);
 		}
-		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan, region);
+		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan, region, pass_index);
 	}
 	typedef ScatterCfg<KT, VT> C1;   // table-ranked fallback (rsx_kernels.hpp)
 	flags &= ~(u32)SCATTER_HOT;      // (its match tables do not care how many lanes share a digit)
@@ -584,6 +584,30 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	*result = cur;                           // radix_sort.hpp:92
 	if (info)
 		info->result_in_aux = cur == aux;
+	return RSX_OK;
+}
+
+// ---- keys only, no host synchronisation: every pass is device-scheduled, the result always ends in `buf` ------------
+template <typename KT>
+int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, int order)
+{
+	if (!c.fast)
+		return fail(RSX_EHIP, "rsx_sort_inplace_async needs the fast scatter kernel (the device self-check failed on this device)");
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	if (n * sizeof(KT) <= SMALL_SORT_BYTES) {
+		hipLaunchKernelGGL((rsx_small_sort_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, buf, scratch, (u32)n, ka, c.dev_host_plan, true);
+		HIP_TRY(hipGetLastError());
+		return RSX_OK;
+	}
+	const Geo g = one_segment(n);
+	const size_t status_total = status_bytes<KT, NoVal>(n) * sizeof(KT);
+	RSX_TRY(plan_phase<KT>(c, buf, n, ka, g, nullptr, status_total));
+	for (u32 i = 0; i < sizeof(KT); ++i)   // pass i = the i-th kept column, if there is one (radix_sort.hpp:83-90)
+		RSX_TRY((scatter_pass<KT, NoVal>(c, buf, scratch, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), (int)i, i)));
+	// an odd number of kept columns leaves the result in `scratch` (radix_sort.hpp:92): bring it home
+	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)buf, (const unsigned char *)scratch,
+	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
+	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
 
@@ -755,6 +779,19 @@ void rsx_release(void)
 		delete kv.second;
 	}
 	g_ctx.clear();
+}
+
+int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order, void *stream)
+{
+	if (!dtype_size(dtype) || (n && (!d_buf || !d_scratch)))
+		return fail(RSX_EINVAL, "rsx_sort_inplace_async: bad argument");
+	if (n < 2)
+		return RSX_OK;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	RSX_DISPATCH_KT(dtype, return sort_keys_inplace_async<KT>(*c, (KT *)d_buf, (KT *)d_scratch, n, dtype, order));
+	return RSX_OK;
 }
 
 int rsx_sort_device(void *d_src, void *d_aux, size_t n, rsx_dtype dtype, rsx_order order, void *stream, void **result,

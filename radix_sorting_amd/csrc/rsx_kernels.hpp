@@ -963,6 +963,21 @@ __global__ __launch_bounds__(256) void rsx_zero3_kernel(u32x4 *a, u64 na, u32x4 
 		c[i] = z;
 }
 
+// dst = src if the device-side plan says that the sort ended in `src`'s buffer (an odd number of kept columns):
+// the last step of rsx_sort_inplace_async.  16-byte granules + a byte tail.
+__global__ __launch_bounds__(256) void rsx_copy_if_odd_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src,
+                                                              u64 bytes, const Plan *__restrict__ plan)
+{
+	if (plan->sorted || !(plan->ncols & 1))
+		return;
+	const u64 n16 = ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) ? bytes / 16 : 0;
+	const u64 stride = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	for (u64 i = t; i < n16; i += stride)
+		((u32x4 *)dst)[i] = ((const u32x4 *)src)[i];
+	for (u64 i = n16 * 16 + t; i < bytes; i += stride)
+		dst[i] = src[i];
+}
+
 // keys[i] = the KT at byte key_off of record i (records rec_bytes apart; any alignment: assembled from bytes unless
 // both the stride and the offset are multiples of sizeof(KT))
 template <typename KT>

@@ -100,19 +100,26 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  u32 shift, const u64 *__restrict__ gbase, u32 tps, ST *status,
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags,
                                                                  const uint8_t *__restrict__ lut, u64 *tl,
-                                                                 const Plan *__restrict__ dplan = nullptr)
+                                                                 const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0)
 {
 	typedef StatusBits<ST> SB_;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, TPS = C::TPS, SB = C::SB, CHUNK = C::CHUNK;
-	// Speculative first pass: launched before the host has seen the plan, so that the host's wait for the plan is hidden
-	// behind it.  The pass finds its column in the device-side plan and does nothing if the input is sorted
-	// (radix_sort.hpp:60-62: `aux` must stay untouched then).  `gbase` is the histogram's column 0 in this case.
+	// Device-scheduled pass: launched before the host has seen the plan (the first pass of every sort, so that the host's
+	// wait for the plan is hidden behind it; every pass of rsx_sort_inplace_async, which never waits).  The pass is the
+	// `pass_index`-th kept column of the device-side plan: it finds its column there, reads from the second buffer when
+	// its index is odd, and does nothing if the input is sorted (radix_sort.hpp:60-62: `aux` must stay untouched then)
+	// or has fewer kept columns.  `gbase` is the histogram's column 0 in this case.
 	if (dplan) {
-		if (dplan->sorted || dplan->ncols == 0)
+		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
-		const u32 col = dplan->cols[0];
+		const u32 col = dplan->cols[pass_index];
 		shift = 8 * col;
 		gbase += 256 * col;
+		if (pass_index & 1) {
+			const KT *t = kin;
+			kin = kout;
+			kout = const_cast<KT *>(t);
+		}
 	}
 	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
 	// One tile per super-tile: the tile's keys stay in registers between the count and the staging, so they

@@ -18,7 +18,8 @@ constexpr u32 SMALL_SORT_BYTES = 65536;   // per LDS buffer
 
 template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_small_sort_kernel(KT *__restrict__ src, KT *__restrict__ aux, u32 n, KdfArgs<KT> ka,
-                                                              Plan *__restrict__ plan_out)   // pinned host memory
+                                                              Plan *__restrict__ plan_out,   // pinned host memory
+                                                              bool inplace = false)          // result in src whatever the parity
 {
 	constexpr int WC = sizeof(KT), NW = 16, BLOCK = 1024;
 	constexpr u32 CAP = SMALL_SORT_BYTES / sizeof(KT);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(1024) void rsx_small_sort_kernel(KT *__restrict__ s
 		__syncthreads();
 		cur ^= 1;
 	}
-	KT *dst = (ncols & 1) ? aux : src;   // :92
+	KT *dst = ((ncols & 1) && !inplace) ? aux : src;   // :92
 	for (u32 i = tid; i < n; i += BLOCK)
 		dst[i] = buf[cur][i];
 }

@@ -413,6 +413,54 @@ def test_records_with_declared_key(layout, order):
     assert res is srt and info.early_exit == 2 and (aux == 0x5A).all()
 
 
+@pytest.mark.parametrize("dt", [ol.U32, ol.I16, ol.F32, ol.U64, ol.F64, ol.U8], ids=lambda d: ol.DTYPE_NAMES[d])
+def test_inplace_async_sort(dt):
+    """rsx_sort_inplace_async: every pass scheduled on the device, no host synchronisation, result always in the first buffer
+    (odd numbers of kept columns are copied back); sorted input leaves the scratch buffer untouched."""
+    size = ol.DTYPE_SIZE[dt]
+    full = (1 << (8 * size)) - 1
+    rng = np.random.default_rng(31 + dt)
+    for trial, n in enumerate((2, 1000, 16384, 16385, 70001, 300001, 1 << 22)):
+        mask = full if trial % 2 == 0 else full & ~(0xFF << (8 * int(rng.integers(0, size))))    # odd / even column counts
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        for order in (ol.ASC, ol.DESC):
+            want, _, winfo = ol.oracle_sort(a, dt, order)
+            buf = to_dev(a)
+            scratch = torch.full_like(buf, int.from_bytes(bytes([0x5A]) * buf.element_size(), "little"))
+            rsa.radix_sort_inplace_async(buf, scratch, dtype=dt, order=order)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_bits(buf, dt), want), (n, hex(mask), order)
+    srt = to_dev(want)
+    scratch = torch.full_like(srt, int.from_bytes(bytes([0x5A]) * srt.element_size(), "little"))
+    keep = scratch.clone()
+    rsa.radix_sort_inplace_async(srt, scratch, dtype=dt, order=order)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_bits(srt, dt), want) and torch.equal(scratch, keep)
+
+
+@pytest.mark.parametrize("n", [5000, 300001, 1 << 23])
+def test_inplace_async_sort_in_a_hip_graph(n):
+    """The whole sort captured into a graph once and replayed on new keys (three different column counts)."""
+    s = torch.cuda.Stream()
+    buf = torch.empty(n, dtype=torch.int32, device="cuda")
+    scratch = torch.empty_like(buf)
+    with torch.cuda.stream(s):
+        rsa.fill_splitmix(buf, seed=1, stream=s)
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=ol.U32, stream=s)     # sizes the workspace outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=ol.U32, stream=torch.cuda.current_stream())
+    for seed, mask in ((11, 0xFFFFFFFF), (12, 0x00FFFFFF), (13, 0x0000FF00)):
+        a = ol.splitmix_fill(n, ol.U32, seed, mask)
+        buf.copy_(to_dev(a))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want, _, _ = ol.oracle_sort(a, ol.U32)
+        assert np.array_equal(to_bits(buf, ol.U32), want), (n, seed)
+
+
 # ---- BASELINE.json sizes: size-independent properties + full comparison where the oracle is quick enough ----
 
 def test_full_size_2p28_u32_properties():
