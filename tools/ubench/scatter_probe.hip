@@ -3,6 +3,7 @@
 #include "rsx_scatter2.hpp"
 #include "rsx_scatter3_experimental.hpp"
 #include "rsx_scatter4_experimental.hpp"
+#include "rsx_scatter5_experimental.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -136,6 +137,64 @@ float run2_once(u32 shift, bool dump, u32 tps)
 		printf(" lifetime %8.0f\n", life / stiles);
 	}
 	return ms;
+}
+
+template <bool TL>
+float run5_once(u32 shift, bool dump, u32 grid)
+{
+	const u64 tiles = n / Sc5Cfg::TILE;
+	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter5_kernel<TL>), dim3(grid), dim3(1024), 0, 0, d_in, d_out, (u64)n, shift, d_hist + 256 * (shift / 8),
+	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, g_flags, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	if (TL && dump) {
+		std::vector<u64> tl(tiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, st = 0, wo = 0, depth = 0;
+		for (u64 s = 0; s < tiles; ++s) {
+			const u64 *r = &tl[s * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			st += (double)(r[4] - r[2]);
+			wo += (double)(r[5] - r[4]);
+			depth += r[12];
+		}
+		printf("  per tile: count %7.0f | layout %6.0f | chain %6.0f (depth %.1f) inside | stage %6.0f | write %6.0f | lifetime %7.0f\n", a / tiles,
+		       lay / tiles, ch / tiles, depth / tiles, st / tiles, wo / tiles, (a + lay + st + wo) / tiles);
+	}
+	return ms;
+}
+
+static void bench5(u32 grid)
+{
+	run5_once<false>(0, false, grid);
+	float best = 1e9, sum = 0;
+	for (int i = 0; i < 5; ++i) {
+		float ms = run5_once<false>(8 * (i % 4), false, grid);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("v5 persistent, loads at stage start, grid %u: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", grid, sum / 5, best,
+	       n * 8.0 / (best * 1e-3) / 1e9);
+	run5_once<true>(0, true, grid);
+	run5_once<false>(0, false, grid);
+	std::vector<u32> out(1 << 20);
+	CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+	size_t bad = 0;
+	for (size_t i = 1; i < out.size(); ++i)
+		bad += (out[i - 1] & 0xFF) > (out[i] & 0xFF);
+	printf("v5 check: digit order violations in the first 2^20 outputs: %zu\n", bad);
 }
 
 template <bool TL>
@@ -304,6 +363,41 @@ void bench(const char *name, u32 tps)
 	run_once<SH, true>(0, true);
 }
 
+// every aligned block of 256 keys holds each digit once in every byte column: a tile's runs are all 128 keys and start
+// on 512-byte boundaries (an upper bound for what aligned runs could give)
+__device__ inline u32 mix15(u32 x, u32 c, u32 m1, u32 m2)
+{
+	x = (x ^ c) & 0x7FFFu;   // every step is a bijection on 15 bits
+	x ^= x >> 7;
+	x = (x * m1) & 0x7FFFu;
+	x ^= x >> 5;
+	x = (x * m2) & 0x7FFFu;
+	x ^= x >> 9;
+	return x;
+}
+
+// mode 1: every tile of 32 Ki keys holds each digit exactly 128 times in every byte column, in scrambled order: all runs are
+// 512 bytes and start on 512-byte boundaries.  mode 2: the same with run lengths 128 +- 16 j (64-byte aligned starts only).
+__global__ void balanced_digits_kernel(u32 *a, u64 n, u32 mode)
+{
+	for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+		const u32 t = (u32)(i >> 15) * 2654435761u, w = (u32)i & 0x7FFFu;
+		u32 k = 0;
+		const u32 m1[4] = {0x2545u, 0x1b0du, 0x6a6bu, 0x4f35u}, m2[4] = {0x5bd1u, 0x3c6fu, 0x0e99u, 0x7ab3u};
+		for (int b = 0; b < 4; ++b) {
+			const u32 x = mix15(w, t >> (4 * b + 1), m1[b], m2[b]);
+			u32 d = x >> 7;
+			if (mode == 2) {
+				// slots of 16 keys (2048 per tile) dealt to digits unevenly: digit pairs (2m, 2m+1) get 8 + s and 8 - s slots
+				const u32 slot = x >> 4, pair = slot >> 4, in = slot & 15u, s = (pair * 5u + (t >> 9)) % 7u;
+				d = 2 * pair + (in < 8 + s ? 0 : 1);
+			}
+			k |= d << (8 * b);
+		}
+		a[i] = k;
+	}
+}
+
 int main(int argc, char **argv)
 {
 	const int log2n = argc > 1 ? atoi(argv[1]) : 28;
@@ -316,6 +410,10 @@ int main(int argc, char **argv)
 	CK(hipMalloc(&d_status, 256 + (n / 1024 + 1) * 256 * 4));
 	CK(hipMalloc(&d_tl, (n / 1024 + 1) * 16 * 8));
 	hipLaunchKernelGGL((rsx_fill_splitmix_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, 1ull, ~0ull, 0ull);
+	if (argc > 2) {
+		printf("balanced digits, mode %d\n", atoi(argv[2]));
+		hipLaunchKernelGGL(balanced_digits_kernel, dim3(2048), dim3(256), 0, 0, d_in, (u64)n, (u32)atoi(argv[2]));
+	}
 	CK(hipMemset(d_hist, 0, 8 * 256 * 8));
 	CK(hipMemset(d_flag, 0, 64));
 	KdfArgs<u32> ka{0, 0, 0};
@@ -327,6 +425,11 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	if (argc > 2)
+		return 0;
+	bench5(256);
+	bench5(512);
+	return 0;
 	bench4();
 	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 16>>("v2 16Ki x2/CU", 1);
 	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 0>>("v2 cell16", 1);
