@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=None, help="keys per GPU (default 28 at N=1, 29 at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="test switch: take the N>1 code path (process group, partition, all-to-all-v) whatever N is")
     args = ap.parse_args()
 
     import torch
@@ -108,12 +110,16 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     rsa.require_gpu()
-    if world > 1:
+    sharded = world > 1 or args.force_exchange
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     K, W = args.steps, args.warmup
-    log2n = args.log2n if args.log2n is not None else (28 if world == 1 else 29)
+    log2n = args.log2n if args.log2n is not None else (29 if sharded else 28)
     n = 1 << log2n
     dev = torch.device("cuda", local_rank)
     nbatches = K + W
@@ -125,20 +131,20 @@ def main():
         rsa.fill_splitmix(t, seed=1 + b, first_index=rank * n)
         batches.append(t)
     engine = multi.HipEngine(rsa.U32)
-    cap = n if world == 1 else n + n // 4
+    cap = n + n // 4 if sharded else n
     scratch = {"aux": torch.empty(cap, dtype=torch.int32, device=dev)}
-    if world > 1:
+    if sharded:
         scratch["part"] = torch.empty(n, dtype=torch.int32, device=dev)
         scratch["recv"] = torch.empty(cap, dtype=torch.int32, device=dev)
 
     def step(i):
-        if world == 1:
+        if not sharded:
             return rsa.radix_sort(batches[i], scratch["aux"], dtype=rsa.U32)
-        return multi.distributed_sort(batches[i], engine, scratch=scratch)
+        return multi.distributed_sort(batches[i], engine, scratch=scratch, force_exchange=args.force_exchange)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -154,7 +160,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = rsa.profile_end()
 
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -163,13 +169,21 @@ def main():
     res = last[0]
     flipped = res ^ torch.tensor(-2 ** 31, dtype=torch.int32, device=dev)
     ok = bool((flipped[1:] >= flipped[:-1]).all().item()) if res.numel() > 1 else True
-    if world > 1:
+    if sharded:
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
     if not ok:
         raise SystemExit("bench: output of the last step is not sorted")
 
+    if sharded:
+        # RCCL writes its version banner to the C stdout (NCCL_DEBUG=VERSION on the GPU boxes): push it out on every rank
+        # before rank 0 prints, so that the JSON line is the last line of the job's output
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        dist.barrier()
+        torch.cuda.synchronize()
     if rank == 0:
         total_keys = float(K) * n * world
         launches = max(int(prof.scatter_launches), 1)
@@ -191,11 +205,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("2^%d uniform-random u32 keys, 4x8-bit LSD passes, keys only (BASELINE.json configs[1])" % log2n)
-                if world == 1 else
+                if not sharded else
                 ("%d x 2^%d u32 keys sharded by MSD digit, RCCL all-to-all-v, local LSD (BASELINE.json configs[4])"
                  % (world, log2n)),
                 "keys_per_gpu": n, "total_keys": n * world, "generator": "splitmix64 seed 1+batch",
-                "parallelism": "1 gpu" if world == 1 else "msd%d" % world, "output_sorted": ok,
+                "parallelism": "msd%d" % world if sharded else "1 gpu", "output_sorted": ok,
             },
             "roofline": {
                 "kernel": "rsx_scatter2_kernel<u32,NoVal,u32>",
@@ -208,13 +222,13 @@ def main():
                 "scatter_ms_per_step": prof.scatter_ms / K,
                 "histogram_ms_per_step": prof.hist_ms / K,
                 "histogram_GBps": (prof.hist_bytes / max(prof.hist_ms, 1e-9) / 1e6) if prof.hist_ms > 0 else None,
-                "sort_algorithmic_GBps": total_keys / world * 36 / elapsed / 1e9 if world == 1 else None,
+                "sort_algorithmic_GBps": None if sharded else total_keys / world * 36 / elapsed / 1e9,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if sharded:
         dist.destroy_process_group()
 
 

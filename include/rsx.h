@@ -186,6 +186,15 @@ int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
                          rsx_order order, const uint8_t *lut, uint32_t nbuckets,
                          const uint64_t *top_hist, uint64_t *counts, void *stream);
 
+/* The MSD split as one ordinary stable scatter pass by the top KDF byte itself
+ * (256 digits; README.md:647-650): d_dst = d_src ordered by that
+ * byte, top_hist (host, 256 uint64) = its counts.  Destinations that are
+ * contiguous ranges of the byte are contiguous ranges of d_dst:
+ * digit d occupies [sum(top_hist[0..d)), +top_hist[d]).  The counts are ready on
+ * return; the pass is enqueued on stream. */
+int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype,
+                         rsx_order order, uint64_t *top_hist, void *stream);
+
 /* ---- measurement hooks and input generator (bench.py, tests) ------------------ */
 
 /* Between rsx_profile_begin() and rsx_profile_end() every histogram and scatter

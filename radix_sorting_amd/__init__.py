@@ -65,6 +65,7 @@ ABI = [
     ("rsx_sort_rank_keys", _I, [_VP, _SZ, _VP, _SZ, _SZ, _PVP, _PINFO]),
     ("rsx_histogram_device", _I, [_VP, _SZ, _I, _I, _VP, _VP, _VP]),
     ("rsx_partition_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _U32, _VP, _VP, _VP]),
+    ("rsx_msd_split_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _VP]),
     ("rsx_profile_begin", _I, []),
     ("rsx_profile_end", _I, [C.POINTER(Profile)]),
     ("rsx_fill_splitmix_device", _I, [_VP, _SZ, _SZ, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),

@@ -729,6 +729,30 @@ bool is_device_ptr(const void *p)
 }
 
 // dispatch on key width
+// ---- one plain scatter pass by the top KDF byte (rsx_msd_split_device) ---------------------------------------------
+template <typename KT>
+int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, const Geo &g, uint64_t *top_hist)
+{
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	const u64 *top = c.ghist() + 256 * (sizeof(KT) - 1);
+	RSX_TRY(launch_hist<KT>(c, src, n, ka, c.ghist(), c.unsorted(), g));
+	HIP_TRY(hipMemcpyAsync(c.host_hist, top, 256 * sizeof(u64), hipMemcpyDeviceToHost, c.stream));   // counts, before the scan
+	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), g.nseg, ka, c.kept());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c.stream));
+	u64 total = 0;
+	u64 most = 0;
+	for (int i = 0; i < 256; ++i) {
+		top_hist[i] = c.host_hist[i];
+		total += top_hist[i];
+		most = std::max<u64>(most, top_hist[i]);
+	}
+	if (total != n)
+		return fail(RSX_EHIP, "rsx_msd_split_device: digit counts sum to %llu, n = %zu", (unsigned long long)total, n);
+	const u32 flags = most >= (u64)n / 8 + 1 ? (u32)SCATTER_HOT : 0u;   // as Plan::hot (rsx_plan_kernel)
+	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, (u32)(8 * (sizeof(KT) - 1)), top, ka, flags, nullptr);
+}
+
 #define RSX_DISPATCH_KT(dtype, CALL)                               \
 	switch (dtype_size(dtype)) {                                   \
 	case 1: { typedef uint8_t KT; CALL; } break;                   \
@@ -1251,6 +1275,34 @@ int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 	                                                       (u32)(8 * (kb - 1)), (const u64 *)c->bbase.p,
 	                                                       make_kdf<KT>(dtype, order), SCATTER_USE_LUT, c->lut()))));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	return RSX_OK;
+}
+
+// The MSD split of the multi-GPU sort as ONE ordinary scatter pass on the top KDF byte.  The destinations of the exchange are
+// contiguous ranges of that byte (multi.py, choose_splitters), so a stable pass by the byte itself leaves every
+// destination's keys contiguous in d_dst -- with 256 digits instead of G buckets there is no crowd of lanes on a handful
+// of LDS counters, and the pass runs on the plain-digit kernel.  Keys of one destination arrive ordered by (top byte,
+// original index) instead of by original index; equal keys have equal top bytes, so the stable order of the final result
+// is the same.  top_hist (host, 256 uint64) receives the counts of the top byte; the pass itself is only enqueued.
+int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order, uint64_t *top_hist,
+                         void *stream)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb || !top_hist || (n && (!d_src || !d_dst)))
+		return fail(RSX_EINVAL, "rsx_msd_split_device: bad argument");
+	for (int i = 0; i < 256; ++i)
+		top_hist[i] = 0;
+	if (n == 0)
+		return RSX_OK;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	const Geo g = one_segment(n);
+	const size_t hist_bytes = (size_t)g.nseg * kb * 256 * sizeof(u64);
+	RSX_TRY(c->hist.ensure(hist_bytes));
+	HIP_TRY(hipMemsetAsync(c->hist.p, 0, hist_bytes, c->stream));
+	HIP_TRY(hipMemsetAsync(c->small.p, 0, 192, c->stream));
+	RSX_DISPATCH_KT(dtype, return msd_split<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, g, top_hist));
 	return RSX_OK;
 }
 

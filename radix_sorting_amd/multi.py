@@ -4,22 +4,28 @@ The reference is single-threaded; its README suggests exactly this hybrid for
 parallelism ("one MSB pass then LSB sort the sub-results", README.md:647-650).
 SURVEY.md section 8e is the contract implemented here, one process per GPU:
 
-  1. every rank histograms the top KDF byte of its shard (rsx_histogram_device);
-  2. the 256 counts are summed over ranks (tiny all-reduce) and every rank derives
-     the same splitters: contiguous top-digit ranges holding ~n/G keys each;
-  3. a stable local partition by destination rank (rsx_partition_device: the
-     scatter kernel with bucket = lut[top digit]);
-  4. the G x G count matrix is exchanged, then the buckets themselves, with
-     ``all_to_all_single`` (RCCL all-to-all-v over xGMI; each directed pair of
-     GPUs has its own link);
-  5. each rank LSD-sorts what it received (rsx_sort_device).
+  1. every rank runs ONE stable scatter pass by the top KDF byte of its shard
+     (rsx_msd_split_device) and gets the 256 counts of that byte;
+  2. the counts of all ranks are all-gathered (G x 256 numbers) and every rank
+     derives the same splitters -- contiguous top-digit ranges holding ~n/G keys
+     each -- and the whole G x G count matrix (no second count exchange);
+  3. a destination's keys are a contiguous range of the split shard, so the
+     buckets go out as they lie with ``all_to_all_single`` (RCCL all-to-all-v
+     over xGMI; each directed pair of GPUs has its own link);
+  4. each rank LSD-sorts what it received (rsx_sort_device).
 
-Receive order is by source rank and the partition is stable, so with shards held
-in global index order the concatenation of the ranks' results is the stable sort
-of the concatenated input -- bit-identical to the reference run on the whole array.
+Splitting by the byte itself (256 digits) and not by destination (G buckets)
+keeps the pass on the plain-digit kernel: with G = 2..8 buckets every LDS counter
+would be hit by 8..32 lanes of each instruction, which serialises them.
+
+Receive order is by source rank and the split is stable, so with shards held in
+global index order the keys of one received bucket range are ordered by (source
+rank, top byte, index) -- equal keys by (source rank, index) -- and the
+concatenation of the ranks' stable local sorts is the stable sort of the
+concatenated input: bit-identical to the reference run on the whole array.
 
 The device work sits behind a small engine object so that the host logic
-(splitters, count exchange, collectives) can be exercised on CPU with the gloo
+(splitters, count matrix, collectives) can be exercised on CPU with the gloo
 backend in tests (tests/ inject an oracle-backed engine); the product engine is
 HipEngine and it fails loudly without a GPU.
 """
@@ -48,6 +54,15 @@ def choose_splitters(top_hist, world):
     r = np.clip(r, 0, world - 1)
     r = np.maximum.accumulate(r)          # monotone even with empty digits
     return r.astype(np.uint8)
+
+
+def count_matrix(hists, lut, world):
+    """matrix[s, d] = number of keys of rank s whose top digit belongs to rank d (hists: world x 256 counts)."""
+    m = np.zeros((world, world), dtype=np.uint64)
+    lut = np.asarray(lut, dtype=np.int64)
+    for d in range(world):
+        m[:, d] = np.asarray(hists, dtype=np.uint64)[:, lut == d].sum(axis=1)
+    return m
 
 
 class HipEngine:
@@ -79,6 +94,13 @@ class HipEngine:
                                          lut.ctypes.data, world, th.ctypes.data, counts.ctypes.data, _stream_ptr()))
         return counts
 
+    def msd_split(self, shard, out):
+        """out = shard in stable order of the top KDF byte (enqueued); returns that byte's 256 counts (host)."""
+        hist = np.zeros(256, dtype=np.uint64)
+        check(lib().rsx_msd_split_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order,
+                                         hist.ctypes.data, _stream_ptr()))
+        return hist
+
     def local_sort(self, keys, aux):
         res, info = radix_sort(keys, aux, dtype=self.dtype, order=self.order)
         return res, info
@@ -87,13 +109,14 @@ class HipEngine:
         return self.torch.empty(n, dtype=like.dtype, device=like.device)
 
 
-def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None):
+def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None, force_exchange=False):
     """Sort the concatenation of every rank's ``shard`` (rank order = global index order).
 
     Returns (sorted_local, stats): rank r ends up with the r-th contiguous slice of
     the globally sorted sequence (slice sizes follow the splitters, not n/G).
     ``scratch`` may carry preallocated tensors {"part", "recv", "aux"} (>= capacity) to keep
-    allocation out of a timed region.
+    allocation out of a timed region.  ``force_exchange`` runs every exchange step even in a one-rank group (the
+    collectives then talk to the rank itself): that is how the RCCL path is exercised on a one-GPU box.
     """
     import torch
     import torch.distributed as dist
@@ -101,27 +124,23 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = shard.numel()
-    if world == 1:
+    if world == 1 and not (force_exchange and dist.is_initialized()):
         aux = scratch["aux"][:n] if scratch else engine.empty(n, shard)
         res, info = engine.local_sort(shard, aux)
         return res, {"sent": 0, "received": n, "local_info": info}
 
-    # 1-2: global histogram of the top digit -> identical splitters on every rank
-    local_hist = engine.top_histogram(shard)
-    global_hist = local_hist.clone()
-    dist.all_reduce(global_hist, group=group)
-    hist_host = torch.stack([local_hist, global_hist]).cpu().numpy().astype(np.uint64)
-    lut = choose_splitters(hist_host[1], world)
-
-    # 3: stable local partition by destination rank
+    # 1: one stable pass by the top KDF byte; its counts
     part = scratch["part"][:n] if scratch else engine.empty(n, shard)
-    send_counts = engine.partition(shard, part, lut, world, hist_host[0])
+    local_hist = engine.msd_split(shard, part)
 
-    # 4: count matrix, then the buckets (all-to-all-v)
-    sc = torch.tensor(send_counts.astype(np.int64), dtype=torch.int64, device=shard.device)
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = rc.cpu().numpy()
+    # 2: everybody's counts -> identical splitters and the whole count matrix on every rank
+    mine = torch.from_numpy(local_hist.astype(np.int64)).to(shard.device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    hists = torch.stack(gathered).cpu().numpy().astype(np.uint64)
+    lut = choose_splitters(hists.sum(axis=0), world)
+    matrix = count_matrix(hists, lut, world)          # matrix[s, d]: keys rank s sends to rank d
+    send_counts, recv_counts = matrix[rank], matrix[:, rank]
     n_recv = int(recv_counts.sum())
     if scratch:
         if n_recv > scratch["recv"].numel():
@@ -132,13 +151,15 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     else:
         recv = engine.empty(n_recv, shard)
         aux = engine.empty(n_recv, shard)
-    # the exchange moves opaque bytes: every key width then works on every backend (gloo has no int16)
+
+    # 3: the buckets (all-to-all-v).  The exchange moves opaque bytes: every key width then works on every backend
+    # (gloo has no int16)
     es = shard.element_size()
     dist.all_to_all_single(recv.view(torch.uint8), part.view(torch.uint8),
                            output_split_sizes=[int(x) * es for x in recv_counts],
                            input_split_sizes=[int(x) * es for x in send_counts], group=group)
 
-    # 5: local LSD sort of the received bucket range
+    # 4: local LSD sort of the received bucket range
     res, info = engine.local_sort(recv, aux)
     sent = int(send_counts.sum() - send_counts[rank])
     return res, {"sent": sent, "received": n_recv, "local_info": info, "lut": lut,

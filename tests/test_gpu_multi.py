@@ -93,9 +93,122 @@ def test_simulated_ranks_match_single_sort(world, dt, mask):
     assert np.array_equal(np.concatenate(results), want)
 
 
+@pytest.mark.parametrize("dt,order,n,mask", [(ol.U32, 0, 1500001, 0xFFFFFFFF), (ol.F32, 1, 700001, 0xFFFFFFFF),
+                                               (ol.U64, 0, 1200007, 0xFFFFFFFFFFFFFFFF), (ol.I16, 0, 900001, 0xFFFF),
+                                               (ol.U8, 0, 500000, 0xFF), (ol.U32, 0, 400000, 0x00FFFFFF),
+                                               (ol.U32, 0, 2000, 0xFFFFFFFF), (ol.I32, 0, 1 << 23, 0x030000FF)])
+def test_msd_split(dt, order, n, mask):
+    """rsx_msd_split_device: dst = src in stable order of the top KDF byte, counts of that byte on the host.  The masks
+    cover a constant top byte (one run: a copy) and four top digits (hot digits)."""
+    a = ol.splitmix_fill(n, dt, 29 + dt, mask)
+    eng = multi.HipEngine(dt, order)
+    shard = to_dev(a)
+    out = torch.zeros_like(shard)
+    hist = eng.msd_split(shard, out)
+    torch.cuda.synchronize()
+    k = ol.kdf_keys(a, dt, order)
+    top = (k >> ol.NP_BITS[dt](8 * (ol.DTYPE_SIZE[dt] - 1))).astype(np.int64)
+    assert np.array_equal(hist, np.bincount(top, minlength=256).astype(np.uint64))
+    assert np.array_equal(out.cpu().numpy().view(ol.NP_BITS[dt]), a[np.argsort(top, kind="stable")])
+    assert np.array_equal(shard.cpu().numpy().view(ol.NP_BITS[dt]), a)          # the source is left alone
+
+
+@pytest.mark.parametrize("world,dt,mask", [(2, ol.U32, 0xFFFFFFFF), (8, ol.U32, 0xFFFFFFFF), (4, ol.F64, 0xFFFFFFFFFFFFFFFF),
+                                             (3, ol.U32, 0x00FFFFFF), (5, ol.I16, 0xFFFF)])
+def test_simulated_ranks_with_msd_split(world, dt, mask):
+    """multi.distributed_sort's steps with `world` ranks played on one GPU: msd_split -> all-gather (stack) -> splitters and
+    count matrix -> exchange (slices) -> local sort; the concatenation is the oracle's sort of the whole input."""
+    n_per_rank = [150000 + 999 * r for r in range(world)]
+    whole = ol.splitmix_fill(sum(n_per_rank), dt, 37, mask)
+    eng = multi.HipEngine(dt)
+    parts, hists, first = [], [], 0
+    for r in range(world):
+        shard = to_dev(whole[first:first + n_per_rank[r]])
+        first += n_per_rank[r]
+        out = torch.zeros_like(shard)
+        hists.append(eng.msd_split(shard, out))
+        parts.append(out)
+    torch.cuda.synchronize()
+    hists = np.stack(hists)
+    lut = multi.choose_splitters(hists.sum(axis=0), world)
+    matrix = multi.count_matrix(hists, lut, world)
+    results = []
+    for dst in range(world):
+        pieces = []
+        for src in range(world):
+            off = int(matrix[src][:dst].sum())
+            pieces.append(parts[src][off:off + int(matrix[src][dst])])
+        recv = torch.cat(pieces)
+        res, info = eng.local_sort(recv, torch.zeros_like(recv))
+        torch.cuda.synchronize()
+        results.append(res.cpu().numpy().view(ol.NP_BITS[dt]))
+    assert np.array_equal(np.concatenate(results), ol.oracle_sort(whole, dt)[0])
+
+
 def test_distributed_sort_single_process():
     """world == 1 path of multi.distributed_sort (what `bench.py --gpus 1` does not use, kept honest anyway)."""
     a = ol.splitmix_fill(300000, ol.U32, 4)
     res, stats = multi.distributed_sort(to_dev(a), multi.HipEngine(ol.U32))
     torch.cuda.synchronize()
     assert np.array_equal(res.cpu().numpy().view(np.uint32), np.sort(a))
+
+
+_RCCL_SELF_EXCHANGE = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+from radix_sorting_amd import multi
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+for dt, carrier in ((ol.U32, np.int32), (ol.U64, np.int64), (ol.I16, np.int16)):
+    a = ol.splitmix_fill(777777, dt, 31)
+    shard = torch.from_numpy(a.view(carrier).copy()).cuda()
+    res, stats = multi.distributed_sort(shard, multi.HipEngine(dt), force_exchange=True)
+    torch.cuda.synchronize()
+    assert stats["received"] == a.size and stats["sent"] == 0 and "lut" in stats, stats
+    want = ol.oracle_sort(a, dt)[0]
+    assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), want), dt
+dist.barrier()
+dist.destroy_process_group()
+print("self-exchange OK")
+"""
+
+
+def _one_rank_env():
+    import os
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_exchange_steps_over_rccl_in_a_one_rank_group():
+    """The N>1 code path end to end over RCCL (all-reduce, count exchange, all-to-all-v of bytes, local sort) with the one
+    rank a one-GPU box can hold: the collectives talk to the rank itself."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _RCCL_SELF_EXCHANGE, root], capture_output=True, text=True, timeout=600,
+                         env=_one_rank_env())
+    assert out.returncode == 0 and "self-exchange OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_sharded_path_in_a_one_rank_group():
+    """bench.py's N>1 branch (scratch buffers, barrier-fenced timing, max over ranks, JSON line) with --force-exchange."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--log2n", "22", "--force-exchange"], capture_output=True, text=True, timeout=600, env=_one_rank_env())
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "msd1" and line["config"]["output_sorted"] is True
+    assert line["value"] > 0 and line["scaling"] == "weak" and "cpu_baseline" not in line

@@ -43,6 +43,13 @@ class OracleEngine:
         out.numpy().view(bits.dtype)[:bits.size] = bits[perm]
         return np.bincount(dest, minlength=world).astype(np.uint64)
 
+    def msd_split(self, shard, out):
+        bits = self._bits(shard)
+        k = ol.kdf_keys(bits, self.dtype, self.order)
+        top = (k >> ol.NP_BITS[self.dtype](8 * (ol.DTYPE_SIZE[self.dtype] - 1))).astype(np.int64)
+        out.numpy().view(bits.dtype)[:bits.size] = bits[np.argsort(top, kind="stable")]
+        return np.bincount(top, minlength=256).astype(np.uint64)
+
     def local_sort(self, keys, aux):
         res, in_aux, info = ol.oracle_sort(self._bits(keys), self.dtype, self.order)
         target = aux if in_aux else keys
@@ -98,6 +105,17 @@ def test_distributed_sort_matches_single_sort(tmp_path, world, dtype, order, mas
     sizes = [np.load(os.path.join(str(tmp_path), "out%d.npy" % r)).size for r in range(world)]
     if mask == 0xFFFFFFFF and dtype == ol.U32:
         assert max(sizes) < 1.2 * sum(sizes) / world      # uniform keys -> balanced splitters
+
+
+def test_count_matrix():
+    rng = np.random.default_rng(11)
+    hists = rng.integers(0, 1000, (3, 256)).astype(np.uint64)
+    lut = multi.choose_splitters(hists.sum(axis=0), 3)
+    m = multi.count_matrix(hists, lut, 3)
+    assert m.shape == (3, 3) and np.array_equal(m.sum(axis=1), hists.sum(axis=1))
+    for s in range(3):
+        for d in range(3):
+            assert m[s, d] == hists[s][lut == d].sum()
 
 
 def test_choose_splitters_properties():
