@@ -140,6 +140,23 @@ T *radix_sort(T *RESTRICT src, T *RESTRICT aux, size_t n, KeyFunc &&kf = basic_k
 	return rsx_detail::sort_dispatch<T>(src, aux, n, kf);
 }
 
+// Not in the reference: the same call with the work spread over several MI355X of this process (rsx_sort_multi).
+// `devices` holds HIP device indices, one per rank.  Scalar T with the default or the descending KDF.
+template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>)>
+T *radix_sort_multi(T *RESTRICT src, T *RESTRICT aux, size_t n, const int *devices, int ndev, KeyFunc &&kf = basic_kdfs::kdf<T>)
+{
+	(void)kf;
+	static_assert(rsx_detail::is_default_kdf_v<T, KeyFunc> || rsx_detail::is_descending_kdf_v<T, KeyFunc>,
+	              "radix_sort_multi takes scalar keys with basic_kdfs::kdf or rsx_kdf::descending");
+	void *result = nullptr;
+	const int rc = rsx_sort_multi(src, aux, n, rsx_detail::dtype_of<T>(),
+	                              rsx_detail::is_descending_kdf_v<T, KeyFunc> ? RSX_DESCENDING : RSX_ASCENDING, devices, ndev,
+	                              &result, nullptr);
+	if (rc != RSX_OK)
+		rsx_detail::fail("radix_sort_multi", rc);
+	return static_cast<T *>(result);
+}
+
 // The reference lets the caller supply the histogram storage (any container with value_type and
 // operator[], radix_sort.hpp:28-33).  The device keeps its own counters; `histogram` is accepted for
 // compatibility and left untouched.

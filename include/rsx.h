@@ -191,9 +191,22 @@ int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
  * byte, top_hist (host, 256 uint64) = its counts.  Destinations that are
  * contiguous ranges of the byte are contiguous ranges of d_dst:
  * digit d occupies [sum(top_hist[0..d)), +top_hist[d]).  The counts are ready on
- * return; the pass is enqueued on stream. */
+ * return; the pass is enqueued on stream.  column < 0: the top byte; otherwise
+ * the byte to split by (a caller that knows the bytes above it to be constant). */
 int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype,
-                         rsx_order order, uint64_t *top_hist, void *stream);
+                         rsx_order order, int column, uint64_t *top_hist, void *stream);
+
+/* radix_sort(src, aux, n, kdf) on HOST buffers with the work spread over `ndev`
+ * devices of this one process (radix_sort.hpp:98-115 semantics: early exits,
+ * kept columns, returned pointer, `aux` untouched on sorted input -- decided
+ * globally, exactly as one rsx_sort call would).  devices: HIP device indices, one
+ * per rank; an index may repeat (several ranks then share a device).  Shard r =
+ * the r-th n/ndev-th of src; MSD split by the highest kept byte, peer-to-peer
+ * exchange of the digit ranges, local LSD sorts, each written to its place in
+ * the result buffer.  Blocking.  The one-process-per-GPU form of the same
+ * algorithm (RCCL all-to-all-v) is radix_sorting_amd/multi.py. */
+int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
+                   const int *devices, int ndev, void **result, rsx_info *info);
 
 /* ---- measurement hooks and input generator (bench.py, tests) ------------------ */
 

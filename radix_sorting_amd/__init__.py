@@ -65,7 +65,8 @@ ABI = [
     ("rsx_sort_rank_keys", _I, [_VP, _SZ, _VP, _SZ, _SZ, _PVP, _PINFO]),
     ("rsx_histogram_device", _I, [_VP, _SZ, _I, _I, _VP, _VP, _VP]),
     ("rsx_partition_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _U32, _VP, _VP, _VP]),
-    ("rsx_msd_split_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _VP]),
+    ("rsx_msd_split_device", _I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP]),
+    ("rsx_sort_multi", _I, [_VP, _VP, _SZ, _I, _I, _VP, _I, _PVP, _PINFO]),
     ("rsx_profile_begin", _I, []),
     ("rsx_profile_end", _I, [C.POINTER(Profile)]),
     ("rsx_fill_splitmix_device", _I, [_VP, _SZ, _SZ, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
@@ -223,6 +224,18 @@ def radix_sort_host(src, aux, dtype, order=ASCENDING):
     """rsx_sort on host numpy buffers; returns (result_array, info)."""
     res, info = C.c_void_p(), Info()
     check(lib().rsx_sort(src.ctypes.data, aux.ctypes.data, src.size, dtype, order, C.byref(res), C.byref(info)))
+    return (aux if info.result_in_aux else src), info
+
+
+def radix_sort_multi_host(src, aux, dtype, order=ASCENDING, devices=None):
+    """rsx_sort_multi on host numpy buffers: one process, the work spread over `devices` (HIP device indices, one per rank;
+    default: every visible device once).  Returns (result_array, info) with the reference's returned-pointer rule."""
+    if devices is None:
+        devices = list(range(max(device_count(), 1)))
+    dev = (C.c_int * len(devices))(*devices)
+    res, info = C.c_void_p(), Info()
+    check(lib().rsx_sort_multi(src.ctypes.data, aux.ctypes.data, src.size, dtype, order, dev, len(devices), C.byref(res),
+                               C.byref(info)))
     return (aux if info.result_in_aux else src), info
 
 

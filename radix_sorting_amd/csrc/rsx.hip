@@ -18,7 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -731,10 +733,10 @@ bool is_device_ptr(const void *p)
 // dispatch on key width
 // ---- one plain scatter pass by the top KDF byte (rsx_msd_split_device) ---------------------------------------------
 template <typename KT>
-int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, const Geo &g, uint64_t *top_hist)
+int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u32 col, const Geo &g, uint64_t *top_hist)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	const u64 *top = c.ghist() + 256 * (sizeof(KT) - 1);
+	const u64 *top = c.ghist() + 256 * col;
 	RSX_TRY(launch_hist<KT>(c, src, n, ka, c.ghist(), c.unsorted(), g));
 	HIP_TRY(hipMemcpyAsync(c.host_hist, top, 256 * sizeof(u64), hipMemcpyDeviceToHost, c.stream));   // counts, before the scan
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), g.nseg, ka, c.kept());
@@ -750,7 +752,106 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, co
 	if (total != n)
 		return fail(RSX_EHIP, "rsx_msd_split_device: digit counts sum to %llu, n = %zu", (unsigned long long)total, n);
 	const u32 flags = most >= (u64)n / 8 + 1 ? (u32)SCATTER_HOT : 0u;   // as Plan::hot (rsx_plan_kernel)
-	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, (u32)(8 * (sizeof(KT) - 1)), top, ka, flags, nullptr);
+	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, top, ka, flags, nullptr);
+}
+
+// ---- single-process multi-device sort (rsx_sort_multi) -----------------------------------------------------------------
+// A "rank" is a (device, stream) pair: its own workspace context, its own host thread while a phase runs.  The streams are
+// pooled per (device, slot) so that repeated calls reuse the contexts.
+std::mutex g_multi_mu;
+std::map<std::pair<int, int>, hipStream_t> g_multi_streams;
+
+struct MultiRank {
+	int dev = 0;
+	hipStream_t stream = nullptr;
+	size_t first = 0, count = 0;         // this rank's shard of the input
+	void *shard = nullptr, *part = nullptr, *recv = nullptr, *aux = nullptr;
+	u64 *d_hist = nullptr;
+	u32 *d_flag = nullptr;
+	std::vector<u64> hist;               // [key bytes][256]
+	u32 unsorted = 0;
+	size_t n_recv = 0, out_first = 0;    // this rank's range of the result
+	int rc = RSX_OK;
+	char err[512] = "";
+};
+
+u64 host_kdf(const void *p, size_t kb, int dtype, int order)
+{
+	u64 raw = 0;
+	memcpy(&raw, p, kb);
+	const u64 ones = kb == 8 ? ~0ull : ((1ull << (8 * kb)) - 1);
+	const u64 high = 1ull << (8 * kb - 1);
+	const bool is_signed = dtype == RSX_I8 || dtype == RSX_I16 || dtype == RSX_I32 || dtype == RSX_I64;
+	const bool is_float = dtype == RSX_F32 || dtype == RSX_F64;
+	u64 k = raw;
+	if (is_float)
+		k ^= (raw & high) ? ones : high;     // radix_sort_basic_kdf.hpp:32-46
+	else if (is_signed)
+		k ^= high;                           // :26-30
+	if (order == RSX_DESCENDING)
+		k ^= ones;                           // README.md:564-574
+	return k & ones;
+}
+
+// digit -> destination rank: contiguous, monotone ranges of ~total/G keys (the midpoint of a digit's run decides)
+void choose_splitters_host(const u64 *hist, int G, uint8_t *lut)
+{
+	long double total = 0;
+	for (int d = 0; d < 256; ++d)
+		total += (long double)hist[d];
+	long double before = 0;
+	int prev = 0;
+	for (int d = 0; d < 256; ++d) {
+		int r = 0;
+		if (total > 0 && G > 1) {
+			const long double mid = before + (long double)hist[d] / 2;
+			r = (int)(mid * G / total);
+			r = r < 0 ? 0 : (r > G - 1 ? G - 1 : r);
+		}
+		if (r < prev)
+			r = prev;
+		prev = r;
+		lut[d] = (uint8_t)r;
+		before += (long double)hist[d];
+	}
+}
+
+// one host thread per rank; the first failure (code + message) becomes the caller's
+int multi_phase(std::vector<MultiRank> &ranks, const std::function<int(MultiRank &)> &body)
+{
+	std::vector<std::thread> threads;
+	for (auto &r : ranks)
+		threads.emplace_back([&r, &body]() {
+			if (hipSetDevice(r.dev) != hipSuccess) {
+				r.rc = RSX_EHIP;
+				snprintf(r.err, sizeof(r.err), "hipSetDevice(%d) failed", r.dev);
+				return;
+			}
+			r.rc = body(r);
+			if (r.rc != RSX_OK)
+				snprintf(r.err, sizeof(r.err), "%s", g_err);
+		});
+	for (auto &t : threads)
+		t.join();
+	for (auto &r : ranks)
+		if (r.rc != RSX_OK)
+			return fail(r.rc, "rsx_sort_multi (device %d): %s", r.dev, r.err);
+	return RSX_OK;
+}
+
+void multi_free(std::vector<MultiRank> &ranks)
+{
+	for (auto &r : ranks) {
+		(void)hipSetDevice(r.dev);
+		if (r.stream)
+			(void)hipStreamSynchronize(r.stream);
+		for (void *p : {r.shard, r.part, r.recv, r.aux, (void *)r.d_hist, (void *)r.d_flag})
+			if (p)
+				(void)hipFree(p);
+		r.shard = r.part = r.recv = r.aux = nullptr;
+		r.d_hist = nullptr;
+		r.d_flag = nullptr;
+	}
 }
 
 #define RSX_DISPATCH_KT(dtype, CALL)                               \
@@ -803,6 +904,11 @@ void rsx_release(void)
 		delete kv.second;
 	}
 	g_ctx.clear();
+	for (auto &kv : g_multi_streams) {
+		(void)hipSetDevice(kv.first.first);
+		(void)hipStreamDestroy(kv.second);
+	}
+	g_multi_streams.clear();
 }
 
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order, void *stream)
@@ -1206,6 +1312,184 @@ int rsx_sort_records_tagged(void *src, void *aux, size_t n, size_t rec_bytes, si
 	return RSX_OK;
 }
 
+// radix_sort(src, aux, n) on host buffers with the work spread over several devices of ONE process (SURVEY.md 8b item 5;
+// the one-process-per-GPU form of the same algorithm is radix_sorting_amd/multi.py).  The front half of rs_sort_main is
+// done globally -- column histograms summed over the shards, the ordered-neighbour test across shard boundaries, the
+// column probe on src[0] -- so early exit, kept columns and the returned pointer are exactly the reference's; then every
+// shard is split by the highest kept byte, the devices pull their digit ranges from each other, sort them and write them
+// to their place in the buffer the parity rule names.
+int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, const int *devices, int ndev,
+                   void **result, rsx_info *info)
+{
+	info_clear(info, dtype);
+	const size_t kb = dtype_size(dtype);
+	if (!kb || !result || ndev < 1 || ndev > 64 || !devices || (n && (!src || !aux)))
+		return fail(RSX_EINVAL, "rsx_sort_multi: bad argument");
+	if (n < 2) {                             // radix_sort.hpp:100-101
+		*result = src;
+		if (info)
+			info->early_exit = 1;
+		return RSX_OK;
+	}
+	{
+		std::lock_guard<std::mutex> lock(g_mu);
+		if (probe_devices() <= 0)
+			return fail(RSX_ENODEVICE, "no gfx950 (MI355X) device visible to HIP; this library has no CPU path");
+	}
+	int visible = 0;
+	HIP_TRY(hipGetDeviceCount(&visible));
+	for (int i = 0; i < ndev; ++i)
+		if (devices[i] < 0 || devices[i] >= visible)
+			return fail(RSX_EINVAL, "rsx_sort_multi: device %d is not one of the %d visible", devices[i], visible);
+	std::lock_guard<std::mutex> multi_lock(g_multi_mu);
+	int home = 0;
+	HIP_TRY(hipGetDevice(&home));
+	const int G = ndev;
+	std::vector<MultiRank> ranks(G);
+	std::map<int, int> slot;
+	for (int r = 0; r < G; ++r) {
+		MultiRank &k = ranks[r];
+		k.dev = devices[r];
+		const auto key = std::make_pair(k.dev, slot[k.dev]++);
+		auto it = g_multi_streams.find(key);
+		if (it == g_multi_streams.end()) {
+			hipStream_t st = nullptr;
+			HIP_TRY(hipSetDevice(k.dev));
+			HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+			it = g_multi_streams.emplace(key, st).first;
+		}
+		k.stream = it->second;
+		k.first = (size_t)((unsigned __int128)n * r / G);
+		k.count = (size_t)((unsigned __int128)n * (r + 1) / G) - k.first;
+		k.hist.assign(kb * 256, 0);
+	}
+	struct Cleanup {
+		std::vector<MultiRank> &ranks;
+		int home;
+		~Cleanup()
+		{
+			multi_free(ranks);
+			(void)hipSetDevice(home);
+		}
+	} cleanup{ranks, home};
+	const char *hsrc = (const char *)src;
+
+	// ---- radix_sort.hpp:47-58 per shard: upload, histogram of every column, ordered-neighbour test
+	RSX_TRY(multi_phase(ranks, [&](MultiRank &k) -> int {
+		if (k.count == 0)
+			return RSX_OK;
+		HIP_TRY(hipMalloc(&k.shard, k.count * kb));
+		HIP_TRY(hipMalloc(&k.part, k.count * kb));
+		HIP_TRY(hipMalloc((void **)&k.d_hist, kb * 256 * sizeof(u64)));
+		HIP_TRY(hipMalloc((void **)&k.d_flag, 64));
+		HIP_TRY(hipMemcpyAsync(k.shard, hsrc + k.first * kb, k.count * kb, hipMemcpyHostToDevice, k.stream));
+		RSX_TRY(rsx_histogram_device(k.shard, k.count, dtype, order, (uint64_t *)k.d_hist, (uint32_t *)k.d_flag, k.stream));
+		HIP_TRY(hipMemcpyAsync(k.hist.data(), k.d_hist, kb * 256 * sizeof(u64), hipMemcpyDeviceToHost, k.stream));
+		HIP_TRY(hipMemcpyAsync(&k.unsorted, k.d_flag, sizeof(u32), hipMemcpyDeviceToHost, k.stream));
+		HIP_TRY(hipStreamSynchronize(k.stream));
+		return RSX_OK;
+	}));
+	std::vector<u64> ghist(kb * 256, 0);
+	bool sorted = true;
+	for (int r = 0; r < G; ++r) {
+		for (size_t i = 0; i < kb * 256; ++i)
+			ghist[i] += ranks[r].hist[i];
+		sorted = sorted && ranks[r].unsorted == 0;
+	}
+	for (int r = 0; r + 1 < G && sorted; ++r) {   // neighbours on either side of a shard boundary
+		const size_t b = ranks[r + 1].first;
+		if (b > 0 && b < n && host_kdf(hsrc + (b - 1) * kb, kb, dtype, order) > host_kdf(hsrc + b * kb, kb, dtype, order))
+			sorted = false;
+	}
+	if (sorted) {                            // radix_sort.hpp:60-62
+		*result = src;
+		if (info)
+			info->early_exit = 2;
+		return RSX_OK;
+	}
+	const u64 key0 = host_kdf(hsrc, kb, dtype, order);   // radix_sort.hpp:64-70
+	u32 cols[8], ncols = 0;
+	for (u32 c = 0; c < kb; ++c)
+		if (ghist[c * 256 + ((key0 >> (8 * c)) & 0xFF)] != n)
+			cols[ncols++] = c;
+	if (ncols == 0)
+		return fail(RSX_EHIP, "rsx_sort_multi: unsorted input without a varying column");
+	void *hres = (ncols & 1) ? aux : src;    // radix_sort.hpp:92
+	if (info) {
+		info->ncols = ncols;
+		for (u32 i = 0; i < ncols; ++i)
+			info->cols[i] = cols[i];
+		info->result_in_aux = hres == aux;
+	}
+
+	// ---- destinations: contiguous digit ranges of the highest kept byte; matrix[s][d] keys go from shard s to rank d
+	const u32 cs = cols[ncols - 1];
+	uint8_t lut[256];
+	choose_splitters_host(&ghist[cs * 256], G, lut);
+	std::vector<u64> matrix((size_t)G * G, 0);
+	for (int s = 0; s < G; ++s)
+		for (int d = 0; d < 256; ++d)
+			matrix[(size_t)s * G + lut[d]] += ranks[s].hist[cs * 256 + d];
+	size_t running = 0;
+	for (int d = 0; d < G; ++d) {
+		ranks[d].out_first = running;
+		ranks[d].n_recv = 0;
+		for (int s = 0; s < G; ++s)
+			ranks[d].n_recv += (size_t)matrix[(size_t)s * G + d];
+		running += ranks[d].n_recv;
+	}
+	if (running != n)
+		return fail(RSX_EHIP, "rsx_sort_multi: the count matrix sums to %zu, n = %zu", running, n);
+
+	// ---- one stable pass by that byte per shard
+	RSX_TRY(multi_phase(ranks, [&](MultiRank &k) -> int {
+		if (k.count == 0)
+			return RSX_OK;
+		uint64_t top[256];
+		RSX_TRY(rsx_msd_split_device(k.shard, k.part, k.count, dtype, order, (int)cs, top, k.stream));
+		for (int d = 0; d < 256; ++d)
+			if (top[d] != k.hist[cs * 256 + d])
+				return fail(RSX_EHIP, "the split counted digit %d differently from the histogram", d);
+		HIP_TRY(hipStreamSynchronize(k.stream));
+		HIP_TRY(hipFree(k.shard));
+		k.shard = nullptr;
+		return RSX_OK;
+	}));
+
+	// ---- exchange (every rank pulls its digit range from every shard, in shard order), local sort, write-back
+	char *hdst = (char *)hres;
+	RSX_TRY(multi_phase(ranks, [&](MultiRank &k) -> int {
+		if (k.n_recv == 0)
+			return RSX_OK;
+		const int d = (int)(&k - &ranks[0]);
+		HIP_TRY(hipMalloc(&k.recv, k.n_recv * kb));
+		HIP_TRY(hipMalloc(&k.aux, k.n_recv * kb));
+		size_t off = 0;
+		for (int s = 0; s < G; ++s) {
+			const size_t cnt = (size_t)matrix[(size_t)s * G + d];
+			if (cnt == 0)
+				continue;
+			size_t soff = 0;
+			for (int e = 0; e < d; ++e)
+				soff += (size_t)matrix[(size_t)s * G + e];
+			const char *from = (const char *)ranks[s].part + soff * kb;
+			if (ranks[s].dev == k.dev)
+				HIP_TRY(hipMemcpyAsync((char *)k.recv + off * kb, from, cnt * kb, hipMemcpyDeviceToDevice, k.stream));
+			else
+				HIP_TRY(hipMemcpyPeerAsync((char *)k.recv + off * kb, k.dev, from, ranks[s].dev, cnt * kb, k.stream));
+			off += cnt;
+		}
+		void *dres = nullptr;
+		rsx_info li;
+		RSX_TRY(rsx_sort_device(k.recv, k.aux, k.n_recv, dtype, order, k.stream, &dres, &li));
+		HIP_TRY(hipMemcpyAsync(hdst + k.out_first * kb, dres, k.n_recv * kb, hipMemcpyDeviceToHost, k.stream));
+		HIP_TRY(hipStreamSynchronize(k.stream));
+		return RSX_OK;
+	}));
+	*result = hres;
+	return RSX_OK;
+}
+
 int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order order, uint64_t *d_hist,
                          uint32_t *d_unsorted, void *stream)
 {
@@ -1283,13 +1567,15 @@ int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 // destination's keys contiguous in d_dst -- with 256 digits instead of G buckets there is no crowd of lanes on a handful
 // of LDS counters, and the pass runs on the plain-digit kernel.  Keys of one destination arrive ordered by (top byte,
 // original index) instead of by original index; equal keys have equal top bytes, so the stable order of the final result
-// is the same.  top_hist (host, 256 uint64) receives the counts of the top byte; the pass itself is only enqueued.
-int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order, uint64_t *top_hist,
-                         void *stream)
+// is the same.  top_hist (host, 256 uint64) receives the counts of the byte; the pass itself is only enqueued.  `column`
+// picks another byte than the top one (a caller that knows the top bytes to be constant splits by the highest varying one).
+int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order, int column,
+                         uint64_t *top_hist, void *stream)
 {
 	const size_t kb = dtype_size(dtype);
-	if (!kb || !top_hist || (n && (!d_src || !d_dst)))
+	if (!kb || !top_hist || column >= (int)kb || (n && (!d_src || !d_dst)))
 		return fail(RSX_EINVAL, "rsx_msd_split_device: bad argument");
+	const u32 col = column < 0 ? (u32)kb - 1 : (u32)column;
 	for (int i = 0; i < 256; ++i)
 		top_hist[i] = 0;
 	if (n == 0)
@@ -1302,7 +1588,7 @@ int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 	RSX_TRY(c->hist.ensure(hist_bytes));
 	HIP_TRY(hipMemsetAsync(c->hist.p, 0, hist_bytes, c->stream));
 	HIP_TRY(hipMemsetAsync(c->small.p, 0, 192, c->stream));
-	RSX_DISPATCH_KT(dtype, return msd_split<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, g, top_hist));
+	RSX_DISPATCH_KT(dtype, return msd_split<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, g, top_hist));
 	return RSX_OK;
 }
 

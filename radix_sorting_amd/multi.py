@@ -97,7 +97,7 @@ class HipEngine:
     def msd_split(self, shard, out):
         """out = shard in stable order of the top KDF byte (enqueued); returns that byte's 256 counts (host)."""
         hist = np.zeros(256, dtype=np.uint64)
-        check(lib().rsx_msd_split_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order,
+        check(lib().rsx_msd_split_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order, -1,
                                          hist.ctypes.data, _stream_ptr()))
         return hist
 

@@ -296,6 +296,31 @@ int main()
 		for (int t = 0; t < 6; ++t)
 			CHECK(bad[t] == 0);
 	}
+	// radix_sort_multi: the same sort spread over three ranks of this process (all on device 0 here); same result, same
+	// returned pointer as radix_sort
+	{
+		const size_t N = 300007;
+		std::vector<int32_t> a(N), aux(N), b, baux(N);
+		uint64_t s = 99;
+		for (auto &x : a) {
+			s = s * 6364136223846793005ull + 1442695040888963407ull;
+			x = (int32_t)(s >> 33) - (1 << 30);
+		}
+		b = a;
+		const int devs[3] = {0, 0, 0};
+		int32_t *r1 = radix_sort_multi(a.data(), aux.data(), N, devs, 3);
+		int32_t *r2 = radix_sort(b.data(), baux.data(), N);
+		CHECK((r1 == a.data()) == (r2 == b.data()));
+		CHECK(std::memcmp(r1, r2, N * sizeof(int32_t)) == 0);
+		std::vector<float> f(N), faux(N), g, gaux(N);
+		for (size_t i = 0; i < N; ++i)
+			f[i] = (float)a[i] * 0.25f;      // a is sorted now: descending order still has to move everything
+		g = f;
+		float *d1 = radix_sort_multi(f.data(), faux.data(), N, devs, 3, rsx_kdf::descending<float>());
+		float *d2 = radix_sort(g.data(), gaux.data(), N, rsx_kdf::descending<float>());
+		CHECK(std::memcmp(d1, d2, N * sizeof(float)) == 0);
+		CHECK(d1[0] >= d1[N - 1]);
+	}
 	if (failures) {
 		printf("dropin_check: %d failures\n", failures);
 		return 1;

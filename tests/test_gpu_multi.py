@@ -212,3 +212,65 @@ def test_bench_sharded_path_in_a_one_rank_group():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "msd1" and line["config"]["output_sorted"] is True
     assert line["value"] > 0 and line["scaling"] == "weak" and "cpu_baseline" not in line
+
+
+# ---- rsx_sort_multi: one process, several ranks (here all on device 0, each with its own stream and workspace) -------------
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0] * 8], ids=["1", "2", "3", "8"])
+@pytest.mark.parametrize("dt,order,n,mask", [
+    (ol.U32, 0, 1000003, 0xFFFFFFFF),
+    (ol.U32, 0, 300001, 0x00FFFFFF),            # constant top byte: split by byte 2, three kept columns -> aux
+    (ol.F32, 1, 400000, 0xFFFFFFFF),
+    (ol.U64, 0, 250007, 0xFFFFFFFFFF),          # five kept columns -> aux
+    (ol.I16, 0, 700001, 0xFFFF),
+    (ol.U8, 0, 100000, 0xFF),
+    (ol.F64, 0, 120001, 0xFFFFFFFFFFFFFFFF),
+    (ol.U32, 0, 5, 0xFFFFFFFF),                 # fewer keys than ranks
+    (ol.I32, 0, 50000, 0x0000FF00),             # one kept column in the middle
+])
+def test_sort_multi_matches_oracle(devices, dt, order, n, mask):
+    a = ol.splitmix_fill(n, dt, 41 + dt, mask)
+    want, in_aux, winfo = ol.oracle_sort(a, dt, order)
+    src = a.copy()
+    aux = np.full_like(src, 0x5A)
+    res, info = rsa.radix_sort_multi_host(src, aux, dt, order, devices)
+    assert info.ncols == winfo.ncols and list(info.cols[:info.ncols]) == list(winfo.cols[:winfo.ncols])
+    assert bool(info.result_in_aux) == bool(in_aux) and (res is aux) == bool(in_aux)      # radix_sort.hpp:92
+    assert np.array_equal(res, want)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]], ids=["1", "3"])
+def test_sort_multi_early_exits(devices):
+    """Sorted input (also sorted only ACROSS the shards' boundaries, or unsorted only there) and n < 2."""
+    a = np.sort(ol.splitmix_fill(90001, ol.U32, 3))
+    src, aux = a.copy(), np.full_like(a, 0x77)
+    res, info = rsa.radix_sort_multi_host(src, aux, ol.U32, 0, devices)
+    assert res is src and info.early_exit == 2 and np.array_equal(src, a) and np.all(aux == 0x77)   # :60-62, aux untouched
+    b = a.copy()                                    # the only descent sits exactly on a shard boundary
+    cut = (b.size * 1) // len(devices) if len(devices) > 1 else b.size // 2
+    b[cut - 1], b[cut] = b[cut], b[cut - 1]
+    if b[cut - 1] != b[cut]:
+        src, aux = b.copy(), np.zeros_like(b)
+        res, info = rsa.radix_sort_multi_host(src, aux, ol.U32, 0, devices)
+        assert info.early_exit == 0 and np.array_equal(res, a)
+    one = np.array([7], dtype=np.uint32)
+    res, info = rsa.radix_sort_multi_host(one, np.zeros_like(one), ol.U32, 0, devices)
+    assert res is one and info.early_exit == 1
+
+
+def test_sort_multi_rejects_bad_devices():
+    a = ol.splitmix_fill(1000, ol.U32, 1)
+    with pytest.raises(rsa.RsxError, match="not one of"):
+        rsa.radix_sort_multi_host(a.copy(), np.zeros_like(a), ol.U32, 0, [0, 99])
+
+
+def test_sort_multi_large_three_ranks():
+    """2^26 keys over three ranks: equality with the oracle's output through a hash, sortedness."""
+    n = 1 << 26
+    a = ol.splitmix_fill(n, ol.U32, 8)
+    src, aux = a.copy(), np.empty_like(a)
+    res, info = rsa.radix_sort_multi_host(src, aux, ol.U32, 0, [0, 0, 0])
+    assert info.ncols == 4 and res is src
+    assert np.all(res[1:] >= res[:-1])
+    assert int(res.sum(dtype=np.uint64)) == int(a.sum(dtype=np.uint64))
+    assert np.array_equal(np.bincount(res >> 24, minlength=256), np.bincount(a >> 24, minlength=256))

@@ -25,3 +25,11 @@ for rep in range(3):
     del src2
 # already-sorted input: early exit, only H2D
 t0 = time.perf_counter(); res, info = rsa.radix_sort_host(res, aux, rsa.U32); print("sorted input (H2D + hist only): %.1f ms, exit %d" % ((time.perf_counter() - t0) * 1e3, info.early_exit))
+# the same sort through rsx_sort_multi with 1, 2, 4 ranks on device 0 (one host thread per rank while a phase runs)
+for ranks in (1, 2, 4, 8):
+    for rep in range(3):
+        np.copyto(src, a)
+        t0 = time.perf_counter()
+        res, info = rsa.radix_sort_multi_host(src, aux, rsa.U32, devices=[0] * ranks)
+        dt = time.perf_counter() - t0
+    print("rsx_sort_multi, %d rank(s) on device 0, reused buffers: %.1f ms (sorted: %s)" % (ranks, dt * 1e3, bool(np.all(res[1:] >= res[:-1]))))
