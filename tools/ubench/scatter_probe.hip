@@ -377,7 +377,8 @@ __device__ inline u32 mix15(u32 x, u32 c, u32 m1, u32 m2)
 }
 
 // mode 1: every tile of 32 Ki keys holds each digit exactly 128 times in every byte column, in scrambled order: all runs are
-// 512 bytes and start on 512-byte boundaries.  mode 2: the same with run lengths 128 +- 16 j (64-byte aligned starts only).
+// 512 bytes and start on 512-byte boundaries.  mode 2: the same with run lengths 128 +- 16 j (64-byte aligned starts only);
+// modes 3 and 4: 128 +- 4 j and 128 +- 8 j (16- and 32-byte aligned starts).
 __global__ void balanced_digits_kernel(u32 *a, u64 n, u32 mode)
 {
 	for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
@@ -391,6 +392,16 @@ __global__ void balanced_digits_kernel(u32 *a, u64 n, u32 mode)
 				// slots of 16 keys (2048 per tile) dealt to digits unevenly: digit pairs (2m, 2m+1) get 8 + s and 8 - s slots
 				const u32 slot = x >> 4, pair = slot >> 4, in = slot & 15u, s = (pair * 5u + (t >> 9)) % 7u;
 				d = 2 * pair + (in < 8 + s ? 0 : 1);
+			}
+			if (mode == 3) {
+				// slots of 4 keys: run lengths 128 +- 4 j, starts aligned to 16 bytes only
+				const u32 slot = x >> 2, pair = slot >> 6, in = slot & 63u, s = (pair * 5u + (t >> 9)) % 7u;
+				d = 2 * pair + (in < 32 + s ? 0 : 1);
+			}
+			if (mode == 4) {
+				// slots of 8 keys: starts aligned to 32 bytes
+				const u32 slot = x >> 3, pair = slot >> 5, in = slot & 31u, s = (pair * 5u + (t >> 9)) % 7u;
+				d = 2 * pair + (in < 16 + s ? 0 : 1);
 			}
 			k |= d << (8 * b);
 		}
