@@ -94,10 +94,10 @@ class HipEngine:
                                          lut.ctypes.data, world, th.ctypes.data, counts.ctypes.data, _stream_ptr()))
         return counts
 
-    def msd_split(self, shard, out):
-        """out = shard in stable order of the top KDF byte (enqueued); returns that byte's 256 counts (host)."""
+    def msd_split(self, shard, out, column=-1):
+        """out = shard in stable order of KDF byte `column` (-1: the top one), enqueued; returns the byte's 256 counts (host)."""
         hist = np.zeros(256, dtype=np.uint64)
-        check(lib().rsx_msd_split_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order, -1,
+        check(lib().rsx_msd_split_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order, column,
                                          hist.ctypes.data, _stream_ptr()))
         return hist
 
@@ -129,15 +129,20 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
         res, info = engine.local_sort(shard, aux)
         return res, {"sent": 0, "received": n, "local_info": info}
 
-    # 1: one stable pass by the top KDF byte; its counts
+    # 1-2: one stable pass by the top KDF byte and its counts; everybody's counts -> identical splitters and the whole
+    # count matrix on every rank.  A byte that is constant over ALL ranks would send every key to one rank: split by the
+    # next byte down instead (every rank sees the same gathered counts and takes the same decision).
     part = scratch["part"][:n] if scratch else engine.empty(n, shard)
-    local_hist = engine.msd_split(shard, part)
-
-    # 2: everybody's counts -> identical splitters and the whole count matrix on every rank
-    mine = torch.from_numpy(local_hist.astype(np.int64)).to(shard.device)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    hists = torch.stack(gathered).cpu().numpy().astype(np.uint64)
+    column = engine.kb - 1
+    while True:
+        local_hist = engine.msd_split(shard, part, column)
+        mine = torch.from_numpy(local_hist.astype(np.int64)).to(shard.device)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+        hists = torch.stack(gathered).cpu().numpy().astype(np.uint64)
+        if column == 0 or np.count_nonzero(hists.sum(axis=0)) > 1:
+            break
+        column -= 1
     lut = choose_splitters(hists.sum(axis=0), world)
     matrix = count_matrix(hists, lut, world)          # matrix[s, d]: keys rank s sends to rank d
     send_counts, recv_counts = matrix[rank], matrix[:, rank]
@@ -162,5 +167,5 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # 4: local LSD sort of the received bucket range
     res, info = engine.local_sort(recv, aux)
     sent = int(send_counts.sum() - send_counts[rank])
-    return res, {"sent": sent, "received": n_recv, "local_info": info, "lut": lut,
+    return res, {"sent": sent, "received": n_recv, "local_info": info, "lut": lut, "split_column": column,
                  "send_counts": send_counts, "recv_counts": recv_counts}

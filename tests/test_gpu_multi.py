@@ -113,6 +113,20 @@ def test_msd_split(dt, order, n, mask):
     assert np.array_equal(shard.cpu().numpy().view(ol.NP_BITS[dt]), a)          # the source is left alone
 
 
+def test_msd_split_by_a_lower_byte():
+    a = ol.splitmix_fill(600001, ol.U32, 9, 0x00FFFFFF)
+    eng = multi.HipEngine(ol.U32)
+    shard = to_dev(a)
+    out = torch.zeros_like(shard)
+    hist = eng.msd_split(shard, out, 2)
+    torch.cuda.synchronize()
+    dig = ((a >> 16) & 0xFF).astype(np.int64)
+    assert np.array_equal(hist, np.bincount(dig, minlength=256).astype(np.uint64))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), a[np.argsort(dig, kind="stable")])
+    with pytest.raises(rsa.RsxError, match="bad argument"):
+        eng.msd_split(shard, out, 4)
+
+
 @pytest.mark.parametrize("world,dt,mask", [(2, ol.U32, 0xFFFFFFFF), (8, ol.U32, 0xFFFFFFFF), (4, ol.F64, 0xFFFFFFFFFFFFFFFF),
                                              (3, ol.U32, 0x00FFFFFF), (5, ol.I16, 0xFFFF)])
 def test_simulated_ranks_with_msd_split(world, dt, mask):

@@ -25,6 +25,7 @@ class OracleEngine:
 
     def __init__(self, dtype, order=0):
         self.dtype, self.order = dtype, order
+        self.kb = ol.DTYPE_SIZE[dtype]
 
     def _bits(self, t):
         return t.numpy().view(ol.NP_BITS[self.dtype])
@@ -43,10 +44,11 @@ class OracleEngine:
         out.numpy().view(bits.dtype)[:bits.size] = bits[perm]
         return np.bincount(dest, minlength=world).astype(np.uint64)
 
-    def msd_split(self, shard, out):
+    def msd_split(self, shard, out, column=-1):
         bits = self._bits(shard)
         k = ol.kdf_keys(bits, self.dtype, self.order)
-        top = (k >> ol.NP_BITS[self.dtype](8 * (ol.DTYPE_SIZE[self.dtype] - 1))).astype(np.int64)
+        column = self.kb - 1 if column < 0 else column
+        top = ((k >> ol.NP_BITS[self.dtype](8 * column)) & ol.NP_BITS[self.dtype](0xFF)).astype(np.int64)
         out.numpy().view(bits.dtype)[:bits.size] = bits[np.argsort(top, kind="stable")]
         return np.bincount(top, minlength=256).astype(np.uint64)
 
@@ -88,7 +90,7 @@ def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir):
 @pytest.mark.parametrize("world,dtype,order,mask", [
     (2, ol.U32, 0, 0xFFFFFFFF),
     (2, ol.F32, 1, 0xFFFFFFFF),
-    (3, ol.U32, 0, 0x00FFFFFF),       # constant top byte: every key lands on one rank
+    (3, ol.U32, 0, 0x00FFFFFF),       # constant top byte: split by byte 2
     (2, ol.I64, 0, 0xFFFFFFFFFFFFFFFF),
     (3, ol.U16, 0, 0xFFFF),
 ])
@@ -103,8 +105,8 @@ def test_distributed_sort_matches_single_sort(tmp_path, world, dtype, order, mas
     assert got.size == want.size
     assert np.array_equal(got, want)          # bit-identical to sorting the whole array on one rank
     sizes = [np.load(os.path.join(str(tmp_path), "out%d.npy" % r)).size for r in range(world)]
-    if mask == 0xFFFFFFFF and dtype == ol.U32:
-        assert max(sizes) < 1.2 * sum(sizes) / world      # uniform keys -> balanced splitters
+    if dtype == ol.U32:
+        assert max(sizes) < 1.2 * sum(sizes) / world      # uniform keys -> balanced splitters, also below a constant top byte
 
 
 def test_count_matrix():
