@@ -414,9 +414,9 @@ int plan_wait(Ctx &c, Plan *out)
 
 // ---- phase 2: one scatter pass (radix_sort.hpp:83-90) -----------------------------
 // gbase[digit]: exclusive offset of the digit for this pass's column
-template <typename KT, typename VT, typename C2>
-int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan, int region, u32 pass_index)
+template <typename KT, typename VT, typename C2, typename KTO = KT>
+int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
+                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan, int region, u32 pass_index, u32 oshift = 0)
 {
 	const u64 tiles = (n + C2::TILE - 1) / C2::TILE;
 	const u32 tps = (u32)C2::TPS;   // 1: a tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
@@ -432,7 +432,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 	}
 	u32 *ticket = (u32 *)base;
 	void *st = base + 256;
-	ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + val_bytes<VT>::value), c.stream);
+	ProfScope prof(1, (u64)n * (sizeof(KT) + sizeof(KTO) + 2 * val_bytes<VT>::value), c.stream);
 	const dim3 grid((unsigned)tiles);
 	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic;
 	// columns with a hot digit (Plan::hot) take the instantiation that tests every round for a wave-uniform digit
@@ -441,8 +441,9 @@ int launch_scatter2(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, si
 	const bool hot = (flags & SCATTER_HOT) != 0;
 	flags &= ~(u32)SCATTER_HOT;
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
-	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, vin, \
-	                   vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan, pass_index)
+	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
+	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan, pass_index,  \
+	                   oshift)
 #define RSX_LAUNCH2_ST(DIGV)                 \
 	do {                                     \
 		if (wide) {                          \
@@ -529,6 +530,42 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 		                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
+}
+
+// ---- a rank-sort pass that writes its keys narrowed (fast kernel only; see KTO in rsx_scatter2.hpp) -------------------
+template <typename KT, typename VT, typename KTO>
+int scatter_pass_narrow(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
+                        KdfArgs<KT> ka, u32 flags, u32 oshift)
+{
+	typedef Sc2Cfg<KT, VT> C2;
+	typedef Sc2SmallCfg<KT, VT> Small;
+	if constexpr (Small::AVAILABLE) {
+		if (use_small_tiles<KT, VT>(n))
+			return launch_scatter2<KT, VT, typename Small::type, KTO>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, nullptr,
+			                                                          nullptr, -1, 0, oshift);
+	}
+	return launch_scatter2<KT, VT, C2, KTO>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, nullptr, nullptr, -1, 0, oshift);
+}
+
+// keys of `out_bytes` bytes out of a pass over KT keys (out_bytes <= sizeof(KT))
+template <typename KT, typename VT>
+int scatter_pass_to(Ctx &c, const KT *kin, void *kout, u32 out_bytes, const VT *vin, VT *vout, size_t n, u32 shift,
+                    const u64 *gbase, KdfArgs<KT> ka, u32 flags, u32 oshift)
+{
+	if (out_bytes == sizeof(KT) && oshift == 0)
+		return scatter_pass<KT, VT>(c, kin, (KT *)kout, vin, vout, n, shift, gbase, ka, flags, nullptr);
+	if constexpr (sizeof(KT) >= 8)
+		if (out_bytes == 8)
+			return scatter_pass_narrow<KT, VT, u64>(c, kin, (u64 *)kout, vin, vout, n, shift, gbase, ka, flags, oshift);
+	if constexpr (sizeof(KT) >= 4)
+		if (out_bytes == 4)
+			return scatter_pass_narrow<KT, VT, u32>(c, kin, (u32 *)kout, vin, vout, n, shift, gbase, ka, flags, oshift);
+	if constexpr (sizeof(KT) >= 2)
+		if (out_bytes == 2)
+			return scatter_pass_narrow<KT, VT, uint16_t>(c, kin, (uint16_t *)kout, vin, vout, n, shift, gbase, ka, flags, oshift);
+	if (out_bytes == 1)
+		return scatter_pass_narrow<KT, VT, uint8_t>(c, kin, (uint8_t *)kout, vin, vout, n, shift, gbase, ka, flags, oshift);
+	return fail(RSX_EINVAL, "scatter_pass_to: %u-byte keys out of %zu-byte keys", out_bytes, sizeof(KT));
 }
 
 // ---- keys only -------------------------------------------------------------------
@@ -661,6 +698,21 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 // index halves H0 = ib, H1 = ib + n ping-pong exactly as radix_sort_rank.hpp:77-89;
 // the keys travel with the indices through two workspace
 // buffers instead of being gathered through the index as Listing 6 does.
+// (a key type no wider than KT: keeps the instantiations of impossible combinations out of the build)
+template <typename KT, typename N> using NarrowerOr = typename std::conditional<(sizeof(N) < sizeof(KT)), N, KT>::type;
+
+// one pass of a rank sort over keys currently held as KCUR (the raw KT keys until the first narrowing, KDF-applied after)
+template <typename KCUR, typename KT, typename IT>
+int rank_pass(Ctx &c, const void *kin, void *kout, u32 out_bytes, const IT *vin, IT *vout, size_t n, u32 shift, const u64 *gbase,
+              const KdfArgs<KT> &ka0, bool applied, u32 flags, u32 oshift)
+{
+	KdfArgs<KCUR> ka{0, 0, 0};
+	if constexpr (std::is_same<KCUR, KT>::value)
+		if (!applied)
+			ka = ka0;
+	return scatter_pass_to<KCUR, IT>(c, (const KCUR *)kin, kout, out_bytes, vin, vout, n, shift, gbase, ka, flags, oshift);
+}
+
 template <typename KT, typename IT>
 int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
@@ -701,6 +753,54 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 			RSX_TRY(c.keys[1].ensure(n * sizeof(KT)));
 	}
 	IT *H[2] = {ib, ib + n};
+	if (c.fast && sizeof(IT) == 4 && !getenv("RSX_NO_NARROW_KEYS")) {
+		// The ranks are the only output, so a pass hands on just the key bytes that later passes look at: once those fit a
+		// narrower type the keys are written as kdf(key) >> (8 * next column) in that type, and the passes after it read
+		// it with the identity KDF.  `base_col`: the column that sits in the low byte of the current representation.
+		const void *kin = src;
+		u32 in_bytes = sizeof(KT), base_col = 0;
+		bool applied = false;
+		for (u32 i = 0; i < P; ++i) {
+			const u32 col = plan.cols[i];
+			u32 flags = (plan.hot >> col & 1) ? SCATTER_HOT : 0;
+			if (i == 0)
+				flags |= SCATTER_GEN_INDEX;
+			if (i == P - 1)
+				flags |= SCATTER_SKIP_KEYS;
+			u32 out_bytes = in_bytes, oshift = 0, next = base_col;
+			if (i + 1 < P) {
+				const u32 need = (u32)sizeof(KT) - plan.cols[i + 1];   // bytes from the next kept column up
+				const u32 fit = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+				if (fit < in_bytes) {
+					out_bytes = fit;
+					next = plan.cols[i + 1];
+					oshift = 8 * (next - base_col);
+				}
+			}
+			void *kout = c.keys[i & 1].p;
+			const u32 shift = 8 * (col - base_col);
+			const u64 *gb = c.ghist() + 256 * col;
+			int rc = RSX_EINVAL;
+			if (in_bytes == sizeof(KT))
+				rc = rank_pass<KT, KT, IT>(c, kin, kout, out_bytes, H[i & 1], H[(i + 1) & 1], n, shift, gb, ka, applied, flags, oshift);
+			else if (in_bytes == 4)
+				rc = rank_pass<NarrowerOr<KT, u32>, KT, IT>(c, kin, kout, out_bytes, H[i & 1], H[(i + 1) & 1], n, shift, gb, ka, true,
+				                                           flags, oshift);
+			else if (in_bytes == 2)
+				rc = rank_pass<NarrowerOr<KT, uint16_t>, KT, IT>(c, kin, kout, out_bytes, H[i & 1], H[(i + 1) & 1], n, shift, gb, ka,
+				                                                true, flags, oshift);
+			else if (in_bytes == 1)
+				rc = rank_pass<uint8_t, KT, IT>(c, kin, kout, out_bytes, H[i & 1], H[(i + 1) & 1], n, shift, gb, ka, true, flags,
+				                                oshift);
+			RSX_TRY(rc);
+			if (out_bytes != in_bytes) {
+				in_bytes = out_bytes;
+				base_col = next;
+				applied = true;
+			}
+			kin = kout;
+		}
+	} else
 	for (u32 i = 0; i < P; ++i) {
 		const u32 col = plan.cols[i];
 		const KT *kin = i == 0 ? src : (const KT *)c.keys[(i - 1) & 1].p;

@@ -93,15 +93,21 @@ __device__ __forceinline__ bool uniform_round(u32 d)
 	return __ballot(d != (u32)__builtin_amdgcn_readfirstlane((int)d)) == 0;
 }
 
+// KTO: the type the keys are written out in.  A rank sort (rsx_sort_rank*) only needs the bytes of a key that later passes
+// still look at: a pass writes kdf(key) >> oshift, narrowed to the smallest type that holds the columns to come, and the
+// next pass reads that type with the identity KDF and its digit in the low byte (2^28 f32 keys -> u32 ranks: 60 -> 50 bytes
+// of traffic per key).
 template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bool TL = false, int DIG = DIG_GENERIC,
-          bool HOT_ = false>
-__global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__restrict__ kin, KT *__restrict__ kout,
+          bool HOT_ = false, typename KTO = KT>
+__global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__restrict__ kin, KTO *__restrict__ kout,
                                                                  const VT *__restrict__ vin, VT *__restrict__ vout, u64 n,
                                                                  u32 shift, const u64 *__restrict__ gbase, u32 tps, ST *status,
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags,
                                                                  const uint8_t *__restrict__ lut, u64 *tl,
-                                                                 const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0)
+                                                                 const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
+                                                                 u32 oshift = 0)
 {
+	constexpr bool NARROW = !std::is_same<KTO, KT>::value;
 	typedef StatusBits<ST> SB_;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, TPS = C::TPS, SB = C::SB, CHUNK = C::CHUNK;
 	// Device-scheduled pass: launched before the host has seen the plan (the first pass of every sort, so that the host's
@@ -115,10 +121,12 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		const u32 col = dplan->cols[pass_index];
 		shift = 8 * col;
 		gbase += 256 * col;
-		if (pass_index & 1) {
-			const KT *t = kin;
-			kin = kout;
-			kout = const_cast<KT *>(t);
+		if constexpr (!NARROW) {
+			if (pass_index & 1) {
+				const KT *t = kin;
+				kin = kout;
+				kout = const_cast<KT *>(t);
+			}
 		}
 	}
 	constexpr bool HAS_VAL = val_bytes<VT>::value != 0;
@@ -501,7 +509,20 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			}
 			if (!(flags & SCATTER_SKIP_KEYS) && !(TL && (flags & SCATTER_DBG_NOSTORE))) {
 				const bool whole = full || i0 + CHUNK <= cnt;
-				if (sizeof(KT) >= 4 && whole && d[0] == d[CHUNK - 1]) {
+				if constexpr (NARROW) {
+					KTO ov[CHUNK];
+#pragma unroll
+					for (int e = 0; e < CHUNK; ++e)
+						ov[e] = (KTO)(kdf_apply(kv[e], ka) >> oshift);
+					if (sizeof(KTO) * CHUNK >= 4 && whole && d[0] == d[CHUNK - 1]) {
+						store_chunk<KTO, CHUNK>(kout + (ST)(delta[d[0]] + i0), ov);
+					} else {
+#pragma unroll
+						for (int e = 0; e < CHUNK; ++e)
+							if (full || i0 + e < cnt)
+								kout[(ST)(delta[d[e]] + i0 + e)] = ov[e];
+					}
+				} else if (sizeof(KT) >= 4 && whole && d[0] == d[CHUNK - 1]) {
 					store_chunk<KT, CHUNK>(kout + (ST)(delta[d[0]] + i0), kv);
 				} else {
 #pragma unroll

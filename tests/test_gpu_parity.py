@@ -315,6 +315,36 @@ def test_rank_vs_oracle(dt):
             assert np.array_equal(ranks.cpu().numpy().astype(np.uint64), want.astype(np.uint64)), (n, hex(mask), order)
 
 
+@pytest.mark.parametrize("dt", [ol.U64, ol.I64, ol.F64, ol.U32, ol.F32, ol.I32, ol.U16])
+def test_rank_narrowed_keys(dt, monkeypatch):
+    """A rank sort hands on only the key bytes later passes need, in the narrowest type that holds them (u64 -> u32 -> u16
+    -> u8).  Column patterns that narrow early, late, twice in one step and never; the same with the switch off."""
+    kb = ol.DTYPE_SIZE[dt]
+    full = (1 << (8 * kb)) - 1
+    masks = [full, full & 0xFF000000000000FF, full & 0x0000FFFF0000FFFF, full & 0x00FF00FF00FF00FF, full & 0xFFFFFFFF00000000,
+             full & 0x000000FFFFFFFFFF, full & 0x00000000FFFF00FF, full & 0xFF00FF0000000000]
+    for j, mask in enumerate(masks):
+        if mask == 0:
+            continue
+        n = (300001, 40001, 1 << 20)[j % 3]
+        a = ol.splitmix_fill(n, dt, 1000 + 7 * j + dt, mask)
+        for order in (ol.ASC, ol.DESC):
+            want, whalf, winfo, _ = ol.oracle_rank(a, dt, 4, order)
+            for off in (False, True):
+                if off:
+                    monkeypatch.setenv("RSX_NO_NARROW_KEYS", "1")
+                else:
+                    monkeypatch.delenv("RSX_NO_NARROW_KEYS", raising=False)
+                src = to_dev(a)
+                ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+                ranks, info = rsa.radix_sort_rank(src, ib, dtype=dt, order=order)
+                torch.cuda.synchronize()
+                assert info.result_in_aux == whalf and info.ncols == winfo.ncols, (hex(mask), order, off)
+                assert np.array_equal(to_bits(ranks, ol.U32), want), (hex(mask), order, off)
+                assert np.array_equal(to_bits(src, dt), a)
+    monkeypatch.delenv("RSX_NO_NARROW_KEYS", raising=False)
+
+
 def test_rank_contract_presorted():
     a = np.sort(ol.splitmix_fill(5000, ol.U32, 1))
     ib = torch.full((10000,), -1, dtype=torch.int32, device="cuda")
