@@ -351,7 +351,7 @@ u32 choose_tps(size_t n, size_t tile)
 
 // ---- phase 1: histogram + plan (radix_sort.hpp:48-80) --------------------------
 template <typename KT>
-int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted, const Geo &g)
+int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted, const Geo &g, u32 colmask = ~0u)
 {
 	typedef HistCfg<KT> C;
 	const u64 per_block = (u64)C::BLOCK * C::U * C::VEC;     // elements one block covers per sweep
@@ -365,7 +365,7 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 	RSX_TRY(c.hpart.ensure((size_t)g.nseg * bps * cols256 * sizeof(u32)));
 	ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
 	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)(g.nseg * bps)), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
-	                   (u32 *)c.hpart.p, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems);
+	                   (u32 *)c.hpart.p, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems, colmask);
 	hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)(g.nseg * sizeof(KT)), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
 	                   (const u32 *)c.hpart.p, d_hist, (u32)bps, cols256);
 	HIP_TRY(hipGetLastError());
@@ -837,7 +837,7 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u3
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	const u64 *top = c.ghist() + 256 * col;
-	RSX_TRY(launch_hist<KT>(c, src, n, ka, c.ghist(), c.unsorted(), g));
+	RSX_TRY(launch_hist<KT>(c, src, n, ka, c.ghist(), c.unsorted(), g, 1u << col));   // only the column split by
 	HIP_TRY(hipMemcpyAsync(c.host_hist, top, 256 * sizeof(u64), hipMemcpyDeviceToHost, c.stream));   // counts, before the scan
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), g.nseg, ka, c.kept());
 	HIP_TRY(hipGetLastError());

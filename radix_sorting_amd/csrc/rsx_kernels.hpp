@@ -89,10 +89,12 @@ template <typename KT, int BLOCK_ = 1024, int U_ = 2, int R_ = (sizeof(KT) == 8 
 };
 
 template <typename KT, int R>
-__device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane)
+__device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane, u32 colmask)
 {
 #pragma unroll
 	for (int j = 0; j < (int)sizeof(KT); ++j) {
+		if (!((colmask >> j) & 1u))
+			continue;
 		const u32 d = (u32)(k >> (8 * j)) & 0xFFu;
 		atomicAdd(&lh[(j * 256 + d) * R + (lane & (R - 1))], 1u);
 	}
@@ -103,8 +105,9 @@ __device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane)
 template <typename KT, typename C = HistCfg<KT>>
 __global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u32 *__restrict__ partial,
                                                             u32 *__restrict__ unsorted, KdfArgs<KT> ka, u32 nseg,
-                                                            u32 blocks_per_seg, u64 seg_elems)
+                                                            u32 blocks_per_seg, u64 seg_elems, u32 colmask = ~0u)
 {
+	// colmask: the columns to count (the MSD split of the multi-GPU path wants one: a quarter of the LDS atomics)
 	constexpr int WC = C::WC, VEC = C::VEC, R = C::R, U = C::U;
 	__shared__ u32 lh[WC * 256 * R];
 	__shared__ u32 s_descent;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict
 			const KT k = kdf_apply(src[e], ka);
 			if (e + 1 < n && k > kdf_apply(src[e + 1], ka))
 				descent = true;
-			hist_add_one<KT, R>(lh, k, lane);
+			hist_add_one<KT, R>(lh, k, lane, colmask);
 		}
 	}
 
@@ -194,6 +197,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict
 			const u64 active = __ballot(1);
 #pragma unroll
 			for (int j = 0; j < WC; ++j) {
+				if (!((colmask >> j) & 1u))
+					continue;
 				const bool differs = ((u32)(diff >> (8 * j)) & 0xFFu) != 0;
 				if (__any(differs)) {
 #pragma unroll
