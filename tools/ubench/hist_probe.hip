@@ -22,6 +22,7 @@ static u64 *d_hist;
 static u32 *d_part;
 static u32 *d_flag;
 static size_t n;
+static u32 g_colmask = ~0u;
 
 template <typename C> void bench(const char *name, unsigned grid)
 {
@@ -33,7 +34,7 @@ template <typename C> void bench(const char *name, unsigned grid)
 		CK(hipEventCreate(&e0));
 		CK(hipEventCreate(&e1));
 		CK(hipEventRecord(e0, 0));
-		hipLaunchKernelGGL((rsx_hist_kernel<u32, C>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, (u64)n, d_part, d_flag, ka, 1u, grid, (u64)n);
+		hipLaunchKernelGGL((rsx_hist_kernel<u32, C>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, (u64)n, d_part, d_flag, ka, 1u, grid, (u64)n, g_colmask);
 		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3(4, HIST_REDUCE_SPLIT), dim3(256), 0, 0, (const u32 *)d_part, d_hist, grid, 1024u);
 		CK(hipGetLastError());
 		CK(hipEventRecord(e1, 0));
@@ -65,6 +66,18 @@ int main(int argc, char **argv)
 	CK(hipMemset(d_flag, 0, 64));
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
+	// how the time follows the number of LDS atomics per key, and lane-private stripes (R = 32: no bank conflicts, one
+	// workgroup per CU)
+	for (u32 m : {0xFu, 0x7u, 0x3u, 0x1u}) {
+		g_colmask = m;
+		printf("columns counted: mask %x\n", m);
+		bench<HistCfg<u32, 1024, 2>>("block 1024 U2 R16", 512);
+		bench<HistCfg<u32, 1024, 2, 32>>("block 1024 U2 R32", 256);
+		bench<HistCfg<u32, 1024, 2, 8>>("block 1024 U2 R8", 512);
+	}
+	g_colmask = ~0u;
+	if (argc > 2)
+		return 0;
 	for (int rep = 0; rep < 2; ++rep) {
 		bench<HistCfg<u32, 1024, 1>>("block 1024 U1", 512);
 		bench<HistCfg<u32, 1024, 2>>("block 1024 U2", 512);
