@@ -234,6 +234,11 @@ int rsx_profile_end(rsx_profile *out);
 int rsx_fill_splitmix_device(void *d_dst, size_t n, size_t elem_bytes, uint64_t seed,
                              uint64_t mask, uint64_t first_index, void *stream);
 
+/* Keeps `stream` busy for about `microseconds` (one spinning wave): a known-length
+ * occupant for stream / hardware-queue experiments (multi.py picks the stream whose
+ * kernels overlap RCCL's with it). */
+int rsx_spin_device(uint64_t microseconds, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,7 @@ ABI = [
     ("rsx_profile_begin", _I, []),
     ("rsx_profile_end", _I, [C.POINTER(Profile)]),
     ("rsx_fill_splitmix_device", _I, [_VP, _SZ, _SZ, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    ("rsx_spin_device", _I, [C.c_uint64, _VP]),
 ]
 
 _lib = None
@@ -206,6 +207,12 @@ def fill_splitmix(t, seed, mask=0xFFFFFFFFFFFFFFFF, first_index=0, stream=None):
     check(lib().rsx_fill_splitmix_device(t.data_ptr(), t.numel(), t.element_size(), seed, mask, first_index,
                                          _stream_ptr(stream)))
     return t
+
+
+def spin(microseconds, stream=None):
+    """Keep the (current) stream busy for about `microseconds`."""
+    require_gpu()
+    check(lib().rsx_spin_device(int(microseconds), _stream_ptr(stream)))
 
 
 def profile_begin():

@@ -1781,4 +1781,15 @@ int rsx_fill_splitmix_device(void *d_dst, size_t n, size_t elem_bytes, uint64_t 
 	return RSX_OK;
 }
 
+int rsx_spin_device(uint64_t microseconds, void *stream)
+{
+	if (microseconds > 1000000)
+		return fail(RSX_EINVAL, "rsx_spin_device: at most one second");
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	hipLaunchKernelGGL(rsx_spin_kernel, dim3(1), dim3(64), 0, c->stream, (u64)microseconds * 100);
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
 }  // extern "C"

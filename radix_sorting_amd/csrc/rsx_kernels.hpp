@@ -483,6 +483,15 @@ __device__ __forceinline__ void store_chunk(T *dst, const T (&v)[E])
 	*(uvec_t *)dst = x;
 }
 
+// Keeps a stream busy for `ticks` of the 100 MHz wall clock (one wave): a known-length occupant for stream / queue
+// experiments (multi.py: which stream overlaps RCCL's kernels).
+__global__ void rsx_spin_kernel(u64 ticks)
+{
+	const u64 t0 = wall_clock64();
+	while (wall_clock64() - t0 < ticks)
+		__builtin_amdgcn_s_sleep(32);
+}
+
 #define RSX_STAMP(k)                                                    \
 	do {                                                                \
 		if (TL && threadIdx.x == 0)                                     \

@@ -10,9 +10,14 @@ SURVEY.md section 8e is the contract implemented here, one process per GPU:
      derives the same splitters -- contiguous top-digit ranges holding ~n/G keys
      each -- and the whole G x G count matrix (no second count exchange);
   3. a destination's keys are a contiguous range of the split shard, so the
-     buckets go out as they lie with ``all_to_all_single`` (RCCL all-to-all-v
-     over xGMI; each directed pair of GPUs has its own link);
-  4. each rank LSD-sorts what it received (rsx_sort_device).
+     buckets go out as they lie (RCCL all-to-all-v over xGMI as grouped
+     send/recv; each directed pair of GPUs has its own link) -- in CHUNKS: a
+     destination's digit range is cut into sub-ranges, which are independent
+     sorting problems, and sub-range j is sorted (step 4) while sub-range j+1 is
+     still on the links;
+  4. each rank LSD-sorts every sub-range it received, in place and without a host
+     synchronisation (rsx_sort_inplace_async).  Sub-ranges are in digit order, so
+     the receive buffer ends up sorted as a whole.
 
 Splitting by the byte itself (256 digits) and not by destination (G buckets)
 keeps the pass on the plain-digit kernel: with G = 2..8 buckets every LDS counter
@@ -30,10 +35,12 @@ backend in tests (tests/ inject an oracle-backed engine); the product engine is
 HipEngine and it fails loudly without a GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
-from . import (ASCENDING, DTYPE_SIZE, Info, RsxError, _stream_ptr, check, lib, radix_sort)
+from . import (ASCENDING, DTYPE_SIZE, Info, RsxError, _stream_ptr, check, lib, radix_sort, radix_sort_inplace_async,
+               spin)
 
 
 def choose_splitters(top_hist, world):
@@ -54,6 +61,9 @@ def choose_splitters(top_hist, world):
     r = np.clip(r, 0, world - 1)
     r = np.maximum.accumulate(r)          # monotone even with empty digits
     return r.astype(np.uint8)
+
+
+_OVERLAP_STREAMS = {}      # (device, group, to_self) -> stream or None (HipEngine.overlap_stream)
 
 
 def count_matrix(hists, lut, world):
@@ -105,18 +115,89 @@ class HipEngine:
         res, info = radix_sort(keys, aux, dtype=self.dtype, order=self.order)
         return res, info
 
+    def sort_inplace_async(self, buf, scratch):
+        """Stable sort of buf in place (scratch: as many elements), only enqueued on the current stream."""
+        radix_sort_inplace_async(buf, scratch, dtype=self.dtype, order=self.order)
+
+    def overlap_stream(self, group=None, to_self=False):
+        """A stream whose kernels run concurrently with the process group's send/recv kernels, or None.
+
+        The HIP runtime maps streams onto a few hardware queues and kernels of two streams that share a queue run one after
+        the other -- measured on MI355X: with the sorts on the default stream the RCCL kernels of the next sub-range ran
+        strictly before them.  So: four candidate streams, each tried against one dummy exchange (every rank does all four
+        rounds: the rounds are collective); the first whose marker kernel finishes well before the exchange wins.  Cached.
+        """
+        torch = self.torch
+        import torch.distributed as dist
+        main = torch.cuda.current_stream()
+        dev = main.device
+        key = (dev.index, id(group), bool(to_self))
+        if key in _OVERLAP_STREAMS:
+            return _OVERLAP_STREAMS[key]
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        nb = 1 << 20
+        sendb = torch.zeros(nb * world, dtype=torch.uint8, device=dev)
+        recvb = torch.zeros(nb * world, dtype=torch.uint8, device=dev)
+        tiny = torch.zeros(256, dtype=torch.float32, device=dev)
+        peers = [p for p in range(world) if p != rank] or ([rank] if to_self else [])
+        chosen = None
+        hold_us = 20000
+        for cand in [torch.cuda.Stream(device=dev) for _ in range(4)]:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            # the exchange waits for the main stream, which spins for 20 ms: whatever shares RCCL's hardware queue is held
+            # up that long, whatever does not finishes at once
+            spin(hold_us)
+            ops = []
+            for p in peers:
+                ops.append(dist.P2POp(dist.isend, sendb[p * nb:(p + 1) * nb], p, group))
+                ops.append(dist.P2POp(dist.irecv, recvb[p * nb:(p + 1) * nb], p, group))
+            works = dist.batch_isend_irecv(ops) if ops else []
+            with torch.cuda.stream(cand):
+                tiny.add_(1.0)
+                e1.record(cand)
+            for w in works:
+                w.wait()
+            torch.cuda.synchronize()
+            if chosen is None and works and e0.elapsed_time(e1) < hold_us / 2000.0:
+                chosen = cand
+        _OVERLAP_STREAMS[key] = chosen
+        return chosen
+
     def empty(self, n, like):
         return self.torch.empty(n, dtype=like.dtype, device=like.device)
 
 
-def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None, force_exchange=False):
+def choose_chunks(global_hist, lut, world, chunks):
+    """Cut every destination's digit range into at most `chunks` contiguous sub-ranges of about equal global counts.
+
+    Returns chunk_of[256] (monotone inside a destination's range).  Keys of different sub-ranges never compare equal in
+    the split byte, so the sub-ranges of a destination are independent sorting problems in digit order.
+    """
+    chunk_of = np.zeros(256, dtype=np.int64)
+    h = np.asarray(global_hist, dtype=np.uint64)
+    lut = np.asarray(lut, dtype=np.int64)
+    for d in range(world):
+        digits = np.nonzero(lut == d)[0]
+        if digits.size == 0:
+            continue
+        sub = np.zeros(256, dtype=np.uint64)
+        sub[digits] = h[digits]
+        chunk_of[digits] = choose_splitters(sub, chunks)[digits]
+    return chunk_of
+
+
+def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None, force_exchange=False, chunks=None):
     """Sort the concatenation of every rank's ``shard`` (rank order = global index order).
 
     Returns (sorted_local, stats): rank r ends up with the r-th contiguous slice of
     the globally sorted sequence (slice sizes follow the splitters, not n/G).
     ``scratch`` may carry preallocated tensors {"part", "recv", "aux"} (>= capacity) to keep
     allocation out of a timed region.  ``force_exchange`` runs every exchange step even in a one-rank group (the
-    collectives then talk to the rank itself): that is how the RCCL path is exercised on a one-GPU box.
+    rank then sends to itself): that is how the RCCL path is exercised on a one-GPU box.  ``chunks``: sub-ranges a
+    destination's digit range is cut into; the exchange of sub-range j+1 overlaps the local sort of sub-range j
+    (default: RSX_MULTI_CHUNKS or 4; 1 = one ``all_to_all_single`` and one local sort, nothing overlapped).
     """
     import torch
     import torch.distributed as dist
@@ -157,15 +238,74 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
         recv = engine.empty(n_recv, shard)
         aux = engine.empty(n_recv, shard)
 
-    # 3: the buckets (all-to-all-v).  The exchange moves opaque bytes: every key width then works on every backend
-    # (gloo has no int16)
+    # 3-4: sub-range by sub-range: the pieces of sub-range j go out (grouped send/recv = all-to-all-v; opaque bytes, so
+    # every key width works on every backend), and as soon as they are in, they are sorted in place while the next
+    # sub-range is on the links.  The split shard is in digit order: piece (destination d, sub-range j) of this rank is
+    # part[first[a] : first[b]] for the digits [a, b) of that sub-range.  Receive layout: sub-range major, source minor.
+    if chunks is None:
+        chunks = int(os.environ.get("RSX_MULTI_CHUNKS", "4"))
+    nchunks = max(1, min(int(chunks), 64))
+    if nchunks == 1:
+        es = shard.element_size()
+        dist.all_to_all_single(recv.view(torch.uint8), part.view(torch.uint8),
+                               output_split_sizes=[int(x) * es for x in recv_counts],
+                               input_split_sizes=[int(x) * es for x in send_counts], group=group)
+        if n_recv > 1:
+            engine.sort_inplace_async(recv, aux)
+        return recv, {"sent": int(send_counts.sum() - send_counts[rank]), "received": n_recv, "local_info": None, "lut": lut,
+                      "split_column": column, "chunks": 1, "send_counts": send_counts, "recv_counts": recv_counts}
+    chunk_of = choose_chunks(hists.sum(axis=0), lut, world, nchunks)
+    first = np.concatenate([[0], np.cumsum(local_hist.astype(np.int64))])     # offset of a digit's run in `part`
     es = shard.element_size()
-    dist.all_to_all_single(recv.view(torch.uint8), part.view(torch.uint8),
-                           output_split_sizes=[int(x) * es for x in recv_counts],
-                           input_split_sizes=[int(x) * es for x in send_counts], group=group)
+    part_b, recv_b = part.view(torch.uint8), recv.view(torch.uint8)
+    mine_digits = lut.astype(np.int64) == rank
+    side = engine.overlap_stream(group, force_exchange) if hasattr(engine, "overlap_stream") else None
+    main = torch.cuda.current_stream() if side is not None else None
 
-    # 4: local LSD sort of the received bucket range
-    res, info = engine.local_sort(recv, aux)
+    def exchange(j, roff):
+        """enqueue sub-range j's pieces; returns (works, begin, end) in elements of recv"""
+        ops, begin = [], roff
+        for p in range(world):
+            sel_r = np.nonzero(mine_digits & (chunk_of == j))[0]               # what rank p sends me for sub-range j
+            rcnt = int(hists[p][sel_r].sum()) if sel_r.size else 0
+            sel_s = np.nonzero((lut.astype(np.int64) == p) & (chunk_of == j))[0]   # what I send rank p
+            scnt = int(local_hist[sel_s].sum()) if sel_s.size else 0
+            soff = int(first[sel_s[0]]) if sel_s.size else 0
+            dst = recv_b[roff * es:(roff + rcnt) * es]
+            src = part_b[soff * es:(soff + scnt) * es]
+            if p == rank and not force_exchange:
+                if rcnt:
+                    dst.copy_(src)
+            else:
+                if scnt:
+                    ops.append(dist.P2POp(dist.isend, src, p, group))
+                if rcnt:
+                    ops.append(dist.P2POp(dist.irecv, dst, p, group))
+            roff += rcnt
+        return (dist.batch_isend_irecv(ops) if ops else []), begin, roff
+
+    # sub-range j+1 is submitted before sub-range j is sorted: with the sorts on a stream of their own (another hardware
+    # queue than RCCL's) the two overlap; on a shared queue the order of submission is simply the order of execution
+    nxt = exchange(0, 0)
+    for j in range(nchunks):
+        works, begin, end = nxt
+        if j + 1 < nchunks:
+            nxt = exchange(j + 1, end)
+        if side is not None:
+            side.wait_stream(main)                     # this rank's own piece was copied on the main stream
+            with torch.cuda.stream(side):
+                for w in works:
+                    w.wait()
+                if end - begin > 1:
+                    engine.sort_inplace_async(recv[begin:end], aux[begin:end])
+        else:
+            for w in works:
+                w.wait()                               # (NCCL: the current stream waits; gloo: the host does)
+            if end - begin > 1:
+                engine.sort_inplace_async(recv[begin:end], aux[begin:end])
+    if side is not None:
+        main.wait_stream(side)
     sent = int(send_counts.sum() - send_counts[rank])
-    return res, {"sent": sent, "received": n_recv, "local_info": info, "lut": lut, "split_column": column,
-                 "send_counts": send_counts, "recv_counts": recv_counts}
+    return recv, {"sent": sent, "received": n_recv, "local_info": None, "lut": lut, "split_column": column,
+                  "chunks": nchunks, "overlap_stream": side is not None, "send_counts": send_counts,
+                  "recv_counts": recv_counts}

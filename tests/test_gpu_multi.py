@@ -182,11 +182,12 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 for dt, carrier in ((ol.U32, np.int32), (ol.U64, np.int64), (ol.I16, np.int16)):
     a = ol.splitmix_fill(777777, dt, 31)
     shard = torch.from_numpy(a.view(carrier).copy()).cuda()
-    res, stats = multi.distributed_sort(shard, multi.HipEngine(dt), force_exchange=True)
-    torch.cuda.synchronize()
-    assert stats["received"] == a.size and stats["sent"] == 0 and "lut" in stats, stats
     want = ol.oracle_sort(a, dt)[0]
-    assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), want), dt
+    for chunks in (1, 4, 9):       # one all_to_all_single + one sort; the pipelined form (grouped send/recv to itself)
+        res, stats = multi.distributed_sort(shard, multi.HipEngine(dt), force_exchange=True, chunks=chunks)
+        torch.cuda.synchronize()
+        assert stats["received"] == a.size and stats["sent"] == 0 and stats["chunks"] == chunks, stats
+        assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), want), (dt, chunks)
 dist.barrier()
 dist.destroy_process_group()
 print("self-exchange OK")

@@ -58,6 +58,10 @@ class OracleEngine:
         target.numpy().view(res.dtype)[:res.size] = res
         return target[:res.size], info
 
+    def sort_inplace_async(self, buf, scratch):
+        res, _, _ = ol.oracle_sort(self._bits(buf), self.dtype, self.order)
+        buf.numpy().view(res.dtype)[:res.size] = res
+
     def empty(self, n, like):
         return torch.empty(n, dtype=like.dtype)
 
@@ -70,7 +74,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir):
+def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chunks=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -80,7 +84,7 @@ def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir):
         first = sum(n_per_rank[:rank])
         whole = ol.splitmix_fill(sum(n_per_rank), dtype, seed, mask)
         shard = torch.from_numpy(whole[first:first + n].view(carrier).copy())
-        res, stats = multi.distributed_sort(shard, OracleEngine(dtype, order))
+        res, stats = multi.distributed_sort(shard, OracleEngine(dtype, order), chunks=chunks)
         np.save(os.path.join(outdir, "out%d.npy" % rank), res.numpy().view(ol.NP_BITS[dtype]).copy())
         np.save(os.path.join(outdir, "recv%d.npy" % rank), np.asarray(stats.get("recv_counts", [n])))
     finally:
@@ -107,6 +111,33 @@ def test_distributed_sort_matches_single_sort(tmp_path, world, dtype, order, mas
     sizes = [np.load(os.path.join(str(tmp_path), "out%d.npy" % r)).size for r in range(world)]
     if dtype == ol.U32:
         assert max(sizes) < 1.2 * sum(sizes) / world      # uniform keys -> balanced splitters, also below a constant top byte
+
+
+@pytest.mark.parametrize("chunks", [1, 3, 16])
+def test_distributed_sort_chunk_counts(tmp_path, chunks):
+    """One all-to-all and one sort (chunks = 1) against the pipelined form with few and with many sub-ranges."""
+    world, dtype = 2, ol.U32
+    n_per_rank = [30000, 41111]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dtype, 0, n_per_rank, 0xFFFFFFFF, 13, str(tmp_path), chunks), nprocs=world, join=True)
+    whole = ol.splitmix_fill(sum(n_per_rank), dtype, 13, 0xFFFFFFFF)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got, ol.oracle_sort(whole, dtype)[0])
+
+
+def test_choose_chunks():
+    rng = np.random.default_rng(5)
+    h = rng.integers(0, 1000, 256).astype(np.uint64)
+    h[40:60] = 0
+    for world in (1, 2, 3, 8):
+        lut = multi.choose_splitters(h, world)
+        for chunks in (1, 4, 8):
+            c = multi.choose_chunks(h, lut, world, chunks)
+            assert c.min() >= 0 and c.max() < chunks
+            for d in range(world):
+                dig = np.nonzero(lut == d)[0]
+                if dig.size:
+                    assert np.all(np.diff(c[dig]) >= 0)          # sub-ranges are contiguous and in digit order
 
 
 def test_count_matrix():
