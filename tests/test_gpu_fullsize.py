@@ -143,3 +143,31 @@ def test_counter_width_above_2p30(dt, tdt):
     assert bool((res[1:] >= res[:-1]).all().item())
     as_index = (res.to(torch.int32) + (0 if dt == rsa.U8 else 32768))
     assert torch.equal(torch.bincount(as_index, minlength=bins), before)
+
+
+def test_rank_above_2p30_narrowed_keys():
+    """A rank sort beyond 2^30 elements (64-bit status words) whose keys narrow on the way (u16 -> u8): 2^30 + 12345 u16 keys
+    -> u32 ranks.  Checked through the definition: keys[rank] is non-decreasing, equal keys keep index order, and the ranks'
+    sum is that of 0 .. n-1."""
+    n = (1 << 30) + 12345
+    keys = torch.empty(n, dtype=torch.int16, device="cuda")
+    rsa.fill_splitmix(keys, seed=99)
+    ib = torch.empty(2 * n, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(keys, ib, dtype=rsa.U16)
+    torch.cuda.synchronize()
+    assert info.ncols == 2 and info.result_in_aux == 0
+    total = 0
+    step = 1 << 28
+    prev_key, prev_rank = None, None
+    for o in range(0, n, step):
+        r = ranks[o:o + step].to(torch.int64) & 0xFFFFFFFF
+        total += int(r.sum().item())
+        k = keys[r].to(torch.int32) & 0xFFFF
+        assert bool((k[1:] >= k[:-1]).all().item())
+        same = k[1:] == k[:-1]
+        assert bool((r[1:][same] > r[:-1][same]).all().item())
+        if prev_key is not None:
+            assert int(k[0]) > prev_key or (int(k[0]) == prev_key and int(r[0]) > prev_rank)
+        prev_key, prev_rank = int(k[-1]), int(r[-1])
+        del r, k, same
+    assert total == n * (n - 1) // 2
