@@ -1,5 +1,7 @@
 """Seeded differential fuzz of the three entry points against the oracle: random sizes (clustered around the small-sort
 limits, tile sizes and their multiples), key types, column masks, skew, orders."""
+import os
+
 import numpy as np
 import pytest
 
@@ -26,7 +28,7 @@ def _size(rng):
         return max(2, int(anchors[rng.integers(0, len(anchors))] + rng.integers(-3, 4)))
     if kind == 2:
         return int(rng.integers(3000, 300000))
-    return int(rng.integers(300000, 1200000))
+    return int(rng.integers(300000, int(os.environ.get("RSX_FUZZ_MAXN", "1200000"))))
 
 
 def _keys(rng, n, dt):
@@ -53,10 +55,15 @@ def _keys(rng, n, dt):
     return a
 
 
-@pytest.mark.parametrize("chunk", range(6))
+# RSX_FUZZ_CHUNKS / RSX_FUZZ_SEED: a longer or a different run of the same fuzz (40 cases per chunk)
+_CHUNKS = int(os.environ.get("RSX_FUZZ_CHUNKS", "6"))
+_SEED = int(os.environ.get("RSX_FUZZ_SEED", "20240"))
+
+
+@pytest.mark.parametrize("chunk", range(_CHUNKS))
 def test_fuzz_keys_pairs_ranks(chunk):
     rsa.require_gpu()
-    rng = np.random.default_rng(20240 + chunk)
+    rng = np.random.default_rng(_SEED + chunk)
     for case in range(40):
         dt = int(rng.integers(0, 10))
         n = _size(rng)
@@ -98,3 +105,45 @@ def test_fuzz_keys_pairs_ranks(chunk):
             torch.cuda.synchronize()
             assert info.result_in_aux == whalf and info.early_exit == winfo.early_exit, tag
             assert np.array_equal(ranks.cpu().numpy().astype(np.uint64), want.astype(np.uint64)), tag
+
+
+@pytest.mark.parametrize("chunk", range(max(2, _CHUNKS // 3)))
+def test_fuzz_host_multi_and_split(chunk):
+    """rsx_sort_multi (1-6 ranks on device 0), the inplace sort and the MSD split against the oracle on fuzzed inputs."""
+    from radix_sorting_amd import multi
+    rsa.require_gpu()
+    rng = np.random.default_rng(_SEED + 7000 + chunk)
+    for case in range(20):
+        dt = int(rng.integers(0, 10))
+        n = _size(rng)
+        order = int(rng.integers(0, 2))
+        a = _keys(rng, n, dt)
+        what = int(rng.integers(0, 3))
+        tag = (chunk, case, ol.DTYPE_NAMES[dt], n, order, what)
+        want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+        if what == 0:
+            ranks = int(rng.integers(1, 7))
+            src, aux = a.copy(), np.full_like(a, 0x5A)
+            res, info = rsa.radix_sort_multi_host(src, aux, dt, order, [0] * ranks)
+            assert bool(info.result_in_aux) == bool(want_aux) and info.early_exit == winfo.early_exit, tag
+            assert np.array_equal(res, want), tag
+            if winfo.early_exit:
+                assert np.all(aux == 0x5A), tag
+        elif what == 1:
+            buf = _dev(a)
+            scratch = torch.zeros_like(buf)
+            rsa.radix_sort_inplace_async(buf, scratch, dtype=dt, order=order)
+            torch.cuda.synchronize()
+            assert np.array_equal(buf.cpu().numpy().view(ol.NP_BITS[dt]), want), tag
+        else:
+            kb = ol.DTYPE_SIZE[dt]
+            col = int(rng.integers(0, kb))
+            eng = multi.HipEngine(dt, order)
+            shard = _dev(a)
+            out = torch.zeros_like(shard)
+            hist = eng.msd_split(shard, out, col)
+            torch.cuda.synchronize()
+            k = ol.kdf_keys(a, dt, order)
+            dig = ((k >> ol.NP_BITS[dt](8 * col)) & ol.NP_BITS[dt](0xFF)).astype(np.int64)
+            assert np.array_equal(hist, np.bincount(dig, minlength=256).astype(np.uint64)), tag
+            assert np.array_equal(out.cpu().numpy().view(ol.NP_BITS[dt]), a[np.argsort(dig, kind="stable")]), tag
