@@ -94,9 +94,15 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * contents afterwards are unspecified, untouched if the input was sorted).  Nothing
  * is returned but the status of the enqueue: the call can be captured into a HIP
  * graph (after one uncaptured call of the same size has sized the workspace) and
- * replayed on new contents of d_buf.  Keys only. */
+ * replayed on new contents of d_buf. */
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
                            void *stream);
+
+/* Key + payload in the same manner: both arrays sorted in place by the keys (stable),
+ * never a host synchronisation, HIP-graph capturable.  payload_bytes: 4 or 8. */
+int rsx_sort_pairs_inplace_async(void *d_keys, void *d_keys_scratch, void *d_vals, void *d_vals_scratch,
+                                 size_t n, rsx_dtype dtype, size_t payload_bytes, rsx_order order,
+                                 void *stream);
 
 /* Device-resident variant for callers that own a HIP stream (`stream` is a
  * hipStream_t, NULL = the default stream).  The column plan has to reach the

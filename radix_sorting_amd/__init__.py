@@ -55,6 +55,7 @@ ABI = [
     ("rsx_release", None, []),
     ("rsx_sort", _I, [_VP, _VP, _SZ, _I, _I, _PVP, _PINFO]),
     ("rsx_sort_inplace_async", _I, [_VP, _VP, _SZ, _I, _I, _VP]),
+    ("rsx_sort_pairs_inplace_async", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP]),
     ("rsx_sort_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _PVP, _PINFO]),
     ("rsx_sort_pairs_device", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP, _PINFO]),
     ("rsx_sort_rank", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _PVP, _PINFO]),
@@ -166,6 +167,18 @@ def radix_sort_inplace_async(buf, scratch, dtype=None, order=ASCENDING, stream=N
         raise RsxError("buf/scratch do not match")
     check(lib().rsx_sort_inplace_async(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream)))
     return buf
+
+
+def radix_sort_pairs_inplace_async(keys, keys_scratch, vals, vals_scratch, dtype=None, order=ASCENDING, stream=None):
+    """rsx_sort_pairs_inplace_async: keys and payloads sorted in place by the keys, no host synchronisation."""
+    _check_dev(keys, keys_scratch, vals, vals_scratch)
+    code = _torch_dtype_code(keys) if dtype is None else dtype
+    if keys.element_size() != DTYPE_SIZE[code] or vals.element_size() not in (4, 8) or vals.numel() != keys.numel() \
+            or keys_scratch.numel() < keys.numel() or vals_scratch.numel() < vals.numel():
+        raise RsxError("keys/vals/scratch do not match")
+    check(lib().rsx_sort_pairs_inplace_async(keys.data_ptr(), keys_scratch.data_ptr(), vals.data_ptr(), vals_scratch.data_ptr(),
+                                             keys.numel(), code, vals.element_size(), order, _stream_ptr(stream)))
+    return keys, vals
 
 
 def radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=None, order=ASCENDING, stream=None):

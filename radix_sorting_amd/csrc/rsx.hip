@@ -650,6 +650,32 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 	return RSX_OK;
 }
 
+// ---- key + payload, no host synchronisation: as sort_keys_inplace_async, the result always in (k, v) -----------------------
+template <typename KT, typename VT>
+int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int dtype, int order)
+{
+	if (!c.fast)
+		return fail(RSX_EHIP, "rsx_sort_pairs_inplace_async needs the fast scatter kernel (the device self-check failed on this device)");
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	if (n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES) {
+		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, VT, false>), dim3(1), dim3(1024), 0, c.stream, (const KT *)k, ks, v, vs, (u32)n,
+		                   ka, c.dev_host_plan, true);
+		HIP_TRY(hipGetLastError());
+		return RSX_OK;
+	}
+	const Geo g = one_segment(n);
+	const size_t status_total = status_bytes<KT, VT>(n) * sizeof(KT);
+	RSX_TRY(plan_phase<KT>(c, k, n, ka, g, nullptr, status_total));
+	for (u32 i = 0; i < sizeof(KT); ++i)
+		RSX_TRY((scatter_pass<KT, VT>(c, k, ks, v, vs, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), (int)i, i)));
+	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)k, (const unsigned char *)ks,
+	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
+	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)v, (const unsigned char *)vs,
+	                   (u64)n * sizeof(VT), (const Plan *)c.plan());
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
 // ---- key + payload -----------------------------------------------------------------
 template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
@@ -1021,6 +1047,27 @@ int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dty
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	RSX_DISPATCH_KT(dtype, return sort_keys_inplace_async<KT>(*c, (KT *)d_buf, (KT *)d_scratch, n, dtype, order));
+	return RSX_OK;
+}
+
+int rsx_sort_pairs_inplace_async(void *d_keys, void *d_keys_scratch, void *d_vals, void *d_vals_scratch, size_t n, rsx_dtype dtype,
+                                 size_t payload_bytes, rsx_order order, void *stream)
+{
+	if (!dtype_size(dtype) || (payload_bytes != 4 && payload_bytes != 8) ||
+	    (n && (!d_keys || !d_keys_scratch || !d_vals || !d_vals_scratch)))
+		return fail(RSX_EINVAL, "rsx_sort_pairs_inplace_async: bad argument");
+	if (n < 2)
+		return RSX_OK;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	if (payload_bytes == 4) {
+		RSX_DISPATCH_KT(dtype, return (sort_pairs_inplace_async<KT, u32>(*c, (KT *)d_keys, (KT *)d_keys_scratch, (u32 *)d_vals,
+		                                                                 (u32 *)d_vals_scratch, n, dtype, order)));
+	} else {
+		RSX_DISPATCH_KT(dtype, return (sort_pairs_inplace_async<KT, u64>(*c, (KT *)d_keys, (KT *)d_keys_scratch, (u64 *)d_vals,
+		                                                                 (u64 *)d_vals_scratch, n, dtype, order)));
+	}
 	return RSX_OK;
 }
 

@@ -126,6 +126,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				const KT *t = kin;
 				kin = kout;
 				kout = const_cast<KT *>(t);
+				const VT *u = vin;
+				vin = vout;
+				vout = const_cast<VT *>(u);
 			}
 		}
 	}

@@ -143,7 +143,8 @@ constexpr u32 SMALL_PAIR_BYTES = 131072;
 template <typename KT, typename VT, bool RANK>
 __global__ __launch_bounds__(1024) void rsx_small_pairs_kernel(const KT *__restrict__ k0, KT *__restrict__ k1, VT *__restrict__ v0,
                                                                VT *__restrict__ v1, u32 n, KdfArgs<KT> ka,
-                                                               Plan *__restrict__ plan_out)
+                                                               Plan *__restrict__ plan_out,
+                                                               bool inplace = false)   // result in (k0, v0) whatever the parity
 {
 	constexpr int WC = sizeof(KT), NW = 16, BLOCK = 1024;
 	constexpr u32 CAP = SMALL_PAIR_BYTES / (2 * (sizeof(KT) + sizeof(VT)));
@@ -250,11 +251,11 @@ __global__ __launch_bounds__(1024) void rsx_small_pairs_kernel(const KT *__restr
 		__syncthreads();
 		cur ^= 1;
 	}
-	VT *vdst = (ncols & 1) ? v1 : v0;   // radix_sort.hpp:92 / radix_sort_rank.hpp:91
+	VT *vdst = ((ncols & 1) && !inplace) ? v1 : v0;   // radix_sort.hpp:92 / radix_sort_rank.hpp:91
 	for (u32 i = tid; i < n; i += BLOCK)
 		vdst[i] = vbuf[cur][i];
 	if (!RANK) {
-		KT *kdst = (ncols & 1) ? k1 : const_cast<KT *>(k0);
+		KT *kdst = ((ncols & 1) && !inplace) ? k1 : const_cast<KT *>(k0);
 		for (u32 i = tid; i < n; i += BLOCK)
 			kdst[i] = kbuf[cur][i];
 	}

@@ -468,6 +468,35 @@ def test_inplace_async_sort(dt):
     assert np.array_equal(to_bits(srt, dt), want) and torch.equal(scratch, keep)
 
 
+@pytest.mark.parametrize("dt,vbytes", [(ol.U32, 4), (ol.F32, 8), (ol.U64, 4), (ol.I64, 8), (ol.U16, 4), (ol.I8, 4)])
+def test_inplace_async_pairs(dt, vbytes):
+    """rsx_sort_pairs_inplace_async: keys and payloads end in the first buffers whatever the number of kept columns; no
+    host synchronisation; a sorted input leaves the scratch buffers untouched."""
+    size = ol.DTYPE_SIZE[dt]
+    full = (1 << (8 * size)) - 1
+    vt = torch.int32 if vbytes == 4 else torch.int64
+    rng = np.random.default_rng(131 + dt + vbytes)
+    cap = 131072 // (2 * (size + vbytes))
+    for trial, n in enumerate((2, 777, cap, cap + 1, 70001, 300001, 1 << 21)):
+        mask = full if trial % 2 == 0 else full & ~(0xFF << (8 * int(rng.integers(0, size))))    # odd / even column counts
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        for order in (ol.ASC, ol.DESC):
+            perm = ol.stable_argsort_by_kdf(a, dt, order)
+            keys, ks = to_dev(a), to_dev(np.zeros_like(a))
+            vals = torch.arange(n, dtype=vt, device="cuda") * 5 + 1
+            vs = torch.zeros_like(vals)
+            rsa.radix_sort_pairs_inplace_async(keys, ks, vals, vs, dtype=dt, order=order)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_bits(keys, dt), a[perm]), (n, hex(mask), order)
+            assert np.array_equal(vals.cpu().numpy(), perm.astype(np.int64) * 5 + 1), (n, hex(mask), order)
+    ks.fill_(7)
+    vs.fill_(9)
+    before_k, before_v = keys.clone(), vals.clone()
+    rsa.radix_sort_pairs_inplace_async(keys, ks, vals, vs, dtype=dt, order=order)     # sorted now: nothing moves
+    torch.cuda.synchronize()
+    assert torch.equal(keys, before_k) and torch.equal(vals, before_v) and bool((ks == 7).all()) and bool((vs == 9).all())
+
+
 @pytest.mark.parametrize("n", [5000, 300001, 1 << 23])
 def test_inplace_async_sort_in_a_hip_graph(n):
     """The whole sort captured into a graph once and replayed on new keys (three different column counts)."""
