@@ -17,7 +17,7 @@ def test_parity_suite_on_the_fallback_kernels():
     rsa.require_gpu()
     env = dict(os.environ, RSX_FORCE_TABLE_RANK="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
-                          "-k", "golden or sweep or contract or pairs or rank or skewed or unaligned or records"],
+                          "-k", "(golden or sweep or contract or pairs or rank or skewed or unaligned or records) and not inplace_async"],
                          capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
