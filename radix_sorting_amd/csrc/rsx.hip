@@ -144,6 +144,7 @@ struct Ctx {
 
 	u64 *ghist() const { return (u64 *)hist.p; }
 	u32 *unsorted() const { return (u32 *)small.p; }
+	u32 *hotd() const { return (u32 *)((char *)small.p + 16); }   // [8] hot digits per column + [1] valid bits (rsx_plan_kernel)
 	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
 	u32 *kept() const { return (u32 *)((char *)small.p + 128); }
 	uint8_t *lut() const { return (uint8_t *)((char *)small.p + 192); }
@@ -390,7 +391,7 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, 
 	}
 	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted(), g));
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), g.nseg, ka,
-	                   c.kept());
+	                   c.kept(), c.hotd());
 	hipLaunchKernelGGL(rsx_plan_finish_kernel, dim3(1), dim3(64), 0, c.stream, (const u32 *)c.kept(), (u32)sizeof(KT),
 	                   (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan);
 	HIP_TRY(hipGetLastError());
@@ -443,7 +444,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
 	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan, pass_index,  \
-	                   oshift)
+	                   oshift, (const u32 *)c.hotd())
 #define RSX_LAUNCH2_ST(DIGV)                 \
 	do {                                     \
 		if (wide) {                          \
@@ -865,7 +866,8 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u3
 	const u64 *top = c.ghist() + 256 * col;
 	RSX_TRY(launch_hist<KT>(c, src, n, ka, c.ghist(), c.unsorted(), g, 1u << col));   // only the column split by
 	HIP_TRY(hipMemcpyAsync(c.host_hist, top, 256 * sizeof(u64), hipMemcpyDeviceToHost, c.stream));   // counts, before the scan
-	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), g.nseg, ka, c.kept());
+	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), g.nseg, ka, c.kept(),
+	                   c.hotd());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(c.stream));
 	u64 total = 0;

@@ -295,7 +295,8 @@ __device__ __forceinline__ void wave_scan_256(u64 *vals, u64 *lsum, u32 lane)
 // (radix_sort.hpp:72-80) refined by segment.  kept[col] answers the column-skip probe (:64-70).
 template <typename KT>
 __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
-                                                       u32 nseg, KdfArgs<KT> ka, u32 *__restrict__ kept)
+                                                       u32 nseg, KdfArgs<KT> ka, u32 *__restrict__ kept,
+                                                       u32 *__restrict__ hotd = nullptr)
 {
 	constexpr int WC = sizeof(KT);
 	__shared__ u64 tot[256];
@@ -313,6 +314,19 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 	if (total >= n / 8 + 1)
 		kept[8 + col] = 1;                                         // a hot digit (see Plan::hot)
 	tot[d] = total;
+	__syncthreads();
+	// hotd[col]: up to four digits that hold a sixteenth of the keys or more, most frequent first, a byte each; hotd[8]:
+	// bit 4 col + r = slot r of column col is valid (all zeroed by the caller).  The HOT scatter kernels rank these
+	// digits with ballots instead of LDS atomics (rsx_scatter2.hpp).
+	if (hotd && total >= n / 16 + 1) {
+		u32 rank = 0;
+		for (u32 e = 0; e < 256; ++e)
+			rank += (tot[e] > total || (tot[e] == total && e < d)) ? 1u : 0u;
+		if (rank < 4) {
+			atomicOr(&hotd[col], d << (8 * rank));
+			atomicOr(&hotd[8], 1u << (4 * col + rank));
+		}
+	}
 	__syncthreads();
 	if (d < 64)
 		wave_scan_256(tot, lsum, d);                               // radix_sort.hpp:74-79

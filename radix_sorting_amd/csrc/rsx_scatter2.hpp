@@ -81,17 +81,16 @@ __device__ __forceinline__ u32 digit2(KT raw, const KdfArgs<KT> ka, u32 shift, u
 		return digit_of(raw, ka, shift, flags, lut);
 }
 
-// ---- one digit for the whole wave (HOT kernels) --------------------------------------------------------------------
-// An LDS atomic serialises the lanes of one instruction that hit the same address.  Where a byte column is constant
-// over long stretches (small integers, floats of one magnitude, Zipf-like keys, the high bytes of sawtooth input) all
-// 64 lanes of a round hit one cell: 64-fold, for the counting and for the ranking atomic alike (2^28 sawtooth keys:
-// 0.89 ms per pass against 0.49 ms for uniform digits).  The HOT instantiation tests every round and handles a uniform
-// one with one atomic by one lane: rank = returned value + lane.  The test costs 2 % on uniform digits, so the host
-// selects HOT per column, from the histogram it has anyway: when one digit holds an eighth of the keys or more.
-__device__ __forceinline__ bool uniform_round(u32 d)
-{
-	return __ballot(d != (u32)__builtin_amdgcn_readfirstlane((int)d)) == 0;
-}
+// ---- hot digits (HOT kernels) -----------------------------------------------------------------------------------------
+// An LDS atomic serialises the lanes of one instruction that hit the same address.  Where a byte column has a few
+// dominant digits (small integers, floats of one magnitude, Zipf-like keys, columns with two or four values) 16 to 64
+// lanes of every round hit one cell, for the counting and for the ranking atomic alike (2^28 keys with four values per
+// byte: 0.80 ms per pass against 0.50 ms for uniform digits).  The HOT instantiation takes up to four hot digits of the
+// column from rsx_plan_kernel (hotd[column]: digits holding a sixteenth of the keys or more) and, in whole tiles, ranks
+// their lanes with one ballot per hot digit -- rank = the wave's running count of the digit + the number of lower lanes
+// that have it -- so that only the lanes with other digits go to the LDS counters.  The ballots cost a few percent
+// on uniform digits, so the host selects HOT per column, from the histogram it has anyway (`Plan::hot`: one digit holds
+// an eighth of the keys or more).
 
 // KTO: the type the keys are written out in.  A rank sort (rsx_sort_rank*) only needs the bytes of a key that later passes
 // still look at: a pass writes kdf(key) >> oshift, narrowed to the smallest type that holds the columns to come, and the
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags,
                                                                  const uint8_t *__restrict__ lut, u64 *tl,
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
-                                                                 u32 oshift = 0)
+                                                                 u32 oshift = 0, const u32 *__restrict__ hotd = nullptr)
 {
 	constexpr bool NARROW = !std::is_same<KTO, KT>::value;
 	typedef StatusBits<ST> SB_;
@@ -137,6 +136,22 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// are read from memory once.  (With more tiles per super-tile they are re-read out of L2 / Infinity Cache.)
 	constexpr bool KEEP = TPS == 1;
 	constexpr bool HOT = HOT_ && !C::CELL16;
+	static_assert(!HOT || TPS == 1, "the hot digits' counts are kept per tile in registers");
+	// HOT: up to four digits of this column that hold a sixteenth of the keys or more (rsx_plan_kernel, hotd[column]).
+	// In whole tiles they never touch the LDS counters: a ballot per hot digit gives a lane its rank among the wave's
+	// lanes with that digit, the counts and the cursors of the wave's hot digits live in (uniform) registers.
+	constexpr int NHOT = 4;
+	u32 hk[NHOT] = {0, 0, 0, 0}, hc[NHOT] = {0, 0, 0, 0};
+	bool hv[NHOT] = {false, false, false, false};
+	if constexpr (HOT) {
+		const u32 hw = hotd ? __builtin_amdgcn_readfirstlane(hotd[shift >> 3]) : 0u;
+		const u32 hb = hotd ? __builtin_amdgcn_readfirstlane(hotd[8]) >> (4 * (shift >> 3)) : 0u;
+#pragma unroll
+		for (int k = 0; k < NHOT; ++k) {
+			hk[k] = (hw >> (8 * k)) & 0xFFu;
+			hv[k] = ((hb >> k) & 1u) != 0;
+		}
+	}
 	KT keep[KEEP ? KPT : 1];
 	__shared__ Sc2Smem<KT, VT, ST, C> sm;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -205,17 +220,28 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 							if constexpr (C::CELL16) {
 								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 							} else if constexpr (HOT) {
-								if (uniform_round(d)) {
-									if (lane == 0)
-										atomicAdd(&wc[d], 64u);
-								} else {
-									atomicAdd(&wc[d], 1u);
+								bool mine = false;
+#pragma unroll
+								for (int k = 0; k < NHOT; ++k) {
+									if (hv[k]) {
+										const bool is = d == hk[k];
+										hc[k] += (u32)__popcll(__ballot(is));
+										mine |= is;
+									}
 								}
+								if (!mine)
+									atomicAdd(&wc[d], 1u);
 							} else {
 								atomicAdd(&wc[d], 1u);
 							}
 						}
 						RSX_COMPILER_FENCE();
+					}
+					if constexpr (HOT) {   // the wave's counts of the hot digits (nobody else touches these cells)
+#pragma unroll
+						for (int k = 0; k < NHOT; ++k)
+							if (hv[k] && lane == (u32)k)
+								wc[hk[k]] = hc[k];
 					}
 				} else {
 #pragma unroll
@@ -399,6 +425,15 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		const u32 wo = full ? wofs : opaque(wofs);
 		u32 *wc = sm.cell[t][wid];
 		const ST *delta = sm.delta[t];
+		u32 hcur[NHOT] = {0, 0, 0, 0};   // HOT: the wave's cursors of the hot digits = their run starts after the layout
+		if constexpr (HOT) {
+			if (full) {
+#pragma unroll
+				for (int k = 0; k < NHOT; ++k)
+					if (hv[k])
+						hcur[k] = (u32)__builtin_amdgcn_readfirstlane((int)wc[hk[k]]);
+			}
+		}
 
 		// rank + stage: the returning atomic on the (wave, digit) cursor is the key's tile-local position.
 		// Rounds are issued in memory order; lanes of a round come back in lane order (see the header).
@@ -433,14 +468,22 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 						const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						pos[r] = (old >> sh) & 0xFFFFu;
 					} else if constexpr (HOT) {
-						if (full && uniform_round(d)) {   // (whole tiles only: every lane is active there)
-							u32 first = 0;
-							if (lane == 0)
-								first = __hip_atomic_fetch_add(&wc[d], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-							pos[r] = (u32)__builtin_amdgcn_readfirstlane((int)first) + lane;
-						} else {
-							pos[r] = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						bool mine = false;
+						if (full) {   // (whole tiles only: every lane is active there)
+#pragma unroll
+							for (int k = 0; k < NHOT; ++k) {
+								if (hv[k]) {
+									const bool is = d == hk[k];
+									const u64 m = __ballot(is);
+									if (is)
+										pos[r] = hcur[k] + mbcnt64(m);
+									hcur[k] += (u32)__popcll(m);
+									mine |= is;
+								}
+							}
 						}
+						if (!mine)
+							pos[r] = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					} else {
 						pos[r] = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
