@@ -413,6 +413,12 @@ int plan_wait(Ctx &c, Plan *out)
 	return RSX_OK;
 }
 
+// the flags of a pass over a column with hot digits (Plan::hot): the HOT kernel + the column, for its hotd word
+inline u32 hot_flags(u32 hotmask, u32 col)
+{
+	return (hotmask >> col & 1u) ? ((u32)SCATTER_HOT | (col << SCATTER_COL_SHIFT)) : 0u;
+}
+
 // ---- phase 2: one scatter pass (radix_sort.hpp:83-90) -----------------------------
 // gbase[digit]: exclusive offset of the digit for this pass's column
 template <typename KT, typename VT, typename C2, typename KTO = KT>
@@ -618,7 +624,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	for (u32 i = spec ? 1 : 0; i < plan.ncols; ++i) {   // radix_sort.hpp:83-90
 		const u32 col = plan.cols[i];
 		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka,
-		                                 (plan.hot >> col & 1) ? SCATTER_HOT : 0, nullptr, nullptr, c.fast ? (int)i : -1)));
+		                                 hot_flags(plan.hot, col), nullptr, nullptr, c.fast ? (int)i : -1)));
 		std::swap(cur, oth);
 	}
 	*result = cur;                           // radix_sort.hpp:92
@@ -711,7 +717,7 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 	VT *vc = v0, *vo = v1;
 	for (u32 i = 0; i < plan.ncols; ++i) {
 		const u32 col = plan.cols[i];
-		RSX_TRY((scatter_pass<KT, VT>(c, kc, ko, vc, vo, n, 8 * col, c.ghist() + 256 * col, ka, (plan.hot >> col & 1) ? SCATTER_HOT : 0,
+		RSX_TRY((scatter_pass<KT, VT>(c, kc, ko, vc, vo, n, 8 * col, c.ghist() + 256 * col, ka, hot_flags(plan.hot, col),
 		                              nullptr)));
 		std::swap(kc, ko);
 		std::swap(vc, vo);
@@ -789,7 +795,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		bool applied = false;
 		for (u32 i = 0; i < P; ++i) {
 			const u32 col = plan.cols[i];
-			u32 flags = (plan.hot >> col & 1) ? SCATTER_HOT : 0;
+			u32 flags = hot_flags(plan.hot, col);
 			if (i == 0)
 				flags |= SCATTER_GEN_INDEX;
 			if (i == P - 1)
@@ -832,7 +838,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		const u32 col = plan.cols[i];
 		const KT *kin = i == 0 ? src : (const KT *)c.keys[(i - 1) & 1].p;
 		KT *kout = (KT *)c.keys[i & 1].p;
-		u32 flags = (plan.hot >> col & 1) ? SCATTER_HOT : 0;
+		u32 flags = hot_flags(plan.hot, col);
 		if (i == 0)
 			flags |= SCATTER_GEN_INDEX;
 		if (i == P - 1)
@@ -879,7 +885,7 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u3
 	}
 	if (total != n)
 		return fail(RSX_EHIP, "rsx_msd_split_device: digit counts sum to %llu, n = %zu", (unsigned long long)total, n);
-	const u32 flags = most >= (u64)n / 8 + 1 ? (u32)SCATTER_HOT : 0u;   // as Plan::hot (rsx_plan_kernel)
+	const u32 flags = most >= (u64)n / 8 + 1 ? hot_flags(1u << col, col) : 0u;   // as Plan::hot (rsx_plan_kernel)
 	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, top, ka, flags, nullptr);
 }
 

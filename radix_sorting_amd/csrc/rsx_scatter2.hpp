@@ -144,8 +144,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	u32 hk[NHOT] = {0, 0, 0, 0}, hc[NHOT] = {0, 0, 0, 0};
 	bool hv[NHOT] = {false, false, false, false};
 	if constexpr (HOT) {
-		const u32 hw = hotd ? __builtin_amdgcn_readfirstlane(hotd[shift >> 3]) : 0u;
-		const u32 hb = hotd ? __builtin_amdgcn_readfirstlane(hotd[8]) >> (4 * (shift >> 3)) : 0u;
+		const u32 hcol = (flags >> SCATTER_COL_SHIFT) & 7u;
+		const u32 hw = hotd ? __builtin_amdgcn_readfirstlane(hotd[hcol]) : 0u;
+		const u32 hb = hotd ? __builtin_amdgcn_readfirstlane(hotd[8]) >> (4 * hcol) : 0u;
 #pragma unroll
 		for (int k = 0; k < NHOT; ++k) {
 			hk[k] = (hw >> (8 * k)) & 0xFFu;
