@@ -210,6 +210,38 @@ def test_skewed_digits():
         assert info.result_in_aux == want_aux and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("nhot", [1, 2, 3, 4, 6])
+def test_hot_digit_columns(nhot):
+    """Byte columns with `nhot` frequent digits (each a sixteenth of the keys or more) next to a uniform rest: the HOT
+    kernels rank up to four of them with ballots, the others with the LDS counters.  Keys (default tiles: n above 96
+    tiles), key + payload, and ranks of float keys (narrowed keys: the column comes through the flags)."""
+    n = 96 * 32768 + 12345
+    rng = np.random.default_rng(400 + nhot)
+    share = 0.9 / nhot
+    def column():
+        hot = rng.choice(256, size=nhot, replace=False)
+        pick = rng.random(n)
+        col = rng.integers(0, 256, n)
+        for k in range(nhot):
+            col = np.where((pick >= k * share) & (pick < (k + 1) * share), hot[k], col)
+        return col.astype(np.uint32)
+    a = column() | (column() << 8) | (column() << 16) | (column() << 24)
+    want, want_aux, winfo = ol.oracle_sort(a, ol.U32)
+    got, info, _, _ = gpu_sort(a, ol.U32)
+    assert info.result_in_aux == want_aux and np.array_equal(got, want)
+    perm = ol.stable_argsort_by_kdf(a, ol.I32, ol.DESC)
+    keys, keys_aux = to_dev(a), torch.zeros(n, dtype=torch.int32, device="cuda")
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    kr, vr, _ = rsa.radix_sort_pairs(keys, keys_aux, vals, torch.zeros_like(vals), dtype=ol.I32, order=ol.DESC)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_bits(kr, ol.U32), a[perm]) and np.array_equal(vr.cpu().numpy().astype(np.int64), perm)
+    wr, whalf, _, _ = ol.oracle_rank(a, ol.F32, 4)
+    ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    ranks, rinfo = rsa.radix_sort_rank(to_dev(a), ib, dtype=ol.F32)
+    torch.cuda.synchronize()
+    assert rinfo.result_in_aux == whalf and np.array_equal(to_bits(ranks, ol.U32), wr)
+
+
 # ---- key + payload and rank ----------------------------------------------------------------
 
 def test_pairs_kv_pin():
