@@ -114,10 +114,16 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// `pass_index`-th kept column of the device-side plan: it finds its column there, reads from the second buffer when
 	// its index is odd, and does nothing if the input is sorted (radix_sort.hpp:60-62: `aux` must stay untouched then)
 	// or has fewer kept columns.  `gbase` is the histogram's column 0 in this case.
+	u32 dcol = 0;
 	if (dplan) {
 		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
 		const u32 col = dplan->cols[pass_index];
+		// launched twice, as the plain and as the HOT instantiation (the host does not know the plan yet): the one the
+		// plan's hot bit of this column does not ask for leaves at once
+		if ((flags & SCATTER_DUAL) && (((dplan->hot >> col) & 1u) != 0) != HOT_)
+			return;
+		dcol = col;
 		shift = 8 * col;
 		gbase += 256 * col;
 		if constexpr (!NARROW) {
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	u32 hk[NHOT] = {0, 0, 0, 0}, hc[NHOT] = {0, 0, 0, 0};
 	bool hv[NHOT] = {false, false, false, false};
 	if constexpr (HOT) {
-		const u32 hcol = (flags >> SCATTER_COL_SHIFT) & 7u;
+		const u32 hcol = dplan ? dcol : (flags >> SCATTER_COL_SHIFT) & 7u;
 		const u32 hw = hotd ? __builtin_amdgcn_readfirstlane(hotd[hcol]) : 0u;
 		const u32 hb = hotd ? __builtin_amdgcn_readfirstlane(hotd[8]) >> (4 * hcol) : 0u;
 #pragma unroll

@@ -91,7 +91,7 @@ float run_once(u32 shift, bool timeline_dump)
 	return ms;
 }
 
-template <typename C, bool TL>
+template <typename C, bool TL, bool HOTV = false>
 float run2_once(u32 shift, bool dump, u32 tps)
 {
 	const u64 tiles = (n + C::TILE - 1) / C::TILE;
@@ -104,9 +104,10 @@ float run2_once(u32 shift, bool dump, u32 tps)
 	CK(hipEventCreate(&e1));
 	KdfArgs<u32> ka{0, 0, 0};
 	CK(hipEventRecord(e0, 0));
-	hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, TL, DIG_PLAIN>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in, d_out,
-	                   (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8), tps,
-	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, (const uint8_t *)nullptr, d_tl);
+	hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, TL, DIG_PLAIN, HOTV>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in,
+	                   d_out, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8), tps,
+	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags | ((shift / 8) << SCATTER_COL_SHIFT),
+	                   (const uint8_t *)nullptr, d_tl, (const Plan *)nullptr, 0u, 0u, (const u32 *)(d_flag + 32));
 	CK(hipGetLastError());
 	CK(hipEventRecord(e1, 0));
 	CK(hipEventSynchronize(e1));
@@ -329,20 +330,20 @@ void bench3(const char *name, u32 grid)
 	run3_once<C, true>(0, true, grid);
 }
 
-template <typename C>
+template <typename C, bool HOTV = false>
 void bench2(const char *name, u32 tps)
 {
-	run2_once<C, false>(0, false, tps);
+	run2_once<C, false, HOTV>(0, false, tps);
 	float best = 1e9, sum = 0;
 	const int reps = 5;
 	for (int i = 0; i < reps; ++i) {
-		float ms = run2_once<C, false>(8 * (i % 4), false, tps);
+		float ms = run2_once<C, false, HOTV>(8 * (i % 4), false, tps);
 		best = std::min(best, ms);
 		sum += ms;
 	}
 	printf("%-12s tps %u tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, tps, C::TILE,
 	       sizeof(Sc2Smem<u32, NoVal, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
-	run2_once<C, true>(0, true, tps);
+	run2_once<C, true, HOTV>(0, true, tps);
 }
 
 template <typename SH>
@@ -416,26 +417,39 @@ int main(int argc, char **argv)
 	CK(hipMalloc(&d_in, n * 4));
 	CK(hipMalloc(&d_out, n * 4));
 	CK(hipMalloc(&d_hist, 8 * 256 * 8));
-	CK(hipMalloc(&d_flag, 64));
+	CK(hipMalloc(&d_flag, 256));
 	CK(hipMalloc(&d_plan, sizeof(Plan)));
 	CK(hipMalloc(&d_status, 256 + (n / 1024 + 1) * 256 * 4));
 	CK(hipMalloc(&d_tl, (n / 1024 + 1) * 16 * 8));
 	hipLaunchKernelGGL((rsx_fill_splitmix_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, 1ull, ~0ull, 0ull);
-	if (argc > 2) {
+	if (argc > 2 && atoi(argv[2]) == 5) {
+		printf("four values per byte (keys & 0x03030303)\n");
+		hipLaunchKernelGGL((rsx_fill_splitmix_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, 1ull, 0x03030303ull, 0ull);
+	} else if (argc > 2) {
 		printf("balanced digits, mode %d\n", atoi(argv[2]));
 		hipLaunchKernelGGL(balanced_digits_kernel, dim3(2048), dim3(256), 0, 0, d_in, (u64)n, (u32)atoi(argv[2]));
 	}
 	CK(hipMemset(d_hist, 0, 8 * 256 * 8));
-	CK(hipMemset(d_flag, 0, 64));
+	CK(hipMemset(d_flag, 0, 256));
 	KdfArgs<u32> ka{0, 0, 0};
 	u32 *d_part;
 	CK(hipMalloc(&d_part, 512 * 1024 * 4));
 	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(512), dim3(HistCfg<u32>::BLOCK), 0, 0, d_in, (u64)n, d_part, d_flag, ka, 1u, 512u, (u64)n);
 	hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3(4, HIST_REDUCE_SPLIT), dim3(256), 0, 0, (const u32 *)d_part, d_hist, 512u, 1024u);
-	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, 1u, ka, d_flag + 8);
+	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, 1u, ka, d_flag + 8, d_flag + 32);
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	if (argc > 2 && atoi(argv[2]) == 5) {
+		u32 hd[9];
+		CK(hipMemcpy(hd, d_flag + 32, sizeof hd, hipMemcpyDeviceToHost));
+		printf("hotd: %08x %08x %08x %08x valid %08x\n", hd[0], hd[1], hd[2], hd[3], hd[8]);
+		bench2<Sc2Cfg<u32, NoVal>, true>("v2 HOT", 1);
+		g_flags = SCATTER_DBG_NOSTORE;
+		printf("-- v2 HOT, no global stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal>, true, true>(0, true, 1));
+		printf("-- v2 plain, no global stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal>, true, false>(0, true, 1));
+		g_flags = 0;
+	}
 	if (argc > 2)
 		return 0;
 	bench5(256);
