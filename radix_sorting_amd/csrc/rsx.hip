@@ -138,7 +138,6 @@ struct Ctx {
 	u64 *host_hist = nullptr;    // pinned, 256 u64
 
 	bool fast = false;           // rsx_scatter2_kernel allowed on this device (LDS atomic order verified)
-	bool prof_mute = false;      // the caller brackets several launches with one ProfScope of its own
 	// The reference is re-entrant (concurrent calls on disjoint buffers are safe); here calls that share a context
 	// (same device and stream) share its workspace, so every entry point holds this for its duration.
 	std::recursive_mutex mu;
@@ -207,7 +206,7 @@ struct ProfScope {
 	bool on;
 	ProfRec rec;
 	hipStream_t stream;
-	ProfScope(int kind, u64 bytes, hipStream_t s) : on(g_prof_on && kind >= 0), stream(s)
+	ProfScope(int kind, u64 bytes, hipStream_t s) : on(g_prof_on), stream(s)
 	{
 		if (!on)
 			return;
@@ -440,7 +439,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 	}
 	u32 *ticket = (u32 *)base;
 	void *st = base + 256;
-	ProfScope prof(c.prof_mute ? -1 : 1, (u64)n * (sizeof(KT) + sizeof(KTO) + 2 * val_bytes<VT>::value), c.stream);
+	ProfScope prof(1, (u64)n * (sizeof(KT) + sizeof(KTO) + 2 * val_bytes<VT>::value), c.stream);
 	const dim3 grid((unsigned)tiles);
 	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic;
 	// columns with a hot digit (Plan::hot) take the instantiation that tests every round for a wave-uniform digit
@@ -605,21 +604,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	const size_t status_total = c.fast ? status_bytes<KT, NoVal>(n) * sizeof(KT) : 0;
 	if (spec) {
 		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, nullptr, status_total));
-		if (n >= ((size_t)1 << 20)) {
-			// both instantiations: the one that matches the plan's hot bit of the first kept column does the pass, the
-			// other's workgroups leave at once (a few microseconds; below 2^20 keys they would show, there the plain
-			// kernel runs whatever the column looks like)
-			ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
-			c.prof_mute = true;
-			int rc = scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, SCATTER_DUAL, nullptr, c.plan(), 0);
-			if (rc == RSX_OK)
-				rc = scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, SCATTER_DUAL | SCATTER_HOT, nullptr,
-				                             c.plan(), 0);
-			c.prof_mute = false;
-			RSX_TRY(rc);
-		} else {
-			RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), 0)));
-		}
+		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), 0)));
 		RSX_TRY(plan_wait(c, &plan));
 	} else {
 		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan, status_total));

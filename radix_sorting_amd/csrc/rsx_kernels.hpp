@@ -417,7 +417,6 @@ enum : u32 {
 	SCATTER_SKIP_KEYS = 2,   // do not write keys (last rank pass: only the indices are wanted)
 	SCATTER_USE_LUT = 4,     // bucket = lut[digit] (MSD split for the multi-GPU sort)
 	SCATTER_COL_SHIFT = 12,  // bits 12-14: the pass's column (HOT kernels: which word of hotd; the shift no longer tells once a rank sort has narrowed its keys)
-	SCATTER_DUAL = 32,       // device-scheduled pass launched in both instantiations: the one that does not match the plan's hot bit of the column exits
 	SCATTER_HOT = 16,        // host side only: one digit holds an eighth of the keys or more -> the HOT kernels (rsx_scatter2.hpp)
 	SCATTER_DBG_LINEAR = 64, // probe only: write the staged tile back to its own position (no scatter)
 	SCATTER_DBG_NOSTORE = 128, // probe only: skip the global stores

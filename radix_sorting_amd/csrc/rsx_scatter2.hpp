@@ -119,10 +119,6 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
 		const u32 col = dplan->cols[pass_index];
-		// launched twice, as the plain and as the HOT instantiation (the host does not know the plan yet): the one the
-		// plan's hot bit of this column does not ask for leaves at once
-		if ((flags & SCATTER_DUAL) && (((dplan->hot >> col) & 1u) != 0) != HOT_)
-			return;
 		dcol = col;
 		shift = 8 * col;
 		gbase += 256 * col;

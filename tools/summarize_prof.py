@@ -11,7 +11,7 @@ from collections import defaultdict
 def short(name):
     name = re.sub(r"\(.*", "", name)
     name = name.replace("rsx::", "").replace("unsigned long long", "u64").replace("unsigned int", "u32")
-    return name.replace("void ", "")[:70]
+    return name.replace("void ", "")[:110]
 
 
 def main(out):
