@@ -9,7 +9,8 @@ of synthetic keys that is already resident in HBM when the timed region starts.
   N = 1   BASELINE.json configs[1]: 2^28 uniform-random u32 keys (splitmix64,
           seed 1 for the first batch), 4 x 8-bit LSD passes, keys only.
   N > 1   configs[4]: each rank holds 2^29 u32 keys (N = 8 -> 2^32 keys in all),
-          one MSD-digit partition + RCCL all-to-all-v + local LSD per step
+          one MSD-digit split pass + RCCL all-to-all-v (in sub-ranges, overlapped
+          with the local LSD sorts of the sub-ranges already received) per step
           (radix_sorting_amd/multi.py); launched by torch.distributed.run, one
           rank per GPU.  Weak scaling: per-GPU work is fixed as N grows.
 
