@@ -451,19 +451,26 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
 	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan, pass_index,  \
 	                   oshift, (const u32 *)c.hotd())
-#define RSX_LAUNCH2_ST(DIGV)                 \
-	do {                                     \
-		if (wide) {                          \
-			if (hot)                         \
-				RSX_LAUNCH2(u64, DIGV, true);  \
-			else                             \
-				RSX_LAUNCH2(u64, DIGV, false); \
-		} else {                             \
-			if (hot)                         \
-				RSX_LAUNCH2(u32, DIGV, true);  \
-			else                             \
-				RSX_LAUNCH2(u32, DIGV, false); \
-		}                                    \
+	// quarter tiles are for arrays of a few million keys: never 2^30 of them, and hot digits cost little there -- those
+	// instantiations are left out of the build
+	constexpr bool SMALL_CFG = C2::KPT < Sc2Cfg<KT, VT>::KPT;
+#define RSX_LAUNCH2_ST(DIGV)                           \
+	do {                                               \
+		if constexpr (SMALL_CFG) {                     \
+			if (wide)                                  \
+				return fail(RSX_EINVAL, "quarter tiles with 2^30 keys or more"); \
+			RSX_LAUNCH2(u32, DIGV, false);             \
+		} else if (wide) {                             \
+			if (hot)                                   \
+				RSX_LAUNCH2(u64, DIGV, true);          \
+			else                                       \
+				RSX_LAUNCH2(u64, DIGV, false);         \
+		} else {                                       \
+			if (hot)                                   \
+				RSX_LAUNCH2(u32, DIGV, true);          \
+			else                                       \
+				RSX_LAUNCH2(u32, DIGV, false);         \
+		}                                              \
 	} while (0)
 	bool launched = false;
 	if constexpr (val_bytes<VT>::value == 0) {
