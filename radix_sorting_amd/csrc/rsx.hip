@@ -144,6 +144,7 @@ struct Ctx {
 
 	u64 *ghist() const { return (u64 *)hist.p; }
 	u32 *unsorted() const { return (u32 *)small.p; }
+	u32 *plan_done() const { return (u32 *)((char *)small.p + 52); }   // blocks of rsx_plan_kernel that are through
 	u32 *hotd() const { return (u32 *)((char *)small.p + 16); }   // [8] hot digits per column + [1] valid bits (rsx_plan_kernel)
 	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
 	u32 *kept() const { return (u32 *)((char *)small.p + 128); }
@@ -365,10 +366,14 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 	const u32 cols256 = (u32)sizeof(KT) * 256;
 	RSX_TRY(c.hpart.ensure((size_t)g.nseg * bps * cols256 * sizeof(u32)));
 	ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
+	// up to 128 workgroups add their counts to the histogram themselves (one launch and its gap less: 7 of the 62 us of
+	// a 10^5-key sort); beyond that the rows are summed by a kernel of their own
+	const bool direct = (u64)g.nseg * bps <= 128;
 	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)(g.nseg * bps)), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
-	                   (u32 *)c.hpart.p, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems, colmask);
-	hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)(g.nseg * sizeof(KT)), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
-	                   (const u32 *)c.hpart.p, d_hist, (u32)bps, cols256);
+	                   (u32 *)c.hpart.p, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems, colmask, direct ? d_hist : (u64 *)nullptr);
+	if (!direct)
+		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)(g.nseg * sizeof(KT)), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
+		                   (const u32 *)c.hpart.p, d_hist, (u32)bps, cols256);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
@@ -391,9 +396,7 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, 
 	}
 	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted(), g));
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), g.nseg, ka,
-	                   c.kept(), c.hotd());
-	hipLaunchKernelGGL(rsx_plan_finish_kernel, dim3(1), dim3(64), 0, c.stream, (const u32 *)c.kept(), (u32)sizeof(KT),
-	                   (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan);
+	                   c.kept(), c.hotd(), c.plan_done(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan);   // (+ the finish)
 	HIP_TRY(hipGetLastError());
 	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
 		if (!c.plan_ev)

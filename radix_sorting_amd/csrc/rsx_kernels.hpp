@@ -105,7 +105,8 @@ __device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane, u32 colmas
 template <typename KT, typename C = HistCfg<KT>>
 __global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u32 *__restrict__ partial,
                                                             u32 *__restrict__ unsorted, KdfArgs<KT> ka, u32 nseg,
-                                                            u32 blocks_per_seg, u64 seg_elems, u32 colmask = ~0u)
+                                                            u32 blocks_per_seg, u64 seg_elems, u32 colmask = ~0u,
+                                                            u64 *__restrict__ direct = nullptr)
 {
 	// colmask: the columns to count (the MSD split of the multi-GPU path wants one: a quarter of the LDS atomics)
 	constexpr int WC = C::WC, VEC = C::VEC, R = C::R, U = C::U;
@@ -223,13 +224,19 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict
 	__syncthreads();
 	if (tid == 0 && s_descent && __hip_atomic_load(unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
 		atomicOr(unsorted, 1u);
+	// `direct` (few workgroups): the counts are added to the segment's histogram at once, no reduce launch follows
 	u32 *row = partial + (u64)blockIdx.x * (WC * 256);
 	for (u32 i = tid; i < WC * 256; i += C::BLOCK) {
 		u32 s = 0;
 #pragma unroll
 		for (int r = 0; r < R; ++r)
 			s += lh[i * R + r];
-		row[i] = s;
+		if (direct) {
+			if (s)
+				atomicAdd(&direct[(u64)seg * (WC * 256) + i], (u64)s);
+		} else {
+			row[i] = s;
+		}
 	}
 }
 
@@ -293,10 +300,14 @@ __device__ __forceinline__ void wave_scan_256(u64 *vals, u64 *lsum, u32 lane)
 // entry; on exit the exclusive offset of (segment, digit): every key with a smaller digit, plus the
 // keys with the same digit in earlier segments -- the reference's exclusive scan
 // (radix_sort.hpp:72-80) refined by segment.  kept[col] answers the column-skip probe (:64-70).
+__device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan);
+
 template <typename KT>
 __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
                                                        u32 nseg, KdfArgs<KT> ka, u32 *__restrict__ kept,
-                                                       u32 *__restrict__ hotd = nullptr)
+                                                       u32 *__restrict__ hotd = nullptr, u32 *done = nullptr,
+                                                       const u32 *unsorted = nullptr, Plan *plan = nullptr,
+                                                       Plan *host_plan = nullptr)
 {
 	constexpr int WC = sizeof(KT);
 	__shared__ u64 tot[256];
@@ -337,33 +348,52 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 		h[s * seg_stride] = running;
 		running += t;
 	}
+	// `done` (zeroed by the caller): the block that finishes last writes the plan (what rsx_plan_finish_kernel does as a
+	// launch of its own: one launch and its gap less per sort)
+	if (done) {
+		__shared__ u32 s_last;
+		__syncthreads();
+		if (d == 0) {
+			__threadfence();
+			s_last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+		}
+		__syncthreads();
+		if (s_last && d == 0) {
+			__threadfence();
+			plan_finish((const u32 *)kept, WC, unsorted, plan, host_plan);
+		}
+	}
 }
 
 // `host_plan`: the same 64 bytes in pinned, device-visible host memory -- the host reads the plan there once this kernel
 // has completed, without a copy of its own (one launch less per sort).
+__device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan)
+{
+	Plan p;
+	for (u32 i = 0; i < 8; ++i)
+		p.cols[i] = 0;
+	u32 nc = 0;
+	for (u32 i = 0; i < wc; ++i)
+		if (kept[i])
+			p.cols[nc++] = i;                                  // LSB first, radix_sort.hpp:66-69
+	p.ncols = nc;
+	p.sorted = *unsorted == 0;                                 // radix_sort.hpp:60
+	p.hot = 0;
+	for (u32 i = 0; i < wc; ++i)
+		p.hot |= (kept[8 + i] ? 1u : 0u) << i;
+	plan->ncols = host_plan->ncols = p.ncols;
+	plan->sorted = host_plan->sorted = p.sorted;
+	plan->hot = host_plan->hot = p.hot;
+	for (u32 i = 0; i < 8; ++i)
+		plan->cols[i] = host_plan->cols[i] = p.cols[i];
+	__threadfence_system();
+}
+
 __global__ void rsx_plan_finish_kernel(const u32 *__restrict__ kept, u32 wc, const u32 *__restrict__ unsorted,
                                        Plan *__restrict__ plan, Plan *__restrict__ host_plan)
 {
-	if (threadIdx.x == 0) {
-		Plan p;
-		for (u32 i = 0; i < 8; ++i)
-			p.cols[i] = 0;
-		u32 nc = 0;
-		for (u32 i = 0; i < wc; ++i)
-			if (kept[i])
-				p.cols[nc++] = i;                                  // LSB first, radix_sort.hpp:66-69
-		p.ncols = nc;
-		p.sorted = *unsorted == 0;                                 // radix_sort.hpp:60
-		p.hot = 0;
-		for (u32 i = 0; i < wc; ++i)
-			p.hot |= (kept[8 + i] ? 1u : 0u) << i;
-		plan->ncols = host_plan->ncols = p.ncols;
-		plan->sorted = host_plan->sorted = p.sorted;
-		plan->hot = host_plan->hot = p.hot;
-		for (u32 i = 0; i < 8; ++i)
-			plan->cols[i] = host_plan->cols[i] = p.cols[i];
-		__threadfence_system();
-	}
+	if (threadIdx.x == 0)
+		plan_finish(kept, wc, unsorted, plan, host_plan);
 }
 
 // Bucket offsets for the MSD split: bucket = lut[digit of column `col`].  cnt[seg][col][256]
