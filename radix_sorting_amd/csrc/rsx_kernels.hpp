@@ -5,10 +5,11 @@
 //   rsx_hist_kernel       loop 1 (:48-58): every 8-bit column's histogram in ONE read of the keys + the pre-sorted
 //   + rsx_hist_reduce_    test.  Histograms are privatised in LDS per workgroup (R lane-striped copies per bin so
 //     kernel              that equal digits do not serialise on one LDS address); each workgroup writes its counts to
-//                         its own row and a split reduce adds the rows up.
+//                         its own row and a split reduce adds the rows up (up to 128 workgroups add them to the
+//                         histogram themselves instead).
 //   rsx_plan_kernel       column-skip probe (:64-70) + exclusive scan (:72-80): the 256-bin scan of a column is done
-//   + rsx_plan_finish_    by one 64-lane wavefront through LDS (4 bins per lane).
-//     kernel
+//                         by one 64-lane wavefront through LDS (4 bins per lane); the column's frequent digits for
+//                         the HOT scatter kernels; the block that finishes last writes the plan.
 //   rsx_scatter2_kernel   one scatter pass (:82-90), the default: rsx_scatter2.hpp.
 //   rsx_scatter_kernel    the same pass without relying on the lane order of returning LDS atomics (the fallback when
 //                         the device self-check fails): a workgroup takes a tile (ticket order), ranks its keys inside
@@ -348,8 +349,7 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 		h[s * seg_stride] = running;
 		running += t;
 	}
-	// `done` (zeroed by the caller): the block that finishes last writes the plan (what rsx_plan_finish_kernel does as a
-	// launch of its own: one launch and its gap less per sort)
+	// `done` (zeroed by the caller): the block that finishes last writes the plan (no launch of its own for that)
 	if (done) {
 		__shared__ u32 s_last;
 		__syncthreads();
@@ -389,12 +389,6 @@ __device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *
 	__threadfence_system();
 }
 
-__global__ void rsx_plan_finish_kernel(const u32 *__restrict__ kept, u32 wc, const u32 *__restrict__ unsorted,
-                                       Plan *__restrict__ plan, Plan *__restrict__ host_plan)
-{
-	if (threadIdx.x == 0)
-		plan_finish(kept, wc, unsorted, plan, host_plan);
-}
 
 // Bucket offsets for the MSD split: bucket = lut[digit of column `col`].  cnt[seg][col][256]
 // (counts) -> bbase[seg][256] exclusive offsets of (segment, bucket), totals[256] bucket sizes.
