@@ -24,9 +24,15 @@ The one JSON line printed by rank 0 carries, besides the contract's fields,
                 bytes per launch = n * 2 * sizeof(key) over the kernel's
                 average duration measured with HIP events on the launch stream inside
                 the timed region (rsx_profile_begin/end), against the 8 TB/s HBM3E peak;
-  cpu_baseline  the real reference (oracle/_ref/libref.so, kind "reference") or, when
-                that is absent, the C restatement (kind "port"), timed on one host core
-                on a bounded sample of the same key stream.  N = 1, rank 0 only.
+  cpu_baseline  the real reference (oracle/_ref/libref*.so, kind "reference") or, when
+                that is absent, the C restatement (kind "port"), timed on ONE pinned host core
+                on the whole 2^28-key batch 0 (median of 5) and on 40 M keys (single shot),
+                CPU model and core count beside it.  N = 1, rank 0 only.
+
+`python bench.py --gpus N` (N > 1) without a launcher starts the ranks itself
+(launch_ranks): the parent never touches the GPU, runs
+`python -m torch.distributed.run --nproc-per-node N ... bench.py ...` as a child and
+relays rank 0's JSON line as the last line of its own stdout.
 """
 import argparse
 import json
@@ -59,31 +65,123 @@ def pmc_traffic_per_launch():
         return None
 
 
-def cpu_baseline(sample_log2=27, reps=3):
-    """Single-core CPU sort of the first 2^sample_log2 keys of the N=1 workload's first batch (default: half of it; 3 sorts,
-    a few seconds of host time on the GPU box, about 20 s on a slow host)."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def _pick_reference_build():
+    """oracle/_ref/libref_native.so (-O3 -march=native as the reference's Makefile:1, built in the build container) when this
+    host's CPU can run it -- tried in a child process, an illegal instruction must not take bench.py down -- else
+    oracle/_ref/libref.so (-march=x86-64-v3), else None (the C restatement is timed, kind "port")."""
+    import subprocess
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    probe = ("import ctypes, sys; import numpy as np; l = ctypes.CDLL(sys.argv[1]); a = np.arange(70000, 0, -1, dtype=np.uint32); "
+             "b = np.zeros_like(a); l.ref_sort.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]; "
+             "r = l.ref_sort(a.ctypes.data, b.ctypes.data, a.size, 2, 0); res = b if r else a; assert res[0] == 1 and res[-1] == 70000")
+    for name, flags in (("libref_native.so", "-O3 -march=native (build container's ISA)"), ("libref.so", "-O3 -march=x86-64-v3")):
+        path = os.path.join(ref_dir, name)
+        if not os.path.exists(path):
+            continue
+        try:
+            if subprocess.run([sys.executable, "-c", probe, path], timeout=120).returncode == 0:
+                return path, flags
+        except Exception:
+            pass
+    return None, None
+
+
+def cpu_baseline(log2n=28, reps=5):
+    """SURVEY.md 8d "CPU baseline beside it": the reference's radix_sort (the real headers compiled in place,
+    oracle/_ref) on ONE pinned host core, the full 2^28-key batch 0 of the N = 1 workload, median of `reps` fresh-copy runs,
+    plus the single-shot 40 M-key sort of configs[0]; CPU model and core count reported.  About 10-15 s of host time."""
+    import ctypes as C
     import numpy as np
     import oracle_lib as ol
-    n = 1 << sample_log2
-    keys = ol.splitmix_fill(n, ol.U32, 1)
-    ref = ol.ref()
-    kind = "reference" if ref is not None else "port"
-    times = []
-    for _ in range(reps):
-        src = keys.copy()
-        aux = np.empty_like(src)
-        aux.fill(0)                       # pre-faulted
-        t0 = time.perf_counter()
-        if ref is not None:
-            ref.ref_sort(ol.ptr(src), ol.ptr(aux), n, ol.U32, 0)
+    pinned = None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        pinned = cores[len(cores) // 2]
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        cores = list(range(os.cpu_count() or 1))
+    try:
+        path, flags = _pick_reference_build()
+        if path is not None:
+            lib = C.CDLL(path)
+            lib.ref_sort.restype = C.c_int
+            lib.ref_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+            kind = "reference"
+
+            def sort(src, aux):
+                return lib.ref_sort(ol.ptr(src), ol.ptr(aux), src.size, ol.U32, 0)
         else:
-            ol.oracle().rso_sort(ol.ptr(src), ol.ptr(aux), n, ol.U32, 0, None)
-        times.append(time.perf_counter() - t0)
-    assert np.all(src[:-1] <= src[1:])
-    best = sorted(times)[len(times) // 2]
-    return {"value": n / best / 1e9, "unit": "Gkeys/s", "cores": 1, "kind": kind,
-            "sample": "first 2^%d keys of batch 0 (splitmix64 seed 1, u32), median of %d fresh-copy sorts, "
-                      "%.0f ms each, 1 thread of %d host cores" % (sample_log2, reps, best * 1e3, os.cpu_count())}
+            kind, flags = "port", "oracle/rs_oracle.c -O3 -march=x86-64-v3"
+
+            def sort(src, aux):
+                return ol.oracle().rso_sort(ol.ptr(src), ol.ptr(aux), src.size, ol.U32, 0, None)
+
+        def timed(keys, repeat):
+            times = []
+            for _ in range(repeat):
+                src = keys.copy()
+                aux = np.zeros_like(src)              # pre-faulted
+                t0 = time.perf_counter()
+                r = sort(src, aux)
+                times.append(time.perf_counter() - t0)
+            res = aux if r else src
+            assert np.all(res[:-1] <= res[1:])
+            return sorted(times)[len(times) // 2]
+
+        n = 1 << log2n
+        t_full = timed(ol.splitmix_fill(n, ol.U32, 1), reps)
+        n40 = 40000000
+        t_40m = timed(ol.splitmix_fill(n40, ol.U32, 40), 1)
+    finally:
+        if pinned is not None:
+            os.sched_setaffinity(0, set(cores))
+    return {"value": n / t_full / 1e9, "unit": "Gkeys/s", "cores": 1, "kind": kind,
+            "cpu": cpu_model(), "host_cores": os.cpu_count(), "build": flags,
+            "ms_2p%d" % log2n: t_full * 1e3, "ms_40M_single_shot": t_40m * 1e3, "Gkeys_per_s_40M": n40 / t_40m / 1e9,
+            "sample": "the whole batch 0 of the workload (2^%d u32 keys, splitmix64 seed 1): median of %d fresh-copy sorts, "
+                      "%.0f ms each; 40 M keys (configs[0], splitmix64 seed 40) single shot %.0f ms; one thread pinned to "
+                      "core %s of %d (%s)" % (log2n, reps, t_full * 1e3, t_40m * 1e3, pinned, os.cpu_count(), cpu_model())}
+
+
+def launch_ranks(args_list, gpus, script=None):
+    """`python bench.py --gpus N` without a launcher: this process stays free of the GPU, starts the N ranks as
+    `python -m torch.distributed.run ... bench.py <same arguments>`, relays their output and ends with rank 0's JSON line
+    as its own last line of stdout and with their exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + args_list
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        text = line.rstrip("\n")
+        if text.startswith("{") and '"metric"' in text:
+            line_json = text                     # held back: it must be the LAST line
+        else:
+            print(text, flush=True)
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench: the ranks printed no result line", file=sys.stderr)
+    raise SystemExit(rc)
 
 
 def main():
@@ -94,8 +192,10 @@ def main():
     ap.add_argument("--log2n", type=int, default=None, help="keys per GPU (default 28 at N=1, 29 at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="test switch: take the N>1 code path (process group, partition, all-to-all-v) whatever N is")
+                    help="test switch: take the N>1 code path (process group, MSD split, all-to-all-v) whatever N is")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(sys.argv[1:], args.gpus)     # (before anything touches the GPU; does not return)
 
     import torch
     import torch.distributed as dist

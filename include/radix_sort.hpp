@@ -78,15 +78,30 @@ template <typename T> constexpr rsx_dtype dtype_of()
 
 // Is KeyFunc the default basic_kdfs::kdf<T> / the tagged descending KDF?  (Specialised on "T is a key
 // scalar" so that basic_kdfs::kdf<T> is never named for record types.)
+// A KeyFunc that is a plain function -- reference or pointer -- only has the default's TYPE: any
+// `uint32_t f(const uint32_t&)` has it (the reference takes every callable, radix_sort.hpp:98-99), so for those
+// "may_be_default" is decided at run time by the function's address (is_default_kdf below).
 template <typename T, typename KeyFunc, bool = basic_kdfs::detail::is_key_scalar_v<T>> struct kdf_kind {
-	static constexpr bool is_default = false, is_descending = false;
+	static constexpr bool may_be_default = false, is_descending = false;
+	static bool is_default(const KeyFunc &) { return false; }
 };
 template <typename T, typename KeyFunc> struct kdf_kind<T, KeyFunc, true> {
 	using F = std::remove_cv_t<std::remove_reference_t<KeyFunc>>;
-	static constexpr bool is_default = std::is_same_v<F, decltype(basic_kdfs::kdf<T>)>;
+	using D = decltype(basic_kdfs::kdf<T>);                         // the default's function type
+	static constexpr bool is_function = std::is_same_v<F, D>, is_pointer = std::is_same_v<F, D *>;
+	static constexpr bool may_be_default = is_function || is_pointer;
 	static constexpr bool is_descending = std::is_same_v<F, rsx_kdf::descending<T>>;
+	template <typename G> static bool is_default(G &kf)
+	{
+		if constexpr (is_function)
+			return &kf == &basic_kdfs::kdf<T>;
+		else if constexpr (is_pointer)
+			return kf == &basic_kdfs::kdf<T>;
+		else
+			return false;
+	}
 };
-template <typename T, typename KeyFunc> constexpr bool is_default_kdf_v = kdf_kind<T, KeyFunc>::is_default;
+template <typename T, typename KeyFunc> constexpr bool may_be_default_kdf_v = kdf_kind<T, KeyFunc>::may_be_default;
 template <typename T, typename KeyFunc> constexpr bool is_descending_kdf_v = kdf_kind<T, KeyFunc>::is_descending;
 
 template <typename KeyFunc> struct is_member_kdf : std::false_type {};
@@ -98,8 +113,47 @@ template <typename KeyFunc> constexpr bool is_member_kdf_v = is_member_kdf<std::
 	throw std::runtime_error(std::string(what) + ": rsx error " + std::to_string(rc) + ": " + rsx_last_error());
 }
 
-template <typename T, typename KeyFunc>
-T *sort_dispatch(T *src, T *aux, size_t n, KeyFunc &&kf)
+// What rs_sort_main leaves in the caller's (pre-zeroed) Hist, from the counts of loop 1 and what the sort decided:
+// nothing for n < 2 (radix_sort.hpp:37-38); the counts after the pre-sorted exit (:48-62) and in skipped columns
+// (:64-70); in every kept column the offsets after the exclusive scan (:72-80) and the scatter loop's post-increments
+// (:85) -- each bin ends at the end of its run -- all in Hist::value_type arithmetic.
+template <typename Hist>
+void hist_post_state(Hist &histogram, const uint64_t *counts, const rsx_info &info, size_t key_bytes)
+{
+	using HVT = typename Hist::value_type;
+	bool kept[8] = {false, false, false, false, false, false, false, false};
+	if (!info.early_exit)
+		for (uint32_t i = 0; i < info.ncols && i < 8; ++i)
+			kept[info.cols[i]] = true;
+	for (size_t j = 0; j < key_bytes; ++j) {
+		if (!kept[j]) {
+			for (size_t d = 0; d < 256; ++d)
+				histogram[256 * j + d] = static_cast<HVT>(histogram[256 * j + d] + static_cast<HVT>(counts[256 * j + d]));
+		} else {
+			HVT a = 0;
+			for (size_t d = 0; d < 256; ++d) {
+				a = static_cast<HVT>(a + static_cast<HVT>(histogram[256 * j + d] + static_cast<HVT>(counts[256 * j + d])));
+				histogram[256 * j + d] = a;
+			}
+		}
+	}
+}
+
+// counts of loop 1 wanted (a caller-supplied Hist): armed before the sort, disarmed whatever happens
+struct hist_capture {
+	std::vector<uint64_t> counts;
+	explicit hist_capture(bool wanted, size_t key_bytes)
+	{
+		if (wanted) {
+			counts.assign(256 * key_bytes, 0);
+			rsx_capture_histogram(counts.data(), counts.size());
+		}
+	}
+	~hist_capture() { rsx_capture_histogram(nullptr, 0); }
+};
+
+template <typename T, typename KeyFunc, typename Hist = void>
+T *sort_dispatch(T *src, T *aux, size_t n, KeyFunc &&kf, Hist *histogram = nullptr)
 {
 	using KeyType = std::remove_cv_t<std::remove_reference_t<std::invoke_result_t<KeyFunc &, const T &>>>;
 	static_assert(sizeof(KeyType) <= 8, "KeyType must be 64-bits or less");        // reference radix_sort.hpp:34
@@ -107,26 +161,38 @@ T *sort_dispatch(T *src, T *aux, size_t n, KeyFunc &&kf)
 	if (n < 2)
 		return src;                                                                // reference radix_sort.hpp:37-38
 	void *result = nullptr;
+	rsx_info info;
 	int rc;
-	if constexpr (is_default_kdf_v<T, KeyFunc>) {
-		rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_ASCENDING, &result, nullptr);
+	hist_capture cap(histogram != nullptr, sizeof(KeyType));
+	// the opaque-callable path: kf once per element on the host, rank sort + gather of the elements on the device
+	auto opaque = [&]() {
+		static_assert(std::is_trivially_copyable_v<T>, "the GPU path moves elements as raw bytes");
+		std::vector<KeyType> keys(n);
+		for (size_t i = 0; i < n; ++i)
+			keys[i] = kf(src[i]);
+		return rsx_sort_records(src, aux, n, sizeof(T), keys.data(), sizeof(KeyType), &result, &info);
+	};
+	if constexpr (may_be_default_kdf_v<T, KeyFunc>) {
+		if (kdf_kind<T, KeyFunc>::is_default(kf))
+			rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_ASCENDING, &result, &info);
+		else
+			rc = opaque();   // some other function with the default's signature (e.g. `uint32_t desc(const uint32_t &v) { return ~v; }`)
 	} else if constexpr (is_descending_kdf_v<T, KeyFunc>) {
-		rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_DESCENDING, &result, nullptr);
+		rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_DESCENDING, &result, &info);
 	} else if constexpr (is_member_kdf_v<KeyFunc>) {
 		using MK = std::remove_cv_t<std::remove_reference_t<KeyFunc>>;
 		static_assert(std::is_trivially_copyable_v<T>, "the GPU path moves elements as raw bytes");
 		static_assert(std::is_same_v<typename MK::record_type, T>, "by_member names a field of another type");
 		rc = rsx_sort_records_tagged(src, aux, n, sizeof(T), MK::offset(src[0]), dtype_of<typename MK::field_type>(),
-		                             MK::descending ? RSX_DESCENDING : RSX_ASCENDING, &result, nullptr);
+		                             MK::descending ? RSX_DESCENDING : RSX_ASCENDING, &result, &info);
 	} else {
-		static_assert(std::is_trivially_copyable_v<T>, "the GPU path moves elements as raw bytes");
-		std::vector<KeyType> keys(n);
-		for (size_t i = 0; i < n; ++i)
-			keys[i] = kf(src[i]);
-		rc = rsx_sort_records(src, aux, n, sizeof(T), keys.data(), sizeof(KeyType), &result, nullptr);
+		rc = opaque();
 	}
 	if (rc != RSX_OK)
 		fail("radix_sort", rc);
+	if constexpr (!std::is_void_v<Hist>)
+		if (histogram)
+			hist_post_state(*histogram, cap.counts.data(), info, sizeof(KeyType));
 	return static_cast<T *>(result);
 }
 
@@ -145,9 +211,11 @@ T *radix_sort(T *RESTRICT src, T *RESTRICT aux, size_t n, KeyFunc &&kf = basic_k
 template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>)>
 T *radix_sort_multi(T *RESTRICT src, T *RESTRICT aux, size_t n, const int *devices, int ndev, KeyFunc &&kf = basic_kdfs::kdf<T>)
 {
-	(void)kf;
-	static_assert(rsx_detail::is_default_kdf_v<T, KeyFunc> || rsx_detail::is_descending_kdf_v<T, KeyFunc>,
+	static_assert(rsx_detail::may_be_default_kdf_v<T, KeyFunc> || rsx_detail::is_descending_kdf_v<T, KeyFunc>,
 	              "radix_sort_multi takes scalar keys with basic_kdfs::kdf or rsx_kdf::descending");
+	if constexpr (rsx_detail::may_be_default_kdf_v<T, KeyFunc>)
+		if (!rsx_detail::kdf_kind<T, KeyFunc>::is_default(kf))
+			throw std::invalid_argument("radix_sort_multi: a function other than basic_kdfs::kdf<T> was passed as KeyFunc");
 	void *result = nullptr;
 	const int rc = rsx_sort_multi(src, aux, n, rsx_detail::dtype_of<T>(),
 	                              rsx_detail::is_descending_kdf_v<T, KeyFunc> ? RSX_DESCENDING : RSX_ASCENDING, devices, ndev,
@@ -158,11 +226,11 @@ T *radix_sort_multi(T *RESTRICT src, T *RESTRICT aux, size_t n, const int *devic
 }
 
 // The reference lets the caller supply the histogram storage (any container with value_type and
-// operator[], radix_sort.hpp:28-33).  The device keeps its own counters; `histogram` is accepted for
-// compatibility and left untouched.
+// operator[], pre-zeroed, 256 * sizeof(KeyType) entries: radix_sort.hpp:28-33).  The device keeps its own counters;
+// the counts of its histogram pass are brought back (rsx_capture_histogram) and `histogram` is left in the state the
+// reference leaves it in (rsx_detail::hist_post_state; pinned against the real rs_sort_main by tests/golden, hist_post).
 template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>), typename Hist>
 T *rs_sort_main(T *RESTRICT src, T *RESTRICT aux, size_t n, Hist &histogram, KeyFunc &&kf = basic_kdfs::kdf<T>)
 {
-	(void)histogram;
-	return rsx_detail::sort_dispatch<T>(src, aux, n, kf);
+	return rsx_detail::sort_dispatch<T>(src, aux, n, kf, &histogram);
 }

@@ -19,8 +19,8 @@
 
 namespace rsx_detail {
 
-template <typename T, typename IdxType, typename KeyFunc>
-IdxType *rank_dispatch(const T *src, IdxType *index_buffer, size_t n, KeyFunc &&kf)
+template <typename T, typename IdxType, typename KeyFunc, typename Hist = void>
+IdxType *rank_dispatch(const T *src, IdxType *index_buffer, size_t n, KeyFunc &&kf, Hist *histogram = nullptr)
 {
 	using KeyType = std::remove_cv_t<std::remove_reference_t<std::invoke_result_t<KeyFunc &, const T &>>>;
 	static_assert(sizeof(KeyType) <= 8, "KeyType must be 64-bits or less");
@@ -33,19 +33,30 @@ IdxType *rank_dispatch(const T *src, IdxType *index_buffer, size_t n, KeyFunc &&
 		return index_buffer;
 	}
 	void *result = nullptr;
+	rsx_info info;
 	int rc;
-	if constexpr (is_default_kdf_v<T, KeyFunc>) {
-		rc = rsx_sort_rank(src, index_buffer, n, dtype_of<T>(), sizeof(IdxType), RSX_ASCENDING, &result, nullptr);
-	} else if constexpr (is_descending_kdf_v<T, KeyFunc>) {
-		rc = rsx_sort_rank(src, index_buffer, n, dtype_of<T>(), sizeof(IdxType), RSX_DESCENDING, &result, nullptr);
-	} else {
+	hist_capture cap(histogram != nullptr, sizeof(KeyType));
+	auto opaque = [&]() {   // kf once per element on the host, the rank sort of those keys on the device
 		std::vector<KeyType> keys(n);
 		for (size_t i = 0; i < n; ++i)
 			keys[i] = kf(src[i]);
-		rc = rsx_sort_rank_keys(keys.data(), sizeof(KeyType), index_buffer, n, sizeof(IdxType), &result, nullptr);
+		return rsx_sort_rank_keys(keys.data(), sizeof(KeyType), index_buffer, n, sizeof(IdxType), &result, &info);
+	};
+	if constexpr (may_be_default_kdf_v<T, KeyFunc>) {
+		if (kdf_kind<T, KeyFunc>::is_default(kf))   // (a plain function: by address, see radix_sort.hpp)
+			rc = rsx_sort_rank(src, index_buffer, n, dtype_of<T>(), sizeof(IdxType), RSX_ASCENDING, &result, &info);
+		else
+			rc = opaque();
+	} else if constexpr (is_descending_kdf_v<T, KeyFunc>) {
+		rc = rsx_sort_rank(src, index_buffer, n, dtype_of<T>(), sizeof(IdxType), RSX_DESCENDING, &result, &info);
+	} else {
+		rc = opaque();
 	}
 	if (rc != RSX_OK)
 		fail("radix_sort_rank", rc);
+	if constexpr (!std::is_void_v<Hist>)
+		if (histogram)
+			hist_post_state(*histogram, cap.counts.data(), info, sizeof(KeyType));   // radix_sort_rank.hpp:44-88: as rs_sort_main
 	return static_cast<IdxType *>(result);
 }
 
@@ -62,6 +73,5 @@ template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>), typename 
 IdxType *rs_sort_rank(const T *RESTRICT src, IdxType *RESTRICT index_buffer, size_t n, Hist &histogram,
                       KeyFunc &&kf = basic_kdfs::kdf<T>)
 {
-	(void)histogram;
-	return rsx_detail::rank_dispatch<T, IdxType>(src, index_buffer, n, kf);
+	return rsx_detail::rank_dispatch<T, IdxType>(src, index_buffer, n, kf, &histogram);
 }

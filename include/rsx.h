@@ -104,6 +104,18 @@ int rsx_sort_pairs_inplace_async(void *d_keys, void *d_keys_scratch, void *d_val
                                  size_t n, rsx_dtype dtype, size_t payload_bytes, rsx_order order,
                                  void *stream);
 
+/* rs_sort_main / rs_sort_rank with a caller-supplied Hist (radix_sort.hpp:28-33,
+ * radix_sort_rank.hpp:22-23): arms the CALLING THREAD's next blocking sort call
+ * (rsx_sort, rsx_sort_device, rsx_sort_rank*, rsx_sort_pairs_device,
+ * rsx_sort_records*) to also write the counts of loop 1 (radix_sort.hpp:48-58):
+ * hist[256 * j + d] = number of keys whose KDF byte j is d, j < key bytes;
+ * `entries` = room in hist (>= 256 * key bytes, or the sort fails with
+ * RSX_EINVAL).  One shot: the sort disarms it; hist == NULL disarms by hand.
+ * Sorts of n < 2 keys and the *_async entry points never write.  From the counts
+ * and rsx_info the template wrapper reproduces what the reference leaves in the
+ * caller's storage (include/radix_sort.hpp, hist_post_state). */
+int rsx_capture_histogram(uint64_t *hist, size_t entries);
+
 /* Device-resident variant for callers that own a HIP stream (`stream` is a
  * hipStream_t, NULL = the default stream).  The column plan has to reach the
  * host to apply the returned-pointer rule, so the call synchronises `stream`
@@ -180,17 +192,6 @@ int rsx_sort_rank_keys(const void *keys, size_t key_bytes, void *index_buffer, s
  * non-zero uint32 iff some kdf(key[i]) > kdf(key[i+1]).  Enqueued on stream. */
 int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order order,
                          uint64_t *d_hist, uint32_t *d_unsorted, void *stream);
-
-/* One stable partition pass by bucket = lut[top KDF byte] (lut: 256 host bytes,
- * values < nbuckets <= 256): the MSD split of the multi-GPU sort
- * (README.md:647-650).  top_hist (host, 256 uint64; may be NULL)
- * is this shard's histogram of the top KDF byte as rsx_histogram_device
- * produced it; when NULL it is recomputed.  counts (host, nbuckets uint64)
- * receives the bucket sizes; bucket b occupies [sum(counts[0..b)), +counts[b])
- * of d_dst.  Blocking on stream. */
-int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype,
-                         rsx_order order, const uint8_t *lut, uint32_t nbuckets,
-                         const uint64_t *top_hist, uint64_t *counts, void *stream);
 
 /* The MSD split as one ordinary stable scatter pass by the top KDF byte itself
  * (256 digits; README.md:647-650): d_dst = d_src ordered by that

@@ -13,11 +13,13 @@
  *   radix_sort(src, aux, n, ~kdf)              README.md:564-574 (descending)
  *   radix_sort on {key, payload} records       radix_tests.cpp:41-43 shape
  *   radix_sort_rank<T, IdxType>(...)           radix_sort_rank.hpp:97-112
+ *   rs_sort_main(src, aux, n, Hist&)           radix_sort.hpp:31-93 (caller-supplied histogram)
  */
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "radix_sort.hpp"
 #include "radix_sort_rank.hpp"
@@ -92,6 +94,32 @@ int sort_kv(void *src_v, void *aux_v, size_t n, int order)
 	return res == src ? 0 : 1;
 }
 
+/* rs_sort_main with a caller-supplied Hist (radix_sort.hpp:28-33): std::vector<HVT>, pre-zeroed */
+template <typename T, typename HVT>
+int sort_main_hist_hvt(void *src_v, void *aux_v, size_t n, uint64_t *hist_out)
+{
+	using KT = decltype(basic_kdfs::kdf(std::declval<const T &>()));
+	std::vector<HVT> hist(256 * sizeof(KT), 0);
+	T *src = static_cast<T *>(src_v);
+	T *aux = static_cast<T *>(aux_v);
+	T *res = rs_sort_main(src, aux, n, hist);
+	for (size_t i = 0; i < hist.size(); ++i)
+		hist_out[i] = hist[i];
+	return res == src ? 0 : 1;
+}
+
+template <typename T>
+int sort_main_hist(void *src, void *aux, size_t n, int hvt_bytes, uint64_t *hist_out)
+{
+	switch (hvt_bytes) {
+	case 1: return sort_main_hist_hvt<T, uint8_t>(src, aux, n, hist_out);
+	case 2: return sort_main_hist_hvt<T, uint16_t>(src, aux, n, hist_out);
+	case 4: return sort_main_hist_hvt<T, uint32_t>(src, aux, n, hist_out);
+	case 8: return sort_main_hist_hvt<T, uint64_t>(src, aux, n, hist_out);
+	default: return -1;
+	}
+}
+
 /* radix_tests.cpp:15-18 record shape: 1-byte key, pointer-sized payload */
 struct sortrec {
 	uint8_t key;
@@ -133,6 +161,25 @@ int ref_sort_rank(const void *src, void *index_buffer, size_t n, int dtype, int 
 	case 7: return rank_scalar<int64_t>(src, index_buffer, n, idx_bytes, order);
 	case 8: return rank_scalar<float>(src, index_buffer, n, idx_bytes, order);
 	case 9: return rank_scalar<double>(src, index_buffer, n, idx_bytes, order);
+	default: return -1;
+	}
+}
+
+/* rs_sort_main(src, aux, n, hist) -- radix_sort.hpp:31-93 -- with a zeroed std::vector<HVT> of
+ * hvt_bytes-wide counters; hist_out (256 * key bytes uint64) receives what it holds on return. */
+int ref_sort_main_hist(void *src, void *aux, size_t n, int dtype, int hvt_bytes, uint64_t *hist_out)
+{
+	switch (dtype) {
+	case 0: return sort_main_hist<uint8_t>(src, aux, n, hvt_bytes, hist_out);
+	case 1: return sort_main_hist<uint16_t>(src, aux, n, hvt_bytes, hist_out);
+	case 2: return sort_main_hist<uint32_t>(src, aux, n, hvt_bytes, hist_out);
+	case 3: return sort_main_hist<uint64_t>(src, aux, n, hvt_bytes, hist_out);
+	case 4: return sort_main_hist<int8_t>(src, aux, n, hvt_bytes, hist_out);
+	case 5: return sort_main_hist<int16_t>(src, aux, n, hvt_bytes, hist_out);
+	case 6: return sort_main_hist<int32_t>(src, aux, n, hvt_bytes, hist_out);
+	case 7: return sort_main_hist<int64_t>(src, aux, n, hvt_bytes, hist_out);
+	case 8: return sort_main_hist<float>(src, aux, n, hvt_bytes, hist_out);
+	case 9: return sort_main_hist<double>(src, aux, n, hvt_bytes, hist_out);
 	default: return -1;
 	}
 }

@@ -143,8 +143,12 @@ static int plan_passes(const void *src, size_t n, size_t rec_size, size_t key_of
 	return ncols;
 }
 
-int rso_sort_records(void *src_v, void *aux_v, size_t n, size_t rec_size, size_t key_off,
-                     int dtype, int order, rso_info *info)
+/* hist_out (may be NULL; 256 * key bytes entries): the state rs_sort_main leaves in the caller's
+ * pre-zeroed Hist (radix_sort.hpp:28-33): untouched for n < 2 (:37-38), the raw counts after the
+ * pre-sorted exit (:48-62) and in skipped columns, and in every kept column the offsets after the
+ * exclusive scan (:72-80) and the post-increments of the scatter loop (:85) -- i.e. end offsets. */
+static int sort_records_impl(void *src_v, void *aux_v, size_t n, size_t rec_size, size_t key_off,
+                             int dtype, int order, rso_info *info, uint64_t *hist_out)
 {
 	unsigned char *src = (unsigned char *)src_v, *aux = (unsigned char *)aux_v;
 	const size_t kb = rso_dtype_size(dtype);
@@ -163,6 +167,8 @@ int rso_sort_records(void *src_v, void *aux_v, size_t n, size_t rec_size, size_t
 	if (ncols < 0) {
 		if (info)
 			info->early_exit = 2;
+		if (hist_out)
+			memcpy(hist_out, hist, sizeof(uint64_t) * 256 * kb);
 		free(hist);
 		return 0;
 	}
@@ -180,10 +186,33 @@ int rso_sort_records(void *src_v, void *aux_v, size_t n, size_t rec_size, size_t
 		unsigned char *t = src; src = aux; aux = t;
 		swapped ^= 1;
 	}
+	if (hist_out)
+		memcpy(hist_out, hist, sizeof(uint64_t) * 256 * kb);
 	free(hist);
 	if (info)
 		info->result_in_aux = (uint32_t)swapped;
 	return swapped; /* radix_sort.hpp:92 */
+}
+
+int rso_sort_records(void *src_v, void *aux_v, size_t n, size_t rec_size, size_t key_off,
+                     int dtype, int order, rso_info *info)
+{
+	return sort_records_impl(src_v, aux_v, n, rec_size, key_off, dtype, order, info, NULL);
+}
+
+/* rs_sort_main(src, aux, n, histogram, kf) with a caller-supplied Hist whose value_type has
+ * hvt_bytes bytes (radix_sort.hpp:28-33; :102-114 picks 1/2/4/8 by n).  hist_out receives the
+ * Hist's final contents, each entry reduced modulo 2^(8 hvt_bytes) as HVT arithmetic does. */
+int rso_sort_main_hist(void *src, void *aux, size_t n, int dtype, int order, int hvt_bytes,
+                       uint64_t *hist_out, rso_info *info)
+{
+	const size_t kb = rso_dtype_size(dtype);
+	memset(hist_out, 0, sizeof(uint64_t) * 256 * kb);
+	const int r = sort_records_impl(src, aux, n, kb, 0, dtype, order, info, hist_out);
+	if (hvt_bytes < 8)
+		for (size_t i = 0; i < 256 * kb; ++i)
+			hist_out[i] &= (1ull << (8 * hvt_bytes)) - 1;
+	return r;
 }
 
 /* ----------------------------------------------- typed scalar fast path --- */

@@ -68,6 +68,13 @@ int rso_sort(void *src, void *aux, size_t n, int dtype, int order, rso_info *inf
 int rso_sort_records(void *src, void *aux, size_t n, size_t rec_size, size_t key_off,
                      int dtype, int order, rso_info *info);
 
+/* rs_sort_main with a caller-supplied Hist (radix_sort.hpp:28-33): the same sort, plus what the
+ * reference leaves in the (pre-zeroed) histogram storage -- raw counts after the pre-sorted exit
+ * (:48-62) and in skipped columns, end offsets (exclusive scan :72-80 + post-increments :85) in
+ * kept columns, nothing for n < 2 -- as 256 * key_bytes uint64, reduced modulo 2^(8 hvt_bytes). */
+int rso_sort_main_hist(void *src, void *aux, size_t n, int dtype, int order, int hvt_bytes,
+                       uint64_t *hist_out, rso_info *info);
+
 /* radix_sort_rank<T,IdxType> (radix_sort_rank.hpp:97-112) with the pass loop of
  * Listing 6 (radix_sort_u32_ranks.c:85-107: digit of src[idx[j]]), i.e. a
  * correct stable argsort.  index_buffer holds 2n entries of idx_bytes (1,2,4,8).

@@ -56,6 +56,7 @@ ABI = [
     ("rsx_sort", _I, [_VP, _VP, _SZ, _I, _I, _PVP, _PINFO]),
     ("rsx_sort_inplace_async", _I, [_VP, _VP, _SZ, _I, _I, _VP]),
     ("rsx_sort_pairs_inplace_async", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP]),
+    ("rsx_capture_histogram", _I, [_VP, _SZ]),
     ("rsx_sort_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _PVP, _PINFO]),
     ("rsx_sort_pairs_device", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP, _PINFO]),
     ("rsx_sort_rank", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _PVP, _PINFO]),
@@ -65,7 +66,6 @@ ABI = [
     ("rsx_sort_records_tagged_device", _I, [_VP, _VP, _SZ, _SZ, _SZ, _I, _I, _VP, _PVP, _PINFO]),
     ("rsx_sort_rank_keys", _I, [_VP, _SZ, _VP, _SZ, _SZ, _PVP, _PINFO]),
     ("rsx_histogram_device", _I, [_VP, _SZ, _I, _I, _VP, _VP, _VP]),
-    ("rsx_partition_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _U32, _VP, _VP, _VP]),
     ("rsx_msd_split_device", _I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP]),
     ("rsx_sort_multi", _I, [_VP, _VP, _SZ, _I, _I, _VP, _I, _PVP, _PINFO]),
     ("rsx_profile_begin", _I, []),
@@ -136,9 +136,34 @@ def _stream_ptr(stream=None):
 
 
 def _check_dev(*tensors):
+    """Every buffer handed to the kernels as a raw pointer: a contiguous tensor on the CURRENT device."""
+    import torch
+    cur = torch.cuda.current_device()
     for t in tensors:
         if not t.is_cuda or not t.is_contiguous():
             raise RsxError("expected contiguous device tensors")
+        if t.device.index != cur:
+            raise RsxError("tensor on cuda:%d but the current device is cuda:%d (the library works on the current device)"
+                           % (t.device.index, cur))
+
+
+def _same_shape(a, b, what):
+    """`b` is the ping-pong partner of `a`: same element size, at least as many elements."""
+    if b.element_size() != a.element_size() or b.numel() < a.numel():
+        raise RsxError("%s does not match its buffer (element size %d vs %d, %d vs %d elements)"
+                       % (what, b.element_size(), a.element_size(), b.numel(), a.numel()))
+
+
+def capture_histogram(hist):
+    """rsx_capture_histogram: arm the calling thread's next blocking sort to write the counts of loop 1
+    (radix_sort.hpp:48-58) into `hist` (numpy uint64, >= 256 * key bytes entries); None disarms."""
+    if hist is None:
+        check(lib().rsx_capture_histogram(None, 0))
+    else:
+        import numpy as np
+        if hist.dtype != np.uint64 or not hist.flags["C_CONTIGUOUS"]:
+            raise RsxError("capture_histogram wants a contiguous numpy uint64 array")
+        check(lib().rsx_capture_histogram(hist.ctypes.data, hist.size))
 
 
 def radix_sort(src, aux, dtype=None, order=ASCENDING, stream=None):
@@ -151,8 +176,9 @@ def radix_sort(src, aux, dtype=None, order=ASCENDING, stream=None):
     """
     _check_dev(src, aux)
     code = _torch_dtype_code(src) if dtype is None else dtype
-    if src.element_size() != DTYPE_SIZE[code] or aux.numel() < src.numel() or aux.element_size() != src.element_size():
-        raise RsxError("src/aux do not match the key type")
+    if src.element_size() != DTYPE_SIZE[code]:
+        raise RsxError("src does not match the key type")
+    _same_shape(src, aux, "aux")
     res, info = C.c_void_p(), Info()
     check(lib().rsx_sort_device(src.data_ptr(), aux.data_ptr(), src.numel(), code, order, _stream_ptr(stream),
                                 C.byref(res), C.byref(info)))
@@ -163,8 +189,9 @@ def radix_sort_inplace_async(buf, scratch, dtype=None, order=ASCENDING, stream=N
     """rsx_sort_inplace_async: no host synchronisation, the sorted keys always end in ``buf`` (graph-capturable)."""
     _check_dev(buf, scratch)
     code = _torch_dtype_code(buf) if dtype is None else dtype
-    if buf.element_size() != DTYPE_SIZE[code] or scratch.numel() < buf.numel():
-        raise RsxError("buf/scratch do not match")
+    if buf.element_size() != DTYPE_SIZE[code]:
+        raise RsxError("buf does not match the key type")
+    _same_shape(buf, scratch, "scratch")
     check(lib().rsx_sort_inplace_async(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream)))
     return buf
 
@@ -173,9 +200,10 @@ def radix_sort_pairs_inplace_async(keys, keys_scratch, vals, vals_scratch, dtype
     """rsx_sort_pairs_inplace_async: keys and payloads sorted in place by the keys, no host synchronisation."""
     _check_dev(keys, keys_scratch, vals, vals_scratch)
     code = _torch_dtype_code(keys) if dtype is None else dtype
-    if keys.element_size() != DTYPE_SIZE[code] or vals.element_size() not in (4, 8) or vals.numel() != keys.numel() \
-            or keys_scratch.numel() < keys.numel() or vals_scratch.numel() < vals.numel():
-        raise RsxError("keys/vals/scratch do not match")
+    if keys.element_size() != DTYPE_SIZE[code] or vals.element_size() not in (4, 8) or vals.numel() != keys.numel():
+        raise RsxError("keys/vals do not match")
+    _same_shape(keys, keys_scratch, "keys_scratch")
+    _same_shape(vals, vals_scratch, "vals_scratch")
     check(lib().rsx_sort_pairs_inplace_async(keys.data_ptr(), keys_scratch.data_ptr(), vals.data_ptr(), vals_scratch.data_ptr(),
                                              keys.numel(), code, vals.element_size(), order, _stream_ptr(stream)))
     return keys, vals
@@ -185,8 +213,10 @@ def radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=None, order=ASCENDING
     """Stable key+payload sort (struct-of-arrays); returns (keys_result, vals_result, info)."""
     _check_dev(keys, keys_aux, vals, vals_aux)
     code = _torch_dtype_code(keys) if dtype is None else dtype
-    if keys.element_size() != DTYPE_SIZE[code] or vals.numel() != keys.numel():
+    if keys.element_size() != DTYPE_SIZE[code] or vals.numel() != keys.numel() or vals.element_size() not in (4, 8):
         raise RsxError("keys/vals do not match")
+    _same_shape(keys, keys_aux, "keys_aux")
+    _same_shape(vals, vals_aux, "vals_aux")
     info = Info()
     check(lib().rsx_sort_pairs_device(keys.data_ptr(), keys_aux.data_ptr(), vals.data_ptr(), vals_aux.data_ptr(),
                                       keys.numel(), code, vals.element_size(), order, _stream_ptr(stream),
@@ -205,6 +235,8 @@ def radix_sort_rank(src, index_buffer, dtype=None, order=ASCENDING, stream=None)
     _check_dev(src, index_buffer)
     code = _torch_dtype_code(src) if dtype is None else dtype
     n = src.numel()
+    if src.element_size() != DTYPE_SIZE[code]:
+        raise RsxError("src does not match the key type")
     if index_buffer.numel() < 2 * n or index_buffer.element_size() not in (4, 8):
         raise RsxError("index_buffer must hold 2n 4- or 8-byte entries")
     res, info = C.c_void_p(), Info()
@@ -280,8 +312,16 @@ def radix_sort_records_tagged_host(src, aux, key_offset, key_dtype, order=ASCEND
 def radix_sort_records_tagged(src, aux, rec_bytes, key_offset, key_dtype, order=ASCENDING, stream=None):
     """rsx_sort_records_tagged_device on torch uint8 tensors holding n records of rec_bytes each."""
     require_gpu()
+    _check_dev(src, aux)
+    nbytes = src.numel() * src.element_size()
+    if rec_bytes <= 0 or nbytes % rec_bytes:
+        raise RsxError("src holds %d bytes: not a whole number of %d-byte records" % (nbytes, rec_bytes))
+    if aux.numel() * aux.element_size() < nbytes:
+        raise RsxError("aux is smaller than src")
+    if key_offset < 0 or key_offset + DTYPE_SIZE[key_dtype] > rec_bytes:
+        raise RsxError("the key does not lie inside the record")
     res, info = C.c_void_p(), Info()
-    n = src.numel() * src.element_size() // rec_bytes
+    n = nbytes // rec_bytes
     check(lib().rsx_sort_records_tagged_device(src.data_ptr(), aux.data_ptr(), n, rec_bytes, key_offset, key_dtype, order,
                                                _stream_ptr(stream), C.byref(res), C.byref(info)))
     return (aux if res.value == aux.data_ptr() else src), info

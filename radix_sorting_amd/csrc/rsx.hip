@@ -122,11 +122,10 @@ struct DevBuf {
 struct Ctx {
 	int device = -1;
 	hipStream_t stream = nullptr;
-	// fixed small state: [unsorted u32 | pad 64][Plan 64][kept 8 u32 | pad 64][lut 256][bucket totals 256 u64]
+	// fixed small state: [unsorted u32 | hotd 9 u32 | plan_done | pad 64][Plan 64][kept 16 u32 64]
 	DevBuf small;
-	DevBuf hist;        // counts / offsets [nseg][key bytes][256] u64 (see "Segments" in rsx_kernels.hpp)
+	DevBuf hist;        // counts, then exclusive offsets [key bytes][256] u64
 	DevBuf hpart;       // the histogram kernel's per-workgroup rows [workgroups][key bytes][256] u32
-	DevBuf bbase;       // MSD split: bucket offsets [nseg][256] u64
 	DevBuf status;      // [ticket u32, pad to 256 B][tiles * 256 status words]
 	DevBuf keys[2];     // key ping-pong for rank sorts / host staging
 	DevBuf vals[2];     // payload ping-pong for host staging / narrow-index rank
@@ -148,9 +147,7 @@ struct Ctx {
 	u32 *hotd() const { return (u32 *)((char *)small.p + 16); }   // [8] hot digits per column + [1] valid bits (rsx_plan_kernel)
 	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
 	u32 *kept() const { return (u32 *)((char *)small.p + 128); }
-	uint8_t *lut() const { return (uint8_t *)((char *)small.p + 192); }
-	u64 *bucket_totals() const { return (u64 *)((char *)small.p + 192 + 256); }
-	static constexpr size_t SMALL_BYTES = 192 + 256 + 256 * 8;
+	static constexpr size_t SMALL_BYTES = 192;
 
 	int init()
 	{
@@ -169,7 +166,6 @@ struct Ctx {
 		small.release();
 		hist.release();
 		hpart.release();
-		bbase.release();
 		status.release();
 		for (int i = 0; i < 2; ++i) {
 			keys[i].release();
@@ -278,6 +274,34 @@ int lds_order_selfcheck(int dev)
 	return ok;
 }
 
+// ---- rsx_capture_histogram: the caller-supplied Hist of rs_sort_main (radix_sort.hpp:28-33) -------------------------
+// Armed per thread; the next sort of that thread that runs the histogram kernels writes the raw per-column digit counts
+// there (hist[256 j + d]) and disarms.  The counts are recovered from the exclusive offsets the plan kernel leaves in the
+// workspace (every column is scanned, kept or not): count[d] = offset[d + 1] - offset[d], the last one n - offset[255].
+thread_local u64 *g_capture_dst = nullptr;
+thread_local size_t g_capture_entries = 0;
+
+inline bool capture_armed() { return g_capture_dst != nullptr; }
+
+int capture_hist(Ctx &c, size_t n, size_t kb)
+{
+	if (!g_capture_dst)
+		return RSX_OK;
+	u64 *dst = g_capture_dst;
+	const size_t entries = g_capture_entries;
+	g_capture_dst = nullptr;
+	g_capture_entries = 0;
+	if (entries < 256 * kb)
+		return fail(RSX_EINVAL, "rsx_capture_histogram: room for %zu entries, the sort has %zu", entries, 256 * kb);
+	std::vector<u64> off(256 * kb);
+	HIP_TRY(hipMemcpyAsync(off.data(), c.ghist(), 256 * kb * sizeof(u64), hipMemcpyDeviceToHost, c.stream));
+	HIP_TRY(hipStreamSynchronize(c.stream));
+	for (size_t j = 0; j < kb; ++j)
+		for (size_t d = 0; d < 256; ++d)
+			dst[256 * j + d] = (d == 255 ? (u64)n : off[256 * j + d + 1]) - off[256 * j + d];
+	return RSX_OK;
+}
+
 int get_ctx(void *stream, Ctx **out)
 {
 	std::lock_guard<std::mutex> lock(g_mu);
@@ -321,24 +345,6 @@ void info_from_plan(rsx_info *info, const Plan &p)
 		info->cols[i] = p.cols[i];
 }
 
-// ---- histogram segment geometry (see "Segments" in rsx_kernels.hpp): the sort uses one segment ----
-struct Geo {
-	u32 nseg;
-	u32 tiles_per_seg;
-	u64 seg_elems;
-	u64 tiles;
-};
-
-Geo one_segment(size_t n)
-{
-	Geo g;
-	g.nseg = 1;
-	g.tiles_per_seg = 1;
-	g.seg_elems = n;
-	g.tiles = 1;
-	return g;
-}
-
 // tiles per super-tile: as many as keeps at least ~2048 super-tiles in flight, at most 8
 u32 choose_tps(size_t n, size_t tile)
 {
@@ -353,35 +359,34 @@ u32 choose_tps(size_t n, size_t tile)
 
 // ---- phase 1: histogram + plan (radix_sort.hpp:48-80) --------------------------
 template <typename KT>
-int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted, const Geo &g, u32 colmask = ~0u)
+int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted, u32 colmask = ~0u)
 {
 	typedef HistCfg<KT> C;
-	const u64 per_block = (u64)C::BLOCK * C::U * C::VEC;     // elements one block covers per sweep
-	u64 bps = (g.seg_elems + per_block - 1) / per_block;
-	const u64 cap = 512 / g.nseg > 0 ? 512 / g.nseg : 1;      // 256 CUs x 2 workgroups of 1024 threads in all
-	if (bps > cap)
-		bps = cap;
-	if (bps < 1)
-		bps = 1;
+	const u64 per_block = (u64)C::BLOCK * C::U * C::VEC;     // elements one workgroup covers per sweep
+	u64 blocks = (n + per_block - 1) / per_block;
+	if (blocks > 512)                                         // 256 CUs x 2 workgroups of 1024 threads
+		blocks = 512;
+	if (blocks < 1)
+		blocks = 1;
 	const u32 cols256 = (u32)sizeof(KT) * 256;
-	RSX_TRY(c.hpart.ensure((size_t)g.nseg * bps * cols256 * sizeof(u32)));
+	RSX_TRY(c.hpart.ensure((size_t)blocks * cols256 * sizeof(u32)));
 	ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
 	// up to 128 workgroups add their counts to the histogram themselves (one launch and its gap less: 7 of the 62 us of
 	// a 10^5-key sort); beyond that the rows are summed by a kernel of their own
-	const bool direct = (u64)g.nseg * bps <= 128;
-	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)(g.nseg * bps)), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
-	                   (u32 *)c.hpart.p, d_unsorted, ka, g.nseg, (u32)bps, g.seg_elems, colmask, direct ? d_hist : (u64 *)nullptr);
+	const bool direct = blocks <= 128;
+	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
+	                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr);
 	if (!direct)
-		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)(g.nseg * sizeof(KT)), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
-		                   (const u32 *)c.hpart.p, d_hist, (u32)bps, cols256);
+		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)sizeof(KT), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
+		                   (const u32 *)c.hpart.p, d_hist, (u32)blocks, cols256);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
 
 template <typename KT>
-int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, Plan *out, size_t status_total = 0)
+int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, size_t status_total = 0)
 {
-	const size_t hist_bytes = (size_t)g.nseg * sizeof(KT) * 256 * sizeof(u64);
+	const size_t hist_bytes = sizeof(KT) * 256 * sizeof(u64);
 	RSX_TRY(c.hist.ensure(hist_bytes));
 	if (status_total) {
 		// flags, histogram and the status words of every pass of this sort in one launch
@@ -394,8 +399,8 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, const Geo &g, 
 		HIP_TRY(hipMemsetAsync(c.hist.p, 0, hist_bytes, c.stream));
 		HIP_TRY(hipMemsetAsync(c.small.p, 0, 192, c.stream));
 	}
-	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted(), g));
-	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), g.nseg, ka,
+	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted()));
+	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), ka,
 	                   c.kept(), c.hotd(), c.plan_done(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan);   // (+ the finish)
 	HIP_TRY(hipGetLastError());
 	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
@@ -426,7 +431,7 @@ inline u32 hot_flags(u32 hotmask, u32 col)
 // gbase[digit]: exclusive offset of the digit for this pass's column
 template <typename KT, typename VT, typename C2, typename KTO = KT>
 int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                    KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan, int region, u32 pass_index, u32 oshift = 0)
+                    KdfArgs<KT> ka, u32 flags, const Plan *dplan, int region, u32 pass_index, u32 oshift = 0)
 {
 	const u64 tiles = (n + C2::TILE - 1) / C2::TILE;
 	const u32 tps = (u32)C2::TPS;   // 1: a tile is its own super-tile (32-bit cells leave no LDS for a second tile's counts)
@@ -446,13 +451,13 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 	const dim3 grid((unsigned)tiles);
 	// keys that are their own KDF (unsigned ascending, no bucket table) take the kernel without the KDF arithmetic;
 	// columns with a hot digit (Plan::hot) take the instantiation that tests every round for a wave-uniform digit
-	const bool integer = val_bytes<VT>::value == 0 && ka.fmask == 0 && !(flags & SCATTER_USE_LUT);
+	const bool integer = val_bytes<VT>::value == 0 && ka.fmask == 0;
 	const bool plain = integer && ka.sflip == 0 && ka.desc == 0;
 	const bool hot = (flags & SCATTER_HOT) != 0;
 	flags &= ~(u32)SCATTER_HOT;
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
-	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, lut, (u64 *)nullptr, dplan, pass_index,  \
+	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, (u64 *)nullptr, dplan, pass_index,  \
 	                   oshift, (const u32 *)c.hotd())
 	// quarter tiles are for arrays of a few million keys: never 2^30 of them, and hot digits cost little there -- those
 	// instantiations are left out of the build
@@ -511,7 +516,7 @@ template <typename KT, typename VT> size_t status_bytes(size_t n)
 
 template <typename KT, typename VT>
 int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, u32 shift, const u64 *gbase,
-                 KdfArgs<KT> ka, u32 flags, const uint8_t *lut, const Plan *dplan = nullptr, int region = -1, u32 pass_index = 0)
+                 KdfArgs<KT> ka, u32 flags, const Plan *dplan = nullptr, int region = -1, u32 pass_index = 0)
 {
 	if ((dplan || region >= 0) && !c.fast)
 		return fail(RSX_EINVAL, "speculative pass / status regions without the fast kernel");
@@ -520,10 +525,10 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 		typedef Sc2SmallCfg<KT, VT> Small;
 		if constexpr (Small::AVAILABLE) {
 			if (use_small_tiles<KT, VT>(n))
-				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan,
+				return launch_scatter2<KT, VT, typename Small::type>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, dplan,
 				                                                     region, pass_index);
 		}
-		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, lut, dplan, region, pass_index);
+		return launch_scatter2<KT, VT, C2>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, dplan, region, pass_index);
 	}
 	typedef ScatterCfg<KT, VT> C1;   // table-ranked fallback (rsx_kernels.hpp)
 	flags &= ~(u32)SCATTER_HOT;      // (its match tables do not care how many lanes share a digit)
@@ -541,10 +546,10 @@ int scatter_pass(Ctx &c, const KT *kin, KT *kout, const VT *vin, VT *vout, size_
 	const dim3 grid((unsigned)stiles);
 	if (wide)
 		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u64>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
-		                   shift, gbase, tps, (u64 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		                   shift, gbase, tps, (u64 *)st, ticket, ka, flags, (u64 *)nullptr);
 	else
 		hipLaunchKernelGGL((rsx_scatter_kernel<KT, VT, u32>), grid, dim3(C1::BLOCK), 0, c.stream, kin, kout, vin, vout, (u64)n,
-		                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, lut, (u64 *)nullptr);
+		                   shift, gbase, tps, (u32 *)st, ticket, ka, flags, (u64 *)nullptr);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
@@ -558,10 +563,10 @@ int scatter_pass_narrow(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vou
 	typedef Sc2SmallCfg<KT, VT> Small;
 	if constexpr (Small::AVAILABLE) {
 		if (use_small_tiles<KT, VT>(n))
-			return launch_scatter2<KT, VT, typename Small::type, KTO>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, nullptr,
+			return launch_scatter2<KT, VT, typename Small::type, KTO>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags,
 			                                                          nullptr, -1, 0, oshift);
 	}
-	return launch_scatter2<KT, VT, C2, KTO>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, nullptr, nullptr, -1, 0, oshift);
+	return launch_scatter2<KT, VT, C2, KTO>(c, kin, kout, vin, vout, n, shift, gbase, ka, flags, nullptr, -1, 0, oshift);
 }
 
 // keys of `out_bytes` bytes out of a pass over KT keys (out_bytes <= sizeof(KT))
@@ -570,7 +575,7 @@ int scatter_pass_to(Ctx &c, const KT *kin, void *kout, u32 out_bytes, const VT *
                     const u64 *gbase, KdfArgs<KT> ka, u32 flags, u32 oshift)
 {
 	if (out_bytes == sizeof(KT) && oshift == 0)
-		return scatter_pass<KT, VT>(c, kin, (KT *)kout, vin, vout, n, shift, gbase, ka, flags, nullptr);
+		return scatter_pass<KT, VT>(c, kin, (KT *)kout, vin, vout, n, shift, gbase, ka, flags);
 	if constexpr (sizeof(KT) >= 8)
 		if (out_bytes == 8)
 			return scatter_pass_narrow<KT, VT, u64>(c, kin, (u64 *)kout, vin, vout, n, shift, gbase, ka, flags, oshift);
@@ -590,7 +595,7 @@ template <typename KT>
 int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	if (c.fast && n * sizeof(KT) <= SMALL_SORT_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
+	if (c.fast && n * sizeof(KT) <= SMALL_SORT_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed()) {
 		// the whole sort in one workgroup and one launch (rsx_small.hpp)
 		ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
 		hipLaunchKernelGGL((rsx_small_sort_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, src, aux, (u32)n, ka, c.dev_host_plan);
@@ -605,7 +610,6 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 			info->result_in_aux = *result == aux;
 		return RSX_OK;
 	}
-	const Geo g = one_segment(n);
 	Plan plan;
 	// The first pass is enqueued before the host knows the plan (it reads the device's copy and does nothing on
 	// sorted input): the host's wait for the plan, 20-25 us of idle GPU otherwise, hides behind it.
@@ -613,13 +617,14 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	// with the fast kernel every pass has its own region of status words, all zeroed together with the histogram
 	const size_t status_total = c.fast ? status_bytes<KT, NoVal>(n) * sizeof(KT) : 0;
 	if (spec) {
-		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, nullptr, status_total));
-		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), 0)));
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total));
+		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, c.plan(), 0)));
 		RSX_TRY(plan_wait(c, &plan));
 	} else {
-		RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan, status_total));
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan, status_total));
 	}
 	info_from_plan(info, plan);
+	RSX_TRY(capture_hist(c, n, sizeof(KT)));
 	if (plan.sorted) {                       // radix_sort.hpp:60-62
 		if (info) {
 			info->early_exit = 2;
@@ -634,7 +639,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	for (u32 i = spec ? 1 : 0; i < plan.ncols; ++i) {   // radix_sort.hpp:83-90
 		const u32 col = plan.cols[i];
 		RSX_TRY((scatter_pass<KT, NoVal>(c, cur, oth, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka,
-		                                 hot_flags(plan.hot, col), nullptr, nullptr, c.fast ? (int)i : -1)));
+		                                 hot_flags(plan.hot, col), nullptr, c.fast ? (int)i : -1)));
 		std::swap(cur, oth);
 	}
 	*result = cur;                           // radix_sort.hpp:92
@@ -655,11 +660,10 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 		HIP_TRY(hipGetLastError());
 		return RSX_OK;
 	}
-	const Geo g = one_segment(n);
 	const size_t status_total = status_bytes<KT, NoVal>(n) * sizeof(KT);
-	RSX_TRY(plan_phase<KT>(c, buf, n, ka, g, nullptr, status_total));
+	RSX_TRY(plan_phase<KT>(c, buf, n, ka, nullptr, status_total));
 	for (u32 i = 0; i < sizeof(KT); ++i)   // pass i = the i-th kept column, if there is one (radix_sort.hpp:83-90)
-		RSX_TRY((scatter_pass<KT, NoVal>(c, buf, scratch, nullptr, nullptr, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), (int)i, i)));
+		RSX_TRY((scatter_pass<KT, NoVal>(c, buf, scratch, nullptr, nullptr, n, 0, c.ghist(), ka, 0, c.plan(), (int)i, i)));
 	// an odd number of kept columns leaves the result in `scratch` (radix_sort.hpp:92): bring it home
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)buf, (const unsigned char *)scratch,
 	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
@@ -680,11 +684,10 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 		HIP_TRY(hipGetLastError());
 		return RSX_OK;
 	}
-	const Geo g = one_segment(n);
 	const size_t status_total = status_bytes<KT, VT>(n) * sizeof(KT);
-	RSX_TRY(plan_phase<KT>(c, k, n, ka, g, nullptr, status_total));
+	RSX_TRY(plan_phase<KT>(c, k, n, ka, nullptr, status_total));
 	for (u32 i = 0; i < sizeof(KT); ++i)
-		RSX_TRY((scatter_pass<KT, VT>(c, k, ks, v, vs, n, 0, c.ghist(), ka, 0, nullptr, c.plan(), (int)i, i)));
+		RSX_TRY((scatter_pass<KT, VT>(c, k, ks, v, vs, n, 0, c.ghist(), ka, 0, c.plan(), (int)i, i)));
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)k, (const unsigned char *)ks,
 	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)v, (const unsigned char *)vs,
@@ -698,7 +701,7 @@ template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	if (c.fast && n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
+	if (c.fast && n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed()) {
 		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, VT, false>), dim3(1), dim3(1024), 0, c.stream, (const KT *)k0, k1, v0, v1,
 		                   (u32)n, ka, c.dev_host_plan);
@@ -712,10 +715,10 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 		}
 		return RSX_OK;
 	}
-	const Geo g = one_segment(n);
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, k0, n, ka, g, &plan));
+	RSX_TRY(plan_phase<KT>(c, k0, n, ka, &plan));
 	info_from_plan(info, plan);
+	RSX_TRY(capture_hist(c, n, sizeof(KT)));
 	if (plan.sorted) {
 		if (info) {
 			info->early_exit = 2;
@@ -727,8 +730,7 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 	VT *vc = v0, *vo = v1;
 	for (u32 i = 0; i < plan.ncols; ++i) {
 		const u32 col = plan.cols[i];
-		RSX_TRY((scatter_pass<KT, VT>(c, kc, ko, vc, vo, n, 8 * col, c.ghist() + 256 * col, ka, hot_flags(plan.hot, col),
-		                              nullptr)));
+		RSX_TRY((scatter_pass<KT, VT>(c, kc, ko, vc, vo, n, 8 * col, c.ghist() + 256 * col, ka, hot_flags(plan.hot, col))));
 		std::swap(kc, ko);
 		std::swap(vc, vo);
 	}
@@ -760,7 +762,7 @@ template <typename KT, typename IT>
 int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT")) {
+	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed()) {
 		ProfScope prof(1, (u64)n * (sizeof(KT) + 2 * sizeof(IT)), c.stream);
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, IT, true>), dim3(1), dim3(1024), 0, c.stream, src, (KT *)nullptr, ib, ib + n,
 		                   (u32)n, ka, c.dev_host_plan);
@@ -775,10 +777,10 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		*result = (p.ncols & 1) ? ib + n : ib;   // radix_sort_rank.hpp:91 (sorted: first half = iota)
 		return RSX_OK;
 	}
-	const Geo g = one_segment(n);
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, src, n, ka, g, &plan));
+	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan));
 	info_from_plan(info, plan);
+	RSX_TRY(capture_hist(c, n, sizeof(KT)));
 	if (plan.sorted) {                       // radix_sort_rank.hpp:52,:55-57: first half = iota
 		hipLaunchKernelGGL((rsx_iota_kernel<IT>), dim3(1024), dim3(256), 0, c.stream, ib, (u64)n);
 		HIP_TRY(hipGetLastError());
@@ -853,8 +855,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 			flags |= SCATTER_GEN_INDEX;
 		if (i == P - 1)
 			flags |= SCATTER_SKIP_KEYS;
-		RSX_TRY((scatter_pass<KT, IT>(c, kin, kout, H[i & 1], H[(i + 1) & 1], n, 8 * col, c.ghist() + 256 * col, ka, flags,
-		                              nullptr)));
+		RSX_TRY((scatter_pass<KT, IT>(c, kin, kout, H[i & 1], H[(i + 1) & 1], n, 8 * col, c.ghist() + 256 * col, ka, flags)));
 	}
 	*result = H[P & 1];                      // radix_sort_rank.hpp:91
 	if (info)
@@ -876,13 +877,13 @@ bool is_device_ptr(const void *p)
 // dispatch on key width
 // ---- one plain scatter pass by the top KDF byte (rsx_msd_split_device) ---------------------------------------------
 template <typename KT>
-int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u32 col, const Geo &g, uint64_t *top_hist)
+int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u32 col, uint64_t *top_hist)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	const u64 *top = c.ghist() + 256 * col;
-	RSX_TRY(launch_hist<KT>(c, src, n, ka, c.ghist(), c.unsorted(), g, 1u << col));   // only the column split by
+	RSX_TRY(launch_hist<KT>(c, src, n, ka, c.ghist(), c.unsorted(), 1u << col));   // only the column split by
 	HIP_TRY(hipMemcpyAsync(c.host_hist, top, 256 * sizeof(u64), hipMemcpyDeviceToHost, c.stream));   // counts, before the scan
-	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), g.nseg, ka, c.kept(),
+	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), ka, c.kept(),
 	                   c.hotd());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(c.stream));
@@ -896,7 +897,7 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u3
 	if (total != n)
 		return fail(RSX_EHIP, "rsx_msd_split_device: digit counts sum to %llu, n = %zu", (unsigned long long)total, n);
 	const u32 flags = most >= (u64)n / 8 + 1 ? hot_flags(1u << col, col) : 0u;   // as Plan::hot (rsx_plan_kernel)
-	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, top, ka, flags, nullptr);
+	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, top, ka, flags);
 }
 
 // ---- single-process multi-device sort (rsx_sort_multi) -----------------------------------------------------------------
@@ -1053,6 +1054,13 @@ void rsx_release(void)
 		(void)hipStreamDestroy(kv.second);
 	}
 	g_multi_streams.clear();
+}
+
+int rsx_capture_histogram(uint64_t *hist, size_t entries)
+{
+	g_capture_dst = (u64 *)hist;
+	g_capture_entries = hist ? entries : 0;
+	return RSX_OK;
 }
 
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order, void *stream)
@@ -1668,62 +1676,8 @@ int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order
 	HIP_TRY(hipMemsetAsync(d_unsorted, 0, sizeof(u32), c->stream));
 	if (n == 0)
 		return RSX_OK;
-	const Geo g = one_segment(n);
 	RSX_DISPATCH_KT(dtype, return launch_hist<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), (u64 *)d_hist,
-	                                              (u32 *)d_unsorted, g));
-	return RSX_OK;
-}
-
-int rsx_partition_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order, const uint8_t *lut,
-                         uint32_t nbuckets, const uint64_t *top_hist, uint64_t *counts, void *stream)
-{
-	const size_t kb = dtype_size(dtype);
-	if (!kb || !lut || !counts || nbuckets == 0 || nbuckets > 256 || (n && (!d_src || !d_dst)))
-		return fail(RSX_EINVAL, "rsx_partition_device: bad argument");
-	for (int i = 0; i < 256; ++i)
-		if (lut[i] >= nbuckets)
-			return fail(RSX_EINVAL, "rsx_partition_device: lut[%d] = %u >= nbuckets", i, (unsigned)lut[i]);
-	for (u32 b = 0; b < nbuckets; ++b)
-		counts[b] = 0;
-	if (n == 0)
-		return RSX_OK;
-	Ctx *c;
-	RSX_TRY(get_ctx(stream, &c));
-	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
-	// per-segment histogram of the top KDF byte -> per-(segment, bucket) offsets -> one scatter pass
-	const Geo g = one_segment(n);
-	const size_t hist_bytes = (size_t)g.nseg * kb * 256 * sizeof(u64);
-	RSX_TRY(c->hist.ensure(hist_bytes));
-	RSX_TRY(c->bbase.ensure((size_t)g.nseg * 256 * sizeof(u64)));
-	HIP_TRY(hipMemsetAsync(c->hist.p, 0, hist_bytes, c->stream));
-	HIP_TRY(hipMemsetAsync(c->small.p, 0, 192, c->stream));
-	HIP_TRY(hipMemcpyAsync(c->lut(), lut, 256, hipMemcpyHostToDevice, c->stream));
-	RSX_DISPATCH_KT(dtype, RSX_TRY(launch_hist<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), c->ghist(),
-	                                              c->unsorted(), g)));
-	hipLaunchKernelGGL(rsx_lut_plan_kernel, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->ghist(), g.nseg, (u32)(kb * 256),
-	                   (u32)(256 * (kb - 1)), (const uint8_t *)c->lut(), (u64 *)c->bbase.p, c->bucket_totals());
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(c->host_hist, c->bucket_totals(), 256 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));   // also: `lut` (caller's buffer) has been consumed
-	u64 total = 0;
-	for (u32 b = 0; b < nbuckets; ++b) {
-		counts[b] = c->host_hist[b];
-		total += counts[b];
-	}
-	if (total != n)
-		return fail(RSX_EHIP, "rsx_partition_device: bucket counts sum to %llu, n = %zu", (unsigned long long)total, n);
-	if (top_hist) {   // cross-check the caller's histogram of the top byte against what the device counted
-		u64 chk[256] = {0};
-		for (int i = 0; i < 256; ++i)
-			chk[lut[i]] += top_hist[i];
-		for (u32 b = 0; b < nbuckets; ++b)
-			if (chk[b] != counts[b])
-				return fail(RSX_EINVAL, "rsx_partition_device: top_hist disagrees with the data for bucket %u", b);
-	}
-	RSX_DISPATCH_KT(dtype, RSX_TRY((scatter_pass<KT, NoVal>(*c, (const KT *)d_src, (KT *)d_dst, nullptr, nullptr, n,
-	                                                       (u32)(8 * (kb - 1)), (const u64 *)c->bbase.p,
-	                                                       make_kdf<KT>(dtype, order), SCATTER_USE_LUT, c->lut()))));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	                                              (u32 *)d_unsorted));
 	return RSX_OK;
 }
 
@@ -1748,40 +1702,11 @@ int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
-	const Geo g = one_segment(n);
-	const size_t hist_bytes = (size_t)g.nseg * kb * 256 * sizeof(u64);
+	const size_t hist_bytes = kb * 256 * sizeof(u64);
 	RSX_TRY(c->hist.ensure(hist_bytes));
 	HIP_TRY(hipMemsetAsync(c->hist.p, 0, hist_bytes, c->stream));
 	HIP_TRY(hipMemsetAsync(c->small.p, 0, 192, c->stream));
-	RSX_DISPATCH_KT(dtype, return msd_split<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, g, top_hist));
-	return RSX_OK;
-}
-
-// Test hook (not in include/rsx.h): runs the histogram + plan kernels exactly as a keys-only sort
-// would and returns the segment geometry and the per-(segment, column, digit) exclusive offsets.
-int rsx_debug_offsets(const void *d_src, size_t n, rsx_dtype dtype, rsx_order order, uint32_t *nseg, uint32_t *tiles_per_seg,
-                      uint64_t *seg_elems, uint64_t *offsets, size_t max_offsets, rsx_info *info)
-{
-	const size_t kb = dtype_size(dtype);
-	if (!kb || n < 2)
-		return fail(RSX_EINVAL, "rsx_debug_offsets: bad argument");
-	Ctx *c;
-	RSX_TRY(get_ctx(nullptr, &c));
-	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
-	info_clear(info, dtype);
-	const Geo g = one_segment(n);
-	Plan plan;
-	RSX_DISPATCH_KT(dtype, RSX_TRY(plan_phase<KT>(*c, (const KT *)d_src, n, make_kdf<KT>(dtype, order), g, &plan)));
-	info_from_plan(info, plan);
-	if (info && plan.sorted)
-		info->early_exit = 2;
-	*nseg = g.nseg;
-	*tiles_per_seg = g.tiles_per_seg;
-	*seg_elems = g.seg_elems;
-	const size_t cnt = (size_t)g.nseg * kb * 256;
-	if (cnt > max_offsets)
-		return fail(RSX_EINVAL, "rsx_debug_offsets: need room for %zu offsets", cnt);
-	HIP_TRY(hipMemcpy(offsets, c->ghist(), cnt * sizeof(u64), hipMemcpyDeviceToHost));
+	RSX_DISPATCH_KT(dtype, return msd_split<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, top_hist));
 	return RSX_OK;
 }
 

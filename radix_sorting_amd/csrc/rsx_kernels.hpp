@@ -66,197 +66,12 @@ __device__ __forceinline__ u32 mbcnt64(u64 m)
 }
 
 // =============================================================================
-// Segments (histogram / plan kernels)
-// =============================================================================
-// The histogram can be kept per contiguous segment of the input: counts[seg][column][256] (u64),
-// turned by the plan kernel into the exclusive offset of (segment, digit).  The sort itself runs
-// with one segment (per-segment counts of the input order are only valid for the first pass);
-// the MSD split of the multi-GPU path uses the same kernels.
-
-// =============================================================================
-// Kernel 1: histogram of all columns + pre-sorted test
+// Kernel 1: histogram of all columns + pre-sorted test: rsx_hist.hpp
 // =============================================================================
 
-// Measured on MI355X, 2^28 u32 (tools/ubench/hist_probe.hip): the kernel is bound by the LDS atomics (four per key,
-// about ten cycles per wave-instruction and CU), so what matters is a full CU (32 waves = two workgroups of 1024), few
-// workgroups, and no more than two or three 16-byte loads in flight per lane (0.23-0.27 ms; four: 0.32; 2048
-// workgroups of 256: 0.36).
-template <typename KT, int BLOCK_ = 1024, int U_ = 2, int R_ = (sizeof(KT) == 8 ? 8 : 16)> struct HistCfg {
-	static constexpr int WC = sizeof(KT);               // columns
-	static constexpr int VEC = 16 / sizeof(KT);         // elements per 16-byte lane load
-	static constexpr int R = R_;                        // lane-striped copies per bin
-	static constexpr int BLOCK = BLOCK_;
-	static constexpr int U = U_;                        // independent 16-byte loads in flight per lane
-};
-
-template <typename KT, int R>
-__device__ __forceinline__ void hist_add_one(u32 *lh, KT k, u32 lane, u32 colmask)
-{
-#pragma unroll
-	for (int j = 0; j < (int)sizeof(KT); ++j) {
-		if (!((colmask >> j) & 1u))
-			continue;
-		const u32 d = (u32)(k >> (8 * j)) & 0xFFu;
-		atomicAdd(&lh[(j * 256 + d) * R + (lane & (R - 1))], 1u);
-	}
-}
-
-// grid = nseg * blocks_per_seg.  With nseg > 1 the host guarantees that src is 16-byte aligned
-// and seg_elems is a multiple of VEC.
-template <typename KT, typename C = HistCfg<KT>>
-__global__ __launch_bounds__(C::BLOCK) void rsx_hist_kernel(const KT *__restrict__ src, u64 n, u32 *__restrict__ partial,
-                                                            u32 *__restrict__ unsorted, KdfArgs<KT> ka, u32 nseg,
-                                                            u32 blocks_per_seg, u64 seg_elems, u32 colmask = ~0u,
-                                                            u64 *__restrict__ direct = nullptr)
-{
-	// colmask: the columns to count (the MSD split of the multi-GPU path wants one: a quarter of the LDS atomics)
-	constexpr int WC = C::WC, VEC = C::VEC, R = C::R, U = C::U;
-	__shared__ u32 lh[WC * 256 * R];
-	__shared__ u32 s_descent;
-	const u32 tid = threadIdx.x;
-	const u32 lane = tid & 63;
-	const u32 seg = blockIdx.x / blocks_per_seg, bis = blockIdx.x % blocks_per_seg;
-	for (u32 i = tid; i < WC * 256 * R; i += C::BLOCK)
-		lh[i] = 0;
-	if (tid == 0)
-		s_descent = 0;
-	__syncthreads();
-
-	// elements before the first 16-byte boundary (single-segment launches only) and after the last full vector
-	u64 head = nseg > 1 ? 0 : ((16 - ((uintptr_t)src & 15)) & 15) / sizeof(KT);
-	if (head > n)
-		head = n;
-	const u64 nvec = (n - head) / VEC;
-	const u64 tail_begin = head + nvec * VEC;
-	const u64 vbeg = nseg > 1 ? (u64)seg * (seg_elems / VEC) : 0;
-	u64 vend = nseg > 1 ? vbeg + seg_elems / VEC : nvec;
-	if (vend > nvec)
-		vend = nvec;
-	bool descent = false;
-
-	if (bis == 0 && (seg == 0 || seg == nseg - 1)) {
-		// scalar fringe (< 2*VEC elements): the head belongs to segment 0, the tail to the last segment
-		const u64 nhead = seg == 0 ? head : 0;
-		const u64 ntail = seg == nseg - 1 ? n - tail_begin : 0;
-		for (u64 i = tid; i < nhead + ntail; i += C::BLOCK) {
-			const u64 e = i < nhead ? i : tail_begin + (i - nhead);
-			const KT k = kdf_apply(src[e], ka);
-			if (e + 1 < n && k > kdf_apply(src[e + 1], ka))
-				descent = true;
-			hist_add_one<KT, R>(lh, k, lane, colmask);
-		}
-	}
-
-	typedef KT vec_t __attribute__((ext_vector_type(VEC)));
-	const vec_t *vsrc = (const vec_t *)(src + head);
-	const u64 stride = (u64)blocks_per_seg * (C::BLOCK * U);
-	for (u64 v0 = vbeg + (u64)bis * (C::BLOCK * U) + tid; v0 < vend; v0 += stride) {
-		vec_t raw[U];
-#pragma unroll
-		for (int u = 0; u < U; ++u) {
-			const u64 v = v0 + (u64)u * C::BLOCK;
-			if (v < vend)
-				raw[u] = vsrc[v];
-		}
-#pragma unroll
-		for (int u = 0; u < U; ++u) {
-			const u64 v = v0 + (u64)u * C::BLOCK;
-			if (v >= vend)
-				break;
-			KT k[VEC];
-#pragma unroll
-			for (int e = 0; e < VEC; ++e)
-				k[e] = kdf_apply((KT)raw[u][e], ka);
-
-			// pre-sorted test (radix_sort.hpp:51-54): inside the vector, then against the
-			// next element, which the next lane holds except at the wave's right edge.
-#pragma unroll
-			for (int e = 0; e + 1 < VEC; ++e)
-				descent |= k[e] > k[e + 1];
-			KT nxt;
-			if (sizeof(KT) == 8) {
-				const u32 lo = __shfl_down((u32)k[0], 1), hi = __shfl_down((u32)((u64)k[0] >> 32), 1);
-				nxt = (KT)(((u64)hi << 32) | lo);
-			} else {
-				nxt = (KT)__shfl_down((u32)k[0], 1);
-			}
-			const u64 next_elem = head + (v + 1) * VEC;
-			const bool edge = lane == 63 || v + 1 >= vend;  // the next lane is idle or holds another row
-			if (edge)
-				nxt = next_elem < n ? kdf_apply(src[next_elem], ka) : k[VEC - 1];
-			descent |= k[VEC - 1] > nxt;
-
-			// histogram.  A column whose digit is identical across the whole wave (the
-			// column-skip case, radix_sort.hpp:64-70) is counted by one lane.
-			const KT first = (KT)(sizeof(KT) == 8
-			                          ? (((u64)__builtin_amdgcn_readfirstlane((u32)((u64)k[0] >> 32)) << 32) |
-			                             __builtin_amdgcn_readfirstlane((u32)k[0]))
-			                          : __builtin_amdgcn_readfirstlane((u32)k[0]));
-			KT diff = 0;
-#pragma unroll
-			for (int e = 0; e < VEC; ++e)
-				diff |= (KT)(k[e] ^ first);
-			const u64 active = __ballot(1);
-#pragma unroll
-			for (int j = 0; j < WC; ++j) {
-				if (!((colmask >> j) & 1u))
-					continue;
-				const bool differs = ((u32)(diff >> (8 * j)) & 0xFFu) != 0;
-				if (__any(differs)) {
-#pragma unroll
-					for (int e = 0; e < VEC; ++e) {
-						const u32 d = (u32)(k[e] >> (8 * j)) & 0xFFu;
-						atomicAdd(&lh[(j * 256 + d) * R + (lane & (R - 1))], 1u);
-					}
-				} else if (mbcnt64(active) == 0) {
-					const u32 d = (u32)(first >> (8 * j)) & 0xFFu;
-					atomicAdd(&lh[(j * 256 + d) * R], (u32)(VEC * __popcll(active)));
-				}
-			}
-		}
-	}
-
-	// One flag for the whole array: on unsorted input every wave has seen a descent, and 8192 atomics on one address
-	// serialise to about 80 us however small n is.  So: one vote per workgroup, and only while the flag is still clear.
-	if (__any(descent) && mbcnt64(__ballot(1)) == 0)
-		s_descent = 1;
-
-	// The workgroup's counts go to its own row of `partial` (plain stores; rsx_hist_reduce_kernel adds the rows up).
-	__syncthreads();
-	if (tid == 0 && s_descent && __hip_atomic_load(unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-		atomicOr(unsorted, 1u);
-	// `direct` (few workgroups): the counts are added to the segment's histogram at once, no reduce launch follows
-	u32 *row = partial + (u64)blockIdx.x * (WC * 256);
-	for (u32 i = tid; i < WC * 256; i += C::BLOCK) {
-		u32 s = 0;
-#pragma unroll
-		for (int r = 0; r < R; ++r)
-			s += lh[i * R + r];
-		if (direct) {
-			if (s)
-				atomicAdd(&direct[(u64)seg * (WC * 256) + i], (u64)s);
-		} else {
-			row[i] = s;
-		}
-	}
-}
-
-// counts[seg][i] += sum over the segment's workgroups of partial[row][i].  grid = (nseg * cols256 / 256, HIST_REDUCE_SPLIT):
-// blockIdx.y takes every HIST_REDUCE_SPLIT-th row, all its loads in flight at once, and adds its share with one global
-// atomic per bin (32 per address instead of one per histogram workgroup); `ghist` is zeroed by the caller.
-constexpr u32 HIST_REDUCE_SPLIT = 32;
-__global__ __launch_bounds__(256) void rsx_hist_reduce_kernel(const u32 *__restrict__ partial, u64 *__restrict__ ghist,
-                                                              u32 blocks_per_seg, u32 cols256)
-{
-	const u32 per_seg = cols256 / 256, seg = blockIdx.x / per_seg, i = (blockIdx.x % per_seg) * 256 + threadIdx.x;
-	const u32 *p = partial + (u64)seg * blocks_per_seg * cols256 + i;
-	u64 s = 0;
-#pragma unroll 16
-	for (u32 b = blockIdx.y; b < blocks_per_seg; b += HIST_REDUCE_SPLIT)
-		s += p[(u64)b * cols256];
-	if (s)
-		atomicAdd(&ghist[(u64)seg * cols256 + i], s);
-}
+}  // namespace rsx
+#include "rsx_hist.hpp"
+namespace rsx {
 
 // =============================================================================
 // Kernel 2: column-skip probe + exclusive scan
@@ -297,15 +112,14 @@ __device__ __forceinline__ void wave_scan_256(u64 *vals, u64 *lsum, u32 lane)
 	}
 }
 
-// One workgroup (256 threads, thread = digit) per column.  ghist[seg][col][256] holds counts on
-// entry; on exit the exclusive offset of (segment, digit): every key with a smaller digit, plus the
-// keys with the same digit in earlier segments -- the reference's exclusive scan
-// (radix_sort.hpp:72-80) refined by segment.  kept[col] answers the column-skip probe (:64-70).
+// One workgroup (256 threads, thread = digit) per column.  ghist[col][256] holds counts on entry; on exit the
+// exclusive offset of the digit: every key with a smaller digit -- the reference's exclusive scan
+// (radix_sort.hpp:72-80).  kept[col] answers the column-skip probe (:64-70).
 __device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan);
 
 template <typename KT>
 __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
-                                                       u32 nseg, KdfArgs<KT> ka, u32 *__restrict__ kept,
+                                                       KdfArgs<KT> ka, u32 *__restrict__ kept,
                                                        u32 *__restrict__ hotd = nullptr, u32 *done = nullptr,
                                                        const u32 *unsorted = nullptr, Plan *plan = nullptr,
                                                        Plan *host_plan = nullptr)
@@ -315,11 +129,8 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 	__shared__ u64 lsum[64];
 	const u32 d = threadIdx.x, col = blockIdx.x;
 	u64 *h = ghist + 256 * col + d;
-	const u64 seg_stride = (u64)WC * 256;
 
-	u64 total = 0;
-	for (u32 s = 0; s < nseg; ++s)
-		total += h[s * seg_stride];
+	const u64 total = *h;
 	const KT key0 = kdf_apply(src[0], ka);                         // radix_sort.hpp:65
 	if (d == ((u32)(key0 >> (8 * col)) & 0xFFu))
 		kept[col] = total != n;                                    // radix_sort.hpp:67
@@ -343,12 +154,7 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 	if (d < 64)
 		wave_scan_256(tot, lsum, d);                               // radix_sort.hpp:74-79
 	__syncthreads();
-	u64 running = tot[d];
-	for (u32 s = 0; s < nseg; ++s) {
-		const u64 t = h[s * seg_stride];
-		h[s * seg_stride] = running;
-		running += t;
-	}
+	*h = tot[d];
 	// `done` (zeroed by the caller): the block that finishes last writes the plan (no launch of its own for that)
 	if (done) {
 		__shared__ u32 s_last;
@@ -390,37 +196,6 @@ __device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *
 }
 
 
-// Bucket offsets for the MSD split: bucket = lut[digit of column `col`].  cnt[seg][col][256]
-// (counts) -> bbase[seg][256] exclusive offsets of (segment, bucket), totals[256] bucket sizes.
-__global__ __launch_bounds__(256) void rsx_lut_plan_kernel(const u64 *__restrict__ cnt, u32 nseg, u32 seg_stride,
-                                                           u32 col_ofs, const uint8_t *__restrict__ lut,
-                                                           u64 *__restrict__ bbase, u64 *__restrict__ totals)
-{
-	__shared__ u64 bucket[256];
-	__shared__ u64 lsum[64];
-	const u32 t = threadIdx.x;
-	const u32 my_bucket = lut[t];
-	u64 running = 0;   // thread t as bucket: keys of bucket t in earlier segments
-	for (u32 s = 0; s < nseg; ++s) {
-		bucket[t] = 0;
-		__syncthreads();
-		atomicAdd(&bucket[my_bucket], cnt[(u64)s * seg_stride + col_ofs + t]);
-		__syncthreads();
-		bbase[(u64)s * 256 + t] = running;
-		running += bucket[t];
-		__syncthreads();
-	}
-	totals[t] = running;
-	bucket[t] = running;
-	__syncthreads();
-	if (t < 64)
-		wave_scan_256(bucket, lsum, t);
-	__syncthreads();
-	const u64 base = bucket[t];
-	for (u32 s = 0; s < nseg; ++s)
-		bbase[(u64)s * 256 + t] += base;
-}
-
 // =============================================================================
 // Kernel 3: one stable scatter pass (onesweep)
 // =============================================================================
@@ -439,7 +214,6 @@ enum : u32 { ST_EMPTY = 0, ST_AGGREGATE = 1, ST_PREFIX = 2 };
 enum : u32 {
 	SCATTER_GEN_INDEX = 1,   // payload of element i is i (first rank pass, radix_sort_rank.hpp:52)
 	SCATTER_SKIP_KEYS = 2,   // do not write keys (last rank pass: only the indices are wanted)
-	SCATTER_USE_LUT = 4,     // bucket = lut[digit] (MSD split for the multi-GPU sort)
 	SCATTER_COL_SHIFT = 12,  // bits 12-14: the pass's column (HOT kernels: which word of hotd; the shift no longer tells once a rank sort has narrowed its keys)
 	SCATTER_HOT = 16,        // host side only: one digit holds an eighth of the keys or more -> the HOT kernels (rsx_scatter2.hpp)
 	SCATTER_DBG_LINEAR = 64, // probe only: write the staged tile back to its own position (no scatter)
@@ -501,11 +275,9 @@ template <typename KT, typename VT, typename ST, typename SH> struct ScatterSmem
 };
 
 template <typename KT>
-__device__ __forceinline__ u32 digit_of(KT raw, const KdfArgs<KT> ka, u32 shift, u32 flags, const uint8_t *__restrict__ lut)
+__device__ __forceinline__ u32 digit_of(KT raw, const KdfArgs<KT> ka, u32 shift)
 {
 	u32 d = (u32)(kdf_apply(raw, ka) >> shift) & 0xFFu;
-	if (flags & SCATTER_USE_LUT)
-		d = lut[d];
 	return d;
 }
 
@@ -543,7 +315,7 @@ template <typename KT, typename VT, typename ST, typename SH, bool FULL, bool TL
 __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, const KT *__restrict__ kin, KT *__restrict__ kout,
                                              const VT *__restrict__ vin, VT *__restrict__ vout, const u32 tile,
                                              const u64 tile_base, const u32 tile_count, const u32 shift, u64 &running,
-                                             const KdfArgs<KT> ka, const u32 flags, const uint8_t *__restrict__ lut, u64 *tl)
+                                             const KdfArgs<KT> ka, const u32 flags, u64 *tl)
 {
 	typedef ScatterCfg<KT, VT, SH> C;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, CHUNK = C::CHUNK;
@@ -581,7 +353,7 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 #pragma unroll
 		for (int r = 0; r < KPT; ++r) {
 			const bool valid = FULL || (wofs + r * 64 < tile_count);
-			const u32 d = digit_of(key[r], ka, shift, flags, lut);
+			const u32 d = digit_of(key[r], ka, shift);
 			if (valid) {
 				const u32 sh = (d & 1u) * 16u;
 				const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -613,7 +385,7 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 #pragma unroll
 		for (int r = 0; r < KPT; ++r) {
 			const bool valid = FULL || (wofs + r * 64 < tile_count);
-			const u32 d = digit_of(key[r], ka, shift, flags, lut);
+			const u32 d = digit_of(key[r], ka, shift);
 			if (valid) {
 				u32 *slot = &tab[d].mask_lo;
 				__hip_atomic_fetch_or(slot + half, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -684,7 +456,7 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 #pragma unroll
 	for (int r = 0; r < KPT; ++r) {
 		const bool valid = FULL || (wofs + r * 64 < tile_count);
-		const u32 d = digit_of(key[r], ka, shift, flags, lut);
+		const u32 d = digit_of(key[r], ka, shift);
 		const u32 pos = (u32)wb[d] + ((rkp[r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
 		if constexpr (HAS_VAL)
 			rkp[r >> 1] = (rkp[r >> 1] & ~(0xFFFFu << (16 * (r & 1)))) | (pos << (16 * (r & 1)));
@@ -715,7 +487,7 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 		}
 #pragma unroll
 		for (int e = 0; e < CHUNK; ++e)
-			d[e] = digit_of(kv[e], ka, shift, flags, lut);
+			d[e] = digit_of(kv[e], ka, shift);
 		if constexpr (HAS_VAL) {
 			u32 p = 0;
 #pragma unroll
@@ -799,8 +571,7 @@ __device__ __forceinline__ void scatter_tile(ScatterSmem<KT, VT, ST, SH> &sm, co
 template <typename KT, typename VT, typename ST, typename SH = DefaultShape<KT, VT>, bool TL = false>
 __global__ __launch_bounds__(SH::NWAVES * 64, (SH::NWAVES * SH::OCC + 3) / 4) void rsx_scatter_kernel(
 	const KT *__restrict__ kin, KT *__restrict__ kout, const VT *__restrict__ vin, VT *__restrict__ vout, u64 n, u32 shift,
-	const u64 *__restrict__ gbase, u32 tps, ST *status, u32 *ticket, KdfArgs<KT> ka, u32 flags,
-	const uint8_t *__restrict__ lut, u64 *tl)
+	const u64 *__restrict__ gbase, u32 tps, ST *status, u32 *ticket, KdfArgs<KT> ka, u32 flags, u64 *tl)
 {
 	typedef ScatterCfg<KT, VT, SH> C;
 	typedef StatusBits<ST> SB;
@@ -839,7 +610,7 @@ __global__ __launch_bounds__(SH::NWAVES * 64, (SH::NWAVES * SH::OCC + 3) / 4) vo
 				for (int r = 0; r < PA; ++r) {
 					const u32 o = wofs + (r0 + r) * 64;
 					if (o < cnt)
-						atomicAdd(&hist[digit_of(cur[r], ka, shift, flags, lut) * HR + (lane & (HR - 1))], 1u);
+						atomicAdd(&hist[digit_of(cur[r], ka, shift) * HR + (lane & (HR - 1))], 1u);
 				}
 			}
 		}
@@ -909,10 +680,10 @@ __global__ __launch_bounds__(SH::NWAVES * 64, (SH::NWAVES * SH::OCC + 3) / 4) vo
 		const u32 tile_count = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
 		if (tile_count == (u32)C::TILE)
 			scatter_tile<KT, VT, ST, SH, true, TL>(sm, kin, kout, vin, vout, tile, base, tile_count, shift, running, ka, flags,
-			                                       lut, tl);
+			                                       tl);
 		else
 			scatter_tile<KT, VT, ST, SH, false, TL>(sm, kin, kout, vin, vout, tile, base, tile_count, shift, running, ka, flags,
-			                                        lut, tl);
+			                                        tl);
 		__syncthreads();   // staging reads done before the next tile's counters / tables are reset
 	}
 }

@@ -64,21 +64,21 @@ template <typename KT, typename VT, typename ST, typename C> struct Sc2Smem {
 	u32 ticket;
 };
 
-// DIG_PLAIN: the key is its own KDF (unsigned, ascending) and there is no bucket table: the digit is one
-// bit-field extract.  DIG_GENERIC: kdf_apply + optional lut, as in rsx_scatter_kernel.
-// DIG_XOR: integer keys of either sign and order (no float mask, no bucket table): the KDF only complements fixed bits,
+// DIG_PLAIN: the key is its own KDF (unsigned, ascending): the digit is one
+// bit-field extract.  DIG_GENERIC: kdf_apply, as in rsx_scatter_kernel.
+// DIG_XOR: integer keys of either sign and order (no float mask): the KDF only complements fixed bits,
 // so the digit is the plain bit field XOR one per-pass constant (0x80 on a signed key's top byte, 0xFF when descending).
 enum { DIG_GENERIC = 0, DIG_PLAIN = 1, DIG_XOR = 2 };
 
 template <int DIG, typename KT>
-__device__ __forceinline__ u32 digit2(KT raw, const KdfArgs<KT> ka, u32 shift, u32 flags, const uint8_t *__restrict__ lut)
+__device__ __forceinline__ u32 digit2(KT raw, const KdfArgs<KT> ka, u32 shift)
 {
 	if constexpr (DIG == DIG_PLAIN)
 		return (u32)(raw >> shift) & 0xFFu;
 	else if constexpr (DIG == DIG_XOR)
 		return ((u32)(raw >> shift) & 0xFFu) ^ ((u32)((ka.sflip ^ ka.desc) >> shift) & 0xFFu);   // (the constant is scalar arithmetic)
 	else
-		return digit_of(raw, ka, shift, flags, lut);
+		return digit_of(raw, ka, shift);
 }
 
 // ---- hot digits (HOT kernels) -----------------------------------------------------------------------------------------
@@ -101,8 +101,7 @@ template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bo
 __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__restrict__ kin, KTO *__restrict__ kout,
                                                                  const VT *__restrict__ vin, VT *__restrict__ vout, u64 n,
                                                                  u32 shift, const u64 *__restrict__ gbase, u32 tps, ST *status,
-                                                                 u32 *ticket, KdfArgs<KT> ka, u32 flags,
-                                                                 const uint8_t *__restrict__ lut, u64 *tl,
+                                                                 u32 *ticket, KdfArgs<KT> ka, u32 flags, u64 *tl,
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
                                                                  u32 oshift = 0, const u32 *__restrict__ hotd = nullptr)
 {
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 							keep[r] = scratch[r * 64 + lane];
 #pragma unroll
 						for (int r = i * VEC; r < (i + 1) * VEC; ++r) {
-							const u32 d = digit2<DIG>(keep[r], ka, shift, flags, lut);
+							const u32 d = digit2<DIG>(keep[r], ka, shift);
 							if constexpr (C::CELL16) {
 								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 							} else if constexpr (HOT) {
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					for (int i = 0; i < NV; ++i) {
 #pragma unroll
 						for (int e = 0; e < VEC; ++e) {
-							const u32 d = digit2<DIG>((KT)v[i][e], ka, shift, flags, lut);
+							const u32 d = digit2<DIG>((KT)v[i][e], ka, shift);
 							if constexpr (C::CELL16)
 								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 							else
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				for (int r = 0; r < KPT; ++r) {
 					const u32 o = wo + r * 64;
 					if (o < cnt) {
-						const u32 d = digit2<DIG>(keep[r], ka, shift, flags, lut);
+						const u32 d = digit2<DIG>(keep[r], ka, shift);
 						if constexpr (C::CELL16)
 							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 						else
@@ -291,7 +290,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					for (int r = 0; r < SB; ++r) {
 						const u32 o = wo + (r0 + r) * 64;
 						if (o < cnt) {
-							const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
+							const u32 d = digit2<DIG>(cur[r], ka, shift);
 							if constexpr (C::CELL16)
 								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 							else
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				const u32 o = wo + (r0 + r) * 64;
 				pos[r] = 0;
 				if (full || o < cnt) {
-					const u32 d = digit2<DIG>(cur[r], ka, shift, flags, lut);
+					const u32 d = digit2<DIG>(cur[r], ka, shift);
 					if constexpr (C::CELL16) {
 						const u32 sh = (d & 1u) * 16u;
 						const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -548,7 +547,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			}
 #pragma unroll
 			for (int e = 0; e < CHUNK; ++e)
-				d[e] = digit2<DIG>(kv[e], ka, shift, flags, lut);
+				d[e] = digit2<DIG>(kv[e], ka, shift);
 			if constexpr (HAS_VAL) {
 				u32 p = 0;
 #pragma unroll

@@ -84,25 +84,6 @@ class HipEngine:
         self.dtype = dtype
         self.order = order
         self.kb = DTYPE_SIZE[dtype]
-        self._hist = None
-        self._flag = None
-
-    def top_histogram(self, shard):
-        torch = self.torch
-        if self._hist is None:
-            self._hist = torch.zeros(256 * self.kb, dtype=torch.int64, device=shard.device)
-            self._flag = torch.zeros(1, dtype=torch.int32, device=shard.device)
-        check(lib().rsx_histogram_device(shard.data_ptr(), shard.numel(), self.dtype, self.order,
-                                         self._hist.data_ptr(), self._flag.data_ptr(), _stream_ptr()))
-        return self._hist[256 * (self.kb - 1):].clone()      # counts of the top KDF byte, on device
-
-    def partition(self, shard, out, lut, world, top_hist_host):
-        counts = np.zeros(world, dtype=np.uint64)
-        lut = np.ascontiguousarray(lut, dtype=np.uint8)
-        th = np.ascontiguousarray(top_hist_host, dtype=np.uint64)
-        check(lib().rsx_partition_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order,
-                                         lut.ctypes.data, world, th.ctypes.data, counts.ctypes.data, _stream_ptr()))
-        return counts
 
     def msd_split(self, shard, out, column=-1):
         """out = shard in stable order of KDF byte `column` (-1: the top one), enqueued; returns the byte's 256 counts (host)."""

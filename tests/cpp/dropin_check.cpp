@@ -3,6 +3,7 @@
 // (radix_tests.cpp:45-207 shapes, radix_experiment.cpp:205), but checks exact results: stable order,
 // returned-pointer parity, untouched aux on the early exits.  Needs a GPU; run by tests/test_gpu_cpp.py.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,140 @@ struct sortrec {
 };
 static const sortrec source_arr[] = {{255, "1st 255"}, {45, "1st 45"}, {3, "3"},  {45, "2nd 45"},
                                      {2, "2"},         {45, "3rd 45"}, {1, "1"}, {255, "2nd 255"}};
+
+// ---- KeyFuncs that are plain functions (the reference takes any callable, radix_sort.hpp:98-99; the shapes of
+// radix_tests.cpp:111-113,:175-177 written as free functions).  Each has the TYPE of the default basic_kdfs::kdf<T>.
+static uint32_t fn_u32_desc(const uint32_t &v) { return ~v; }
+static uint32_t fn_u32_flip(const uint32_t &v) { return v ^ 0x80000000u; }
+static uint32_t fn_u32_ident(const uint32_t &v) { return v; }
+static uint32_t fn_i32_desc(const int32_t &v) { return ~((uint32_t)v ^ 0x80000000u); }
+static uint32_t fn_i32_plain(const int32_t &v) { return (uint32_t)v; }              // orders negatives after positives
+static uint32_t fn_f32_desc(const float &v) { return ~basic_kdfs::kdf(v); }
+static uint32_t fn_f32_bits(const float &v) { uint32_t u; std::memcpy(&u, &v, 4); return u; }
+static uint64_t fn_u64_desc(const uint64_t &v) { return ~v; }
+
+// radix_sort and radix_sort_rank with `fn` passed as a function, as a function pointer and wrapped in a lambda must all
+// give std::stable_sort's order by fn
+template <typename T, typename K>
+static void check_free_function(K (&fn)(const T &), size_t n, uint64_t mask, unsigned seed)
+{
+	std::mt19937_64 rng(seed);
+	std::vector<T> in(n);
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t bits = rng() & mask;
+		std::memcpy(&in[i], &bits, sizeof(T));
+	}
+	std::vector<T> want = in;
+	std::stable_sort(want.begin(), want.end(), [&](const T &a, const T &b) { return fn(a) < fn(b); });
+	std::vector<uint32_t> wr(n);
+	std::iota(wr.begin(), wr.end(), 0u);
+	std::stable_sort(wr.begin(), wr.end(), [&](uint32_t a, uint32_t b) { return fn(in[a]) < fn(in[b]); });
+	{
+		std::vector<T> src = in, aux(n);
+		T *res = radix_sort(src.data(), aux.data(), n, fn);                  // KeyFunc = K (&)(const T &)
+		CHECK(std::memcmp(res, want.data(), n * sizeof(T)) == 0);
+	}
+	{
+		std::vector<T> src = in, aux(n);
+		K (*fp)(const T &) = fn;
+		T *res = radix_sort(src.data(), aux.data(), n, fp);                  // KeyFunc = K (*&)(const T &)
+		CHECK(std::memcmp(res, want.data(), n * sizeof(T)) == 0);
+		T *res2 = radix_sort(src.data(), aux.data(), 0, &fn);                // rvalue pointer, n = 0
+		CHECK(res2 == src.data());
+	}
+	{
+		std::vector<uint32_t> ib(2 * n);
+		uint32_t *ranks = radix_sort_rank(in.data(), ib.data(), n, fn);
+		CHECK(std::memcmp(ranks, wr.data(), n * 4) == 0);
+		K (*fp)(const T &) = fn;
+		std::vector<uint32_t> ib2(2 * n);
+		uint32_t *ranks2 = radix_sort_rank(in.data(), ib2.data(), n, fp);
+		CHECK(std::memcmp(ranks2, wr.data(), n * 4) == 0);
+	}
+}
+
+// FNV-1a-64 (as oracle/rs_oracle.c, rso_fnv1a64) and the splitmix64 generator of SURVEY.md section 4
+static uint64_t fnv1a64(const void *p, size_t bytes)
+{
+	uint64_t h = 0xcbf29ce484222325ull;
+	for (size_t i = 0; i < bytes; ++i)
+		h = (h ^ ((const unsigned char *)p)[i]) * 0x100000001b3ull;
+	return h;
+}
+template <typename T> static std::vector<T> splitmix_fill(size_t n, uint64_t seed, uint64_t mask)
+{
+	std::vector<T> a(n);
+	uint64_t st = seed;
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z = (z ^ (z >> 31)) & mask;
+		std::memcpy(&a[i], &z, sizeof(T));
+	}
+	return a;
+}
+
+// rs_sort_main / rs_sort_rank with the caller's Hist (radix_sort.hpp:28-33): prints what is left in the histogram storage
+// as "HIST <dtype code> <n> <seed> <mask> <presorted> <hvt bytes> <fnv of result> <in_aux> <fnv of the Hist as uint64>";
+// tests/test_gpu_cpp.py compares the lines with tests/golden/kat_table.json (hist_post: generated from the real reference).
+template <typename T, typename HVT, typename Hist>
+static void hist_row(int dtype_code, size_t n, uint64_t seed, uint64_t mask, int presorted, Hist &hist)
+{
+	std::vector<T> src = splitmix_fill<T>(n, seed, mask), aux(n);
+	if (presorted)
+		std::stable_sort(src.begin(), src.end(), [](const T &a, const T &b) { return basic_kdfs::kdf(a) < basic_kdfs::kdf(b); });
+	const std::vector<T> in = src;
+	T *res = rs_sort_main(src.data(), aux.data(), n, hist);
+	std::vector<uint64_t> h64(256 * sizeof(T));
+	for (size_t i = 0; i < h64.size(); ++i)
+		h64[i] = hist[i];
+	printf("HIST %d %zu %llu %016llx %d %zu %016llx %d %016llx\n", dtype_code, n, (unsigned long long)seed, (unsigned long long)mask,
+	       presorted, sizeof(HVT), (unsigned long long)fnv1a64(res, n * sizeof(T)), res == aux.data() ? 1 : 0,
+	       (unsigned long long)fnv1a64(h64.data(), h64.size() * 8));
+	// rs_sort_rank leaves the same histogram (radix_sort_rank.hpp:44-88 has the same three loops) ...
+	std::vector<HVT> hr(256 * sizeof(T), 0);
+	std::vector<size_t> ib(2 * n + 1);
+	size_t *ranks = rs_sort_rank(in.data(), ib.data(), n, hr);
+	bool same = true;
+	for (size_t i = 0; i < h64.size(); ++i)
+		same &= (uint64_t)hr[i] == h64[i];
+	CHECK(same);
+	// ... and its ranks are the stable argsort
+	std::vector<size_t> wr(n);
+	std::iota(wr.begin(), wr.end(), (size_t)0);
+	std::stable_sort(wr.begin(), wr.end(), [&](size_t a, size_t b) { return basic_kdfs::kdf(in[a]) < basic_kdfs::kdf(in[b]); });
+	CHECK(n == 0 || std::memcmp(ranks, wr.data(), n * sizeof(size_t)) == 0);
+}
+
+template <typename T> static void hist_rows(int dtype_code)
+{
+	const uint64_t FULL = ~0ull, seed = 40 + dtype_code;   // tools/gen_golden.py, HIST_ROWS
+	{
+		std::array<uint8_t, 256 * sizeof(T)> h{};           // n < 256: radix_sort.hpp:103-105
+		hist_row<T, uint8_t>(dtype_code, 200, seed, FULL, 0, h);
+	}
+	{
+		std::array<uint16_t, 256 * sizeof(T)> h{};
+		hist_row<T, uint16_t>(dtype_code, 3000, seed, FULL, 0, h);
+	}
+	{
+		std::vector<uint32_t> h(256 * sizeof(T), 0);
+		hist_row<T, uint32_t>(dtype_code, 100000, seed, FULL, 0, h);
+	}
+	{
+		std::array<uint32_t, 256 * sizeof(T)> h{};
+		hist_row<T, uint32_t>(dtype_code, 100000, seed, 0x00FFFF00FF00FFFFull, 0, h);
+	}
+	{
+		std::vector<uint16_t> h(256 * sizeof(T), 0);
+		hist_row<T, uint16_t>(dtype_code, 5000, seed, FULL, 1, h);
+	}
+	{
+		std::vector<uint16_t> h(256 * sizeof(T), 0);
+		hist_row<T, uint16_t>(dtype_code, 300, seed, 0xFF, 0, h);
+	}
+}
 
 template <typename T>
 static void check_scalar(size_t n, uint64_t mask, unsigned seed)
@@ -320,6 +455,48 @@ int main()
 		float *d2 = radix_sort(g.data(), gaux.data(), N, rsx_kdf::descending<float>());
 		CHECK(std::memcmp(d1, d2, N * sizeof(float)) == 0);
 		CHECK(d1[0] >= d1[N - 1]);
+	}
+	// a plain function as KeyFunc has the default KDF's type but not its order (radix_sort.hpp:98-99 takes any callable)
+	check_free_function<uint32_t>(fn_u32_desc, 100003, 0xFFFFFFFFull, 21);
+	check_free_function<uint32_t>(fn_u32_flip, 70001, 0xFFFFFFFFull, 22);
+	check_free_function<uint32_t>(fn_u32_ident, 70001, 0x00FFFFFFull, 23);
+	check_free_function<uint32_t>(fn_u32_desc, 300, 0xFFFFull, 24);
+	check_free_function<int32_t>(fn_i32_desc, 100003, 0xFFFFFFFFull, 25);
+	check_free_function<int32_t>(fn_i32_plain, 5000, 0xFFFFFFFFull, 26);
+	check_free_function<float>(fn_f32_desc, 100003, 0xFFFFFFFFull, 27);
+	check_free_function<float>(fn_f32_bits, 65536, 0xFFF000FFull, 28);
+	check_free_function<uint64_t>(fn_u64_desc, 50000, 0xFFFFFFFFFFull, 29);
+	{
+		// ... while the default itself, named explicitly as a function or through a pointer, stays the default
+		std::vector<int32_t> a = splitmix_fill<int32_t>(50001, 5, ~0ull), aux(a.size()), want = a;
+		std::sort(want.begin(), want.end());
+		int32_t *r = radix_sort(a.data(), aux.data(), a.size(), basic_kdfs::kdf<int32_t>);
+		CHECK(std::memcmp(r, want.data(), a.size() * 4) == 0);
+		std::vector<int32_t> b = splitmix_fill<int32_t>(50001, 5, ~0ull);
+		auto *fp = &basic_kdfs::kdf<int32_t>;
+		r = radix_sort(b.data(), aux.data(), b.size(), fp);
+		CHECK(std::memcmp(r, want.data(), b.size() * 4) == 0);
+	}
+	// rs_sort_main / rs_sort_rank with caller-supplied histogram storage (std::array and std::vector; radix_sort.hpp:28-33)
+	hist_rows<uint8_t>(0);
+	hist_rows<uint16_t>(1);
+	hist_rows<uint32_t>(2);
+	hist_rows<uint64_t>(3);
+	hist_rows<int8_t>(4);
+	hist_rows<int16_t>(5);
+	hist_rows<int32_t>(6);
+	hist_rows<int64_t>(7);
+	hist_rows<float>(8);
+	hist_rows<double>(9);
+	{
+		// a lambda KeyFunc with a caller's Hist: one column of a record
+		const size_t N = sizeof(source_arr) / sizeof(source_arr[0]);
+		std::vector<sortrec> src(source_arr, source_arr + N), aux(N);
+		std::array<uint8_t, 256> h{};
+		auto kdf_sortrec = [](const sortrec &e) -> uint8_t { return e.key; };
+		sortrec *res = rs_sort_main(src.data(), aux.data(), N, h, kdf_sortrec);
+		CHECK(res == aux.data());
+		CHECK(h[0] == 0 && h[1] == 1 && h[2] == 2 && h[3] == 3 && h[44] == 3 && h[45] == 6 && h[254] == 6 && h[255] == 8);   // end offsets
 	}
 	if (failures) {
 		printf("dropin_check: %d failures\n", failures);

@@ -61,6 +61,9 @@ def oracle():
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int,
                           C.c_size_t, C.POINTER(Info)]
+        lib.rso_sort_main_hist.restype = C.c_int
+        lib.rso_sort_main_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.POINTER(Info)]
         lib.rso_fnv1a64.restype = C.c_uint64
         lib.rso_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
         lib.rso_fill_splitmix.restype = None
@@ -91,6 +94,8 @@ def ref():
         lib.ref_rank_sortrec_u8idx.restype = C.c_int
         lib.ref_rank_sortrec_u8idx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.ref_sizeof_sortrec.restype = C.c_size_t
+        lib.ref_sort_main_hist.restype = C.c_int
+        lib.ref_sort_main_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         _ref = lib
     return _ref
 
@@ -129,6 +134,31 @@ def ref_sort(bits, dtype, order=ASC):
     r = ref().ref_sort(ptr(src), ptr(aux), src.size, dtype, order)
     assert r in (0, 1)
     return (aux if r else src), r
+
+
+def hvt_bytes_for(n):
+    """Counter width radix_sort picks by n (radix_sort.hpp:102-114)."""
+    return 1 if n < 256 else 2 if n < (1 << 16) else 4 if n < (1 << 32) else 8
+
+
+def oracle_sort_main_hist(bits, dtype, hvt_bytes, order=ASC):
+    """rs_sort_main with a caller's Hist through the C restatement: (result, in_aux, hist[256*kb] uint64)."""
+    src = np.array(bits, dtype=NP_BITS[dtype], copy=True)
+    aux = np.full_like(src, 0xA5)
+    hist = np.zeros(256 * DTYPE_SIZE[dtype], dtype=np.uint64)
+    info = Info()
+    r = oracle().rso_sort_main_hist(ptr(src), ptr(aux), src.size, dtype, order, hvt_bytes, ptr(hist), C.byref(info))
+    return (aux if r else src), r, hist
+
+
+def ref_sort_main_hist(bits, dtype, hvt_bytes):
+    """The same through the real reference's rs_sort_main with a zeroed std::vector<HVT>."""
+    src = np.array(bits, dtype=NP_BITS[dtype], copy=True)
+    aux = np.full_like(src, 0xA5)
+    hist = np.zeros(256 * DTYPE_SIZE[dtype], dtype=np.uint64)
+    r = ref().ref_sort_main_hist(ptr(src), ptr(aux), src.size, dtype, hvt_bytes, ptr(hist))
+    assert r in (0, 1)
+    return (aux if r else src), r, hist
 
 
 def oracle_rank(bits, dtype, idx_bytes=4, order=ASC, asheader=False):

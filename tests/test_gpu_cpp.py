@@ -4,6 +4,7 @@ tests/cpp/dropin_check   our own program: exact stable order / returned pointer 
 oracle/_ref/radix_tests_dropin   the reference's UNMODIFIED radix_tests.cpp compiled against include/ and linked
                          with librsx.so (built where /root/reference exists; it travels to the GPU box as a binary).
 """
+import json
 import os
 import subprocess
 
@@ -21,11 +22,28 @@ def _need_gpu():
 
 
 def test_dropin_check_program():
+    """Own C++ checks through the templates: exact stable order, returned pointers, free-function KeyFuncs (a9), and
+    rs_sort_main / rs_sort_rank with caller-supplied histogram storage (a11) -- whose final contents must hash to what
+    the REAL rs_sort_main left in a std::vector<HVT> (tests/golden/kat_table.json, hist_post)."""
     exe = os.path.join(ROOT, "tests", "cpp", "dropin_check")
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", ROOT, "cpp"], check=True)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "dropin_check OK" in out.stdout, out.stdout + out.stderr
+    with open(os.path.join(ROOT, "tests", "golden", "kat_table.json")) as f:
+        golden = json.load(f)["hist_post"]
+    want = {(r["dtype_code"], r["n"], r["seed"], r["mask"], r["presorted"], r["hvt_bytes"]):
+            (r["fnv_out"], r["result_in_aux"], r["fnv_hist_u64"]) for r in golden}
+    seen = 0
+    for line in out.stdout.splitlines():
+        if not line.startswith("HIST "):
+            continue
+        _, dt, n, seed, mask, pre, hvt, fnv_out, in_aux, fnv_hist = line.split()
+        key = (int(dt), int(n), int(seed), mask, int(pre), int(hvt))
+        assert key in want, line
+        assert want[key] == (fnv_out, int(in_aux), fnv_hist), (line, want[key])
+        seen += 1
+    assert seen == len(golden) == 60
 
 
 def test_reference_tests_run_unmodified_on_our_headers():

@@ -1,7 +1,7 @@
 """Device steps of the multi-GPU sort (HipEngine) on one MI355X.
 
 The driver runs the 8-GPU job itself; here the G ranks of a job are played one after the other on a
-single GPU, with the all-to-all-v replaced by slicing, so that the histogram / MSD-partition / local
+single GPU, with the all-to-all-v replaced by slicing, so that the histogram / MSD-split / local
 sort kernels and the splitter logic are checked bit for bit against the oracle.
 """
 import numpy as np
@@ -28,41 +28,31 @@ def to_dev(bits):
 
 
 @pytest.mark.parametrize("dt,order", [(ol.U32, 0), (ol.F32, 1), (ol.U64, 0), (ol.I16, 0), (ol.U8, 0)])
-def test_top_histogram_and_partition(dt, order):
+def test_histogram_device_counts_every_column(dt, order):
+    """rsx_histogram_device (the building block the one-process multi-device sort sums over its shards)."""
+    import ctypes as C
     n = 1500001
     a = ol.splitmix_fill(n, dt, 17 + dt)
-    eng = multi.HipEngine(dt, order)
+    kb = ol.DTYPE_SIZE[dt]
     shard = to_dev(a)
-    hist = eng.top_histogram(shard).cpu().numpy()
+    hist = torch.zeros(256 * kb, dtype=torch.int64, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rsa.check(rsa.lib().rsx_histogram_device(shard.data_ptr(), n, dt, order, hist.data_ptr(), flag.data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
     k = ol.kdf_keys(a, dt, order)
-    top = (k >> ol.NP_BITS[dt](8 * (ol.DTYPE_SIZE[dt] - 1))).astype(np.int64)
-    assert np.array_equal(hist, np.bincount(top, minlength=256))
-    for world in (2, 8, 256):
-        lut = multi.choose_splitters(hist.astype(np.uint64), world) if world < 256 else np.arange(256, dtype=np.uint8)
-        out = torch.zeros_like(shard)
-        counts = eng.partition(shard, out, lut, world, hist.astype(np.uint64))
-        torch.cuda.synchronize()
-        dest = lut[top]
-        assert np.array_equal(counts, np.bincount(dest, minlength=world).astype(np.uint64))
-        want = a[np.argsort(dest, kind="stable")]                     # stable partition by destination
-        assert np.array_equal(out.cpu().numpy().view(ol.NP_BITS[dt]), want)
-
-
-def test_partition_rejects_a_wrong_histogram():
-    a = ol.splitmix_fill(100000, ol.U32, 5)
-    eng = multi.HipEngine(ol.U32)
-    shard = to_dev(a)
-    hist = eng.top_histogram(shard).cpu().numpy().astype(np.uint64)
-    hist[3] += 1
-    hist[200] -= 1
-    with pytest.raises(rsa.RsxError, match="disagrees"):
-        eng.partition(shard, torch.zeros_like(shard), np.arange(256, dtype=np.uint8) // 64, 4, hist)
+    got = hist.cpu().numpy()
+    for j in range(kb):
+        dig = ((k >> ol.NP_BITS[dt](8 * j)) & ol.NP_BITS[dt](0xFF)).astype(np.int64)
+        assert np.array_equal(got[256 * j:256 * j + 256], np.bincount(dig, minlength=256))
+    assert int(flag.item()) == 1
 
 
 @pytest.mark.parametrize("world,dt,mask", [(4, ol.U32, 0xFFFFFFFF), (8, ol.F32, 0xFFFFFFFF), (3, ol.U32, 0x00FFFFFF),
                                              (8, ol.U64, 0xFFFFFFFFFFFFFFFF)])
 def test_simulated_ranks_match_single_sort(world, dt, mask):
-    """Play `world` ranks on one GPU: histogram -> all-reduce (sum) -> splitters -> partition -> exchange -> local sort."""
+    """Play `world` ranks on one GPU: split by the highest varying byte -> counts summed -> splitters -> exchange (slicing)
+    -> local sorts."""
     n_per_rank = [200000 + 1000 * r for r in range(world)]
     whole = ol.splitmix_fill(sum(n_per_rank), dt, 23, mask)
     eng = multi.HipEngine(dt)
@@ -70,20 +60,25 @@ def test_simulated_ranks_match_single_sort(world, dt, mask):
     for r in range(world):
         shards.append(to_dev(whole[first:first + n_per_rank[r]]))
         first += n_per_rank[r]
-    hists = [eng.top_histogram(s).cpu().numpy().astype(np.uint64) for s in shards]
-    lut = multi.choose_splitters(sum(hists), world)
-    parts, counts = [], []
-    for r in range(world):
-        out = torch.zeros_like(shards[r])
-        counts.append(eng.partition(shards[r], out, lut, world, hists[r]))
-        parts.append(out)
+    column = eng.kb - 1
+    while True:
+        parts, hists = [], []
+        for r in range(world):
+            out = torch.zeros_like(shards[r])
+            hists.append(eng.msd_split(shards[r], out, column))
+            parts.append(out)
+        if column == 0 or np.count_nonzero(sum(hists)) > 1:
+            break
+        column -= 1
     torch.cuda.synchronize()
+    lut = multi.choose_splitters(sum(hists), world)
+    matrix = multi.count_matrix(np.stack(hists), lut, world)
     results = []
     for dst in range(world):                       # what the all-to-all-v delivers to rank dst, in source order
         pieces = []
         for src in range(world):
-            off = int(counts[src][:dst].sum())
-            pieces.append(parts[src][off:off + int(counts[src][dst])])
+            off = int(matrix[src][:dst].sum())
+            pieces.append(parts[src][off:off + int(matrix[src][dst])])
         recv = torch.cat(pieces) if pieces else shards[0][:0]
         aux = torch.zeros_like(recv)
         res, info = eng.local_sort(recv, aux)

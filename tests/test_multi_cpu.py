@@ -30,20 +30,6 @@ class OracleEngine:
     def _bits(self, t):
         return t.numpy().view(ol.NP_BITS[self.dtype])
 
-    def top_histogram(self, shard):
-        k = ol.kdf_keys(self._bits(shard), self.dtype, self.order)
-        top = (k >> ol.NP_BITS[self.dtype](8 * (ol.DTYPE_SIZE[self.dtype] - 1))).astype(np.int64)
-        return torch.from_numpy(np.bincount(top, minlength=256).astype(np.int64))
-
-    def partition(self, shard, out, lut, world, top_hist_host):
-        bits = self._bits(shard)
-        k = ol.kdf_keys(bits, self.dtype, self.order)
-        top = (k >> ol.NP_BITS[self.dtype](8 * (ol.DTYPE_SIZE[self.dtype] - 1))).astype(np.int64)
-        dest = np.asarray(lut)[top]
-        perm = np.argsort(dest, kind="stable")
-        out.numpy().view(bits.dtype)[:bits.size] = bits[perm]
-        return np.bincount(dest, minlength=world).astype(np.uint64)
-
     def msd_split(self, shard, out, column=-1):
         bits = self._bits(shard)
         k = ol.kdf_keys(bits, self.dtype, self.order)
@@ -163,3 +149,29 @@ def test_choose_splitters_properties():
     # uniform histogram -> equal shares
     lut = multi.choose_splitters(np.full(256, 100, dtype=np.uint64), 8)
     assert np.array_equal(np.bincount(lut, minlength=8), np.full(8, 32))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher: the GPU-free parent starts N ranks through
+    torch.distributed.run, relays their output and prints rank 0's JSON line LAST; a failing rank fails the parent."""
+    import subprocess
+    script = tmp_path / "fake_bench.py"
+    script.write_text(
+        "import os, sys, json\n"
+        "r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "if r == 0:\n"
+        "    print(json.dumps({'metric': 'm', 'value': 1.5, 'n_gpus': w, 'argv': sys.argv[1:]}), flush=True)\n"
+        "print('noise from rank %d' % r, flush=True)\n"
+        "sys.exit(3 if '--fail' in sys.argv and r == 1 else 0)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    driver = ("import sys; sys.path.insert(0, %r); import bench; bench.launch_ranks(sys.argv[1:], 2, script=%r)" % (root, str(script)))
+    out = subprocess.run([sys.executable, "-c", driver, "--gpus", "2", "--steps", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    import json
+    last = json.loads(lines[-1])
+    assert last["n_gpus"] == 2 and last["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert any("noise from rank 1" in l for l in lines[:-1])
+    bad = subprocess.run([sys.executable, "-c", driver, "--fail"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0

@@ -241,6 +241,42 @@ def test_histogram_is_loop1():
     assert nu.value == a.size - int(np.sum(a[:-1] <= a[1:]))
 
 
+# ---- rs_sort_main with a caller-supplied Hist (radix_sort.hpp:28-33) -----------------------------
+
+def hist_rows_input(row):
+    a = ol.splitmix_fill(row["n"], row["dtype_code"], row["seed"], int(row["mask"], 16))
+    if row["presorted"]:
+        a = a[ol.stable_argsort_by_kdf(a, row["dtype_code"])]
+    return a
+
+
+@pytest.mark.parametrize("row", KAT["hist_post"], ids=lambda r: _id(r) + ("-pre" if r["presorted"] else ""))
+def test_oracle_hist_post_state_matches_golden(row):
+    """What the reference leaves in the caller's histogram storage: golden hashes from the real rs_sort_main."""
+    dt = row["dtype_code"]
+    a = hist_rows_input(row)
+    assert "%016x" % ol.fnv1a64(a) == row["fnv_in"]
+    res, in_aux, hist = ol.oracle_sort_main_hist(a, dt, row["hvt_bytes"])
+    assert "%016x" % ol.fnv1a64(res) == row["fnv_out"] and in_aux == row["result_in_aux"]
+    assert "%016x" % ol.fnv1a64(hist) == row["fnv_hist_u64"]
+
+
+@needs_ref
+def test_oracle_hist_post_state_vs_reference_sweep():
+    rng = np.random.default_rng(77)
+    for trial in range(120):
+        dt = int(rng.integers(0, 10))
+        n = int(rng.choice([0, 1, 2, 100, 255, 256, 3000, 65535, 65536, 70001]))
+        full = (1 << (8 * ol.DTYPE_SIZE[dt])) - 1
+        mask = full if trial % 2 else full & int(rng.integers(0, full, dtype=np.uint64, endpoint=True))
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        if trial % 5 == 4 and n:
+            a = a[ol.stable_argsort_by_kdf(a, dt)]
+        hv = ol.hvt_bytes_for(n)
+        r1, r2 = ol.oracle_sort_main_hist(a, dt, hv), ol.ref_sort_main_hist(a, dt, hv)
+        assert r1[1] == r2[1] and np.array_equal(r1[0], r2[0]) and np.array_equal(r1[2], r2[2]), (dt, n, hex(mask))
+
+
 # ---- randomized differential sweep against the real reference ------------------------------------
 
 @needs_ref

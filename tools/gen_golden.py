@@ -71,6 +71,13 @@ RANK_ROWS = [
 ]
 
 
+# caller-supplied histogram rows: (dtype, n, seed, mask, presorted)
+HIST_ROWS = [(dt, n, 40 + dt, mask, pre)
+             for dt in range(10)
+             for (n, mask, pre) in ((200, FULL, 0), (3000, FULL, 0), (100000, FULL, 0), (100000, 0x00FFFF00FF00FFFF, 0),
+                                    (5000, FULL, 1), (300, 0xFF, 0))]
+
+
 def hx(v):
     return "%016x" % v
 
@@ -81,7 +88,7 @@ def main():
     assert ref is not None, "needs /root/reference (build container only)"
     out = {"generator": "tools/gen_golden.py", "source": "oracle/_ref/libref.so (reference headers compiled in place)",
            "prng": "splitmix64, one call per element, & mask, low sizeof(T) bytes", "hash": "FNV-1a-64 over result bytes",
-           "scalar": [], "scalar_extra": [], "rank": [], "kv": [], "test_int": {}}
+           "scalar": [], "scalar_extra": [], "rank": [], "kv": [], "test_int": {}, "hist_post": []}
 
     for dt, n, seed, mask, s_in, s_out, s_aux in SCALAR_ROWS:
         a = ol.splitmix_fill(n, dt, seed, mask)
@@ -151,10 +158,22 @@ def main():
     assert out["test_int"]["fnv_ascending"] == "9e66d085f1dd25c0"
     assert out["test_int"]["fnv_descending"] == "7a6a54dc00ad17bc"
 
+    # rs_sort_main with a caller-supplied Hist (radix_sort.hpp:28-33): what the reference leaves in the histogram storage
+    for dt, n, seed, mask, presorted in HIST_ROWS:
+        a = ol.splitmix_fill(n, dt, seed, mask)
+        if presorted:
+            a = a[ol.stable_argsort_by_kdf(a, dt)]
+        hv = ol.hvt_bytes_for(n)
+        res, in_aux, hist = ol.ref_sort_main_hist(a, dt, hv)
+        out["hist_post"].append({"dtype": ol.DTYPE_NAMES[dt], "dtype_code": dt, "n": n, "seed": seed, "mask": hx(mask),
+                                 "presorted": presorted, "hvt_bytes": hv, "fnv_in": hx(ol.fnv1a64(a)),
+                                 "fnv_out": hx(ol.fnv1a64(res)), "result_in_aux": in_aux,
+                                 "fnv_hist_u64": hx(ol.fnv1a64(hist))})
+
     path = os.path.join(ROOT, "tests", "golden", "kat_table.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote", path, "rows:", len(out["scalar"]), len(out["scalar_extra"]), len(out["rank"]))
+    print("wrote", path, "rows:", len(out["scalar"]), len(out["scalar_extra"]), len(out["rank"]), len(out["hist_post"]))
 
 
 if __name__ == "__main__":

@@ -1,9 +1,9 @@
-// scatter_probe: tuning harness for rsx_scatter_kernel (tile shapes, phase timeline).
+// scatter_probe: tuning harness for the scatter kernels (tile shapes, phase timeline, inputs with aligned runs).
+// (The persistent / two-window / early-load experiments of round 1 -- rsx_scatter{3,4,5}_experimental.hpp -- are in the
+// history up to commit 71d1354; DESIGN.md section 4 has their numbers.)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc -I tools/ubench tools/ubench/scatter_probe.hip -o tools/ubench/scatter_probe.bin
 #include "rsx_scatter2.hpp"
-#include "rsx_scatter3_experimental.hpp"
-#include "rsx_scatter4_experimental.hpp"
-#include "rsx_scatter5_experimental.hpp"
+#include "rsx_scatter3.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -49,7 +49,7 @@ float run_once(u32 shift, bool timeline_dump)
 	CK(hipEventRecord(e0, 0));
 	hipLaunchKernelGGL((rsx_scatter_kernel<u32, NoVal, u32, SH, TL>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in, d_out,
 	                   (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8), g_tps,
-	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, (const uint8_t *)nullptr, d_tl);
+	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl);
 	CK(hipGetLastError());
 	CK(hipEventRecord(e1, 0));
 	CK(hipEventSynchronize(e1));
@@ -107,7 +107,7 @@ float run2_once(u32 shift, bool dump, u32 tps)
 	hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, TL, DIG_PLAIN, HOTV>), dim3((unsigned)stiles), dim3(C::BLOCK), 0, 0, d_in,
 	                   d_out, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift, d_hist + 256 * (shift / 8), tps,
 	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags | ((shift / 8) << SCATTER_COL_SHIFT),
-	                   (const uint8_t *)nullptr, d_tl, (const Plan *)nullptr, 0u, 0u, (const u32 *)(d_flag + 32));
+	                   d_tl, (const Plan *)nullptr, 0u, 0u, (const u32 *)(d_flag + 32));
 	CK(hipGetLastError());
 	CK(hipEventRecord(e1, 0));
 	CK(hipEventSynchronize(e1));
@@ -140,127 +140,8 @@ float run2_once(u32 shift, bool dump, u32 tps)
 	return ms;
 }
 
-template <bool TL>
-float run5_once(u32 shift, bool dump, u32 grid)
-{
-	const u64 tiles = n / Sc5Cfg::TILE;
-	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
-	if (TL)
-		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
-	hipEvent_t e0, e1;
-	CK(hipEventCreate(&e0));
-	CK(hipEventCreate(&e1));
-	CK(hipEventRecord(e0, 0));
-	hipLaunchKernelGGL((rsx_scatter5_kernel<TL>), dim3(grid), dim3(1024), 0, 0, d_in, d_out, (u64)n, shift, d_hist + 256 * (shift / 8),
-	                   (u32 *)((char *)d_status + 256), (u32 *)d_status, g_flags, d_tl);
-	CK(hipGetLastError());
-	CK(hipEventRecord(e1, 0));
-	CK(hipEventSynchronize(e1));
-	float ms;
-	CK(hipEventElapsedTime(&ms, e0, e1));
-	if (TL && dump) {
-		std::vector<u64> tl(tiles * 16);
-		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
-		double a = 0, lay = 0, ch = 0, st = 0, wo = 0, depth = 0;
-		for (u64 s = 0; s < tiles; ++s) {
-			const u64 *r = &tl[s * 16];
-			a += (double)(r[1] - r[0]);
-			lay += (double)(r[2] - r[1]);
-			ch += (double)(r[3] - r[2]);
-			st += (double)(r[4] - r[2]);
-			wo += (double)(r[5] - r[4]);
-			depth += r[12];
-		}
-		printf("  per tile: count %7.0f | layout %6.0f | chain %6.0f (depth %.1f) inside | stage %6.0f | write %6.0f | lifetime %7.0f\n", a / tiles,
-		       lay / tiles, ch / tiles, depth / tiles, st / tiles, wo / tiles, (a + lay + st + wo) / tiles);
-	}
-	return ms;
-}
-
-static void bench5(u32 grid)
-{
-	run5_once<false>(0, false, grid);
-	float best = 1e9, sum = 0;
-	for (int i = 0; i < 5; ++i) {
-		float ms = run5_once<false>(8 * (i % 4), false, grid);
-		best = std::min(best, ms);
-		sum += ms;
-	}
-	printf("v5 persistent, loads at stage start, grid %u: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", grid, sum / 5, best,
-	       n * 8.0 / (best * 1e-3) / 1e9);
-	run5_once<true>(0, true, grid);
-	run5_once<false>(0, false, grid);
-	std::vector<u32> out(1 << 20);
-	CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
-	size_t bad = 0;
-	for (size_t i = 1; i < out.size(); ++i)
-		bad += (out[i - 1] & 0xFF) > (out[i] & 0xFF);
-	printf("v5 check: digit order violations in the first 2^20 outputs: %zu\n", bad);
-}
-
-template <bool TL>
-float run4_once(u32 shift, bool dump)
-{
-	const u64 tiles = n / Sc4Cfg::TILE;
-	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
-	if (TL)
-		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
-	hipEvent_t e0, e1;
-	CK(hipEventCreate(&e0));
-	CK(hipEventCreate(&e1));
-	CK(hipEventRecord(e0, 0));
-	hipLaunchKernelGGL((rsx_scatter4_kernel<TL>), dim3((unsigned)tiles), dim3(1024), 0, 0, d_in, d_out, (u64)n, shift,
-	                   d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, g_flags, d_tl);
-	CK(hipGetLastError());
-	CK(hipEventRecord(e1, 0));
-	CK(hipEventSynchronize(e1));
-	float ms;
-	CK(hipEventElapsedTime(&ms, e0, e1));
-	if (TL && dump) {
-		std::vector<u64> tl(tiles * 16);
-		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
-		double a = 0, lay = 0, ch = 0, s0 = 0, w0 = 0, s1 = 0, w1 = 0, depth = 0;
-		for (u64 s = 0; s < tiles; ++s) {
-			const u64 *r = &tl[s * 16];
-			a += (double)(r[1] - r[0]);
-			lay += (double)(r[2] - r[1]);
-			ch += (double)(r[3] - r[2]);
-			s0 += (double)(r[4] - r[2]);
-			w0 += (double)(r[5] - r[4]);
-			s1 += (double)(r[6] - r[5]);
-			w1 += (double)(r[7] - r[6]);
-			depth += r[12];
-		}
-		printf("  per 64 Ki-key tile: phase A %7.0f | layout %6.0f | chain %6.0f (depth %.1f) inside | stage0 %6.0f write0 %6.0f | stage1 %6.0f write1 %6.0f | lifetime %7.0f\n",
-		       a / tiles, lay / tiles, ch / tiles, depth / tiles, s0 / tiles, w0 / tiles, s1 / tiles, w1 / tiles,
-		       (a + lay + s0 + w0 + s1 + w1) / tiles);
-	}
-	return ms;
-}
-
-static void bench4()
-{
-	run4_once<false>(0, false);
-	float best = 1e9, sum = 0;
-	for (int i = 0; i < 5; ++i) {
-		float ms = run4_once<false>(8 * (i % 4), false);
-		best = std::min(best, ms);
-		sum += ms;
-	}
-	printf("v4 64Ki tiles, 2 windows, lds %zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", sizeof(Sc4Smem), sum / 5, best,
-	       n * 8.0 / (best * 1e-3) / 1e9);
-	run4_once<true>(0, true);
-	run4_once<false>(0, false);
-	std::vector<u32> out(1 << 20);
-	CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
-	size_t bad = 0;
-	for (size_t i = 1; i < out.size(); ++i)
-		bad += (out[i - 1] & 0xFF) > (out[i] & 0xFF);
-	printf("v4 check: digit order violations in the first 2^20 outputs: %zu\n", bad);
-}
-
 template <typename C, bool TL>
-float run3_once(u32 shift, bool dump, u32 grid)
+float run3_once(u32 shift, bool dump)
 {
 	const u64 tiles = (n + C::TILE - 1) / C::TILE;
 	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
@@ -271,63 +152,63 @@ float run3_once(u32 shift, bool dump, u32 grid)
 	CK(hipEventCreate(&e1));
 	KdfArgs<u32> ka{0, 0, 0};
 	CK(hipEventRecord(e0, 0));
-	hipLaunchKernelGGL((rsx_scatter3_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, d_out, (u64)n, shift,
-	                   d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags,
-	                   (const uint8_t *)nullptr, d_tl);
+	hipLaunchKernelGGL((rsx_scatter3_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, 0, d_in, d_out, (u64)n,
+	                   shift, d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl,
+	                   (const Plan *)nullptr, 0u);
 	CK(hipGetLastError());
 	CK(hipEventRecord(e1, 0));
 	CK(hipEventSynchronize(e1));
 	float ms;
 	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
 	if (TL && dump) {
 		std::vector<u64> tl(tiles * 16);
 		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
-		double a = 0, lay = 0, ch = 0, st = 0, depth = 0, life = 0;
-		u64 cntd = 0;
-		for (u64 s = 0; s < tiles; ++s) {
-			const u64 *r = &tl[s * 16];
-			if (r[0] == 0 || r[4] == 0)
-				continue;
+		double a = 0, lay = 0, rk = 0, ch = 0, w0 = 0, s1 = 0, w1 = 0, depth = 0, life = 0;
+		for (u64 t = 0; t < tiles; ++t) {
+			const u64 *r = &tl[t * 16];
 			a += (double)(r[1] - r[0]);
 			lay += (double)(r[2] - r[1]);
 			ch += (double)(r[3] - r[2]);
-			st += (double)(r[4] - r[2]);
-			life += (double)(r[4] - r[0]);
+			rk += (double)(r[4] - r[2]);
+			w0 += (double)(r[5] - r[4]);
+			s1 += (double)(r[6] - r[5]);
+			w1 += (double)(r[7] - r[6]);
+			life += (double)(r[7] - r[0]);
 			depth += r[12];
-			++cntd;
 		}
-		if (tiles > 4400) {
-			// how 256 consecutive tiles (one per CU) lie in time: spread of each stamp, relative to the first tile's F start
-			for (int k = 9; k <= 10; ++k) {
-				std::vector<double> ts;
-				for (u64 s2 = 4096; s2 < 4096 + 256; ++s2)
-					ts.push_back(((double)tl[s2 * 16 + k] - (double)tl[4096 * 16 + 9]) * 24.0);   // 100 MHz ticks -> ~2.4 GHz cycles
-				std::sort(ts.begin(), ts.end());
-				printf("    %s of tiles 4096..4351 (cycles after tile 4096's barrier #1): min %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f\n",
-				       k == 9 ? "barrier #1" : "barrier #4", ts[0], ts[25], ts[128], ts[230], ts[255]);
-			}
-			printf("    barrier #1 of tile 4352 (next round): %8.0f\n", ((double)tl[4352 * 16 + 9] - (double)tl[4096 * 16 + 9]) * 24.0);
-		}
-		printf("  per tile: F (write-out of the previous + refill + count) %8.0f | layout %6.0f | chain %7.0f (depth %.1f) | stage(incl chain) %7.0f | lifetime %8.0f\n",
-		       a / cntd, lay / cntd, ch / cntd, depth / cntd, st / cntd, life / cntd);
+		printf("  per tile: load+count %7.0f | layout %6.0f | rank+stage0 (chain inside) %7.0f (digit thread 0: chain done after %7.0f, depth %.1f) | "
+		       "write0 %6.0f | stage1 %6.0f | write1 %6.0f | lifetime %7.0f\n",
+		       a / tiles, lay / tiles, rk / tiles, ch / tiles, depth / tiles, w0 / tiles, s1 / tiles, w1 / tiles, life / tiles);
 	}
 	return ms;
 }
 
 template <typename C>
-void bench3(const char *name, u32 grid)
+void bench3(const char *name)
 {
-	run3_once<C, false>(0, false, grid);
+	run3_once<C, false>(0, false);
 	float best = 1e9, sum = 0;
 	const int reps = 5;
 	for (int i = 0; i < reps; ++i) {
-		float ms = run3_once<C, false>(8 * (i % 4), false, grid);
+		float ms = run3_once<C, false>(8 * (i % 4), false);
 		best = std::min(best, ms);
 		sum += ms;
 	}
-	printf("%-12s grid %u tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, grid, C::TILE,
+	printf("%-14s tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
 	       sizeof(Sc3Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
-	run3_once<C, true>(0, true, grid);
+	run3_once<C, true>(0, true);
+	// same output as the reference kernel of this probe (rsx_scatter2_kernel)?
+	std::vector<u32> a(1 << 22), b(1 << 22);
+	run3_once<C, false>(8, false);
+	CK(hipMemcpy(a.data(), d_out + (n / 2 - (1 << 21)), a.size() * 4, hipMemcpyDeviceToHost));
+	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+	CK(hipMemcpy(b.data(), d_out + (n / 2 - (1 << 21)), b.size() * 4, hipMemcpyDeviceToHost));
+	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (2^22 keys around the middle, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run3_once<C, true>(0, false));
+	g_flags = 0;
 }
 
 template <typename C, bool HOTV = false>
@@ -434,9 +315,9 @@ int main(int argc, char **argv)
 	KdfArgs<u32> ka{0, 0, 0};
 	u32 *d_part;
 	CK(hipMalloc(&d_part, 512 * 1024 * 4));
-	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(512), dim3(HistCfg<u32>::BLOCK), 0, 0, d_in, (u64)n, d_part, d_flag, ka, 1u, 512u, (u64)n);
+	hipLaunchKernelGGL((rsx_hist_kernel<u32>), dim3(512), dim3(HistCfg<u32>::BLOCK), 0, 0, d_in, (u64)n, d_part, d_flag, ka, ~0u, (u64 *)nullptr);
 	hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3(4, HIST_REDUCE_SPLIT), dim3(256), 0, 0, (const u32 *)d_part, d_hist, 512u, 1024u);
-	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, 1u, ka, d_flag + 8, d_flag + 32);
+	hipLaunchKernelGGL((rsx_plan_kernel<u32>), dim3(4), dim3(256), 0, 0, d_in, (u64)n, d_hist, ka, d_flag + 8, d_flag + 32);
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
@@ -450,34 +331,18 @@ int main(int argc, char **argv)
 		printf("-- v2 plain, no global stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal>, true, false>(0, true, 1));
 		g_flags = 0;
 	}
+	bench3<Sc3Cfg<u32>>("v3 2wg/CU");
+	bench3<Sc3Cfg<u32, 8, 8, 0, false>>("v3 elem loads");
+	bench3<Sc3Cfg<u32, 8, 16>>("v3 LB16");
+	bench3<Sc3Cfg<u32, 8, 8, 48>>("v3 KPT48");
+	bench3<Sc3Cfg<u32, 8, 8, 32>>("v3 KPT32");
+	// what the pass costs without its global stores (the keys are read, counted, chained, staged and read back)
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("-- v2 default, no global stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal>, true, false>(0, true, 1));
+	g_flags = 0;
 	if (argc > 2)
 		return 0;
-	bench5(256);
-	bench5(512);
-	return 0;
-	bench4();
-	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 16>>("v2 16Ki x2/CU", 1);
-	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, true, 0>>("v2 cell16", 1);
-	bench2<Sc2Cfg<u32, NoVal, 16, 1, 8, false, 16>>("v2 16Ki cell32", 1);
-	bench2<Sc2Cfg<u32, NoVal, 8, 1, 8, true, 0>>("v2 8 waves", 1);
-	bench3<Sc3Cfg<u32>>("v3 default", 256);
-		g_flags = SCATTER_DBG_NOSTORE;
-	printf("-- v3 no stores: %.3f ms\n", run3_once<Sc3Cfg<u32>, true>(0, true, 256));
-	g_flags = 0;
-	bench3<Sc3Cfg<u32, 16, 8, 0>>("v3 nostagger", 256);
-	bench3<Sc3Cfg<u32, 16, 8, 60000>>("v3 stag60k", 256);
-	bench3<Sc3Cfg<u32, 16, 4>>("v3 lb4", 256);
-	bench3<Sc3Cfg<u32, 16, 16>>("v3 lb16", 256);
-	{
-		typedef Sc3Cfg<u32> C;
-		run3_once<C, false>(0, false, 256);
-		std::vector<u32> out(1 << 20);
-		CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
-		size_t bad = 0;
-		for (size_t i = 1; i < out.size(); ++i)
-			bad += (out[i - 1] & 0xFF) > (out[i] & 0xFF);
-		printf("v3 check: digit order violations in the first 2^20 outputs: %zu\n", bad);
-	}
+	bench<DefaultShape<u32, NoVal, RANK_TABLE>>("v1 table", 4);
 	// correctness of v2: digits of the output must be non-decreasing and the multiset preserved (checked via sum)
 	{
 		typedef Sc2Cfg<u32, NoVal> C;
