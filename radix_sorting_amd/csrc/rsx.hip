@@ -374,8 +374,13 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 	// up to 128 workgroups add their counts to the histogram themselves (one launch and its gap less: 7 of the 62 us of
 	// a 10^5-key sort); beyond that the rows are summed by a kernel of their own
 	const bool direct = blocks <= 128;
-	hipLaunchKernelGGL((rsx_hist_kernel<KT>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
-	                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr);
+	// keys that are their own KDF (unsigned, ascending) take the instantiation without the KDF arithmetic
+	if (ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0)
+		hipLaunchKernelGGL((rsx_hist_kernel<KT, C, HIST_PLAIN>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
+		                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr);
+	else
+		hipLaunchKernelGGL((rsx_hist_kernel<KT, C, HIST_GENERIC>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
+		                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr);
 	if (!direct)
 		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)sizeof(KT), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
 		                   (const u32 *)c.hpart.p, d_hist, (u32)blocks, cols256);

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// ---- phase A: count, per tile and wave.  Order inside a wave's slice does not matter here, so the
 	// slice is streamed with 16-byte loads (when the keys are 16-byte aligned), all of them in flight.
 	constexpr int VEC = 16 / sizeof(KT);
-	const bool vec_ok = (((uintptr_t)kin) & 15) == 0;
+	const bool vec_ok = (((uintptr_t)kin) & 15) == 0 && !(flags & SCATTER_ELEM_LOADS);
 #pragma unroll
 	for (int t = 0; t < TPS; ++t) {
 		const u64 base = beg + (u64)t * C::TILE;
@@ -256,6 +256,23 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 							else
 								atomicAdd(&wc[d], 1u);
 						}
+					}
+				}
+			} else if (KEEP && cnt == (u32)C::TILE) {
+				// whole tile, element loads: lane l of round r loads element 64 r + l itself (a wave-instruction reads 64
+				// consecutive keys): four times the load instructions of the vector path, but no transposition through the LDS
+				if constexpr (KEEP) {
+					const KT *p = kin + base + wofs;
+#pragma unroll
+					for (int r = 0; r < KPT; ++r)
+						keep[r] = p[r * 64];
+#pragma unroll
+					for (int r = 0; r < KPT; ++r) {
+						const u32 d = digit2<DIG>(keep[r], ka, shift);
+						if constexpr (C::CELL16)
+							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
+						else
+							atomicAdd(&wc[d], 1u);
 					}
 				}
 			} else if constexpr (KEEP) {

@@ -44,35 +44,49 @@ from . import (ASCENDING, DTYPE_SIZE, Info, RsxError, _stream_ptr, check, lib, r
 
 
 def choose_splitters(top_hist, world):
-    """Map each of the 256 top digits to a destination rank.
+    """Map each bin (a top digit, or a (top digit, next digit) pair where a digit was refined: see split_plan) to a
+    destination rank.
 
-    Contiguous, monotone ranges; digit d goes to the rank whose ideal share
-    [r*total/world, (r+1)*total/world) contains the midpoint of d's run.  Every
-    rank computes this from the same all-reduced histogram, so the result is identical everywhere.
+    Contiguous, monotone ranges; bin b goes to the rank whose ideal share
+    [r*total/world, (r+1)*total/world) contains the midpoint of b's run.  Every
+    rank computes this from the same gathered histogram, so the result is identical everywhere.
     """
     h = np.asarray(top_hist, dtype=np.uint64).astype(np.float64)
     total = float(h.sum())
-    lut = np.zeros(256, dtype=np.uint8)
+    lut = np.zeros(h.size, dtype=np.uint8 if world <= 256 else np.int64)
     if total == 0 or world == 1:
         return lut
     before = np.concatenate([[0.0], np.cumsum(h)[:-1]])
     mid = before + h / 2.0
     r = np.floor(mid * world / total).astype(np.int64)
     r = np.clip(r, 0, world - 1)
-    r = np.maximum.accumulate(r)          # monotone even with empty digits
-    return r.astype(np.uint8)
+    r = np.maximum.accumulate(r)          # monotone even with empty bins
+    return r.astype(lut.dtype)
 
 
 _OVERLAP_STREAMS = {}      # (device, group, to_self) -> stream or None (HipEngine.overlap_stream)
 
 
 def count_matrix(hists, lut, world):
-    """matrix[s, d] = number of keys of rank s whose top digit belongs to rank d (hists: world x 256 counts)."""
+    """matrix[s, d] = number of keys of rank s whose bin belongs to rank d (hists: world x bins counts)."""
     m = np.zeros((world, world), dtype=np.uint64)
     lut = np.asarray(lut, dtype=np.int64)
     for d in range(world):
         m[:, d] = np.asarray(hists, dtype=np.uint64)[:, lut == d].sum(axis=1)
     return m
+
+
+HEAVY_FACTOR = 1.25      # a digit holding more than this many fair shares (total / world) is split by the next byte too
+
+
+def heavy_digits(global_hist, world, column):
+    """Digits of the split byte that cannot be balanced as a whole (SURVEY.md section 7 "Skew in the exchange"; the
+    one-line spec is README.md:647-650): more than HEAVY_FACTOR * total / world keys, and a lower byte to refine by."""
+    h = np.asarray(global_hist, dtype=np.uint64)
+    total = int(h.sum())
+    if column == 0 or world < 2 or total == 0:
+        return []
+    return [int(d) for d in np.nonzero(h.astype(np.float64) > HEAVY_FACTOR * total / world)[0]]
 
 
 class HipEngine:
@@ -151,22 +165,72 @@ class HipEngine:
 
 
 def choose_chunks(global_hist, lut, world, chunks):
-    """Cut every destination's digit range into at most `chunks` contiguous sub-ranges of about equal global counts.
+    """Cut every destination's bin range into at most `chunks` contiguous sub-ranges of about equal global counts.
 
-    Returns chunk_of[256] (monotone inside a destination's range).  Keys of different sub-ranges never compare equal in
-    the split byte, so the sub-ranges of a destination are independent sorting problems in digit order.
+    Returns chunk_of[bins] (monotone inside a destination's range).  Keys of different sub-ranges never compare equal in
+    the split byte(s), so the sub-ranges of a destination are independent sorting problems in key order.
     """
-    chunk_of = np.zeros(256, dtype=np.int64)
     h = np.asarray(global_hist, dtype=np.uint64)
+    chunk_of = np.zeros(h.size, dtype=np.int64)
     lut = np.asarray(lut, dtype=np.int64)
     for d in range(world):
-        digits = np.nonzero(lut == d)[0]
-        if digits.size == 0:
+        bins = np.nonzero(lut == d)[0]
+        if bins.size == 0:
             continue
-        sub = np.zeros(256, dtype=np.uint64)
-        sub[digits] = h[digits]
-        chunk_of[digits] = choose_splitters(sub, chunks)[digits]
+        sub = np.zeros(h.size, dtype=np.uint64)
+        sub[bins] = h[bins]
+        chunk_of[bins] = choose_splitters(sub, chunks)[bins]
     return chunk_of
+
+
+def split_plan(shard, part, engine, group, world, tmp=None):
+    """Steps 1-2 of the distributed sort: split the shard into BINS in key order and gather every rank's bin counts.
+
+    A bin is a digit of the split byte -- the highest byte that varies over all ranks -- or, for a digit that holds more
+    than HEAVY_FACTOR fair shares of all the keys (a dominant top byte cannot be divided among ranks as a whole), one of
+    the 256 (digit, next lower byte) pairs: such a digit's run of `part` gets a second stable pass by the next byte.
+    Returns (counts[world, bins] uint64, column, heavy): `part` holds the shard ordered by bin, every rank has the same
+    bins in the same order.  `tmp`: a scratch tensor for the second pass (allocated when absent).
+    """
+    import torch
+    import torch.distributed as dist
+
+    def gather(local):
+        mine = torch.from_numpy(np.ascontiguousarray(local).astype(np.int64)).to(shard.device)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+        return torch.stack(gathered).cpu().numpy().astype(np.uint64)
+
+    # one stable pass by the top KDF byte and its counts.  A byte that is constant over ALL ranks would send every key to
+    # one rank: split by the next byte down instead (every rank sees the same gathered counts and decides the same).
+    column = engine.kb - 1
+    while True:
+        local = engine.msd_split(shard, part, column)
+        hists = gather(local)
+        if column == 0 or np.count_nonzero(hists.sum(axis=0)) > 1:
+            break
+        column -= 1
+    heavy = heavy_digits(hists.sum(axis=0), world, column)
+    if not heavy:
+        return hists, column, heavy
+    # second pass over the runs of the heavy digits, by the next byte (the run of digit d of `part` is contiguous)
+    first = np.concatenate([[0], np.cumsum(local.astype(np.int64))])
+    sub_local = np.zeros((len(heavy), 256), dtype=np.uint64)
+    for i, d in enumerate(heavy):
+        a, b = int(first[d]), int(first[d + 1])
+        if b > a:
+            run = part[a:b]
+            t = tmp[:b - a] if tmp is not None and tmp.numel() >= b - a else engine.empty(b - a, shard)
+            sub_local[i] = engine.msd_split(run, t, column - 1)
+            run.copy_(t)
+    sub_all = gather(sub_local.reshape(-1)).reshape(world, len(heavy), 256)
+    cols = []
+    for d in range(256):
+        if d in heavy:
+            cols.append(sub_all[:, heavy.index(d), :])
+        else:
+            cols.append(hists[:, d:d + 1])
+    return np.concatenate(cols, axis=1), column, heavy
 
 
 def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None, force_exchange=False, chunks=None):
@@ -191,33 +255,24 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
         res, info = engine.local_sort(shard, aux)
         return res, {"sent": 0, "received": n, "local_info": info}
 
-    # 1-2: one stable pass by the top KDF byte and its counts; everybody's counts -> identical splitters and the whole
-    # count matrix on every rank.  A byte that is constant over ALL ranks would send every key to one rank: split by the
-    # next byte down instead (every rank sees the same gathered counts and takes the same decision).
+    # 1-2: the shard ordered by bin (split_plan) and everybody's bin counts -> identical splitters and the whole count
+    # matrix on every rank, no second count exchange.  The receive buffer is sized from the counts, never from n / G:
+    # preallocated scratch is used when it is large enough and replaced when it is not.
     part = scratch["part"][:n] if scratch else engine.empty(n, shard)
-    column = engine.kb - 1
-    while True:
-        local_hist = engine.msd_split(shard, part, column)
-        mine = torch.from_numpy(local_hist.astype(np.int64)).to(shard.device)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine, group=group)
-        hists = torch.stack(gathered).cpu().numpy().astype(np.uint64)
-        if column == 0 or np.count_nonzero(hists.sum(axis=0)) > 1:
-            break
-        column -= 1
+    hists, column, heavy = split_plan(shard, part, engine, group, world, tmp=scratch.get("aux") if scratch else None)
+    local_hist = hists[rank]
     lut = choose_splitters(hists.sum(axis=0), world)
     matrix = count_matrix(hists, lut, world)          # matrix[s, d]: keys rank s sends to rank d
     send_counts, recv_counts = matrix[rank], matrix[:, rank]
     n_recv = int(recv_counts.sum())
-    if scratch:
-        if n_recv > scratch["recv"].numel():
-            raise RsxError("rank %d receives %d keys, more than the %d-key receive buffer" %
-                           (rank, n_recv, scratch["recv"].numel()))
+    if scratch and n_recv <= scratch["recv"].numel() and n_recv <= scratch["aux"].numel():
         recv = scratch["recv"][:n_recv]
         aux = scratch["aux"][:n_recv]
     else:
         recv = engine.empty(n_recv, shard)
         aux = engine.empty(n_recv, shard)
+        if scratch is not None:                        # keep the larger buffers for the next call
+            scratch["recv"], scratch["aux"] = recv, aux
 
     # 3-4: sub-range by sub-range: the pieces of sub-range j go out (grouped send/recv = all-to-all-v; opaque bytes, so
     # every key width works on every backend), and as soon as they are in, they are sorted in place while the next
@@ -234,9 +289,10 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
         if n_recv > 1:
             engine.sort_inplace_async(recv, aux)
         return recv, {"sent": int(send_counts.sum() - send_counts[rank]), "received": n_recv, "local_info": None, "lut": lut,
-                      "split_column": column, "chunks": 1, "send_counts": send_counts, "recv_counts": recv_counts}
+                      "split_column": column, "heavy_digits": heavy, "chunks": 1, "send_counts": send_counts,
+                      "recv_counts": recv_counts}
     chunk_of = choose_chunks(hists.sum(axis=0), lut, world, nchunks)
-    first = np.concatenate([[0], np.cumsum(local_hist.astype(np.int64))])     # offset of a digit's run in `part`
+    first = np.concatenate([[0], np.cumsum(local_hist.astype(np.int64))])     # offset of a bin's run in `part`
     es = shard.element_size()
     part_b, recv_b = part.view(torch.uint8), recv.view(torch.uint8)
     mine_digits = lut.astype(np.int64) == rank
@@ -288,5 +344,5 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
         main.wait_stream(side)
     sent = int(send_counts.sum() - send_counts[rank])
     return recv, {"sent": sent, "received": n_recv, "local_info": None, "lut": lut, "split_column": column,
-                  "chunks": nchunks, "overlap_stream": side is not None, "send_counts": send_counts,
+                  "heavy_digits": heavy, "chunks": nchunks, "overlap_stream": side is not None, "send_counts": send_counts,
                   "recv_counts": recv_counts}

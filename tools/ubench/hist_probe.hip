@@ -107,11 +107,11 @@ template <typename KT, typename C> void bench_r1(const char *name, unsigned grid
 	check_and_print<KT>(name, grid, C::BLOCK, C::U, best);
 }
 
-template <typename KT, typename C> void bench_new(const char *name, unsigned grid)
+template <typename KT, typename C, int MODE = HIST_PLAIN> void bench_new(const char *name, unsigned grid)
 {
 	KdfArgs<KT> ka{0, 0, 0};
 	const float best = time_it<KT>([&] {
-		hipLaunchKernelGGL((rsx_hist_kernel<KT, C>), dim3(grid), dim3(C::BLOCK), 0, 0, (const KT *)d_in, (u64)n, d_part, d_flag, ka,
+		hipLaunchKernelGGL((rsx_hist_kernel<KT, C, MODE>), dim3(grid), dim3(C::BLOCK), 0, 0, (const KT *)d_in, (u64)n, d_part, d_flag, ka,
 		                   g_colmask, (u64 *)nullptr);
 		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3(sizeof(KT), HIST_REDUCE_SPLIT), dim3(256), 0, 0, (const u32 *)d_part, d_hist, grid,
 		                   (u32)sizeof(KT) * 256u);
@@ -136,18 +136,15 @@ template <typename KT> void run(u64 mask)
 	printf("n = %zu keys of %zu bytes, mask %016llx\n", n, sizeof(KT), (unsigned long long)mask);
 	for (int rep = 0; rep < 2; ++rep) {
 		bench_r1<KT, HistR1Cfg<KT, 1024, 2>>("round 1", 512);
-		bench_new<KT, HistCfg<KT, 1024, 2>>("new", 512);
-		bench_new<KT, HistCfg<KT, 1024, 1>>("new", 512);
-		bench_new<KT, HistCfg<KT, 1024, 3>>("new", 512);
-		bench_new<KT, HistCfg<KT, 1024, 4>>("new", 512);
-		bench_new<KT, HistCfg<KT, 512, 2>>("new", 1024);
-		bench_new<KT, HistCfg<KT, 512, 4>>("new", 1024);
-		bench_new<KT, HistCfg<KT, 1024, 2>>("new", 1024);
-		bench_new<KT, HistCfg<KT, 1024, 2>>("new", 2048);
-		if (sizeof(KT) == 8) {
-			bench_new<KT, HistCfg<KT, 1024, 2, false>>("new, 32-bit counters", 256);
-			bench_new<KT, HistCfg<KT, 1024, 4, false>>("new, 32-bit counters", 256);
-		}
+		bench_new<KT, HistCfg<KT, 1024, 2>>("new, plain", 512);
+		bench_new<KT, HistCfg<KT, 1024, 2>, HIST_GENERIC>("new, generic KDF", 512);
+		bench_new<KT, HistCfg<KT, 1024, 1>>("new, plain", 512);
+		bench_new<KT, HistCfg<KT, 1024, 3>>("new, plain", 512);
+		bench_new<KT, HistCfg<KT, 1024, 4>>("new, plain", 512);
+		bench_new<KT, HistCfg<KT, 512, 2>>("new, plain", 1024);
+		bench_new<KT, HistCfg<KT, 512, 4>>("new, plain", 1024);
+		bench_new<KT, HistCfg<KT, 1024, 2>>("new, plain", 1024);
+		bench_new<KT, HistCfg<KT, 1024, 2>>("new, plain", 2048);
 		bench_read<KT, 1024, 2>(512);
 		bench_read<KT, 1024, 4>(512);
 		bench_read<KT, 1024, 4>(2048);

@@ -331,11 +331,11 @@ int main(int argc, char **argv)
 		printf("-- v2 plain, no global stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal>, true, false>(0, true, 1));
 		g_flags = 0;
 	}
-	bench3<Sc3Cfg<u32>>("v3 2wg/CU");
-	bench3<Sc3Cfg<u32, 8, 8, 0, false>>("v3 elem loads");
-	bench3<Sc3Cfg<u32, 8, 16>>("v3 LB16");
+	g_flags = SCATTER_ELEM_LOADS;
+	bench2<Sc2Cfg<u32, NoVal>>("v2 elem loads", 1);
+	g_flags = 0;
 	bench3<Sc3Cfg<u32, 8, 8, 48>>("v3 KPT48");
-	bench3<Sc3Cfg<u32, 8, 8, 32>>("v3 KPT32");
+	bench3<Sc3Cfg<u32, 8, 8, 48, false>>("v3 KPT48 elem");
 	// what the pass costs without its global stores (the keys are read, counted, chained, staged and read back)
 	g_flags = SCATTER_DBG_NOSTORE;
 	printf("-- v2 default, no global stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal>, true, false>(0, true, 1));
