@@ -910,9 +910,16 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u3
 // pooled per (device, slot) so that repeated calls reuse the contexts.
 std::mutex g_multi_mu;
 std::map<std::pair<int, int>, hipStream_t> g_multi_streams;
+// device buffers of a rank, kept per (device, slot) between calls (grown when a larger sort comes, freed by rsx_release)
+struct MultiBufs {
+	DevBuf shard, part, recv, aux, misc;   // misc: [key bytes][256] u64 histogram + 64 bytes for the flag
+};
+std::map<std::pair<int, int>, MultiBufs> g_multi_bufs;
+std::map<std::pair<int, int>, int> g_peer_enabled;   // (device, peer) -> 1 enabled, 0 not possible
 
 struct MultiRank {
 	int dev = 0;
+	MultiBufs *bufs = nullptr;
 	hipStream_t stream = nullptr;
 	size_t first = 0, count = 0;         // this rank's shard of the input
 	void *shard = nullptr, *part = nullptr, *recv = nullptr, *aux = nullptr;
@@ -989,19 +996,34 @@ int multi_phase(std::vector<MultiRank> &ranks, const std::function<int(MultiRank
 	return RSX_OK;
 }
 
-void multi_free(std::vector<MultiRank> &ranks)
+// the ranks' buffers belong to g_multi_bufs; a call only has to be sure that nothing of it is still running
+void multi_quiesce(std::vector<MultiRank> &ranks)
 {
 	for (auto &r : ranks) {
 		(void)hipSetDevice(r.dev);
 		if (r.stream)
 			(void)hipStreamSynchronize(r.stream);
-		for (void *p : {r.shard, r.part, r.recv, r.aux, (void *)r.d_hist, (void *)r.d_flag})
-			if (p)
-				(void)hipFree(p);
-		r.shard = r.part = r.recv = r.aux = nullptr;
-		r.d_hist = nullptr;
-		r.d_flag = nullptr;
 	}
+}
+
+// direct peer-to-peer copies dev <- peer over xGMI where the topology allows them (without it hipMemcpyPeerAsync stages
+// through the host); enabled once per ordered pair of devices
+void enable_peer(int dev, int peer)
+{
+	if (dev == peer)
+		return;
+	std::lock_guard<std::mutex> lock(g_mu);
+	const auto key = std::make_pair(dev, peer);
+	if (g_peer_enabled.count(key))
+		return;
+	int can = 0;
+	int ok = 0;
+	if (hipDeviceCanAccessPeer(&can, dev, peer) == hipSuccess && can) {
+		const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);   // (for the current device, which is `dev` here)
+		ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+	}
+	(void)hipGetLastError();
+	g_peer_enabled[key] = ok;
 }
 
 #define RSX_DISPATCH_KT(dtype, CALL)                               \
@@ -1059,6 +1081,15 @@ void rsx_release(void)
 		(void)hipStreamDestroy(kv.second);
 	}
 	g_multi_streams.clear();
+	for (auto &kv : g_multi_bufs) {
+		(void)hipSetDevice(kv.first.first);
+		kv.second.shard.release();
+		kv.second.part.release();
+		kv.second.recv.release();
+		kv.second.aux.release();
+		kv.second.misc.release();
+	}
+	g_multi_bufs.clear();
 }
 
 int rsx_capture_histogram(uint64_t *hist, size_t entries)
@@ -1537,6 +1568,7 @@ int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order or
 			it = g_multi_streams.emplace(key, st).first;
 		}
 		k.stream = it->second;
+		k.bufs = &g_multi_bufs[key];
 		k.first = (size_t)((unsigned __int128)n * r / G);
 		k.count = (size_t)((unsigned __int128)n * (r + 1) / G) - k.first;
 		k.hist.assign(kb * 256, 0);
@@ -1546,7 +1578,7 @@ int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order or
 		int home;
 		~Cleanup()
 		{
-			multi_free(ranks);
+			multi_quiesce(ranks);
 			(void)hipSetDevice(home);
 		}
 	} cleanup{ranks, home};
@@ -1556,10 +1588,13 @@ int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order or
 	RSX_TRY(multi_phase(ranks, [&](MultiRank &k) -> int {
 		if (k.count == 0)
 			return RSX_OK;
-		HIP_TRY(hipMalloc(&k.shard, k.count * kb));
-		HIP_TRY(hipMalloc(&k.part, k.count * kb));
-		HIP_TRY(hipMalloc((void **)&k.d_hist, kb * 256 * sizeof(u64)));
-		HIP_TRY(hipMalloc((void **)&k.d_flag, 64));
+		RSX_TRY(k.bufs->shard.ensure(k.count * kb));
+		RSX_TRY(k.bufs->part.ensure(k.count * kb));
+		RSX_TRY(k.bufs->misc.ensure(kb * 256 * sizeof(u64) + 64));
+		k.shard = k.bufs->shard.p;
+		k.part = k.bufs->part.p;
+		k.d_hist = (u64 *)k.bufs->misc.p;
+		k.d_flag = (u32 *)((char *)k.bufs->misc.p + kb * 256 * sizeof(u64));
 		HIP_TRY(hipMemcpyAsync(k.shard, hsrc + k.first * kb, k.count * kb, hipMemcpyHostToDevice, k.stream));
 		RSX_TRY(rsx_histogram_device(k.shard, k.count, dtype, order, (uint64_t *)k.d_hist, (uint32_t *)k.d_flag, k.stream));
 		HIP_TRY(hipMemcpyAsync(k.hist.data(), k.d_hist, kb * 256 * sizeof(u64), hipMemcpyDeviceToHost, k.stream));
@@ -1629,8 +1664,6 @@ int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order or
 			if (top[d] != k.hist[cs * 256 + d])
 				return fail(RSX_EHIP, "the split counted digit %d differently from the histogram", d);
 		HIP_TRY(hipStreamSynchronize(k.stream));
-		HIP_TRY(hipFree(k.shard));
-		k.shard = nullptr;
 		return RSX_OK;
 	}));
 
@@ -1640,8 +1673,13 @@ int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order or
 		if (k.n_recv == 0)
 			return RSX_OK;
 		const int d = (int)(&k - &ranks[0]);
-		HIP_TRY(hipMalloc(&k.recv, k.n_recv * kb));
-		HIP_TRY(hipMalloc(&k.aux, k.n_recv * kb));
+		RSX_TRY(k.bufs->recv.ensure(k.n_recv * kb));   // sized from the count matrix, whatever the skew
+		RSX_TRY(k.bufs->aux.ensure(k.n_recv * kb));
+		k.recv = k.bufs->recv.p;
+		k.aux = k.bufs->aux.p;
+		for (int s = 0; s < G; ++s)
+			if (matrix[(size_t)s * G + d])
+				enable_peer(k.dev, ranks[s].dev);
 		size_t off = 0;
 		for (int s = 0; s < G; ++s) {
 			const size_t cnt = (size_t)matrix[(size_t)s * G + d];

@@ -60,7 +60,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chunks=None):
+def _skew(whole, dtype, skew):
+    """`skew` percent of the keys get the top KDF byte 0x42 (ascending unsigned view): one dominant top digit."""
+    if not skew:
+        return whole
+    bits = 8 * ol.DTYPE_SIZE[dtype]
+    out = whole.copy()
+    sel = (np.arange(out.size) % 100) < skew
+    top = ol.NP_BITS[dtype](0x42) << ol.NP_BITS[dtype](bits - 8)
+    low = ol.NP_BITS[dtype]((1 << (bits - 8)) - 1)
+    out[sel] = (out[sel] & low) | top
+    return out
+
+
+def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chunks=None, skew=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -68,11 +81,16 @@ def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chu
         carrier = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[ol.DTYPE_SIZE[dtype]]
         n = n_per_rank[rank]
         first = sum(n_per_rank[:rank])
-        whole = ol.splitmix_fill(sum(n_per_rank), dtype, seed, mask)
+        whole = _skew(ol.splitmix_fill(sum(n_per_rank), dtype, seed, mask), dtype, skew)
         shard = torch.from_numpy(whole[first:first + n].view(carrier).copy())
-        res, stats = multi.distributed_sort(shard, OracleEngine(dtype, order), chunks=chunks)
+        scratch = None
+        if skew:      # preallocated buffers that are too small for what this rank receives must be replaced, not trusted
+            scratch = {"part": torch.empty(n, dtype=shard.dtype), "recv": torch.empty(n // 2, dtype=shard.dtype),
+                       "aux": torch.empty(n // 2, dtype=shard.dtype)}
+        res, stats = multi.distributed_sort(shard, OracleEngine(dtype, order), chunks=chunks, scratch=scratch)
         np.save(os.path.join(outdir, "out%d.npy" % rank), res.numpy().view(ol.NP_BITS[dtype]).copy())
         np.save(os.path.join(outdir, "recv%d.npy" % rank), np.asarray(stats.get("recv_counts", [n])))
+        np.save(os.path.join(outdir, "heavy%d.npy" % rank), np.asarray(stats.get("heavy_digits", []), dtype=np.int64))
     finally:
         dist.destroy_process_group()
 
@@ -99,6 +117,29 @@ def test_distributed_sort_matches_single_sort(tmp_path, world, dtype, order, mas
         assert max(sizes) < 1.2 * sum(sizes) / world      # uniform keys -> balanced splitters, also below a constant top byte
 
 
+@pytest.mark.parametrize("world,dtype,order,skew,chunks", [(2, ol.U32, 0, 90, None), (3, ol.U32, 0, 90, 1), (2, ol.F32, 1, 95, None),
+                                                            (3, ol.U64, 0, 60, 4), (2, ol.U8, 0, 90, None)])
+def test_distributed_sort_with_a_dominant_top_digit(tmp_path, world, dtype, order, skew, chunks):
+    """SURVEY.md section 7 "Skew in the exchange" (README.md:647-650 is the one-line spec): 60-95 % of the keys share one top
+    byte.  An 8-bit MSD digit cannot split them; the heavy digit is split by the next byte as well, the receive buffers
+    follow the exchanged counts, and the result is still bit-identical to one rank sorting everything."""
+    n_per_rank = [30000 + 211 * r for r in range(world)]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dtype, order, n_per_rank, (1 << 64) - 1, 77, str(tmp_path), chunks, skew), nprocs=world,
+             join=True)
+    whole = _skew(ol.splitmix_fill(sum(n_per_rank), dtype, 77), dtype, skew)
+    want, _, _ = ol.oracle_sort(whole, dtype, order)
+    outs = [np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate(outs), want)
+    heavy = np.load(os.path.join(str(tmp_path), "heavy0.npy"))
+    if ol.DTYPE_SIZE[dtype] > 1:
+        assert heavy.size == 1                                  # the dominant digit was refined by the next byte ...
+        sizes = [o.size for o in outs]
+        assert max(sizes) < 1.35 * sum(sizes) / world           # ... and the ranks are balanced again
+    else:
+        assert heavy.size == 0                                  # one-byte keys: nothing below to refine by
+
+
 @pytest.mark.parametrize("chunks", [1, 3, 16])
 def test_distributed_sort_chunk_counts(tmp_path, chunks):
     """One all-to-all and one sort (chunks = 1) against the pipelined form with few and with many sub-ranges."""
@@ -109,6 +150,18 @@ def test_distributed_sort_chunk_counts(tmp_path, chunks):
     whole = ol.splitmix_fill(sum(n_per_rank), dtype, 13, 0xFFFFFFFF)
     got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
     assert np.array_equal(got, ol.oracle_sort(whole, dtype)[0])
+
+
+def test_heavy_digits():
+    h = np.full(256, 100, dtype=np.uint64)
+    assert multi.heavy_digits(h, 8, 3) == []
+    h[7] = 100000
+    assert multi.heavy_digits(h, 8, 3) == [7]
+    assert multi.heavy_digits(h, 8, 0) == []          # no lower byte
+    assert multi.heavy_digits(h, 1, 3) == []
+    h[9] = 90000
+    assert multi.heavy_digits(h, 2, 3) == []          # 47 % and 53 %: each below 1.25 fair shares of two
+    assert multi.heavy_digits(h, 4, 3) == [7, 9]
 
 
 def test_choose_chunks():

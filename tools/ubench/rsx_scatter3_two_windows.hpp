@@ -1,3 +1,8 @@
+// EXPERIMENT (round 2), not part of the library.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_2wg_*.txt):
+// 64 keys per lane spill (0.84 ms); 48 keys per lane (24 Ki-key tiles): 0.55-0.57 ms against 0.506 for rsx_scatter2_kernel,
+// 0.361 ms without global stores (0.34): two workgroups per CU do not overlap anything that matters -- a key is offered to
+// the LDS once more (the second, predicated staging pass), eight waves hide the LDS latency worse than sixteen, and the
+// chain gets deeper (22 tiles, three round trips behind the digit waves' own 9 k cycles of ranking).
 // rsx_scatter3.hpp -- the scatter pass (radix_sort.hpp:82-90) with TWO workgroups per CU: keys only, gfx950.
 //
 // rsx_scatter2_kernel keeps a 32 Ki-key tile's keys in registers, ranks them, stages the whole tile in LDS (128 KiB) and

@@ -3,7 +3,10 @@
 // history up to commit 71d1354; DESIGN.md section 4 has their numbers.)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc -I tools/ubench tools/ubench/scatter_probe.hip -o tools/ubench/scatter_probe.bin
 #include "rsx_scatter2.hpp"
-#include "rsx_scatter3.hpp"
+#include "rsx_scatter3_two_windows.hpp"
+#include "rsx_scatter4_pairs.hpp"
+#include "rsx_scatter5_persistent_prefetch.hpp"
+#include "rsx_scatter6_digit_waves.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -211,6 +214,216 @@ void bench3(const char *name)
 	g_flags = 0;
 }
 
+template <typename C, bool TL>
+float run4_once(u32 shift, bool dump)
+{
+	const u64 npairs = n / (2 * (u64)C::TILE);
+	CK(hipMemsetAsync(d_status, 0, 256 + npairs * 2 * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, npairs * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter4_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3((unsigned)npairs), dim3(C::BLOCK), 0, 0, d_in, d_out, npairs,
+	                   shift, d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl,
+	                   (const Plan *)nullptr, 0u);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(npairs * 16);
+		CK(hipMemcpy(tl.data(), d_tl, npairs * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, sa = 0, wa = 0, lb = 0, sb = 0, wb = 0, depth = 0, life = 0;
+		for (u64 t = 0; t < npairs; ++t) {
+			const u64 *r = &tl[t * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			sa += (double)(r[4] - r[2]);
+			wa += (double)(r[5] - r[4]);
+			lb += (double)(r[6] - r[5]);
+			sb += (double)(r[7] - r[6]);
+			wb += (double)(r[8] - r[7]);
+			life += (double)(r[8] - r[0]);
+			depth += r[12];
+		}
+		printf("  per pair: load+count %7.0f | layout A %6.0f | stage A %7.0f (chain %6.0f, depth %.1f tiles, inside) | write A %6.0f | layout B %6.0f | "
+		       "stage B %6.0f | write B %6.0f | lifetime %7.0f (%.0f per tile)\n",
+		       a / npairs, lay / npairs, sa / npairs, ch / npairs, depth / npairs, wa / npairs, lb / npairs, sb / npairs, wb / npairs, life / npairs,
+		       life / npairs / 2);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench4(const char *name)
+{
+	run4_once<C, false>(0, false);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run4_once<C, false>(8 * (i % 4), false);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-14s tile %6d x 2, lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
+	       sizeof(Sc4Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run4_once<C, true>(0, true);
+	// same output as the reference kernel of this probe (rsx_scatter2_kernel)?  the whole array, column 1
+	std::vector<u32> a(n), b(n);
+	run4_once<C, false>(8, false);
+	CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+	CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (the whole array, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run4_once<C, true>(0, false));
+	g_flags = 0;
+}
+
+template <typename C, bool TL>
+float run5_once(u32 shift, bool dump, u32 grid)
+{
+	const u32 ntiles = (u32)(n / C::TILE);
+	CK(hipMemsetAsync(d_status, 0, 256 + (size_t)ntiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, (size_t)ntiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter5_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, d_out, ntiles, shift,
+	                   d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl, (const Plan *)nullptr,
+	                   0u);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(ntiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, (size_t)ntiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, st = 0, wo = 0, depth = 0, life = 0;
+		for (u64 t = 0; t < ntiles; ++t) {
+			const u64 *r = &tl[t * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			st += (double)(r[4] - r[2]);
+			wo += (double)(r[5] - r[4]);
+			life += (double)(r[5] - r[0]);
+			depth += r[12];
+		}
+		printf("  per tile: wait + count %7.0f | layout %6.0f | stage %7.0f (chain %6.0f, depth %.1f, inside) | write-out %6.0f | lifetime %7.0f\n",
+		       a / ntiles, lay / ntiles, st / ntiles, ch / ntiles, depth / ntiles, wo / ntiles, life / ntiles);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench5(const char *name, u32 grid)
+{
+	run5_once<C, false>(0, false, grid);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run5_once<C, false>(8 * (i % 4), false, grid);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-14s grid %u tile %6d, lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, grid, C::TILE,
+	       sizeof(Sc5Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run5_once<C, true>(0, true, grid);
+	std::vector<u32> a(n), b(n);
+	run5_once<C, false>(8, false, grid);
+	CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+	CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (the whole array, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run5_once<C, true>(0, false, grid));
+	g_flags = 0;
+}
+
+template <typename C, bool TL>
+float run6_once(u32 shift, bool dump)
+{
+	const u64 tiles = (n + C::TILE - 1) / C::TILE;
+	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter6_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, 0, d_in, d_out, (u64)n,
+	                   shift, d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl,
+	                   (const Plan *)nullptr, 0u);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(tiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, st = 0, kw = 0, wo = 0, depth = 0, life = 0;
+		const u64 nt = tiles - 1;   // (whole tiles)
+		for (u64 t = 0; t < nt; ++t) {
+			const u64 *r = &tl[t * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			kw += (double)(r[6] - r[2]);
+			st += (double)(r[4] - r[2]);
+			wo += (double)(r[5] - r[4]);
+			life += (double)(r[5] - r[0]);
+			depth += r[12];
+		}
+		printf("  per tile: load+count %7.0f | layout %6.0f | stage phase %7.0f (chain %6.0f, depth %.1f; key wave 0 staged after %6.0f) | write-out %6.0f | "
+		       "lifetime %7.0f (%.0f per 32 Ki keys)\n",
+		       a / nt, lay / nt, st / nt, ch / nt, depth / nt, kw / nt, wo / nt, life / nt, life / nt * 32768.0 / C::TILE);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench6(const char *name)
+{
+	run6_once<C, false>(0, false);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run6_once<C, false>(8 * (i % 4), false);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-14s tile %6d, lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
+	       sizeof(Sc6Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run6_once<C, true>(0, true);
+	std::vector<u32> a(n), b(n);
+	run6_once<C, false>(8, false);
+	CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+	CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (the whole array, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run6_once<C, true>(0, false));
+	g_flags = 0;
+}
+
 template <typename C, bool HOTV = false>
 void bench2(const char *name, u32 tps)
 {
@@ -334,8 +547,16 @@ int main(int argc, char **argv)
 	g_flags = SCATTER_ELEM_LOADS;
 	bench2<Sc2Cfg<u32, NoVal>>("v2 elem loads", 1);
 	g_flags = 0;
-	bench3<Sc3Cfg<u32, 8, 8, 48>>("v3 KPT48");
-	bench3<Sc3Cfg<u32, 8, 8, 48, false>>("v3 KPT48 elem");
+	if (getenv("RSX_PROBE_ALL")) {
+		// round 2's structural experiments (each a header of its own next to this file, with its numbers)
+		bench3<Sc3Cfg<u32, 8, 8, 48>>("v3 2 WG/CU, 2 windows");
+		bench4<Sc4Cfg<u32>>("v4 pairs");
+		bench5<Sc5Cfg<u32>>("v5 persistent + prefetch", 256);
+		g_flags = SCATTER_DBG_LINEAR;
+		bench5<Sc5Cfg<u32>>("v5 persistent, no prefetch", 256);
+		g_flags = 0;
+		bench6<Sc6Cfg<u32>>("v6 digit waves");
+	}
 	// what the pass costs without its global stores (the keys are read, counted, chained, staged and read back)
 	g_flags = SCATTER_DBG_NOSTORE;
 	printf("-- v2 default, no global stores: %.3f ms\n", run2_once<Sc2Cfg<u32, NoVal>, true, false>(0, true, 1));
