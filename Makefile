@@ -27,8 +27,8 @@ tests/cpp/dropin_check: tests/cpp/dropin_check.cpp include/radix_sort.hpp includ
 cli: tools/radix tools/radix_bench
 
 tools/radix: tools/radix.cpp include/radix_sort.hpp include/radix_sort_basic_kdf.hpp include/rsx.h radix_sorting_amd/librsx.so
-	g++ -std=gnu++17 -O2 -Wall -Iinclude tools/radix.cpp -Lradix_sorting_amd -lrsx \
-	-Wl,-rpath,'$$ORIGIN/../radix_sorting_amd' -Wl,-rpath-link,/opt/rocm/lib -o $@
+	g++ -std=gnu++17 -O2 -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/radix.cpp -Lradix_sorting_amd -lrsx \
+	-L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../radix_sorting_amd' -Wl,-rpath,/opt/rocm/lib -o $@
 
 tools/radix_bench: tools/radix_bench.cpp include/radix_sort.hpp include/radix_sort_rank.hpp include/radix_sort_basic_kdf.hpp include/rsx.h radix_sorting_amd/librsx.so
 	g++ -std=gnu++17 -O2 -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/radix_bench.cpp -Lradix_sorting_amd -lrsx \

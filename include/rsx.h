@@ -26,6 +26,15 @@
  *     not returned has unspecified contents except in those early exits.
  *   - Order is a stable sort by kdf(key): output element images are bit-exact
  *     copies of the input's (NaN payloads, -0.0), radix_sort.hpp:85-87.
+ *
+ * Environment switches (read by the library)
+ *   RSX_VERIFY=1            after every host-scheduled scatter pass one tile is
+ *                           re-ranked without LDS atomics and compared with the
+ *                           pass's output; a mismatch fails the call (RSX_EVERIFY).
+ *   RSX_FORCE_TABLE_RANK=1  use the table-ranked scatter kernel, which does not rely
+ *                           on the lane order of returning LDS atomics (slower).
+ *   RSX_NO_SMALL_SORT, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION, RSX_NO_NARROW_KEYS
+ *                           switch single optimisations off (tests).
  */
 #ifndef RSX_H
 #define RSX_H
@@ -55,7 +64,8 @@ enum {
 	RSX_EINVAL = -1,     /* bad dtype / size / null pointer                */
 	RSX_ENODEVICE = -2,  /* no usable gfx950 device / HIP runtime failure  */
 	RSX_ENOMEM = -3,     /* device workspace allocation failed             */
-	RSX_EHIP = -4        /* a HIP call failed (see rsx_last_error)         */
+	RSX_EHIP = -4,       /* a HIP call failed (see rsx_last_error)         */
+	RSX_EVERIFY = -5     /* RSX_VERIFY=1: a pass disagreed with its re-computation */
 };
 
 /* What the front half of rs_sort_main decided (radix_sort.hpp:48-80). */
@@ -77,6 +87,10 @@ size_t      rsx_dtype_size(rsx_dtype dtype);
 size_t      rsx_workspace_bytes(size_t n, rsx_dtype dtype, size_t payload_bytes);
 /* Release every cached workspace / stream context of the calling process. */
 void        rsx_release(void);
+/* One context is kept per (device, stream) the library has been called with; a
+ * program that creates many short-lived streams releases them one by one: frees the
+ * workspace of (current device, stream) after synchronising the stream. */
+void        rsx_release_stream(void *stream);
 
 /* ---- radix_sort<T>(src, aux, n) -- radix_sort.hpp:98-115 ------------------ */
 
@@ -97,6 +111,24 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * replayed on new contents of d_buf. */
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
                            void *stream);
+
+/* LIFETIME of what a captured graph refers to.  The two *_inplace_async entry points
+ * above and below keep their device state (flags, plan, histograms, status words of
+ * the look-back) in the library's workspace of (current device, stream), which is
+ * cached, GROWN -- freed and reallocated -- by a later larger sort on the same
+ * (device, stream), and freed by rsx_release / rsx_release_stream.  A graph
+ * captured from them is valid only until one of these happens, and its replays
+ * must be ordered (stream order) against every other sort that uses the same
+ * (device, stream) workspace.  A caller that keeps a graph should use the *_ws forms:
+ * there all device state lies in d_workspace (256-byte aligned, at least
+ * rsx_workspace_bytes(n, dtype, payload_bytes) bytes, owned by the caller for as
+ * long as the graph lives; contents are scratch), so nothing the graph touches can
+ * move, and graphs with different workspaces may replay on any streams. */
+int rsx_sort_inplace_async_ws(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
+                              void *d_workspace, size_t workspace_bytes, void *stream);
+int rsx_sort_pairs_inplace_async_ws(void *d_keys, void *d_keys_scratch, void *d_vals, void *d_vals_scratch,
+                                    size_t n, rsx_dtype dtype, size_t payload_bytes, rsx_order order,
+                                    void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* Key + payload in the same manner: both arrays sorted in place by the keys (stable),
  * never a host synchronisation, HIP-graph capturable.  payload_bytes: 4 or 8. */

@@ -54,7 +54,10 @@ ABI = [
     ("rsx_workspace_bytes", _SZ, [_SZ, _I, _SZ]),
     ("rsx_release", None, []),
     ("rsx_sort", _I, [_VP, _VP, _SZ, _I, _I, _PVP, _PINFO]),
+    ("rsx_release_stream", None, [_VP]),
     ("rsx_sort_inplace_async", _I, [_VP, _VP, _SZ, _I, _I, _VP]),
+    ("rsx_sort_inplace_async_ws", _I, [_VP, _VP, _SZ, _I, _I, _VP, _SZ, _VP]),
+    ("rsx_sort_pairs_inplace_async_ws", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP, _SZ, _VP]),
     ("rsx_sort_pairs_inplace_async", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP]),
     ("rsx_capture_histogram", _I, [_VP, _SZ]),
     ("rsx_sort_device", _I, [_VP, _VP, _SZ, _I, _I, _VP, _PVP, _PINFO]),
@@ -194,6 +197,42 @@ def radix_sort_inplace_async(buf, scratch, dtype=None, order=ASCENDING, stream=N
     _same_shape(buf, scratch, "scratch")
     check(lib().rsx_sort_inplace_async(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream)))
     return buf
+
+
+def workspace_bytes(n, dtype, payload_bytes=0):
+    """rsx_workspace_bytes: what a workspace for the *_ws entry points must hold at least."""
+    return int(lib().rsx_workspace_bytes(n, dtype, payload_bytes))
+
+
+def radix_sort_inplace_async_ws(buf, scratch, workspace, dtype=None, order=ASCENDING, stream=None):
+    """rsx_sort_inplace_async_ws: as radix_sort_inplace_async with every piece of device state in `workspace` (a uint8 device
+    tensor the caller keeps for as long as a graph captured from this call lives)."""
+    _check_dev(buf, scratch, workspace)
+    code = _torch_dtype_code(buf) if dtype is None else dtype
+    if buf.element_size() != DTYPE_SIZE[code]:
+        raise RsxError("buf does not match the key type")
+    _same_shape(buf, scratch, "scratch")
+    check(lib().rsx_sort_inplace_async_ws(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, workspace.data_ptr(),
+                                          workspace.numel() * workspace.element_size(), _stream_ptr(stream)))
+    return buf
+
+
+def radix_sort_pairs_inplace_async_ws(keys, keys_scratch, vals, vals_scratch, workspace, dtype=None, order=ASCENDING, stream=None):
+    _check_dev(keys, keys_scratch, vals, vals_scratch, workspace)
+    code = _torch_dtype_code(keys) if dtype is None else dtype
+    if keys.element_size() != DTYPE_SIZE[code] or vals.element_size() not in (4, 8) or vals.numel() != keys.numel():
+        raise RsxError("keys/vals do not match")
+    _same_shape(keys, keys_scratch, "keys_scratch")
+    _same_shape(vals, vals_scratch, "vals_scratch")
+    check(lib().rsx_sort_pairs_inplace_async_ws(keys.data_ptr(), keys_scratch.data_ptr(), vals.data_ptr(), vals_scratch.data_ptr(),
+                                                keys.numel(), code, vals.element_size(), order, workspace.data_ptr(),
+                                                workspace.numel() * workspace.element_size(), _stream_ptr(stream)))
+    return keys, vals
+
+
+def release_stream(stream=None):
+    """rsx_release_stream: free the library's workspace of (current device, stream)."""
+    lib().rsx_release_stream(_stream_ptr(stream))
 
 
 def radix_sort_pairs_inplace_async(keys, keys_scratch, vals, vals_scratch, dtype=None, order=ASCENDING, stream=None):

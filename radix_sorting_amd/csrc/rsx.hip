@@ -84,10 +84,14 @@ KdfArgs<KT> make_kdf(int dtype, int order)
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
+	bool external = false;   // a slice of a caller-owned workspace (rsx_sort_inplace_async_ws): never grown, never freed
 	int ensure(size_t bytes)
 	{
 		if (bytes <= cap)
 			return RSX_OK;
+		if (external)
+			return fail(RSX_EINVAL, "the caller's workspace is too small: %zu bytes needed where %zu were set aside "
+			                        "(size it with rsx_workspace_bytes)", bytes, cap);
 		if (p) {
 			(void)hipFree(p);
 			p = nullptr;
@@ -111,10 +115,16 @@ struct DevBuf {
 	}
 	void release()
 	{
-		if (p)
+		if (p && !external)
 			(void)hipFree(p);
 		p = nullptr;
 		cap = 0;
+	}
+	void borrow(void *ptr, size_t bytes)
+	{
+		p = ptr;
+		cap = bytes;
+		external = true;
 	}
 };
 
@@ -131,6 +141,7 @@ struct Ctx {
 	DevBuf vals[2];     // payload ping-pong for host staging / narrow-index rank
 	DevBuf recs[2];     // record gather staging
 	DevBuf tkeys;       // keys extracted from records (rsx_sort_records_tagged*)
+	DevBuf ckeys;       // rank sorts: the keys' varying bits packed together (RSX_COMPACT_BITS)
 	Plan *host_plan = nullptr;   // pinned, written by the kernels themselves (dev_host_plan: its device address)
 	Plan *dev_host_plan = nullptr;
 	hipEvent_t plan_ev = nullptr;   // recorded behind the plan's copy to the host
@@ -144,6 +155,7 @@ struct Ctx {
 	u64 *ghist() const { return (u64 *)hist.p; }
 	u32 *unsorted() const { return (u32 *)small.p; }
 	u32 *plan_done() const { return (u32 *)((char *)small.p + 52); }   // blocks of rsx_plan_kernel that are through
+	u64 *verify_bad() const { return (u64 *)((char *)small.p + 56); }  // RSX_VERIFY: mismatches found by rsx_verify_tile_kernel
 	u32 *hotd() const { return (u32 *)((char *)small.p + 16); }   // [8] hot digits per column + [1] valid bits (rsx_plan_kernel)
 	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
 	u32 *kept() const { return (u32 *)((char *)small.p + 128); }
@@ -173,6 +185,7 @@ struct Ctx {
 			recs[i].release();
 		}
 		tkeys.release();
+		ckeys.release();
 		if (plan_ev)
 			(void)hipEventDestroy(plan_ev);
 		plan_ev = nullptr;
@@ -188,6 +201,57 @@ struct Ctx {
 std::mutex g_mu;
 std::map<std::pair<int, void *>, Ctx *> g_ctx;
 std::map<int, int> g_lds_order_ok;   // device -> result of lds_order_selfcheck (1 ok, 0 not)
+
+// ---- RSX_HOST_REGISTER=1: the caller's host buffers are page-locked (hipHostRegister) the first time they are seen and
+// stay so, cached per (pointer, bytes), so that repeated sorts of the same buffers copy by DMA straight from / to them
+// instead of through the runtime's bounce buffers.  Opt-in: the registration outlives the call (until rsx_release or
+// until 16 younger buffers have pushed it out), which is only safe for buffers the caller keeps.
+struct HostReg {
+	void *p;
+	size_t bytes;
+};
+std::vector<HostReg> g_host_regs;
+std::mutex g_host_reg_mu;
+
+bool host_register_mode()
+{
+	static const bool on = [] {
+		const char *e = getenv("RSX_HOST_REGISTER");
+		return e && e[0] == '1';
+	}();
+	return on;
+}
+
+void host_register(void *p, size_t bytes)
+{
+	if (!host_register_mode() || bytes < ((size_t)1 << 20))
+		return;
+	std::lock_guard<std::mutex> lock(g_host_reg_mu);
+	for (auto &r : g_host_regs)
+		if (r.p == p && r.bytes >= bytes)
+			return;
+	for (size_t i = 0; i < g_host_regs.size(); ++i)   // overlapping older registrations of other sizes: drop them
+		if ((char *)g_host_regs[i].p < (char *)p + bytes && (char *)p < (char *)g_host_regs[i].p + g_host_regs[i].bytes) {
+			(void)hipHostUnregister(g_host_regs[i].p);
+			g_host_regs.erase(g_host_regs.begin() + i--);
+		}
+	if (g_host_regs.size() >= 16) {
+		(void)hipHostUnregister(g_host_regs.front().p);
+		g_host_regs.erase(g_host_regs.begin());
+	}
+	if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess)
+		g_host_regs.push_back({p, bytes});
+	(void)hipGetLastError();   // (a buffer that cannot be registered is copied the ordinary way)
+}
+
+void host_unregister_all()
+{
+	std::lock_guard<std::mutex> lock(g_host_reg_mu);
+	for (auto &r : g_host_regs)
+		(void)hipHostUnregister(r.p);
+	g_host_regs.clear();
+	(void)hipGetLastError();
+}
 
 // ---- optional HIP-event bracketing of the kernels (rsx_profile_begin/end) ------
 struct ProfRec {
@@ -262,7 +326,10 @@ int lds_order_selfcheck(int dev)
 	if (!(force && force[0] == '1') && hipMalloc((void **)&d_bad, sizeof(u64)) == hipSuccess) {
 		u64 bad = ~0ull;
 		if (hipMemset(d_bad, 0, sizeof(u64)) == hipSuccess) {
+			// two shapes: eight waves of bare atomics on collision-heavy digits, and the production shape of
+			// rsx_scatter2_kernel (16 waves, eight atomics in flight, staging stores and 16-byte rows between them)
 			hipLaunchKernelGGL(rsx_lds_order_check_kernel, dim3(1024), dim3(512), 0, 0, d_bad, 0x9E3779B9u, 512);
+			hipLaunchKernelGGL(rsx_lds_order_check2_kernel, dim3(512), dim3(1024), 0, 0, d_bad, 0x85EBCA6Bu, 256);
 			if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
 			    hipMemcpy(&bad, d_bad, sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess)
 				ok = bad == 0;
@@ -301,6 +368,20 @@ int capture_hist(Ctx &c, size_t n, size_t kb)
 			dst[256 * j + d] = (d == 255 ? (u64)n : off[256 * j + d + 1]) - off[256 * j + d];
 	return RSX_OK;
 }
+
+// RSX_VERIFY=1 (read once per process): after every host-scheduled scatter pass of the fast kernel one pseudo-randomly
+// chosen tile is re-ranked without LDS atomics (rsx_verify_tile_kernel) and compared with what the pass wrote; a
+// mismatch fails the call with RSX_EVERIFY.  Passes are then serialised by the check's read-back and no pass is
+// speculative; the *_inplace_async entry points, which never synchronise, are not verified.
+bool verify_mode()
+{
+	static const bool on = [] {
+		const char *e = getenv("RSX_VERIFY");
+		return e && e[0] == '1';
+	}();
+	return on;
+}
+u32 g_verify_seq = 0;
 
 int get_ctx(void *stream, Ctx **out)
 {
@@ -409,6 +490,8 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, siz
 	                   c.kept(), c.hotd(), c.plan_done(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan);   // (+ the finish)
 	HIP_TRY(hipGetLastError());
 	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
+		if (c.small.external)
+			return RSX_OK;   // (a caller-owned workspace: nobody waits for this plan on the host)
 		if (!c.plan_ev)
 			HIP_TRY(hipEventCreateWithFlags(&c.plan_ev, hipEventDisableTiming));
 		HIP_TRY(hipEventRecord(c.plan_ev, c.stream));
@@ -460,6 +543,14 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 	const bool plain = integer && ka.sflip == 0 && ka.desc == 0;
 	const bool hot = (flags & SCATTER_HOT) != 0;
 	flags &= ~(u32)SCATTER_HOT;
+	// RSX_ELEM_LOADS=1: whole tiles are read with element loads instead of 16-byte loads + a transposition through the LDS
+	// (measured on 2^28 u32 keys: 0.490-0.505 against 0.503-0.513 ms per pass in the probe; off by default)
+	static const bool elem_loads = [] {
+		const char *e = getenv("RSX_ELEM_LOADS");
+		return e && e[0] == '1';
+	}();
+	if (elem_loads)
+		flags |= SCATTER_ELEM_LOADS;
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
 	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, (u64 *)nullptr, dplan, pass_index,  \
@@ -500,6 +591,28 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 #undef RSX_LAUNCH2_ST
 #undef RSX_LAUNCH2
 	HIP_TRY(hipGetLastError());
+	if (verify_mode() && !dplan && tiles > 0) {
+		const u32 vt = (u32)(((u64)(++g_verify_seq) * 2654435761ull) % tiles);
+		const void *vi = (flags & SCATTER_GEN_INDEX) ? nullptr : (const void *)vin;
+#define RSX_VERIFY_TILE(ST)                                                                                             \
+		hipLaunchKernelGGL((rsx_verify_tile_kernel<KT, ST>), dim3(1), dim3(64), 0, c.stream, kin, (const void *)kout, vi,       \
+		                   (const void *)vout, (u64)n, shift, gbase, (const ST *)st, vt, (u32)C2::TILE, ka, (u32)sizeof(KTO),  \
+		                   oshift, (u32)val_bytes<VT>::value, (u32)((flags & SCATTER_SKIP_KEYS) ? 1 : 0), c.verify_bad(),           \
+		                   (u32)(getenv("RSX_VERIFY_INJECT") ? 1 : 0))
+		if (wide)
+			RSX_VERIFY_TILE(u64);
+		else
+			RSX_VERIFY_TILE(u32);
+#undef RSX_VERIFY_TILE
+		HIP_TRY(hipGetLastError());
+		u64 bad = 0;
+		HIP_TRY(hipMemcpyAsync(&bad, c.verify_bad(), sizeof(bad), hipMemcpyDeviceToHost, c.stream));
+		HIP_TRY(hipStreamSynchronize(c.stream));
+		if (bad)
+			return fail(RSX_EVERIFY, "RSX_VERIFY: tile %u of a scatter pass (shift %u, %zu keys) differs from its ballot-ranked "
+			                         "re-computation in %llu places: the LDS did not return same-address atomics in lane order",
+			            vt, shift, n, (unsigned long long)bad);
+	}
 	return RSX_OK;
 }
 
@@ -618,7 +731,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	Plan plan;
 	// The first pass is enqueued before the host knows the plan (it reads the device's copy and does nothing on
 	// sorted input): the host's wait for the plan, 20-25 us of idle GPU otherwise, hides behind it.
-	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION");
+	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION") && !verify_mode();
 	// with the fast kernel every pass has its own region of status words, all zeroed together with the histogram
 	const size_t status_total = c.fast ? status_bytes<KT, NoVal>(n) * sizeof(KT) : 0;
 	if (spec) {
@@ -763,11 +876,39 @@ int rank_pass(Ctx &c, const void *kin, void *kout, u32 out_bytes, const IT *vin,
 	return scatter_pass_to<KCUR, IT>(c, (const KCUR *)kin, kout, out_bytes, vin, vout, n, shift, gbase, ka, flags, oshift);
 }
 
+// the runs of contiguous set bits of `mask`, lowest first, packed towards bit 0; false if there are more than eight
+bool bit_runs(u64 mask, BitRuns *out)
+{
+	out->n = 0;
+	u32 dst = 0;
+	for (u32 b = 0; b < 64;) {
+		if (!((mask >> b) & 1)) {
+			++b;
+			continue;
+		}
+		u32 e = b;
+		while (e < 64 && ((mask >> e) & 1))
+			++e;
+		if (out->n == 8)
+			return false;
+		out->src[out->n] = (uint8_t)b;
+		out->len[out->n] = (uint8_t)(e - b);
+		out->dst[out->n] = (uint8_t)dst;
+		dst += e - b;
+		++out->n;
+		b = e;
+	}
+	return true;
+}
+
+// want_half: -1 = the half the number of kept columns dictates (radix_sort_rank.hpp:91); 0 / 1 = leave the ranks in that half
+// whatever the number of passes is (the first pass generates its indices, so it can write to either half).
 template <typename KT, typename IT>
-int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info)
+int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info, int want_half = -1)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed()) {
+	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed() &&
+	    want_half < 0) {
 		ProfScope prof(1, (u64)n * (sizeof(KT) + 2 * sizeof(IT)), c.stream);
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, IT, true>), dim3(1), dim3(1024), 0, c.stream, src, (KT *)nullptr, ib, ib + n,
 		                   (u32)n, ka, c.dev_host_plan);
@@ -797,12 +938,53 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		return RSX_OK;
 	}
 	const u32 P = plan.ncols;
+	// README.md:716-758, "key compaction" (SURVEY.md 8 f4), behind RSX_COMPACT_BITS=1: when the bits that vary among the
+	// keys (plan.vary, read off the histograms) fit fewer bytes than there are varying byte columns, the keys' varying bits
+	// are packed together (one elementwise pass) and the packed values are rank-sorted instead: ceil(bits / 8) passes over
+	// narrower keys.  The ranks are the same (all other bits are equal in every key) and they are left in the half the
+	// reference's number of passes dictates.
+	if (want_half < 0 && c.fast && sizeof(IT) == 4 && P > 1) {
+		static const bool compact_on = [] {
+			const char *e = getenv("RSX_COMPACT_BITS");
+			return e && e[0] == '1';
+		}();
+		const u64 vary = ((u64)plan.vary_hi << 32) | plan.vary_lo;
+		const u32 bits = (u32)__builtin_popcountll(vary), P2 = (bits + 7) / 8;
+		BitRuns runs;
+		if (compact_on && vary && P2 < P && bit_runs(vary, &runs)) {
+			const u32 ob = P2 <= 1 ? 1 : P2 <= 2 ? 2 : P2 <= 4 ? 4 : 8;
+			RSX_TRY(c.ckeys.ensure(n * ob));
+			const dim3 grid(4096), block(256);
+			rsx_info inner;
+			int rc = RSX_EINVAL;
+			const int half = (int)(P & 1);
+			if (ob == 1) {
+				hipLaunchKernelGGL((rsx_compact_bits_kernel<KT, uint8_t>), grid, block, 0, c.stream, src, (uint8_t *)c.ckeys.p, (u64)n, ka, runs);
+				rc = sort_rank_device<uint8_t, IT>(c, (const uint8_t *)c.ckeys.p, ib, n, RSX_U8, RSX_ASCENDING, result, &inner, half);
+			} else if (ob == 2) {
+				hipLaunchKernelGGL((rsx_compact_bits_kernel<KT, uint16_t>), grid, block, 0, c.stream, src, (uint16_t *)c.ckeys.p, (u64)n, ka, runs);
+				rc = sort_rank_device<uint16_t, IT>(c, (const uint16_t *)c.ckeys.p, ib, n, RSX_U16, RSX_ASCENDING, result, &inner, half);
+			} else if (ob == 4) {
+				hipLaunchKernelGGL((rsx_compact_bits_kernel<KT, u32>), grid, block, 0, c.stream, src, (u32 *)c.ckeys.p, (u64)n, ka, runs);
+				rc = sort_rank_device<u32, IT>(c, (const u32 *)c.ckeys.p, ib, n, RSX_U32, RSX_ASCENDING, result, &inner, half);
+			} else {
+				hipLaunchKernelGGL((rsx_compact_bits_kernel<KT, u64>), grid, block, 0, c.stream, src, (u64 *)c.ckeys.p, (u64)n, ka, runs);
+				rc = sort_rank_device<u64, IT>(c, (const u64 *)c.ckeys.p, ib, n, RSX_U64, RSX_ASCENDING, result, &inner, half);
+			}
+			RSX_TRY(rc);
+			if (info)
+				info->result_in_aux = P & 1;   // (ncols / cols stay the reference's: those of the original keys)
+			return RSX_OK;
+		}
+	}
 	if (P > 1) {
 		RSX_TRY(c.keys[0].ensure(n * sizeof(KT)));
 		if (P > 2)
 			RSX_TRY(c.keys[1].ensure(n * sizeof(KT)));
 	}
-	IT *H[2] = {ib, ib + n};
+	// want_half: the halves swap roles when the number of passes would leave the ranks in the other one
+	const bool swap_halves = want_half >= 0 && (int)(P & 1) != want_half;
+	IT *H[2] = {swap_halves ? ib + n : ib, swap_halves ? ib : ib + n};
 	if (c.fast && sizeof(IT) == 4 && !getenv("RSX_NO_NARROW_KEYS")) {
 		// The ranks are the only output, so a pass hands on just the key bytes that later passes look at: once those fit a
 		// narrower type the keys are written as kdf(key) >> (8 * next column) in that type, and the passes after it read
@@ -864,7 +1046,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 	}
 	*result = H[P & 1];                      // radix_sort_rank.hpp:91
 	if (info)
-		info->result_in_aux = P & 1;
+		info->result_in_aux = *result != (void *)ib;
 	return RSX_OK;
 }
 
@@ -1064,7 +1246,7 @@ size_t rsx_workspace_bytes(size_t n, rsx_dtype dtype, size_t payload_bytes)
 	const size_t tile = elem == 8 ? 4096 : 8192;
 	const size_t tiles = (n + tile - 1) / tile;
 	const size_t status = (256 + tiles * 256 * (n >= (1ull << 30) ? 8 : 4)) * kb;
-	return Ctx::SMALL_BYTES + kb * 256 * 8 + status + (size_t)512 * kb * 256 * 4;
+	return 512 + kb * 256 * 8 + ((status + 255) & ~(size_t)255) + (size_t)512 * kb * 256 * 4 + 256;
 }
 
 void rsx_release(void)
@@ -1090,7 +1272,56 @@ void rsx_release(void)
 		kv.second.misc.release();
 	}
 	g_multi_bufs.clear();
+	host_unregister_all();
 }
+
+namespace {
+
+// A context whose device state lies in the caller's workspace: [flags 256][plan 64 + pad][histogram][status regions]
+// [histogram rows].  Everything a captured graph of the *_ws entry points refers to is inside that workspace.
+int borrow_ctx(Ctx &v, void *stream, void *ws, size_t ws_bytes, size_t n, size_t kb, size_t status_total)
+{
+	// (no context of the library's own is created or touched: the call may be inside a stream capture, where nothing may
+	// be allocated; the device self-check has run when any other entry point was used before, otherwise it runs now)
+	int dev = 0;
+	{
+		std::lock_guard<std::mutex> lock(g_mu);
+		if (probe_devices() <= 0)
+			return fail(RSX_ENODEVICE, "no gfx950 (MI355X) device visible to HIP; this library has no CPU path");
+		HIP_TRY(hipGetDevice(&dev));
+		hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+		if (g_lds_order_ok.find(dev) == g_lds_order_ok.end() && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess &&
+		    cap != hipStreamCaptureStatusNone)
+			return fail(RSX_EINVAL, "the library's first use on this device is inside a stream capture: call rsx_device_count() "
+			                        "and any sort (or rsx_sort_inplace_async_ws itself) once before capturing -- the device "
+			                        "self-check cannot run inside a capture");
+		(void)hipGetLastError();
+		if (!lds_order_selfcheck(dev))
+			return fail(RSX_EHIP, "the device-scheduled sorts need the fast scatter kernel (the device self-check failed on this device)");
+	}
+	if (((uintptr_t)ws & 255) != 0)
+		return fail(RSX_EINVAL, "the workspace must be 256-byte aligned");
+	const size_t hist_bytes = kb * 256 * sizeof(u64), hpart_bytes = (size_t)512 * kb * 256 * sizeof(u32);
+	const size_t need = 512 + hist_bytes + ((status_total + 255) & ~(size_t)255) + hpart_bytes;
+	if (!ws || ws_bytes < need)
+		return fail(RSX_EINVAL, "workspace of %zu bytes, %zu needed for %zu keys (rsx_workspace_bytes gives an upper bound)", ws_bytes, need, n);
+	char *p = (char *)ws;
+	v.device = dev;
+	v.stream = (hipStream_t)stream;
+	v.fast = true;
+	v.small.borrow(p, 256);
+	v.dev_host_plan = (Plan *)(p + 256);          // (the kernels' second copy of the plan: nobody reads it on the host)
+	v.host_plan = nullptr;
+	p += 512;
+	v.hist.borrow(p, hist_bytes);
+	p += hist_bytes;
+	v.status.borrow(p, (status_total + 255) & ~(size_t)255);
+	p += (status_total + 255) & ~(size_t)255;
+	v.hpart.borrow(p, hpart_bytes);
+	return RSX_OK;
+}
+
+}  // namespace
 
 int rsx_capture_histogram(uint64_t *hist, size_t entries)
 {
@@ -1110,6 +1341,68 @@ int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dty
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	RSX_DISPATCH_KT(dtype, return sort_keys_inplace_async<KT>(*c, (KT *)d_buf, (KT *)d_scratch, n, dtype, order));
 	return RSX_OK;
+}
+
+int rsx_sort_inplace_async_ws(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order, void *d_workspace,
+                              size_t workspace_bytes, void *stream)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb || (n && (!d_buf || !d_scratch)))
+		return fail(RSX_EINVAL, "rsx_sort_inplace_async_ws: bad argument");
+	if (n < 2)
+		return RSX_OK;
+	Ctx view;
+	size_t status_total = 0;
+	RSX_DISPATCH_KT(dtype, status_total = (status_bytes<KT, NoVal>(n) * sizeof(KT)));
+	RSX_TRY(borrow_ctx(view, stream, d_workspace, workspace_bytes, n, kb, status_total));
+	RSX_DISPATCH_KT(dtype, return sort_keys_inplace_async<KT>(view, (KT *)d_buf, (KT *)d_scratch, n, dtype, order));
+	return RSX_OK;
+}
+
+int rsx_sort_pairs_inplace_async_ws(void *d_keys, void *d_keys_scratch, void *d_vals, void *d_vals_scratch, size_t n, rsx_dtype dtype,
+                                    size_t payload_bytes, rsx_order order, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb || (payload_bytes != 4 && payload_bytes != 8) || (n && (!d_keys || !d_keys_scratch || !d_vals || !d_vals_scratch)))
+		return fail(RSX_EINVAL, "rsx_sort_pairs_inplace_async_ws: bad argument");
+	if (n < 2)
+		return RSX_OK;
+	Ctx view;
+	size_t status_total = 0;
+	if (payload_bytes == 4) {
+		RSX_DISPATCH_KT(dtype, status_total = (status_bytes<KT, u32>(n) * sizeof(KT)));
+	} else {
+		RSX_DISPATCH_KT(dtype, status_total = (status_bytes<KT, u64>(n) * sizeof(KT)));
+	}
+	RSX_TRY(borrow_ctx(view, stream, d_workspace, workspace_bytes, n, kb, status_total));
+	if (payload_bytes == 4) {
+		RSX_DISPATCH_KT(dtype, return (sort_pairs_inplace_async<KT, u32>(view, (KT *)d_keys, (KT *)d_keys_scratch, (u32 *)d_vals,
+		                                                                 (u32 *)d_vals_scratch, n, dtype, order)));
+	} else {
+		RSX_DISPATCH_KT(dtype, return (sort_pairs_inplace_async<KT, u64>(view, (KT *)d_keys, (KT *)d_keys_scratch, (u64 *)d_vals,
+		                                                                 (u64 *)d_vals_scratch, n, dtype, order)));
+	}
+	return RSX_OK;
+}
+
+void rsx_release_stream(void *stream)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) {
+		(void)hipGetLastError();
+		return;
+	}
+	auto it = g_ctx.find(std::make_pair(dev, stream));
+	if (it == g_ctx.end())
+		return;
+	{
+		std::lock_guard<std::recursive_mutex> ctx_lock(it->second->mu);
+		(void)hipStreamSynchronize(it->second->stream);
+		it->second->release();
+	}
+	delete it->second;
+	g_ctx.erase(it);
 }
 
 int rsx_sort_pairs_inplace_async(void *d_keys, void *d_keys_scratch, void *d_vals, void *d_vals_scratch, size_t n, rsx_dtype dtype,
@@ -1236,6 +1529,8 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, v
 	// buffer the returned-pointer rule names (the other one is left as it was)
 	RSX_TRY(c->keys[0].ensure(n * kb));
 	RSX_TRY(c->keys[1].ensure(n * kb));
+	host_register(src, n * kb);
+	host_register(aux, n * kb);
 	HIP_TRY(hipMemcpyAsync(c->keys[0].p, src, n * kb, hipMemcpyHostToDevice, c->stream));
 	void *dres = nullptr;
 	rsx_info li;

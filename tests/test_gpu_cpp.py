@@ -84,13 +84,41 @@ def test_radix_cli_counterpart(tmp_path, ktype, mask, where):
 
 
 def test_radix_bench_counterpart(tmp_path):
-    """tools/radix_bench prints the reference's row names and columns for the sizes 1 .. 4*10^7."""
-    out = subprocess.run([_cli("radix_bench"), "--min-time", "0.05", "--filter", "radix_sort", "--device"], capture_output=True,
-                         text=True, timeout=900, cwd=tmp_path)
+    """tools/radix_bench prints the reference's row names and columns for the sizes 1 .. 4*10^7, and with --verify every
+    radix row's output -- the 40 M-key rows of BASELINE.json configs[0] included -- is compared with std::sort / the stable
+    argsort outside the timed region (what radix_experiment.cpp:137-174 does for `radix`)."""
+    out = subprocess.run([_cli("radix_bench"), "--min-time", "0.05", "--filter", "radix_sort", "--device", "0", "--verify"],
+                         capture_output=True, text=True, timeout=1200, cwd=tmp_path)
     assert out.returncode == 0, out.stdout + out.stderr
     rows = [l.split() for l in out.stdout.splitlines() if l.startswith("FSu32/")]
     names = [r[0] for r in rows]
-    for kind in ("radix_sort", "radix_sort_rank", "radix_sort_device"):
+    for kind, ref in (("radix_sort", "std::sort of the same keys"), ("radix_sort_rank", "the stable argsort"),
+                      ("radix_sort_device", "std::sort of the same keys")):
         for n in (1, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 40000000):
             assert "FSu32/%s/%d" % (kind, n) in names
+            assert "verified: FSu32/%s/%d == %s" % (kind, n, ref) in out.stdout
+    assert "DIFFERS" not in out.stdout
     assert "KeyRate" in out.stdout and "bytes_per_second" in out.stdout
+    bad = subprocess.run([_cli("radix_bench"), "--device", "99"], capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert bad.returncode == 3 and "no such HIP device" in bad.stderr
+
+
+def test_radix_cli_device_flag(tmp_path):
+    ok = subprocess.run([_cli("radix"), "100000", "0", "0", "uint32_t", "--device", "0"], capture_output=True, text=True, timeout=300,
+                        cwd=tmp_path)
+    assert ok.returncode == 0 and "Verifying sort... Forward sorted OK." in ok.stdout, ok.stdout + ok.stderr
+    bad = subprocess.run([_cli("radix"), "--device", "99", "100000"], capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert bad.returncode == 3 and "no such HIP device" in bad.stdout
+
+
+def test_report_script(tmp_path):
+    """tools/report.sh, the counterpart of the reference's bench.sh:6-18: uname, git revision, lscpu, the GPU, four `radix`
+    runs on the whole key file and `radix_bench --device --verify`, written to bench-<date>.txt."""
+    out = subprocess.run(["sh", os.path.join(ROOT, "tools", "report.sh"), "0"], capture_output=True, text=True, timeout=1800, cwd=tmp_path)
+    assert out.returncode == 0, out.stdout + out.stderr
+    name = out.stdout.strip().splitlines()[-1]
+    text = open(os.path.join(str(tmp_path), name)).read()
+    assert text.count("Sorted 40000000 entries in ") == 4 and text.count("Forward sorted OK.") == 4
+    assert "Linux" in text and "gfx950" in text and "CPU(s):" in text
+    assert "verified: FSu32/radix_sort/40000000 == std::sort of the same keys" in text
+    assert "verified: FSu32/radix_sort_device/40000000 == std::sort of the same keys" in text

@@ -552,6 +552,60 @@ def test_inplace_async_sort_in_a_hip_graph(n):
         assert np.array_equal(to_bits(buf, ol.U32), want), (n, seed)
 
 
+@pytest.mark.parametrize("n", [5000, 300001, 1 << 22])
+def test_graph_with_a_caller_owned_workspace_survives_larger_sorts(n):
+    """a graph captured from rsx_sort_inplace_async refers to the library's cached workspace, which a later
+    larger sort on the same (device, stream) frees and reallocates.  The *_ws forms keep every piece of device state in a
+    workspace the caller owns: the graph is replayed after much larger sorts, after rsx_release_stream and rsx_release, on
+    the capture stream and on another one, keys and key + payload."""
+    s = torch.cuda.Stream()
+    buf = torch.empty(n, dtype=torch.int32, device="cuda")
+    scratch = torch.empty_like(buf)
+    vals = torch.empty(n, dtype=torch.int64, device="cuda")
+    vscratch = torch.empty_like(vals)
+    ws = torch.empty(rsa.workspace_bytes(n, ol.U32, 0), dtype=torch.uint8, device="cuda")
+    ws2 = torch.empty(rsa.workspace_bytes(n, ol.U32, 8), dtype=torch.uint8, device="cuda")
+    with pytest.raises(rsa.RsxError, match="workspace"):
+        rsa.radix_sort_inplace_async_ws(buf, scratch, ws[:1024], dtype=ol.U32)
+    g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        rsa.radix_sort_inplace_async_ws(buf, scratch, ws, dtype=ol.U32, stream=torch.cuda.current_stream())
+    with torch.cuda.graph(g2, stream=s):
+        rsa.radix_sort_pairs_inplace_async_ws(buf, scratch, vals, vscratch, ws2, dtype=ol.U32, stream=torch.cuda.current_stream())
+
+    def check(seed, mask, pairs):
+        a = ol.splitmix_fill(n, ol.U32, seed, mask)
+        buf.copy_(to_dev(a))
+        vals.copy_(torch.arange(n, dtype=torch.int64, device="cuda"))
+        torch.cuda.synchronize()
+        (g2 if pairs else g).replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(to_bits(buf, ol.U32), ol.oracle_sort(a, ol.U32)[0]), (n, seed, pairs)
+        if pairs:
+            assert np.array_equal(vals.cpu().numpy().astype(np.uint64), ol.stable_argsort_by_kdf(a, ol.U32).astype(np.uint64))
+
+    check(11, 0xFFFFFFFF, False)
+    check(12, 0x00FFFFFF, True)
+    # much larger sorts on the capture stream and on the default stream: the library's own workspaces grow
+    big = torch.empty(1 << 25, dtype=torch.int32, device="cuda")
+    baux = torch.empty_like(big)
+    with torch.cuda.stream(s):
+        rsa.fill_splitmix(big, seed=5, stream=s)
+        rsa.radix_sort(big, baux, dtype=ol.U32, stream=s)
+        rsa.radix_sort_inplace_async(big, baux, dtype=ol.U32, stream=s)
+    s.synchronize()                      # (the default stream is about to overwrite `big`)
+    rsa.fill_splitmix(big, seed=6)
+    rsa.radix_sort(big, baux, dtype=ol.U32)
+    torch.cuda.synchronize()
+    check(13, 0x0000FF00, False)
+    check(14, 0xFFFFFFFF, True)
+    rsa.release_stream(s)
+    check(15, 0xFF00FFFF, False)
+    rsa.lib().rsx_release()
+    check(16, 0xFFFFFFFF, True)
+    check(17, 0xFFFFFFFF, False)
+
+
 # ---- BASELINE.json sizes: size-independent properties + full comparison where the oracle is quick enough ----
 
 def test_full_size_2p28_u32_properties():

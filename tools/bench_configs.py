@@ -6,11 +6,20 @@ sys.path.insert(0, ROOT)
 import torch
 import radix_sorting_amd as rsa
 
-N, K, W = 1 << 28, 8, 2
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--only", default="", help="substring of the configurations to run")
+ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_configs.json"))
+args = ap.parse_args()
+N, K, W = 1 << 28, args.steps, args.warmup
 rsa.require_gpu()
 out = []
 
 def timed(name, make, run, bytes_per_key):
+    if args.only and args.only not in name:
+        return
     batches = [make(i) for i in range(K + W)]
     for i in range(W):
         run(batches[i])
@@ -61,5 +70,15 @@ def mk_pm1(i):    # SURVEY.md 8d cfg 4 (ii): (int24 - 2^23) * 2^-23, uniform in 
     f = (((r >> 40) & 0xFFFFFF) - (1 << 23)).to(torch.float32) * (2.0 ** -23)
     return f.view(torch.int32).contiguous()
 timed("cfg4 f32 uniform [-1,1) -> u32 ranks", mk_pm1, runrank, lambda P: 4 + P * 2 * 8)
-os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
+# cfg 4 as key + payload pairs (struct of arrays): f32 keys, u32 payload = element index, both ping-pong
+del ib
+vals = torch.arange(N, dtype=torch.int32, device="cuda")
+kaux = torch.empty(N, dtype=torch.int32, device="cuda")
+vaux = torch.empty(N, dtype=torch.int32, device="cuda")
+vwork = torch.empty(N, dtype=torch.int32, device="cuda")
+def runpairs(t):
+    vwork.copy_(vals)
+    return rsa.radix_sort_pairs(t, kaux, vwork, vaux, dtype=rsa.F32)[2]
+timed("cfg4 f32 random bits + u32 payload (pairs)", mk32(0xFFFFFFFF), runpairs, lambda P: 4 + P * 2 * 8)
+os.makedirs(os.path.dirname(args.out), exist_ok=True)
+json.dump(out, open(args.out, "w"), indent=1)

@@ -1,7 +1,7 @@
 // radix -- counterpart of the reference's `radix` command (radix_experiment.cpp:241-285) on
 // top of this repo's include/radix_sort.hpp (MI355X through librsx.so).
 //
-//   ./radix <count> [<use_mmap> <use_huge> <uint8_t|uint16_t|uint32_t|uint64_t|int32_t|int64_t|float|double> <hex-mask>]
+//   ./radix <count> [<use_mmap> <use_huge> <uint8_t|uint16_t|uint32_t|uint64_t|int32_t|int64_t|float|double> <hex-mask>] [--device N]
 //
 // Same positional arguments and the same output lines, so that a run can be laid next to a report of the
 // reference: the header line (:259), "Allocating ... bytes for ..." (:59), "Applying value mask to input." (:190),
@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "radix_sort.hpp"
 
@@ -154,15 +156,29 @@ template <typename T> static int run(size_t entries, uint64_t mask)
 	return 0;
 }
 
-int main(int argc, char *argv[])
+int main(int argc0, char *argv0[])
 {
+	// --device N anywhere on the line selects the HIP device (not in the reference: it has no devices); the remaining
+	// arguments are the reference's positional ones (radix_experiment.cpp:241-257)
+	int argc = 0, device = -1;
+	char *argv[8] = {nullptr};
+	for (int i = 0; i < argc0; ++i) {
+		if (!strcmp(argv0[i], "--device") && i + 1 < argc0)
+			device = atoi(argv0[++i]);
+		else if (argc < 8)
+			argv[argc++] = argv0[i];
+	}
+	if (device >= 0 && hipSetDevice(device) != hipSuccess) {
+		printf("Error: --device %d: no such HIP device.\n", device);
+		return 3;
+	}
 	const long entries = argc > 1 ? atol(argv[1]) : 0;
 	const int use_mmap = argc > 2 ? atoi(argv[2]) : 0;
 	const int use_huge = argc > 3 ? atoi(argv[3]) : 0;
 	const char *ktype = argc > 4 ? argv[4] : "uint32_t";
 	const uint64_t mask = argc > 5 ? strtoull(argv[5], nullptr, 16) : ~0ull;
 	if (argc == 1) {
-		printf("Usage: %s <count> [<use_mmap> <use_huge> <uint8_t|uint16_t|uint32_t|uint64_t|int32_t|int64_t|float|double> <hex-mask>]\n",
+		printf("Usage: %s <count> [<use_mmap> <use_huge> <uint8_t|uint16_t|uint32_t|uint64_t|int32_t|int64_t|float|double> <hex-mask>] [--device N]\n",
 		       argv[0]);
 		return 0;
 	}

@@ -1,26 +1,74 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 output dirs produced by tools/profile_bench.sh: per-kernel stats and PMC sums/averages."""
+"""Summarise the rocprofv3 output directories of tools/profile_bench.sh.
+
+Per kernel instantiation: calls and average duration (kernel trace), the PMC counters per dispatch, and -- for the
+histogram and scatter kernels, whose algorithmic bytes per launch follow from the template arguments and n = 2^28 --
+achieved algorithmic TB/s, its fraction of the 8 TB/s HBM peak, and the counter traffic beside it:
+    fabric bytes = 2 * FETCH_SIZE + WRITE_SIZE   [KiB units -> bytes]
+(MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced streaming read).
+"""
 import csv
 import glob
+import json
 import os
 import re
 import sys
 from collections import defaultdict
 
+N = 1 << 28
+SIZES = {"unsigned int": 4, "unsigned long long": 8, "unsigned long": 8, "unsigned short": 2, "unsigned char": 1, "rsx::NoVal": 0,
+         "float": 4, "double": 8, "int": 4}
+
 
 def short(name):
     name = re.sub(r"\(.*", "", name)
-    name = name.replace("rsx::", "").replace("unsigned long long", "u64").replace("unsigned int", "u32")
-    return name.replace("void ", "")[:110]
+    name = name.replace("rsx::", "").replace("unsigned long long", "u64").replace("unsigned long", "u64").replace("unsigned int", "u32")
+    name = name.replace("unsigned short", "u16").replace("unsigned char", "u8")
+    return name.replace("void ", "")[:120]
+
+
+def template_types(name):
+    m = re.search(r"<(.*)>", name)
+    if not m:
+        return []
+    parts, depth, cur = [], 0, ""
+    for ch in m.group(1):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    parts.append(cur.strip())
+    return parts
+
+
+def algorithmic_bytes(name):
+    """n * (key read + key written + 2 * payload) for a scatter launch, n * key for a histogram launch."""
+    t = template_types(re.sub(r"\(.*", "", name))
+    if "rsx_scatter2_kernel" in name and len(t) >= 3:
+        kin = SIZES.get(t[0], 0)
+        val = SIZES.get(t[1], 0)
+        kout = SIZES.get(t[-1], kin) if t[-1] in SIZES else kin
+        return N * (kin + kout + 2 * val)
+    if "rsx_hist_kernel" in name and t:
+        return N * SIZES.get(t[0], 0)
+    return None
 
 
 def main(out):
+    durations = {}
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         print("== kernel stats (%s)" % os.path.relpath(f, out))
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                print("%-72s calls %6s  total %12s ns  avg %12s ns  %6s%%" % (
+                print("%-100s calls %6s  total %12s ns  avg %12s ns  %6s%%" % (
                     short(row["Name"]), row["Calls"], row["TotalDurationNs"], row["AverageNs"], row["Percentage"]))
+                durations[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]))
+    counters = defaultdict(dict)
     for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         if not os.path.isdir(d):
             continue
@@ -29,16 +77,41 @@ def main(out):
             calls = defaultdict(lambda: defaultdict(int))
             with open(f) as fh:
                 for row in csv.DictReader(fh):
-                    k = short(row["Kernel_Name"])
+                    k = row["Kernel_Name"]
                     acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
                     calls[k][row["Counter_Name"]] += 1
             print("== counters (%s): per-dispatch averages" % os.path.relpath(f, out))
             for k in sorted(acc):
                 if "rsx_" not in k:
                     continue
-                print("  " + k)
+                print("  " + short(k))
                 for cn in sorted(acc[k]):
-                    print("      %-24s %16.1f   (over %d dispatches)" % (cn, acc[k][cn] / calls[k][cn], calls[k][cn]))
+                    avg = acc[k][cn] / calls[k][cn]
+                    counters[k][cn] = avg
+                    print("      %-24s %16.1f   (over %d dispatches)" % (cn, avg, calls[k][cn]))
+    print("== roofline per instantiation (algorithmic bytes at n = 2^28 / average duration; peak 8000 GB/s)")
+    table = []
+    for name, (calls, avg_ns) in sorted(durations.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        ab = algorithmic_bytes(name)
+        if ab is None or avg_ns <= 0:
+            continue
+        key = next((k for k in counters if re.sub(r"\(.*", "", k) == re.sub(r"\(.*", "", name)), None)
+        fetch = counters.get(key, {}).get("FETCH_SIZE")
+        write = counters.get(key, {}).get("WRITE_SIZE")
+        traffic = (2 * fetch + write) * 1024 if fetch is not None and write is not None else None
+        lds_c, lds_a = counters.get(key, {}).get("SQ_LDS_BANK_CONFLICT"), counters.get(key, {}).get("SQ_LDS_IDX_ACTIVE")
+        gbps = ab / avg_ns
+        row = {"kernel": short(name), "calls": calls, "avg_us": avg_ns / 1e3, "algorithmic_bytes": ab, "achieved_GBps": gbps,
+               "frac_of_8TBps": gbps / 8000.0, "fabric_bytes_per_launch": traffic,
+               "traffic_over_algorithmic": traffic / ab if traffic else None,
+               "lds_bank_conflict_share": lds_c / lds_a if lds_c is not None and lds_a else None}
+        table.append(row)
+        print("%-100s %5d x %9.1f us  %6.0f GB/s  frac %.3f  traffic %s  LDS conflicts %s" % (
+            row["kernel"], calls, row["avg_us"], gbps, row["frac_of_8TBps"],
+            "%.2fx" % row["traffic_over_algorithmic"] if traffic else "n/a",
+            "%.0f%%" % (100 * row["lds_bank_conflict_share"]) if row["lds_bank_conflict_share"] is not None else "n/a"))
+    with open(os.path.join(out, "roofline_table.json"), "w") as f:
+        json.dump(table, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-// EXPERIMENT (round 2), not part of the library.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_2wg_*.txt):
+// EXPERIMENT (round 2), not part of the library.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_all_experiments.txt):
 // 64 keys per lane spill (0.84 ms); 48 keys per lane (24 Ki-key tiles): 0.55-0.57 ms against 0.506 for rsx_scatter2_kernel,
 // 0.361 ms without global stores (0.34): two workgroups per CU do not overlap anything that matters -- a key is offered to
 // the LDS once more (the second, predicated staging pass), eight waves hide the LDS latency worse than sixteen, and the

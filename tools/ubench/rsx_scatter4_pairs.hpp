@@ -1,5 +1,5 @@
 // EXPERIMENT (round 2), not part of the library; the carry described below was NOT built, because the first half of the
-// idea already lost.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_v4_v5.txt): 0.570 ms per pass against 0.506 for
+// idea already lost.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_all_experiments.txt): 0.570 ms per pass against 0.506 for
 // rsx_scatter2_kernel.  Loading two tiles at once takes 35 k cycles, not 13 k: a CU pulls about 10 bytes per cycle from HBM
 // however much it has in flight (MI355X_MICROARCH.md: ~10 B/cyc/CU), so the load phase is proportional to the bytes and the
 // second tile's load is not hidden by the first's; the chain grows to 22 tiles (9.7 k cycles).

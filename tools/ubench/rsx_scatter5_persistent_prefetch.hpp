@@ -1,4 +1,4 @@
-// EXPERIMENT (round 2), not part of the library.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_v4_v5.txt):
+// EXPERIMENT (round 2), not part of the library.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_all_experiments.txt):
 //   prefetch issued by each wave after its staging: wait + count 5.0 k cycles (from 13 k) but chain 16.9 k (from 5.7 k) --
 //     the status words of the look-back queue behind the key loads in the CU's memory pipeline -- 0.556 ms;
 //   prefetch issued behind the barrier, before the write-out's stores: the STORES queue behind the loads, write-out

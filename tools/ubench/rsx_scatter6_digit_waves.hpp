@@ -1,4 +1,4 @@
-// EXPERIMENT (round 2), not part of the library.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_v6_digit_waves.txt):
+// EXPERIMENT (round 2), not part of the library.  Measured on 2^28 u32 keys (profiles/r02/scatter_probe_all_experiments.txt):
 // 0.528 ms per pass against 0.506 for rsx_scatter2_kernel.  The chain (6.0 k cycles) is hidden as intended, but the twelve
 // key waves need 8.0 k cycles to rank and stage 40 keys per lane: the staging phase is bound by the LDS (one returning
 // atomic and one store per key at random addresses: about 17 cycles per 64 keys with their bank conflicts), not by the chain.

@@ -7,6 +7,7 @@
 #include "rsx_scatter4_pairs.hpp"
 #include "rsx_scatter5_persistent_prefetch.hpp"
 #include "rsx_scatter6_digit_waves.hpp"
+#include "rsx_scatter7_rerank_windows.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -424,6 +425,75 @@ void bench6(const char *name)
 	g_flags = 0;
 }
 
+template <typename C, bool TL>
+float run7_once(u32 shift, bool dump)
+{
+	const u64 tiles = n / C::TILE;
+	CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, tiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter7_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3((unsigned)tiles), dim3(C::BLOCK), 0, 0, d_in, d_out, (u64)n,
+	                   shift, d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(tiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, tiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, s0 = 0, w0 = 0, s1 = 0, w1 = 0, depth = 0, life = 0;
+		for (u64 t = 0; t < tiles; ++t) {
+			const u64 *r = &tl[t * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			s0 += (double)(r[4] - r[2]);
+			w0 += (double)(r[5] - r[4]);
+			s1 += (double)(r[6] - r[5]);
+			w1 += (double)(r[7] - r[6]);
+			life += (double)(r[7] - r[0]);
+			depth += r[12];
+		}
+		printf("  per tile: load+count %7.0f | layout %6.0f | rank+stage0 %7.0f (chain %6.0f, depth %.1f, inside) | write0 %6.0f | rank+stage1 %6.0f | "
+		       "write1 %6.0f | lifetime %7.0f\n",
+		       a / tiles, lay / tiles, s0 / tiles, ch / tiles, depth / tiles, w0 / tiles, s1 / tiles, w1 / tiles, life / tiles);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench7(const char *name)
+{
+	run7_once<C, false>(0, false);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run7_once<C, false>(8 * (i % 4), false);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-14s tile %6d lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
+	       sizeof(Sc7Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run7_once<C, true>(0, true);
+	std::vector<u32> a(n), b(n);
+	run7_once<C, false>(8, false);
+	CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+	CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (the whole array, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run7_once<C, true>(0, false));
+	g_flags = 0;
+}
+
 template <typename C, bool HOTV = false>
 void bench2(const char *name, u32 tps)
 {
@@ -547,6 +617,7 @@ int main(int argc, char **argv)
 	g_flags = SCATTER_ELEM_LOADS;
 	bench2<Sc2Cfg<u32, NoVal>>("v2 elem loads", 1);
 	g_flags = 0;
+	bench7<Sc7Cfg<u32>>("v7 2 WG/CU, re-ranked windows");
 	if (getenv("RSX_PROBE_ALL")) {
 		// round 2's structural experiments (each a header of its own next to this file, with its numbers)
 		bench3<Sc3Cfg<u32, 8, 8, 48>>("v3 2 WG/CU, 2 windows");
