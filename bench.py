@@ -326,6 +326,12 @@ def main():
                 "sort_algorithmic_GBps": None if sharded else total_keys / world * 36 / elapsed / 1e9,
             },
         }
+        if sharded and isinstance(last[1], dict) and "host_ms_submit_exchange_and_sorts" in last[1]:
+            # the host's share of a step (multi.py is Python): how long rank 0 took to get the counts back (includes the split
+            # pass on the device) and to submit the exchange and the local sorts (nothing of it waits for the device)
+            out["host"] = {"ms_split_and_counts_last_step": last[1]["host_ms_split_and_counts"],
+                           "ms_submit_exchange_and_sorts_last_step": last[1]["host_ms_submit_exchange_and_sorts"],
+                           "chunks": last[1].get("chunks"), "heavy_digits": last[1].get("heavy_digits")}
         if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

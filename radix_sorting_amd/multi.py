@@ -244,9 +244,11 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     destination's digit range is cut into; the exchange of sub-range j+1 overlaps the local sort of sub-range j
     (default: RSX_MULTI_CHUNKS or 4; 1 = one ``all_to_all_single`` and one local sort, nothing overlapped).
     """
+    import time
     import torch
     import torch.distributed as dist
 
+    t_enter = time.perf_counter()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = shard.numel()
@@ -260,6 +262,7 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # preallocated scratch is used when it is large enough and replaced when it is not.
     part = scratch["part"][:n] if scratch else engine.empty(n, shard)
     hists, column, heavy = split_plan(shard, part, engine, group, world, tmp=scratch.get("aux") if scratch else None)
+    t_planned = time.perf_counter()     # (includes the split pass's one synchronisation and the gather of the counts)
     local_hist = hists[rank]
     lut = choose_splitters(hists.sum(axis=0), world)
     matrix = count_matrix(hists, lut, world)          # matrix[s, d]: keys rank s sends to rank d
@@ -343,6 +346,8 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     if side is not None:
         main.wait_stream(side)
     sent = int(send_counts.sum() - send_counts[rank])
-    return recv, {"sent": sent, "received": n_recv, "local_info": None, "lut": lut, "split_column": column,
+    t_submitted = time.perf_counter()
+    return recv, {"host_ms_split_and_counts": (t_planned - t_enter) * 1e3, "host_ms_submit_exchange_and_sorts": (t_submitted - t_planned) * 1e3,
+                  "sent": sent, "received": n_recv, "local_info": None, "lut": lut, "split_column": column,
                   "heavy_digits": heavy, "chunks": nchunks, "overlap_stream": side is not None, "send_counts": send_counts,
                   "recv_counts": recv_counts}
