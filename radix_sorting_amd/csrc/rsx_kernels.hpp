@@ -244,7 +244,9 @@ enum : u32 {
 	SCATTER_ELEM_LOADS = 32, // whole tiles are read with element loads instead of 16-byte loads + a transposition through the LDS
 	SCATTER_DBG_LINEAR = 64, // probe only: write the staged tile back to its own position (no scatter)
 	SCATTER_DBG_NOSTORE = 128, // probe only: skip the global stores
-	SCATTER_DBG_NOLOADB = 256  // probe only: phase B fabricates keys instead of re-reading them
+	SCATTER_DBG_NOLOADB = 256, // probe only: phase B fabricates keys instead of re-reading them
+	SCATTER_DBG_XCD_RUNS = 512, // probe only: tiles by workgroup index, runs of 2^(bits 16-19) consecutive tiles per XCD (no ticket)
+	SCATTER_XCD_RUN_SHIFT = 16
 };
 
 // Tile shape: NWAVES wavefronts per workgroup, KPT keys per lane => NWAVES*64*KPT keys per tile.

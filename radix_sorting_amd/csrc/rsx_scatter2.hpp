@@ -165,7 +165,14 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	for (u32 i = tid; i < TPS * NWAVES * CW; i += BLOCK)
 		(&sm.cell[0][0][0])[i] = 0;
 	__syncthreads();
-	const u32 stile = __builtin_amdgcn_readfirstlane(sm.ticket);
+	u32 stile = __builtin_amdgcn_readfirstlane(sm.ticket);
+	if (flags & SCATTER_DBG_XCD_RUNS) {
+		// probe only (grid a multiple of 8 << lr, lr <= 5): workgroup i runs on XCD i % 8 and takes its k = i / 8 -th tile
+		// there, tiles dealt to the XCDs in runs of 2^lr.  Measured: no faster than tickets.
+		const u32 lr = (flags >> SCATTER_XCD_RUN_SHIFT) & 15u, R = 1u << lr;
+		const u32 x = blockIdx.x & 7u, k = blockIdx.x >> 3;
+		stile = ((k >> lr) * 8u + x) * R + (k & (R - 1u));
+	}
 	const u64 beg = (u64)stile * tps * C::TILE;
 	u64 end = beg + (u64)tps * C::TILE;
 	if (end > n)

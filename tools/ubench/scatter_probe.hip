@@ -8,6 +8,7 @@
 #include "rsx_scatter5_persistent_prefetch.hpp"
 #include "rsx_scatter6_digit_waves.hpp"
 #include "rsx_scatter7_rerank_windows.hpp"
+#include "rsx_scatter8_pipelined.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -593,6 +594,77 @@ void bench_read_ahead()
 	printf("  %s\n", a == b ? "output identical with and without the helper" : "OUTPUT DIFFERS with the helper");
 }
 
+template <typename C, bool TL>
+float run8_once(u32 shift, bool dump, u32 grid)
+{
+	const u32 ntiles = (u32)(n / C::TILE);
+	CK(hipMemsetAsync(d_status, 0, 256 + (size_t)ntiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, (size_t)ntiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter8_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, d_out, ntiles, shift,
+	                   d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(ntiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, (size_t)ntiles * 16 * 8, hipMemcpyDeviceToHost));
+		double lay = 0, st = 0, bar = 0, wr = 0, depth = 0, steps = 0, life = 0;
+		u64 cnt = 0;
+		for (u64 t = 0; t < ntiles; ++t) {
+			const u64 *r = &tl[t * 16];
+			lay += (double)(r[1] - r[0]);
+			st += (double)(r[2] - r[1]);
+			bar += (double)(r[3] - r[1]);
+			wr += (double)(r[4] - r[3]);
+			life += (double)(r[4] - r[0]);
+			depth += r[12];
+			steps += r[13];
+			++cnt;
+		}
+		printf("  per tile: layout + chain %6.0f (depth %.1f, %.2f steps) | prefetch issue + stage (wave 0) %6.0f, barrier at %6.0f | write-out + rank next %6.0f | "
+		       "period %7.0f\n",
+		       lay / cnt, depth / cnt, steps / cnt, st / cnt, bar / cnt, wr / cnt, life / cnt);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench8(const char *name, u32 grid)
+{
+	run8_once<C, false>(0, false, grid);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run8_once<C, false>(8 * (i % 4), false, grid);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-14s grid %u tile %6d, lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, grid, C::TILE,
+	       sizeof(Sc8Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run8_once<C, true>(0, true, grid);
+	std::vector<u32> a(n), b(n);
+	run8_once<C, false>(8, false, grid);
+	CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	const u32 keepf = g_flags;
+	g_flags = 0;
+	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+	CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (the whole array, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	g_flags = keepf | SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run8_once<C, true>(0, false, grid));
+	g_flags = 0;
+}
+
 template <typename C, bool HOTV = false>
 void bench2(const char *name, u32 tps)
 {
@@ -716,8 +788,29 @@ int main(int argc, char **argv)
 	g_flags = SCATTER_ELEM_LOADS;
 	bench2<Sc2Cfg<u32, NoVal>>("v2 elem loads", 1);
 	g_flags = 0;
-	bench7<Sc7Cfg<u32>>("v7 2 WG/CU, re-ranked windows");
-	bench_read_ahead();
+	if (getenv("RSX_PROBE_ALL"))
+		bench7<Sc7Cfg<u32>>("v7 2 WG/CU, re-ranked windows");
+	if (getenv("RSX_PROBE_ALL")) {
+		bench8<Sc8Cfg<u32, 8>>("v8 pipelined LB 8", 256);
+		bench8<Sc8Cfg<u32, 16>>("v8 pipelined LB 16", 256);
+		bench8<Sc8Cfg<u32, 24>>("v8 pipelined LB 24", 256);
+	}
+	if (getenv("RSX_PROBE_READ_AHEAD"))
+		bench_read_ahead();
+	for (u32 lr = 0; lr <= 5 && getenv("RSX_PROBE_XCD_RUNS"); ++lr) {
+		// tiles by workgroup index: runs of 2^lr consecutive tiles on one XCD (their ragged run ends meet in one L2)
+		g_flags = SCATTER_DBG_XCD_RUNS | (lr << SCATTER_XCD_RUN_SHIFT);
+		char nm[64];
+		snprintf(nm, sizeof nm, "v2 xcd runs %u", 1u << lr);
+		bench2<Sc2Cfg<u32, NoVal>>(nm, 1);
+		std::vector<u32> a(n), b(n);
+		run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+		CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+		g_flags = 0;
+		run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+		CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+		printf("  %s\n", a == b ? "output identical" : "OUTPUT DIFFERS");
+	}
 	if (getenv("RSX_PROBE_ALL")) {
 		// round 2's structural experiments (each a header of its own next to this file, with its numbers)
 		bench3<Sc3Cfg<u32, 8, 8, 48>>("v3 2 WG/CU, 2 windows");
