@@ -9,6 +9,7 @@
 #include "rsx_scatter6_digit_waves.hpp"
 #include "rsx_scatter7_rerank_windows.hpp"
 #include "rsx_scatter8_pipelined.hpp"
+#include "rsx_scatter9_handoff.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -665,6 +666,86 @@ void bench8(const char *name, u32 grid)
 	g_flags = 0;
 }
 
+static u32 *d_mailbox;
+
+template <typename C, bool TL, bool HANDOFF, int HEAD_AT = 8>
+float run9_once(u32 shift, bool dump)
+{
+	const u32 ntiles = (u32)(n / C::TILE);
+	if (!d_mailbox) {
+		CK(hipMalloc(&d_mailbox, (size_t)C::RING * 256 * 64));
+		CK(hipMemset(d_mailbox, 0, (size_t)C::RING * 256 * 64));
+	}
+	CK(hipMemsetAsync(d_status, 0, 256 + (size_t)ntiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, (size_t)ntiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter9_kernel<u32, u32, C, TL, DIG_PLAIN, HANDOFF, HEAD_AT>), dim3(ntiles), dim3(C::BLOCK), 0, 0, d_in, d_out, ntiles, shift,
+	                   d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, d_mailbox, ka, g_flags, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(ntiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, (size_t)ntiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, st = 0, wo = 0, depth = 0, life = 0, w1 = 0, w2 = 0, w3 = 0;
+		for (u64 t = 0; t < ntiles; ++t) {
+			const u64 *r = &tl[t * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			st += (double)(r[4] - r[2]);
+			wo += (double)(r[5] - r[4]);
+			life += (double)(r[5] - r[0]);
+			depth += r[12];
+			w1 += (double)(r[6] - r[4]);
+			w2 += (double)(r[7] - r[6]) + (double)(r[5] - r[8]);
+			w3 += (double)(r[8] - r[7]);
+		}
+		printf("  per tile: load + count %7.0f | layout %6.0f | stage %7.0f (chain %6.0f, depth %.1f, inside) | write-out %6.0f (records %5.0f, runs %5.0f, first atoms %5.0f; wave 0) | lifetime %7.0f\n",
+		       a / ntiles, lay / ntiles, st / ntiles, ch / ntiles, depth / ntiles, wo / ntiles, w1 / ntiles, w2 / ntiles, w3 / ntiles, life / ntiles);
+	}
+	return ms;
+}
+
+template <typename C, bool HANDOFF, int HEAD_AT = 8>
+void bench9(const char *name)
+{
+	run9_once<C, false, HANDOFF, HEAD_AT>(0, false);
+	float best = 1e9, sum = 0;
+	const int reps = 9;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run9_once<C, false, HANDOFF, HEAD_AT>(8 * (i % 4), false);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-22s tile %6d, lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
+	       sizeof(Sc9Smem<u32, u32, C, HANDOFF>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run9_once<C, true, HANDOFF, HEAD_AT>(0, true);
+	std::vector<u32> a(n), b(n);
+	for (u32 sh = 0; sh < 32; sh += 8) {
+		run9_once<C, false, HANDOFF, HEAD_AT>(sh, false);
+		CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+		run2_once<Sc2Cfg<u32, NoVal>, false, false>(sh, false, 1);
+		CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+		printf("  column %u: %s\n", sh / 8, a == b ? "output identical to rsx_scatter2_kernel's (the whole array)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	}
+	std::vector<u32> mb((size_t)C::RING * 256 * 16);
+	CK(hipMemcpy(mb.data(), d_mailbox, mb.size() * 4, hipMemcpyDeviceToHost));
+	size_t left = 0;
+	for (size_t i = 15; i < mb.size(); i += 16)
+		left += mb[i] != 0;
+	printf("  records left unread: %zu\n", left);
+}
+
 template <typename C, bool HOTV = false>
 void bench2(const char *name, u32 tps)
 {
@@ -790,6 +871,28 @@ int main(int argc, char **argv)
 	g_flags = 0;
 	if (getenv("RSX_PROBE_ALL"))
 		bench7<Sc7Cfg<u32>>("v7 2 WG/CU, re-ranked windows");
+	if (getenv("RSX_PROBE_HANDOFF") || getenv("RSX_PROBE_ALL")) {
+		bench9<Sc9Cfg<u32>, false>("v9 plain");
+		bench9<Sc9Cfg<u32>, true, 8>("v9 handed on, atoms last");
+		{
+			const struct { const char *name; u32 f; } dbg[] = {
+				{"no deposit, no read", SC9_DBG_NODEPOSIT | SC9_DBG_NOSPIN | SC9_DBG_NOREAD},
+				{"no deposit, read unchecked", SC9_DBG_NODEPOSIT | SC9_DBG_NOSPIN},
+				{"plain deposit, no read", SC9_DBG_PLAINDEPOSIT | SC9_DBG_NOSPIN | SC9_DBG_NOREAD},
+				{"sc1 deposit, no read", SC9_DBG_NOSPIN | SC9_DBG_NOREAD},
+			};
+			for (const auto &v : dbg) {
+				g_flags = v.f;
+				float best = 1e9;
+				for (int i = 0; i < 6; ++i)
+					best = std::min(best, run9_once<Sc9Cfg<u32>, false, true, 8>(8 * (i % 4), false));
+				printf("v9 timing only (wrong output), %s: best %.3f ms\n", v.name, best);
+				run9_once<Sc9Cfg<u32>, true, true, 8>(0, true);
+				g_flags = 0;
+				CK(hipMemset(d_mailbox, 0, (size_t)Sc9Cfg<u32>::RING * 256 * 64));
+			}
+		}
+	}
 	if (getenv("RSX_PROBE_ALL")) {
 		bench8<Sc8Cfg<u32, 8>>("v8 pipelined LB 8", 256);
 		bench8<Sc8Cfg<u32, 16>>("v8 pipelined LB 16", 256);
