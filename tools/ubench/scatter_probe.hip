@@ -856,6 +856,12 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	if (getenv("RSX_PROBE_LB")) {
+		bench2<Sc2Cfg<u32, NoVal, 16, 1, 4>>("v2 LB 4", 1);
+		bench2<Sc2Cfg<u32, NoVal, 16, 1, 12>>("v2 LB 12", 1);
+		bench2<Sc2Cfg<u32, NoVal, 16, 1, 16>>("v2 LB 16", 1);
+		bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	}
 	if (argc > 2 && atoi(argv[2]) == 5) {
 		u32 hd[9];
 		CK(hipMemcpy(hd, d_flag + 32, sizeof hd, hipMemcpyDeviceToHost));
