@@ -3,5 +3,5 @@
 set -x
 cd /root/repo
 mkdir -p gpurun_out/r02k
-RSX_PROBE_LB=1 timeout 120 tools/ubench/scatter_probe.bin 28 > gpurun_out/r02k/scatter_probe_lb.txt 2>&1
-grep -E "^v2|per super" gpurun_out/r02k/scatter_probe_lb.txt
+timeout 120 tools/ubench/scatter_probe.bin 28 > gpurun_out/r02k/scatter_probe_v10.txt 2>&1
+grep -E "^v2 default|^v9|^v10|per tile|identical|DIFFERS|without" gpurun_out/r02k/scatter_probe_v10.txt

@@ -10,6 +10,7 @@
 #include "rsx_scatter7_rerank_windows.hpp"
 #include "rsx_scatter8_pipelined.hpp"
 #include "rsx_scatter9_handoff.hpp"
+#include "rsx_scatter10_one_atomic.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -746,6 +747,73 @@ void bench9(const char *name)
 	printf("  records left unread: %zu\n", left);
 }
 
+template <typename C, bool TL, bool CHAIN_FIRST>
+float run10_once(u32 shift, bool dump)
+{
+	const u32 ntiles = (u32)(n / C::TILE);
+	CK(hipMemsetAsync(d_status, 0, 256 + (size_t)ntiles * 256 * 4, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, (size_t)ntiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter10_kernel<u32, u32, C, TL, DIG_PLAIN, CHAIN_FIRST>), dim3(ntiles), dim3(C::BLOCK), 0, 0, d_in, d_out, ntiles,
+	                   shift, d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(ntiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, (size_t)ntiles * 16 * 8, hipMemcpyDeviceToHost));
+		double a = 0, lay = 0, ch = 0, st = 0, wo = 0, depth = 0, life = 0, own = 0;
+		for (u64 t = 0; t < ntiles; ++t) {
+			const u64 *r = &tl[t * 16];
+			a += (double)(r[1] - r[0]);
+			lay += (double)(r[2] - r[1]);
+			ch += (double)(r[3] - r[2]);
+			st += (double)(r[4] - r[2]);
+			wo += (double)(r[5] - r[4]);
+			life += (double)(r[5] - r[0]);
+			depth += r[12];
+			own += r[6] ? (double)(r[6] - r[2]) : 0;
+		}
+		printf("  per tile: load + rank %7.0f | layout %6.0f | stage %7.0f (chain done at %6.0f, depth %.1f; wave 0 staged at %6.0f) | write-out %6.0f | lifetime %7.0f\n",
+		       a / ntiles, lay / ntiles, st / ntiles, ch / ntiles, depth / ntiles, own / ntiles, wo / ntiles, life / ntiles);
+	}
+	return ms;
+}
+
+template <typename C, bool CHAIN_FIRST>
+void bench10(const char *name)
+{
+	run10_once<C, false, CHAIN_FIRST>(0, false);
+	float best = 1e9, sum = 0;
+	const int reps = 9;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run10_once<C, false, CHAIN_FIRST>(8 * (i % 4), false);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-30s tile %6d, lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
+	       sizeof(Sc10Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
+	run10_once<C, true, CHAIN_FIRST>(0, true);
+	std::vector<u32> a(n), b(n);
+	run10_once<C, false, CHAIN_FIRST>(8, false);
+	CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
+	CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
+	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (the whole array, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run10_once<C, true, CHAIN_FIRST>(0, false));
+	g_flags = 0;
+}
+
 template <typename C, bool HOTV = false>
 void bench2(const char *name, u32 tps)
 {
@@ -877,6 +945,15 @@ int main(int argc, char **argv)
 	g_flags = 0;
 	if (getenv("RSX_PROBE_ALL"))
 		bench7<Sc7Cfg<u32>>("v7 2 WG/CU, re-ranked windows");
+	if (getenv("RSX_PROBE_ONE_ATOMIC") || getenv("RSX_PROBE_ALL")) {
+		bench9<Sc9Cfg<u32>, false>("v9 plain");
+		bench10<Sc10Cfg<u32>, true>("v10 one atomic, chain first");
+		bench10<Sc10Cfg<u32>, false>("v10 one atomic, stage first");
+		bench10<Sc10Cfg<u32, 8, 8>, true>("v10 8 waves, 2 WG/CU, chain first");
+		bench10<Sc10Cfg<u32, 8, 8>, false>("v10 8 waves, 2 WG/CU, stage first");
+		bench10<Sc10Cfg<u32, 16, 8>, true>("v10 8 waves, 2 WG/CU, LB 16");
+		bench9<Sc9Cfg<u32>, false>("v9 plain");
+	}
 	if (getenv("RSX_PROBE_HANDOFF") || getenv("RSX_PROBE_ALL")) {
 		bench9<Sc9Cfg<u32>, false>("v9 plain");
 		bench9<Sc9Cfg<u32>, true, 8>("v9 handed on, atoms last");
