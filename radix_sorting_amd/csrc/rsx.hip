@@ -146,6 +146,10 @@ struct Ctx {
 	Plan *dev_host_plan = nullptr;
 	hipEvent_t plan_ev = nullptr;   // recorded behind the plan's copy to the host
 	u64 *host_hist = nullptr;    // pinned, 256 u64
+	// Small sorts of host buffers (rsx_sort, rsx_sort_rank on arrays the one-launch kernels take): pinned, mapped staging the
+	// kernel reads and writes over PCIe itself -- one launch and one synchronisation instead of two copies around them.
+	char *hstage = nullptr, *hstage_dev = nullptr;
+	static constexpr size_t HSTAGE_BYTES = 5 * (size_t)SMALL_SORT_BYTES;   // keys, keys, and two halves of 8-byte indices
 
 	bool fast = false;           // rsx_scatter2_kernel allowed on this device (LDS atomic order verified)
 	// The reference is re-entrant (concurrent calls on disjoint buffers are safe); here calls that share a context
@@ -173,8 +177,19 @@ struct Ctx {
 			HIP_TRY(hipHostMalloc((void **)&host_hist, 256 * sizeof(u64), hipHostMallocDefault));
 		return RSX_OK;
 	}
+	int ensure_hstage()
+	{
+		if (!hstage) {
+			HIP_TRY(hipHostMalloc((void **)&hstage, HSTAGE_BYTES, hipHostMallocMapped));
+			HIP_TRY(hipHostGetDevicePointer((void **)&hstage_dev, hstage, 0));
+		}
+		return RSX_OK;
+	}
 	void release()
 	{
+		if (hstage)
+			(void)hipHostFree(hstage);
+		hstage = hstage_dev = nullptr;
 		small.release();
 		hist.release();
 		hpart.release();
@@ -1503,6 +1518,12 @@ int rsx_sort_rank_device(const void *d_src, void *d_index_buffer, size_t n, rsx_
 	return RSX_OK;
 }
 
+// host arrays the one-launch kernels take (sort_keys_device, sort_rank_device: the same conditions)
+static bool host_small_path(const Ctx &c, size_t key_bytes)
+{
+	return c.fast && key_bytes <= SMALL_SORT_BYTES && !getenv("RSX_NO_SMALL_SORT") && !getenv("RSX_NO_HOST_SMALL") && !capture_armed();
+}
+
 int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, void **result, rsx_info *info)
 {
 	info_clear(info, dtype);
@@ -1523,6 +1544,24 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, v
 			return fail(RSX_EINVAL, "rsx_sort: src is a device pointer but aux is not");
 		RSX_TRY(rsx_sort_device(src, aux, n, dtype, order, nullptr, result, info));
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		return RSX_OK;
+	}
+	if (host_small_path(*c, n * kb)) {
+		// small host arrays: the one-launch kernel reads the keys from pinned memory and writes the result there
+		RSX_TRY(c->ensure_hstage());
+		memcpy(c->hstage, src, n * kb);
+		void *dres = nullptr;
+		rsx_info li;
+		RSX_TRY(rsx_sort_device(c->hstage_dev, c->hstage_dev + SMALL_SORT_BYTES, n, dtype, order, nullptr, &dres, &li));
+		if (info)
+			*info = li;
+		if (li.early_exit) {
+			*result = src;
+			return RSX_OK;
+		}
+		void *hres = li.result_in_aux ? aux : src;
+		memcpy(hres, c->hstage + ((char *)dres - c->hstage_dev), n * kb);
+		*result = hres;
 		return RSX_OK;
 	}
 	// host buffers: stage over PCIe, sort in HBM, bring the result back into the
@@ -1576,9 +1615,34 @@ int rsx_sort_rank(const void *src, void *index_buffer, size_t n, rsx_dtype dtype
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		return RSX_OK;
 	}
+	const size_t wide = idx_bytes == 8 ? 8 : 4;
+	if (!dev && host_small_path(*c, 0) && n * 2 * (kb + wide) <= SMALL_PAIR_BYTES) {
+		// small host arrays: keys read from and ranks written to pinned memory by the one-launch kernel, narrowed here
+		RSX_TRY(c->ensure_hstage());
+		memcpy(c->hstage, src, n * kb);
+		char *hib = c->hstage + SMALL_SORT_BYTES, *dib = c->hstage_dev + SMALL_SORT_BYTES;
+		void *dres = nullptr;
+		rsx_info li;
+		RSX_TRY(rsx_sort_rank_device(c->hstage_dev, dib, n, dtype, wide, order, nullptr, &dres, &li));
+		if (info)
+			*info = li;
+		const bool second = dres != (void *)dib;
+		char *out = (char *)index_buffer + (second ? n * idx_bytes : 0);
+		const char *from = hib + ((char *)dres - dib);
+		if (idx_bytes >= 4) {
+			memcpy(out, from, n * idx_bytes);
+		} else if (idx_bytes == 2) {
+			for (size_t i = 0; i < n; ++i)
+				((uint16_t *)out)[i] = (uint16_t)((const u32 *)from)[i];
+		} else {
+			for (size_t i = 0; i < n; ++i)
+				((uint8_t *)out)[i] = (uint8_t)((const u32 *)from)[i];
+		}
+		*result = out;
+		return RSX_OK;
+	}
 	// staged path: keys in recs[0] (host keys) or in place (device keys); indices computed
 	// as 4- or 8-byte values in vals[0], narrowed into vals[1] when IdxType is 1 or 2 bytes
-	const size_t wide = idx_bytes == 8 ? 8 : 4;
 	const void *dkeys = src;
 	if (!dev) {
 		RSX_TRY(c->recs[0].ensure(n * kb));

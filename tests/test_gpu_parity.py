@@ -414,6 +414,45 @@ def test_host_pointer_sort_and_rank():
     assert info.result_in_aux == whalf and np.array_equal(ranks, wr)
 
 
+@pytest.mark.parametrize("dt", [ol.U8, ol.I16, ol.U32, ol.I32, ol.F32, ol.U64, ol.F64])
+def test_small_host_arrays_through_pinned_staging(dt, monkeypatch):
+    """rsx_sort / rsx_sort_rank on host arrays the one-launch kernels take: keys read from and results written to pinned memory
+    by the kernel itself (rsx.hip, host_small_path).  Same results, returned buffer and untouched other buffer as the staged
+    path (RSX_NO_HOST_SMALL=1) and as the oracle, at sizes on either side of the limits (64 KiB of keys; 128 KiB of keys and
+    two index halves), both orders, every index width that holds n."""
+    kb = ol.DTYPE_SIZE[dt]
+    lim = 65536 // kb
+    sizes = [2, 3, 257, 4097, lim - 1, lim, lim + 1]
+    for n in sizes:
+        for order in (rsa.ASCENDING, rsa.DESCENDING):
+            a = ol.splitmix_fill(n, dt, 900 + n % 97 + dt, mask=0xFFFFFFFFFFFFFFFF if n % 2 else 0x0000FF00FF0000FF)
+            want, want_aux, _ = ol.oracle_sort(a, dt, order)
+            src, aux = a.copy(), np.full_like(a, 0x5A)
+            res, info = rsa.radix_sort_host(src, aux, dt, order)
+            assert info.result_in_aux == want_aux and np.array_equal(res, want), (n, order)
+            other = src if info.result_in_aux else aux
+            assert np.array_equal(other, a if info.result_in_aux else np.full_like(a, 0x5A)), (n, order, "other buffer")
+            monkeypatch.setenv("RSX_NO_HOST_SMALL", "1")
+            src2, aux2 = a.copy(), np.full_like(a, 0x5A)
+            res2, info2 = rsa.radix_sort_host(src2, aux2, dt, order)
+            monkeypatch.delenv("RSX_NO_HOST_SMALL")
+            assert info2.result_in_aux == info.result_in_aux and np.array_equal(res2, res), (n, order, "staged path")
+    for n in (2, 200, 256, 5000, 65536 // (kb + 4) - 1, 65536 // (kb + 4), 65536 // (kb + 4) + 1, 65536 // (kb + 8) + 1):
+        a = ol.splitmix_fill(n, dt, 77 + n % 31 + dt, mask=0xFFFFFFFFFFFFFFFF if n % 3 else 0x000000FFFF000000)
+        for ibytes, it in ((1, np.uint8), (2, np.uint16), (4, np.uint32), (8, np.uint64)):
+            if ibytes < 8 and n > (1 << (8 * ibytes)):
+                continue
+            ib = np.full(2 * n, 0xEE, dtype=it)
+            ranks, info = rsa.radix_sort_rank_host(a, ib, dt)
+            wr, whalf, _, _ = ol.oracle_rank(a, dt, ibytes)
+            assert info.result_in_aux == whalf and np.array_equal(ranks, wr), (n, ibytes)
+    # pre-sorted small host input: aux untouched, src returned
+    a = np.sort(ol.splitmix_fill(3000, ol.U32, 2))
+    src, aux = a.copy(), np.full_like(a, 0x5A5A5A5A)
+    res, info = rsa.radix_sort_host(src, aux, ol.U32)
+    assert res is src and info.early_exit == 2 and np.all(aux == 0x5A5A5A5A) and np.array_equal(src, a)
+
+
 def test_records_with_host_keys():
     """radix_tests.cpp:45-69 / :121-146 shapes: 16-byte records, 1-byte key from an opaque KeyFunc."""
     recs = np.zeros(8, dtype=np.dtype([("key", np.uint8), ("pad", np.uint8, 7), ("name", np.uint64)]))
