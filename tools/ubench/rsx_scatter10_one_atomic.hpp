@@ -4,6 +4,7 @@
 //   16 waves, 32 Ki-key tiles, chain first:  0.494-0.499 ms; without global stores 0.309-0.315 (two atomics: 0.337)
 //   16 waves, the digit threads stage first: 0.492-0.493 ms; wave 0 has staged after 2.4 k cycles, the chain is done at 7.7 k
 //   8 waves, 16 Ki-key tiles, two workgroups per CU: 0.602 ms (chain done at 15.6-17.4 k cycles, 33-37 tiles deep; LB 16: 0.628)
+//   NEXT_HIST (the next column's histogram counted in the pass, README.md:774-779): 0.505 against 0.499 ms, histogram correct
 // The staging itself is four times cheaper than with a second atomic, and the pass is exactly as long as before: the phase
 // now ends when the chain is resolved (5.9 k cycles), and what bounds the kernel with its stores is the CU's memory
 // pipeline (a tile's 128 KiB of loads and 128 KiB of stores one after the other) plus the phases in which it idles.
@@ -37,12 +38,13 @@ template <typename KT, typename ST, typename C> struct Sc10Smem {
 	ST delta[256];
 	u32 wsum[4];
 	u32 ticket;
+	u32 nh[256];   // NEXT_HIST: the tile's counts of the NEXT column's digits (README.md:774-779, the histogram fused into the pass)
 };
 
-template <typename KT, typename ST, typename C = Sc10Cfg<KT>, bool TL = false, int DIG = DIG_GENERIC, bool CHAIN_FIRST = true>
+template <typename KT, typename ST, typename C = Sc10Cfg<KT>, bool TL = false, int DIG = DIG_GENERIC, bool CHAIN_FIRST = true, bool NEXT_HIST = false>
 __global__ __launch_bounds__(C::BLOCK) void rsx_scatter10_kernel(const KT *__restrict__ kin, KT *__restrict__ kout, u32 ntiles, u32 shift,
                                                                  const u64 *__restrict__ gbase, ST *status, u32 *ticket, KdfArgs<KT> ka,
-                                                                 u32 flags, u64 *tl)
+                                                                 u32 flags, u64 *tl, unsigned long long *next_hist = nullptr)
 {
 	typedef StatusBits<ST> SB_;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, SB = C::SB, CHUNK = C::CHUNK, LB = C::LB;
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter10_kernel(const KT *__res
 		sm.ticket = atomicAdd(ticket, 1u);
 	for (u32 i = tid; i < NWAVES * 256; i += BLOCK)
 		(&sm.cell[0][0])[i] = 0;
+	if (NEXT_HIST && tid < 256)
+		sm.nh[tid] = 0;
 	__syncthreads();
 	const u32 tile = __builtin_amdgcn_readfirstlane(sm.ticket);
 	if (tile >= ntiles)
@@ -77,6 +81,11 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter10_kernel(const KT *__res
 			const u32 a = __hip_atomic_fetch_add(&wc[digit2<DIG>(keep[r], ka, shift)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			const u32 b = __hip_atomic_fetch_add(&wc[digit2<DIG>(keep[r + 1], ka, shift)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			rk[r / 2] = a | (b << 16);
+		}
+		if constexpr (NEXT_HIST) {
+#pragma unroll
+			for (int r = 0; r < KPT; ++r)
+				atomicAdd(&sm.nh[digit2<DIG>(keep[r], ka, shift + 8)], 1u);
 		}
 	}
 	__syncthreads();
@@ -222,6 +231,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter10_kernel(const KT *__res
 			}
 		}
 	}
+	if (NEXT_HIST && tid < 256 && sm.nh[tid] != 0)
+		atomicAdd(next_hist + tid, (unsigned long long)sm.nh[tid]);
 	if (TL && tid == 0)
 		tl[(u64)tile * 16 + 5] = __builtin_readcyclecounter();
 }

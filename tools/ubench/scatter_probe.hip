@@ -747,7 +747,7 @@ void bench9(const char *name)
 	printf("  records left unread: %zu\n", left);
 }
 
-template <typename C, bool TL, bool CHAIN_FIRST>
+template <typename C, bool TL, bool CHAIN_FIRST, bool NEXT_HIST = false>
 float run10_once(u32 shift, bool dump)
 {
 	const u32 ntiles = (u32)(n / C::TILE);
@@ -759,8 +759,9 @@ float run10_once(u32 shift, bool dump)
 	CK(hipEventCreate(&e1));
 	KdfArgs<u32> ka{0, 0, 0};
 	CK(hipEventRecord(e0, 0));
-	hipLaunchKernelGGL((rsx_scatter10_kernel<u32, u32, C, TL, DIG_PLAIN, CHAIN_FIRST>), dim3(ntiles), dim3(C::BLOCK), 0, 0, d_in, d_out, ntiles,
-	                   shift, d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl);
+	hipLaunchKernelGGL((rsx_scatter10_kernel<u32, u32, C, TL, DIG_PLAIN, CHAIN_FIRST, NEXT_HIST>), dim3(ntiles), dim3(C::BLOCK), 0, 0, d_in, d_out, ntiles,
+	                   shift, d_hist + 256 * (shift / 8), (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, g_flags, d_tl,
+	                   (unsigned long long *)(d_hist + 256 * 4));
 	CK(hipGetLastError());
 	CK(hipEventRecord(e1, 0));
 	CK(hipEventSynchronize(e1));
@@ -789,28 +790,28 @@ float run10_once(u32 shift, bool dump)
 	return ms;
 }
 
-template <typename C, bool CHAIN_FIRST>
+template <typename C, bool CHAIN_FIRST, bool NEXT_HIST = false>
 void bench10(const char *name)
 {
-	run10_once<C, false, CHAIN_FIRST>(0, false);
+	run10_once<C, false, CHAIN_FIRST, NEXT_HIST>(0, false);
 	float best = 1e9, sum = 0;
 	const int reps = 9;
 	for (int i = 0; i < reps; ++i) {
-		float ms = run10_once<C, false, CHAIN_FIRST>(8 * (i % 4), false);
+		float ms = run10_once<C, false, CHAIN_FIRST, NEXT_HIST>(8 * (i % 4), false);
 		best = std::min(best, ms);
 		sum += ms;
 	}
 	printf("%-30s tile %6d, lds %6zu B: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, C::TILE,
 	       sizeof(Sc10Smem<u32, u32, C>), sum / reps, best, n * 8.0 / (best * 1e-3) / 1e9);
-	run10_once<C, true, CHAIN_FIRST>(0, true);
+	run10_once<C, true, CHAIN_FIRST, NEXT_HIST>(0, true);
 	std::vector<u32> a(n), b(n);
-	run10_once<C, false, CHAIN_FIRST>(8, false);
+	run10_once<C, false, CHAIN_FIRST, NEXT_HIST>(8, false);
 	CK(hipMemcpy(a.data(), d_out, n * 4, hipMemcpyDeviceToHost));
 	run2_once<Sc2Cfg<u32, NoVal>, false, false>(8, false, 1);
 	CK(hipMemcpy(b.data(), d_out, n * 4, hipMemcpyDeviceToHost));
 	printf("  %s\n", a == b ? "output identical to rsx_scatter2_kernel's (the whole array, column 1)" : "OUTPUT DIFFERS from rsx_scatter2_kernel's");
 	g_flags = SCATTER_DBG_NOSTORE;
-	printf("  without global stores: %.3f ms\n", run10_once<C, true, CHAIN_FIRST>(0, false));
+	printf("  without global stores: %.3f ms\n", run10_once<C, true, CHAIN_FIRST, NEXT_HIST>(0, false));
 	g_flags = 0;
 }
 
@@ -949,7 +950,21 @@ int main(int argc, char **argv)
 		bench9<Sc9Cfg<u32>, false>("v9 plain");
 		bench10<Sc10Cfg<u32>, true>("v10 one atomic, chain first");
 		bench10<Sc10Cfg<u32>, false>("v10 one atomic, stage first");
-		bench10<Sc10Cfg<u32, 8, 8>, true>("v10 8 waves, 2 WG/CU, chain first");
+		bench10<Sc10Cfg<u32>, true, true>("v10 + next column's histogram");
+	{
+		// the fused histogram of column 1 (shift 0 run) against the one the histogram kernel made
+		CK(hipMemset(d_hist + 256 * 4, 0, 256 * 8));
+		run10_once<Sc10Cfg<u32>, false, true, true>(0, false);
+		std::vector<u64> a(256), b(256);
+		CK(hipMemcpy(a.data(), d_hist + 256 * 4, 256 * 8, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(b.data(), d_hist + 256 * 1, 256 * 8, hipMemcpyDeviceToHost));
+		// (d_hist holds exclusive offsets after the plan kernel: compare differences)
+		bool same = true;
+		for (int i = 0; i + 1 < 256; ++i)
+			same &= a[i] == b[i + 1] - b[i];
+		printf("  fused histogram of column 1 %s the histogram kernel's\n", same ? "equals" : "DIFFERS from");
+	}
+	bench10<Sc10Cfg<u32, 8, 8>, true>("v10 8 waves, 2 WG/CU, chain first");
 		bench10<Sc10Cfg<u32, 8, 8>, false>("v10 8 waves, 2 WG/CU, stage first");
 		bench10<Sc10Cfg<u32, 16, 8>, true>("v10 8 waves, 2 WG/CU, LB 16");
 		bench9<Sc9Cfg<u32>, false>("v9 plain");
