@@ -33,7 +33,8 @@
  *                           pass's output; a mismatch fails the call (RSX_EVERIFY).
  *   RSX_FORCE_TABLE_RANK=1  use the table-ranked scatter kernel, which does not rely
  *                           on the lane order of returning LDS atomics (slower).
- *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION, RSX_NO_NARROW_KEYS
+ *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,
+ *   RSX_NO_NARROW_KEYS
  *                           switch single optimisations off (tests).
  */
 #ifndef RSX_H

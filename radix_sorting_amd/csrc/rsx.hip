@@ -744,6 +744,32 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 		return RSX_OK;
 	}
 	Plan plan;
+	if constexpr (sizeof(KT) == 1) {
+		// 1-byte keys: at most one column, so the sorted array is the histogram written out (rsx_fill_runs_kernel) -- a read
+		// and a write of the keys instead of a read, a read and a scatter
+		if (!getenv("RSX_NO_FILL_RUNS") && (((uintptr_t)aux) & 15) == 0) {
+			RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, 0));
+			const unsigned blocks = (unsigned)std::min<u64>((n / 16 + 255) / 256 + 1, 8192);
+			hipLaunchKernelGGL((rsx_fill_runs_kernel<KT>), dim3(blocks), dim3(256), 0, c.stream, aux, (u64)n, (const u64 *)c.ghist(),
+			                   (const KT *)src, ka, (const Plan *)c.plan());
+			HIP_TRY(hipGetLastError());
+			RSX_TRY(plan_wait(c, &plan));
+			info_from_plan(info, plan);
+			RSX_TRY(capture_hist(c, n, sizeof(KT)));
+			if (plan.sorted) {                   // radix_sort.hpp:60-62
+				if (info) {
+					info->early_exit = 2;
+					info->ncols = 0;
+				}
+				*result = src;
+				return RSX_OK;
+			}
+			*result = aux;                       // one pass: radix_sort.hpp:92
+			if (info)
+				info->result_in_aux = 1;
+			return RSX_OK;
+		}
+	}
 	// The first pass is enqueued before the host knows the plan (it reads the device's copy and does nothing on
 	// sorted input): the host's wait for the plan, 20-25 us of idle GPU otherwise, hides behind it.
 	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION") && !verify_mode();

@@ -961,6 +961,73 @@ __global__ void rsx_iota_kernel(IT *dst, u64 n)
 		dst[i] = (IT)i;
 }
 
+// Keys only, ONE kept column (always the case for 1-byte keys): every other byte of kdf(key) is the same in all keys
+// (radix_sort.hpp:64-70: that is what skipping a column means) and the KDF is a bijection on bit patterns, so the sorted
+// array IS the histogram -- count[d] copies of the key whose kept byte is d, for d ascending.  No scatter: `out` is written
+// from the kept column's exclusive offsets.  Does nothing unless the device-side plan says "not sorted, one column".
+template <typename KT> __device__ __forceinline__ KT kdf_invert(KT y, const KdfArgs<KT> a)
+{
+	typedef typename std::make_signed<KT>::type ST;
+	y = (KT)(y ^ a.desc);
+	const KT nsign = (KT)~(KT)((ST)y >> (sizeof(KT) * 8 - 1));   // all ones iff the top bit of the derived key is clear
+	return (KT)(y ^ ((nsign & a.fmask) | a.sflip));
+}
+
+template <typename KT>
+__global__ __launch_bounds__(256) void rsx_fill_runs_kernel(KT *__restrict__ out, u64 n, const u64 *__restrict__ ghist,
+                                                            const KT *__restrict__ src, KdfArgs<KT> ka, const Plan *__restrict__ plan)
+{
+	if (plan->sorted || plan->ncols != 1)
+		return;
+	const u32 col = plan->cols[0];
+	__shared__ u64 offs[257];
+	const u32 tid = threadIdx.x;
+	offs[tid] = ghist[256 * col + tid];
+	if (tid == 0)
+		offs[256] = n;
+	__syncthreads();
+	const KT k0 = (KT)(kdf_apply(src[0], ka) & (KT)~((KT)0xFF << (8 * col)));
+	constexpr u32 V = 16 / sizeof(KT);
+	typedef KT kvec_t __attribute__((ext_vector_type(V)));
+	const u64 nvec = n / V, stride = (u64)gridDim.x * blockDim.x;
+	// the digit of output position i: the last d with offs[d] <= i
+	auto digit_at = [&](u64 i) {
+		u32 lo = 0, hi = 256;   // offs[lo] <= i < offs[hi]
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {
+			const u32 mid = (lo + hi) >> 1;
+			if (offs[mid] <= i)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		return lo;
+	};
+	for (u64 v = (u64)blockIdx.x * blockDim.x + tid; v < nvec; v += stride) {
+		const u64 i0 = v * V;
+		u32 d = digit_at(i0);
+		kvec_t x;
+		if (offs[d + 1] >= i0 + V) {   // the whole vector inside one run
+			const KT k = kdf_invert<KT>((KT)(k0 | ((KT)d << (8 * col))), ka);
+#pragma unroll
+			for (u32 e = 0; e < V; ++e)
+				x[e] = k;
+		} else {
+#pragma unroll
+			for (u32 e = 0; e < V; ++e) {
+				while (offs[d + 1] <= i0 + e)
+					++d;
+				x[e] = kdf_invert<KT>((KT)(k0 | ((KT)d << (8 * col))), ka);
+			}
+		}
+		*(kvec_t *)(out + i0) = x;
+	}
+	if (blockIdx.x == 0 && tid < (u32)(n - nvec * V)) {
+		const u64 i = nvec * V + tid;
+		out[i] = kdf_invert<KT>((KT)(k0 | ((KT)digit_at(i) << (8 * col))), ka);
+	}
+}
+
 // dst[i] = (narrower or wider) src[i]
 template <typename DT, typename ST_>
 __global__ void rsx_convert_kernel(DT *dst, const ST_ *src, u64 n)

@@ -414,6 +414,55 @@ def test_host_pointer_sort_and_rank():
     assert info.result_in_aux == whalf and np.array_equal(ranks, wr)
 
 
+@pytest.mark.parametrize("dt", [ol.U8, ol.I8])
+@pytest.mark.parametrize("order", [rsa.ASCENDING, rsa.DESCENDING])
+def test_one_byte_keys_are_written_from_the_histogram(dt, order, monkeypatch):
+    """Keys-only sorts of 1-byte keys never scatter: the sorted array is the histogram written out (rsx_fill_runs_kernel).
+    Bit-exact against the oracle and against the scatter path (RSX_NO_FILL_RUNS=1), returned buffer and untouched source
+    included; value sets with gaps, one dominant value, two values, sorted and constant inputs; an unaligned second buffer
+    takes the scatter path."""
+    import torch
+    tdt = torch.uint8 if dt == ol.U8 else torch.int8
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in (17, 70001, (1 << 20) + 3, (1 << 24) + 5):
+        cases.append(("uniform", ol.splitmix_fill(n, dt, 3 + n % 11)))
+        cases.append(("gaps", ol.splitmix_fill(n, dt, 5, mask=0xA5)))
+        a = ol.splitmix_fill(n, dt, 9)
+        a[rng.random(n) < 0.97] = a[0]
+        cases.append(("dominant", a))
+        cases.append(("two values", (ol.splitmix_fill(n, dt, 11) & 1).astype(a.dtype) * 200))
+        cases.append(("constant", np.full(n, 77, dtype=a.dtype)))
+        cases.append(("sorted", np.sort(ol.splitmix_fill(n, dt, 13).view(np.int8 if dt == ol.I8 else np.uint8)).view(a.dtype)
+                      if order == rsa.ASCENDING else ol.splitmix_fill(n, dt, 13)))
+    for name, a in cases:
+        want, want_aux, _ = ol.oracle_sort(a, dt, order)
+        outs = []
+        for no_fill in (False, True):
+            if no_fill:
+                monkeypatch.setenv("RSX_NO_FILL_RUNS", "1")
+            src = torch.from_numpy(a.view(np.int8 if dt == ol.I8 else np.uint8).copy()).to("cuda").view(tdt)
+            aux = torch.full_like(src, 0x5A)
+            res, info = rsa.radix_sort(src, aux, dt, order)
+            if no_fill:
+                monkeypatch.delenv("RSX_NO_FILL_RUNS")
+            got = res.cpu().numpy().view(a.dtype)
+            assert info.result_in_aux == want_aux and np.array_equal(got, want), (name, a.size, no_fill)
+            assert np.array_equal(src.cpu().numpy().view(a.dtype), a), (name, a.size, "source untouched")
+            if not info.result_in_aux:
+                assert bool((aux == 0x5A).all()), (name, a.size, "aux untouched")
+            outs.append(got)
+        assert np.array_equal(outs[0], outs[1])
+    # a second buffer that is not 16-byte aligned: the scatter path, same result
+    a = ol.splitmix_fill(100003, dt, 21)
+    want, want_aux, _ = ol.oracle_sort(a, dt, order)
+    src = torch.from_numpy(a.view(np.uint8).copy()).to("cuda").view(tdt)
+    big = torch.zeros(a.size + 16, dtype=tdt, device="cuda")
+    aux = big[3:3 + a.size]
+    res, info = rsa.radix_sort(src, aux, dt, order)
+    assert info.result_in_aux == want_aux and np.array_equal(res.cpu().numpy().view(a.dtype), want)
+
+
 @pytest.mark.parametrize("dt", [ol.U8, ol.I16, ol.U32, ol.I32, ol.F32, ol.U64, ol.F64])
 def test_small_host_arrays_through_pinned_staging(dt, monkeypatch):
     """rsx_sort / rsx_sort_rank on host arrays the one-launch kernels take: keys read from and results written to pinned memory
