@@ -775,9 +775,21 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION") && !verify_mode();
 	// with the fast kernel every pass has its own region of status words, all zeroed together with the histogram
 	const size_t status_total = c.fast ? status_bytes<KT, NoVal>(n) * sizeof(KT) : 0;
+	// One kept column (keys that differ in one byte only): the sorted array is written from the histogram instead of
+	// scattered (rsx_fill_runs_kernel).  With a speculative first pass both kernels are enqueued and the device-side plan
+	// decides which of them works, which costs an empty launch in the usual case: only for arrays where that is noise.
+	const bool fill_one = sizeof(KT) > 1 && !getenv("RSX_NO_FILL_RUNS") && (((uintptr_t)aux) & 15) == 0 && (!spec || n >= ((size_t)1 << 22));
+	auto launch_fill = [&]() {
+		const unsigned blocks = (unsigned)std::min<u64>((n * sizeof(KT) / 16 + 255) / 256 + 1, 8192);
+		hipLaunchKernelGGL((rsx_fill_runs_kernel<KT>), dim3(blocks), dim3(256), 0, c.stream, aux, (u64)n, (const u64 *)c.ghist(),
+		                   (const KT *)src, ka, (const Plan *)c.plan());
+		return hipGetLastError();
+	};
 	if (spec) {
 		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total));
-		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, 0, c.plan(), 0)));
+		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, fill_one ? SCATTER_ONE_COL_FILLED : 0, c.plan(), 0)));
+		if (fill_one)
+			HIP_TRY(launch_fill());
 		RSX_TRY(plan_wait(c, &plan));
 	} else {
 		RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan, status_total));
@@ -790,6 +802,14 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 			info->ncols = 0;
 		}
 		*result = src;
+		return RSX_OK;
+	}
+	if (fill_one && plan.ncols == 1) {
+		if (!spec)
+			HIP_TRY(launch_fill());
+		*result = aux;                       // one pass: radix_sort.hpp:92
+		if (info)
+			info->result_in_aux = 1;
 		return RSX_OK;
 	}
 	KT *cur = src, *oth = aux;

@@ -240,6 +240,7 @@ enum : u32 {
 	SCATTER_GEN_INDEX = 1,   // payload of element i is i (first rank pass, radix_sort_rank.hpp:52)
 	SCATTER_SKIP_KEYS = 2,   // do not write keys (last rank pass: only the indices are wanted)
 	SCATTER_COL_SHIFT = 12,  // bits 12-14: the pass's column (HOT kernels: which word of hotd; the shift no longer tells once a rank sort has narrowed its keys)
+	SCATTER_ONE_COL_FILLED = 8, // device-scheduled pass 0 of a keys-only sort: do nothing if ONE column is kept (rsx_fill_runs_kernel writes the result)
 	SCATTER_HOT = 16,        // host side only: one digit holds an eighth of the keys or more -> the HOT kernels (rsx_scatter2.hpp)
 	SCATTER_ELEM_LOADS = 32, // whole tiles are read with element loads instead of 16-byte loads + a transposition through the LDS
 	SCATTER_DBG_LINEAR = 64, // probe only: write the staged tile back to its own position (no scatter)

@@ -117,6 +117,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	if (dplan) {
 		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
+		if ((flags & SCATTER_ONE_COL_FILLED) && dplan->ncols == 1)
+			return;   // keys only, one kept column: the sorted array is written from the histogram (rsx_fill_runs_kernel)
 		const u32 col = dplan->cols[pass_index];
 		dcol = col;
 		shift = 8 * col;

@@ -463,6 +463,34 @@ def test_one_byte_keys_are_written_from_the_histogram(dt, order, monkeypatch):
     assert info.result_in_aux == want_aux and np.array_equal(res.cpu().numpy().view(a.dtype), want)
 
 
+@pytest.mark.parametrize("dt,mask,const", [(ol.U32, 0x00FF0000, 0x12000034), (ol.I32, 0xFF000000, 0x00ABCDEF),
+                                            (ol.F32, 0x000000FF, 0xC2F00000), (ol.U64, 0x0000FF0000000000, 0x0123000000456789),
+                                            (ol.I16, 0x00FF, 0x8100), (ol.F64, 0x00FF000000000000, 0x4000000000000001)])
+def test_keys_that_differ_in_one_byte_are_written_from_the_histogram(dt, mask, const, monkeypatch):
+    """One kept column (radix_sort.hpp:64-70): the sorted array is written from that column's histogram, whatever the key
+    width.  Large arrays decide on the device (speculative first pass and fill kernel both enqueued), small ones and
+    RSX_NO_SPECULATION=1 on the host; RSX_NO_FILL_RUNS=1 scatters.  All bit-exact against the oracle, both orders."""
+    import torch
+    bits = ol.NP_BITS[dt]
+    tdt = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[ol.DTYPE_SIZE[dt]]
+    for n in (100003, (1 << 22) + 5):
+        a = (ol.splitmix_fill(n, dt, 31 + n % 7, mask=mask) | np.array(const, dtype=bits)).astype(bits)
+        for order in (rsa.ASCENDING, rsa.DESCENDING):
+            want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+            for env in ({}, {"RSX_NO_SPECULATION": "1"}, {"RSX_NO_FILL_RUNS": "1"}):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                src = torch.from_numpy(a.view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[ol.DTYPE_SIZE[dt]]).copy()).to("cuda")
+                aux = torch.full_like(src, 0x5A)
+                res, info = rsa.radix_sort(src, aux, dt, order)
+                for k in env:
+                    monkeypatch.delenv(k)
+                got = res.cpu().numpy().view(bits)
+                assert info.ncols == 1 and info.result_in_aux == want_aux == 1, (n, order, env)
+                assert np.array_equal(got, want), (n, order, env)
+                assert np.array_equal(src.cpu().numpy().view(bits), a), (n, order, env, "source untouched")
+
+
 @pytest.mark.parametrize("dt", [ol.U8, ol.I16, ol.U32, ol.I32, ol.F32, ol.U64, ol.F64])
 def test_small_host_arrays_through_pinned_staging(dt, monkeypatch):
     """rsx_sort / rsx_sort_rank on host arrays the one-launch kernels take: keys read from and results written to pinned memory

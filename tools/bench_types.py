@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import radix_sorting_amd as rsa
 
-CASES = [("u8", rsa.U8, torch.uint8, rsa.ASCENDING), ("i8 desc", rsa.I8, torch.int8, rsa.DESCENDING),
+CASES = [("u32 1 byte", rsa.U32, torch.int32, rsa.ASCENDING), ("u64 1 byte", rsa.U64, torch.int64, rsa.ASCENDING),
+         ("u8", rsa.U8, torch.uint8, rsa.ASCENDING), ("i8 desc", rsa.I8, torch.int8, rsa.DESCENDING),
          ("i16", rsa.I16, torch.int16, rsa.ASCENDING), ("f64", rsa.F64, torch.float64, rsa.ASCENDING),
          ("i32 desc", rsa.I32, torch.int32, rsa.DESCENDING)]
 
@@ -18,7 +19,7 @@ def main():
         best, cols = 1e9, 0
         for r in range(6):
             b = bufs[r & 1]
-            rsa.fill_splitmix(b, 50 + r)
+            rsa.fill_splitmix(b, 50 + r, mask=0x00FF0000 if "1 byte" in name else 0xFFFFFFFFFFFFFFFF)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res, info = rsa.radix_sort(b, aux, code, order)
