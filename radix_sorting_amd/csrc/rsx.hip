@@ -142,6 +142,7 @@ struct Ctx {
 	DevBuf recs[2];     // record gather staging
 	DevBuf tkeys;       // keys extracted from records (rsx_sort_records_tagged*)
 	DevBuf ckeys;       // rank sorts: the keys' varying bits packed together (RSX_COMPACT_BITS)
+	DevBuf joint;       // 2-byte keys: [65536 u32 counts][65537 u64 offsets] of the 16-bit digit (rsx_joint16_kernel)
 	Plan *host_plan = nullptr;   // pinned, written by the kernels themselves (dev_host_plan: its device address)
 	Plan *dev_host_plan = nullptr;
 	hipEvent_t plan_ev = nullptr;   // recorded behind the plan's copy to the host
@@ -201,6 +202,7 @@ struct Ctx {
 		}
 		tkeys.release();
 		ckeys.release();
+		joint.release();
 		if (plan_ev)
 			(void)hipEventDestroy(plan_ev);
 		plan_ev = nullptr;
@@ -775,6 +777,43 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION") && !verify_mode();
 	// with the fast kernel every pass has its own region of status words, all zeroed together with the histogram
 	const size_t status_total = c.fast ? status_bytes<KT, NoVal>(n) * sizeof(KT) : 0;
+	if constexpr (sizeof(KT) == 2) {
+		// 2-byte keys, large arrays: one 16-bit digit.  The sorted array is written from the joint histogram of the two bytes
+		// (rsx_joint16_kernel ... rsx_fill16_kernel) into `src` -- where two passes end (radix_sort.hpp:92) --, from one
+		// byte's histogram into `aux` if only one column is kept; the device-side plan decides, no kernel scatters.
+		if (!getenv("RSX_NO_FILL_RUNS") && n >= ((size_t)1 << 20) && ((((uintptr_t)aux) | ((uintptr_t)src)) & 15) == 0) {
+			RSX_TRY(c.joint.ensure(65536 * sizeof(u32) + 65537 * sizeof(u64) + 8));
+			u32 *jt = (u32 *)c.joint.p;
+			u64 *offs = (u64 *)((char *)c.joint.p + 65536 * sizeof(u32));
+			HIP_TRY(hipMemsetAsync(jt, 0, 65536 * sizeof(u32), c.stream));
+			RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, 0));
+			hipLaunchKernelGGL(rsx_joint16_kernel, dim3(512), dim3(1024), 0, c.stream, (const uint16_t *)src, (u64)n, ka, jt,
+			                   (const Plan *)c.plan());
+			hipLaunchKernelGGL(rsx_joint16_scan_kernel, dim3(1), dim3(1024), 0, c.stream, (const u32 *)jt, offs, (u64)n,
+			                   (const Plan *)c.plan());
+			const unsigned blocks = (unsigned)std::min<u64>((n / 8 + 255) / 256 + 1, 8192);
+			hipLaunchKernelGGL(rsx_fill16_kernel, dim3(blocks), dim3(256), 0, c.stream, (uint16_t *)src, (u64)n, (const u64 *)offs, ka,
+			                   (const Plan *)c.plan());
+			hipLaunchKernelGGL((rsx_fill_runs_kernel<KT>), dim3(blocks), dim3(256), 0, c.stream, aux, (u64)n, (const u64 *)c.ghist(),
+			                   (const KT *)src, ka, (const Plan *)c.plan());
+			HIP_TRY(hipGetLastError());
+			RSX_TRY(plan_wait(c, &plan));
+			info_from_plan(info, plan);
+			RSX_TRY(capture_hist(c, n, sizeof(KT)));
+			if (plan.sorted) {                   // radix_sort.hpp:60-62
+				if (info) {
+					info->early_exit = 2;
+					info->ncols = 0;
+				}
+				*result = src;
+				return RSX_OK;
+			}
+			*result = plan.ncols == 1 ? aux : src;
+			if (info)
+				info->result_in_aux = plan.ncols == 1;
+			return RSX_OK;
+		}
+	}
 	// One kept column (keys that differ in one byte only): the sorted array is written from the histogram instead of
 	// scattered (rsx_fill_runs_kernel).  With a speculative first pass both kernels are enqueued and the device-side plan
 	// decides which of them works, which costs an empty launch in the usual case: only for arrays where that is noise.

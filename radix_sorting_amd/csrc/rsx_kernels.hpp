@@ -1029,6 +1029,180 @@ __global__ __launch_bounds__(256) void rsx_fill_runs_kernel(KT *__restrict__ out
 	}
 }
 
+// ---- 2-byte keys, keys only, both columns kept: ONE 16-bit digit (README.md:781-811, "wider digits") -- the sorted array is the
+// joint histogram of the two bytes written out, so the keys are read (twice, see below) and written once instead of
+// read once and read + scattered twice.  The three kernels do nothing unless the device-side plan says "not sorted, two columns".
+//
+// rsx_joint16_kernel: 65536 bins do not fit the LDS as 32-bit counters, so a workgroup counts the half of the bins its
+// parity names (derived keys with the top bit clear / set) in 128 KiB and skips the other keys; every key is read by one
+// workgroup of either kind.  The counts are added to the global table once per workgroup.
+__global__ __launch_bounds__(1024) void rsx_joint16_kernel(const uint16_t *__restrict__ src, u64 n, KdfArgs<uint16_t> ka,
+                                                           u32 *__restrict__ joint, const Plan *__restrict__ plan)
+{
+	if (plan->sorted || plan->ncols != 2)
+		return;
+	__shared__ u32 tab[32768];
+	// workgroups b and b + 8 (the same XCD: workgroups are dealt to the 8 XCDs in turn) read the same keys, one for each half
+	// of the bins, so that the second read finds them in that XCD's L2
+	const u32 tid = threadIdx.x, half = (blockIdx.x >> 3) & 1u, slot = (blockIdx.x & 7u) | ((blockIdx.x >> 4) << 3),
+	          nslots = gridDim.x >> 1;
+	for (u32 i = tid; i < 32768u; i += 1024u)
+		tab[i] = 0;
+	__syncthreads();
+	typedef uint16_t kvec_t __attribute__((ext_vector_type(8)));
+	const u64 nvec = n / 8;
+	const bool aligned = (((uintptr_t)src) & 15) == 0;
+	auto count = [&](const uint16_t raw) {
+		const u32 k = kdf_apply(raw, ka);
+		if ((k >> 15) == half)
+			atomicAdd(&tab[k & 0x7FFFu], 1u);
+	};
+	if (aligned) {
+		for (u64 v = (u64)slot * 1024u + tid; v < nvec; v += (u64)nslots * 1024u) {
+			const kvec_t x = *(const kvec_t *)(src + v * 8);
+#pragma unroll
+			for (int e = 0; e < 8; ++e)
+				count(x[e]);
+		}
+		for (u64 i = nvec * 8 + (u64)slot * 1024u + tid; i < n; i += (u64)nslots * 1024u)
+			count(src[i]);
+	} else {
+		for (u64 i = (u64)slot * 1024u + tid; i < n; i += (u64)nslots * 1024u)
+			count(src[i]);
+	}
+	__syncthreads();
+	for (u32 i = tid; i < 32768u; i += 1024u)
+		if (tab[i])
+			atomicAdd(&joint[half * 32768u + i], tab[i]);
+}
+
+// joint[65536] counts -> offs[65537] exclusive offsets (one workgroup: 64 bins per thread, a scan of the 1024 sums; 36 us --
+// a version with coalesced loads and in-wave scans of 64 chunks per thread needs 192 registers and takes 99)
+__global__ __launch_bounds__(1024) void rsx_joint16_scan_kernel(const u32 *__restrict__ joint, u64 *__restrict__ offs, u64 n,
+                                                                const Plan *__restrict__ plan)
+{
+	if (plan->sorted || plan->ncols != 2)
+		return;
+	__shared__ u64 part[1024];
+	const u32 tid = threadIdx.x;
+	const u32x4 *j4 = (const u32x4 *)joint + tid * 16;   // this thread's 64 bins: sixteen 16-byte loads, twice
+	u64 sum = 0;
+#pragma unroll 4
+	for (u32 j = 0; j < 16; ++j) {
+		const u32x4 v = j4[j];
+		sum += (u64)v.x + v.y + v.z + v.w;
+	}
+	part[tid] = sum;
+	__syncthreads();
+	for (u32 off = 1; off < 1024; off <<= 1) {
+		const u64 add = tid >= off ? part[tid - off] : 0;
+		__syncthreads();
+		part[tid] += add;
+		__syncthreads();
+	}
+	u64 run = part[tid] - sum;
+	typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+	u64x2 *o2 = (u64x2 *)(offs + tid * 64);
+#pragma unroll 4
+	for (u32 j = 0; j < 16; ++j) {
+		const u32x4 v = j4[j];
+		u64x2 a, c;
+		a.x = run;
+		a.y = run + v.x;
+		c.x = a.y + v.y;
+		c.y = c.x + v.z;
+		run = c.y + v.w;
+		o2[2 * j] = a;
+		o2[2 * j + 1] = c;
+	}
+	if (tid == 1023)
+		offs[65536] = n;
+}
+
+// out[i] = the key whose derived value is the last bin b with offs[b] <= i.  A workgroup writes a contiguous piece of the
+// output; the bins that piece spans (found by two searches of the global table) are searched in the LDS if they fit.
+__global__ __launch_bounds__(256) void rsx_fill16_kernel(uint16_t *__restrict__ out, u64 n, const u64 *__restrict__ offs,
+                                                         KdfArgs<uint16_t> ka, const Plan *__restrict__ plan)
+{
+	if (plan->sorted || plan->ncols != 2)
+		return;
+	typedef uint16_t kvec_t __attribute__((ext_vector_type(8)));
+	constexpr u32 VPB = 256 * 8, WIN = 4096;   // vectors per workgroup and step; bins searched in the LDS
+	__shared__ u64 win[WIN + 1];
+	__shared__ u32 s_lo, s_hi;
+	const u32 tid = threadIdx.x;
+	const u64 nvec = n / 8;
+	auto bin_at = [&](u64 i) {
+		u32 lo = 0, hi = 65536;   // offs[lo] <= i < offs[hi]
+#pragma unroll
+		for (int s = 0; s < 16; ++s) {
+			const u32 mid = (lo + hi) >> 1;
+			if (offs[mid] <= i)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		return lo;
+	};
+	for (u64 v0 = (u64)blockIdx.x * VPB; v0 < nvec; v0 += (u64)gridDim.x * VPB) {
+		const u64 v1 = v0 + VPB < nvec ? v0 + VPB : nvec;
+		__syncthreads();   // (the window of the previous step has been used)
+		if (tid == 0)
+			s_lo = bin_at(v0 * 8);
+		if (tid == 64)
+			s_hi = bin_at(v1 * 8 - 1);
+		__syncthreads();
+		const u32 blo = s_lo, bhi = s_hi;
+		const bool inlds = bhi - blo < WIN;
+		if (inlds)
+			for (u32 j = tid; j <= bhi - blo + 1; j += 256)
+				win[j] = offs[blo + j];
+		__syncthreads();
+		for (u64 v = v0 + tid; v < v1; v += 256) {
+			const u64 i0 = v * 8;
+			u32 b;
+			kvec_t x;
+			if (inlds) {
+				u32 lo = 0, hi = bhi - blo + 1;   // win[lo] <= i0 < win[hi]
+				while (hi - lo > 1) {
+					const u32 mid = (lo + hi) >> 1;
+					if (win[mid] <= i0)
+						lo = mid;
+					else
+						hi = mid;
+				}
+				b = lo;
+				if (win[b + 1] >= i0 + 8) {
+					const uint16_t k = kdf_invert<uint16_t>((uint16_t)(blo + b), ka);
+#pragma unroll
+					for (u32 e = 0; e < 8; ++e)
+						x[e] = k;
+				} else {
+#pragma unroll
+					for (u32 e = 0; e < 8; ++e) {
+						while (win[b + 1] <= i0 + e)
+							++b;
+						x[e] = kdf_invert<uint16_t>((uint16_t)(blo + b), ka);
+					}
+				}
+			} else {
+				b = bin_at(i0);
+#pragma unroll
+				for (u32 e = 0; e < 8; ++e) {
+					while (offs[b + 1] <= i0 + e)
+						++b;
+					x[e] = kdf_invert<uint16_t>((uint16_t)b, ka);
+				}
+			}
+			*(kvec_t *)(out + i0) = x;
+		}
+	}
+	if (blockIdx.x == 0 && tid < (u32)(n - nvec * 8)) {
+		const u64 i = nvec * 8 + tid;
+		out[i] = kdf_invert<uint16_t>((uint16_t)bin_at(i), ka);
+	}
+}
+
 // dst[i] = (narrower or wider) src[i]
 template <typename DT, typename ST_>
 __global__ void rsx_convert_kernel(DT *dst, const ST_ *src, u64 n)

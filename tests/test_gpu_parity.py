@@ -491,6 +491,49 @@ def test_keys_that_differ_in_one_byte_are_written_from_the_histogram(dt, mask, c
                 assert np.array_equal(src.cpu().numpy().view(bits), a), (n, order, env, "source untouched")
 
 
+@pytest.mark.parametrize("dt", [ol.U16, ol.I16])
+@pytest.mark.parametrize("order", [rsa.ASCENDING, rsa.DESCENDING])
+def test_two_byte_keys_as_one_sixteen_bit_digit(dt, order, monkeypatch):
+    """Keys-only sorts of 2-byte keys from 2^20 keys on: the joint histogram of both bytes written out (rsx_joint16_kernel,
+    rsx_fill16_kernel) -- result in `src` as after two passes; one kept column: from that byte's histogram into `aux`; sorted:
+    nothing.  Bit-exact against the oracle and against the scatter passes (RSX_NO_FILL_RUNS=1), returned buffer included."""
+    import torch
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (1 << 20, (1 << 20) + 3, (1 << 24) + 5):
+        cases.append(("uniform", ol.splitmix_fill(n, dt, 3 + n % 11)))
+        cases.append(("high byte constant", ol.splitmix_fill(n, dt, 5, mask=0x00FF) | np.uint16(0x4200)))
+        cases.append(("low byte constant", ol.splitmix_fill(n, dt, 6, mask=0xFF00) | np.uint16(0x0042)))
+        cases.append(("few values", (ol.splitmix_fill(n, dt, 7) % 5).astype(np.uint16) * np.uint16(13001)))
+        a = ol.splitmix_fill(n, dt, 9)
+        a[rng.random(n) < 0.98] = a[0]
+        cases.append(("dominant", a))
+        cases.append(("constant", np.full(n, 0x8001, dtype=np.uint16)))
+    for name, a in cases:
+        want, want_aux, _ = ol.oracle_sort(a, dt, order)
+        for no_fill in (False, True):
+            if no_fill:
+                monkeypatch.setenv("RSX_NO_FILL_RUNS", "1")
+            src = torch.from_numpy(a.view(np.int16).copy()).to("cuda")
+            aux = torch.full_like(src, 0x5A5A)
+            res, info = rsa.radix_sort(src, aux, dt, order)
+            if no_fill:
+                monkeypatch.delenv("RSX_NO_FILL_RUNS")
+            got = res.cpu().numpy().view(np.uint16)
+            assert info.result_in_aux == want_aux and np.array_equal(got, want), (name, a.size, no_fill)
+            if info.early_exit:
+                assert bool((aux == 0x5A5A).all()) and np.array_equal(src.cpu().numpy().view(np.uint16), a), (name, "early exit")
+    # unaligned buffers: the scatter passes
+    a = ol.splitmix_fill((1 << 20) + 9, dt, 21)
+    want, want_aux, _ = ol.oracle_sort(a, dt, order)
+    big = torch.zeros(a.size + 16, dtype=torch.int16, device="cuda")
+    src = big[1:1 + a.size]
+    src.copy_(torch.from_numpy(a.view(np.int16).copy()))
+    aux = torch.zeros(a.size, dtype=torch.int16, device="cuda")
+    res, info = rsa.radix_sort(src, aux, dt, order)
+    assert info.result_in_aux == want_aux and np.array_equal(res.cpu().numpy().view(np.uint16), want)
+
+
 @pytest.mark.parametrize("dt", [ol.U8, ol.I16, ol.U32, ol.I32, ol.F32, ol.U64, ol.F64])
 def test_small_host_arrays_through_pinned_staging(dt, monkeypatch):
     """rsx_sort / rsx_sort_rank on host arrays the one-launch kernels take: keys read from and results written to pinned memory

@@ -7,13 +7,16 @@ import radix_sorting_amd as rsa
 
 CASES = [("u32 1 byte", rsa.U32, torch.int32, rsa.ASCENDING), ("u64 1 byte", rsa.U64, torch.int64, rsa.ASCENDING),
          ("u8", rsa.U8, torch.uint8, rsa.ASCENDING), ("i8 desc", rsa.I8, torch.int8, rsa.DESCENDING),
-         ("i16", rsa.I16, torch.int16, rsa.ASCENDING), ("f64", rsa.F64, torch.float64, rsa.ASCENDING),
+         ("i16", rsa.I16, torch.int16, rsa.ASCENDING), ("u16 desc", rsa.U16, torch.int16, rsa.DESCENDING), ("f64", rsa.F64, torch.float64, rsa.ASCENDING),
          ("i32 desc", rsa.I32, torch.int32, rsa.DESCENDING)]
 
 def main():
     rsa.require_gpu()
     n = 1 << 28
+    only = os.environ.get("RSX_BENCH_TYPES")   # e.g. "i16,u8": a subset
     for name, code, tdt, order in CASES:
+        if only and name not in only.split(","):
+            continue
         bufs = [torch.empty(n, dtype=tdt, device="cuda") for _ in range(2)]
         aux = torch.empty(n, dtype=tdt, device="cuda")
         best, cols = 1e9, 0
