@@ -529,6 +529,8 @@ int plan_wait(Ctx &c, Plan *out)
 // the flags of a pass over a column with hot digits (Plan::hot): the HOT kernel + the column, for its hotd word
 inline u32 hot_flags(u32 hotmask, u32 col)
 {
+	if (getenv("RSX_NO_HOT"))   // (diagnostic: the plain kernels on columns with hot digits)
+		return 0u;
 	return (hotmask >> col & 1u) ? ((u32)SCATTER_HOT | (col << SCATTER_COL_SHIFT)) : 0u;
 }
 

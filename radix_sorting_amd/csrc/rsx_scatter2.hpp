@@ -157,6 +157,19 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		}
 	}
 	KT keep[KEEP ? KPT : 1];
+	// RANK1: ONE returning LDS atomic per key.  The count phase's atomic already is the key's rank inside its (wave, digit)
+	// run (rounds in memory order, lanes in lane order); it is kept in 16 bits, and after the layout the staging position is
+	// the run's start + rank -- an LDS read where a second atomic used to be.  On uniform digits the pass is as long as with
+	// two atomics (the phase ends with the chain either way), on skewed digits, where lanes queue at one cell, 25-30 % shorter
+	// (tools/ubench/rsx_scatter10_one_atomic.hpp).
+	// (keys-only passes: in the pair passes sixteen more registers live across the layout make several instantiations spill)
+	constexpr bool RANK1 = KEEP && !C::CELL16 && !HAS_VAL;
+	u32 rk[RANK1 ? KPT / 2 : 1];
+	if constexpr (RANK1) {
+#pragma unroll
+		for (int i = 0; i < KPT / 2; ++i)
+			rk[i] = 0;
+	}
 	__shared__ Sc2Smem<KT, VT, ST, C> sm;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const u64 t_start = TL ? __builtin_readcyclecounter() : 0;
@@ -231,17 +244,30 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 							if constexpr (C::CELL16) {
 								atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
 							} else if constexpr (HOT) {
+								// a hot digit's rank: the wave's count of it so far + the lower lanes of this round that have it
 								bool mine = false;
+								u32 rank = 0;
 #pragma unroll
 								for (int k = 0; k < NHOT; ++k) {
 									if (hv[k]) {
 										const bool is = d == hk[k];
-										hc[k] += (u32)__popcll(__ballot(is));
+										const u64 m = __ballot(is);
+										if (is)
+											rank = hc[k] + mbcnt64(m);
+										hc[k] += (u32)__popcll(m);
 										mine |= is;
 									}
 								}
-								if (!mine)
+								if constexpr (RANK1) {
+									if (!mine)
+										rank = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+									rk[r >> 1] |= rank << (16 * (r & 1));
+								} else if (!mine) {
 									atomicAdd(&wc[d], 1u);
+								}
+							} else if constexpr (RANK1) {
+								const u32 rank = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+								rk[r >> 1] |= rank << (16 * (r & 1));
 							} else {
 								atomicAdd(&wc[d], 1u);
 							}
@@ -278,10 +304,14 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 #pragma unroll
 					for (int r = 0; r < KPT; ++r) {
 						const u32 d = digit2<DIG>(keep[r], ka, shift);
-						if constexpr (C::CELL16)
+						if constexpr (C::CELL16) {
 							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
-						else
+						} else if constexpr (RANK1) {
+							const u32 rank = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							rk[r >> 1] |= rank << (16 * (r & 1));
+						} else {
 							atomicAdd(&wc[d], 1u);
+						}
 					}
 				}
 			} else if constexpr (KEEP) {
@@ -296,10 +326,14 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					const u32 o = wo + r * 64;
 					if (o < cnt) {
 						const u32 d = digit2<DIG>(keep[r], ka, shift);
-						if constexpr (C::CELL16)
+						if constexpr (C::CELL16) {
 							atomicAdd(&wc[d >> 1], 1u << ((d & 1u) * 16u));
-						else
+						} else if constexpr (RANK1) {
+							const u32 rank = __hip_atomic_fetch_add(&wc[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							rk[r >> 1] |= rank << (16 * (r & 1));
+						} else {
 							atomicAdd(&wc[d], 1u);
+						}
 					}
 				}
 			} else {
@@ -454,7 +488,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		u32 *wc = sm.cell[t][wid];
 		const ST *delta = sm.delta[t];
 		u32 hcur[NHOT] = {0, 0, 0, 0};   // HOT: the wave's cursors of the hot digits = their run starts after the layout
-		if constexpr (HOT) {
+		if constexpr (HOT && !RANK1) {
 			if (full) {
 #pragma unroll
 				for (int k = 0; k < NHOT; ++k)
@@ -465,11 +499,12 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 
 		// rank + stage: the returning atomic on the (wave, digit) cursor is the key's tile-local position.
 		// Rounds are issued in memory order; lanes of a round come back in lane order (see the header).
-		u32 posp[HAS_VAL ? KPT / 2 : 1];
+		u32 posp[(HAS_VAL && !RANK1) ? KPT / 2 : 1];   // (RANK1: a key's staged position replaces its rank in rk[])
 		if constexpr (HAS_VAL) {
 #pragma unroll
 			for (int i = 0; i < KPT / 2; ++i)
-				posp[i] = 0;
+				if constexpr (!RANK1)
+					posp[i] = 0;
 		}
 		auto load_batch = [&](KT (&dst)[SB], const int r0) {
 #pragma unroll
@@ -491,7 +526,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				pos[r] = 0;
 				if (full || o < cnt) {
 					const u32 d = digit2<DIG>(cur[r], ka, shift);
-					if constexpr (C::CELL16) {
+					if constexpr (RANK1) {
+						pos[r] = wc[d] + ((rk[(r0 + r) >> 1] >> (16 * ((r0 + r) & 1))) & 0xFFFFu);
+					} else if constexpr (C::CELL16) {
 						const u32 sh = (d & 1u) * 16u;
 						const u32 old = __hip_atomic_fetch_add(&wc[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						pos[r] = (old >> sh) & 0xFFFFu;
@@ -523,7 +560,13 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				if (full || o < cnt) {
 					stage_k[pos[r]] = cur[r];
 					if constexpr (HAS_VAL)
-						posp[(r0 + r) >> 1] |= pos[r] << (16 * ((r0 + r) & 1));
+					{
+						const u32 sh = 16 * ((r0 + r) & 1);
+						if constexpr (RANK1)
+							rk[(r0 + r) >> 1] = (rk[(r0 + r) >> 1] & ~(0xFFFFu << sh)) | (pos[r] << sh);
+						else
+							posp[(r0 + r) >> 1] |= pos[r] << sh;
+					}
 				}
 			}
 		};
@@ -623,7 +666,10 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				for (int r = 0; r < SB; ++r) {
 					const u32 o = wo + (r0 + r) * 64;
 					if (full || o < cnt)
-						stage_v[(posp[(r0 + r) >> 1] >> (16 * ((r0 + r) & 1))) & 0xFFFFu] = val[r];
+					{
+						const u32 packed = RANK1 ? rk[RANK1 ? (r0 + r) >> 1 : 0] : posp[RANK1 ? 0 : (r0 + r) >> 1];
+						stage_v[(packed >> (16 * ((r0 + r) & 1))) & 0xFFFFu] = val[r];
+					}
 				}
 			}
 			__syncthreads();

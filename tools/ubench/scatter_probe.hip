@@ -865,6 +865,12 @@ __device__ inline u32 mix15(u32 x, u32 c, u32 m1, u32 m2)
 // mode 1: every tile of 32 Ki keys holds each digit exactly 128 times in every byte column, in scrambled order: all runs are
 // 512 bytes and start on 512-byte boundaries.  mode 2: the same with run lengths 128 +- 16 j (64-byte aligned starts only);
 // modes 3 and 4: 128 +- 4 j and 128 +- 8 j (16- and 32-byte aligned starts).
+__global__ void sawtooth_kernel(u32 *a, u64 n)
+{
+	for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+		a[i] = (u32)(i % 1000003ull * 4099ull % (1ull << 31));
+}
+
 __global__ void balanced_digits_kernel(u32 *a, u64 n, u32 mode)
 {
 	for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
@@ -910,6 +916,9 @@ int main(int argc, char **argv)
 	if (argc > 2 && atoi(argv[2]) == 5) {
 		printf("four values per byte (keys & 0x03030303)\n");
 		hipLaunchKernelGGL((rsx_fill_splitmix_kernel<u32>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, 1ull, 0x03030303ull, 0ull);
+	} else if (argc > 2 && atoi(argv[2]) == 6) {
+		printf("sawtooth (i %% 1000003 * 4099 %% 2^31: digits constant locally, flat globally)\n");
+		hipLaunchKernelGGL(sawtooth_kernel, dim3(2048), dim3(256), 0, 0, d_in, (u64)n);
 	} else if (argc > 2) {
 		printf("balanced digits, mode %d\n", atoi(argv[2]));
 		hipLaunchKernelGGL(balanced_digits_kernel, dim3(2048), dim3(256), 0, 0, d_in, (u64)n, (u32)atoi(argv[2]));
