@@ -17,6 +17,10 @@
 //                         offsets with a decoupled look-back over agent-scope status words, stages the tile in LDS in
 //                         output order and writes coalesced runs.
 //   rsx_small_sort_kernel, rsx_small_pairs_kernel   the whole sort in one workgroup for small arrays: rsx_small.hpp.
+//   rsx_fill_runs_kernel  keys only, ONE kept column (1-byte keys; wider keys that differ in one byte): no scatter at all --
+//                         the sorted array is that column's histogram written out.
+//   rsx_joint16_kernel, rsx_joint16_scan_kernel, rsx_fill16_kernel   keys only, 2-byte keys with both columns kept: one
+//                         16-bit digit -- the joint histogram of the two bytes, scanned and written out.
 //
 // Also here: the key derivation (kdf_apply), the status-word format of the look-back chain, and the small helper
 // kernels (fill, iota, convert, key extraction, record gather).
