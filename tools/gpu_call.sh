@@ -1,14 +1,11 @@
 #!/bin/bash
-# scratch: the commands of the current gpurun call
+# scratch: the commands of the current gpurun call (here: what the driver runs at the end of a round)
 set -x
 cd /root/repo
-for i in 1 2; do
-timeout 600 python tools/bench_configs.py --only cfg4 --steps 6 --out /tmp/a.json 2>/dev/null | grep "^{" | python3 -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l); print('HOT   ', d['config'][:44].ljust(44), round(d['ms_per_sort'],3))"
-RSX_NO_HOT=1 timeout 600 python tools/bench_configs.py --only cfg4 --steps 6 --out /tmp/b.json 2>/dev/null | grep "^{" | python3 -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l); print('no HOT', d['config'][:44].ljust(44), round(d['ms_per_sort'],3))"
-done
+mkdir -p gpurun_out/final
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/final/pytest_gpu.txt 2>&1
+tail -3 gpurun_out/final/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.txt 2>&1
+tail -1 gpurun_out/final/smoke.txt
+timeout 600 python bench.py > gpurun_out/final/bench.txt 2>&1
+tail -1 gpurun_out/final/bench.txt | cut -c1-400
