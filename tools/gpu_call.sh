@@ -1,11 +1,16 @@
 #!/bin/bash
-# scratch: the commands of the current gpurun call (here: what the driver runs at the end of a round)
+# scratch: the commands of the current gpurun call
 set -x
 cd /root/repo
-mkdir -p gpurun_out/final
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/final/pytest_gpu.txt 2>&1
-tail -3 gpurun_out/final/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.txt 2>&1
-tail -1 gpurun_out/final/smoke.txt
-timeout 600 python bench.py > gpurun_out/final/bench.txt 2>&1
-tail -1 gpurun_out/final/bench.txt | cut -c1-400
+cp radix_sorting_amd/librsx.so /tmp/librsx_new.so
+for round in 1 2 3; do
+for v in new alt; do
+  if [ $v = new ]; then cp /tmp/librsx_new.so radix_sorting_amd/librsx.so; else cp radix_sorting_amd/librsx_alt.so radix_sorting_amd/librsx.so; fi
+  echo "== $v (round $round)"
+  timeout 600 python tools/bench_configs.py --only cfg4 --steps 8 --out /tmp/bc.json 2>/dev/null | grep "^{" | python3 -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('  ', d['config'][:44].ljust(44), round(d['ms_per_sort'],3))"
+done
+done
+cp /tmp/librsx_new.so radix_sorting_amd/librsx.so
