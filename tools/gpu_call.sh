@@ -2,15 +2,12 @@
 # scratch: the commands of the current gpurun call
 set -x
 cd /root/repo
-cp radix_sorting_amd/librsx.so /tmp/librsx_new.so
-for round in 1 2 3; do
-for v in new alt; do
-  if [ $v = new ]; then cp /tmp/librsx_new.so radix_sorting_amd/librsx.so; else cp radix_sorting_amd/librsx_alt.so radix_sorting_amd/librsx.so; fi
-  echo "== $v (round $round)"
-  timeout 600 python tools/bench_configs.py --only cfg4 --steps 8 --out /tmp/bc.json 2>/dev/null | grep "^{" | python3 -c "
+mkdir -p gpurun_out/r02u
+timeout 600 python tools/bench_configs.py --out gpurun_out/r02u/bench_configs.json 2>&1 | grep "^{" | python3 -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print('  ', d['config'][:44].ljust(44), round(d['ms_per_sort'],3))"
-done
-done
-cp /tmp/librsx_new.so radix_sorting_amd/librsx.so
+    d=json.loads(l); print('  ', d['config'][:44].ljust(44), round(d['ms_per_sort'],3), round(d['Gkeys_per_s'],1))"
+timeout 600 python bench.py > gpurun_out/r02u/bench.txt 2>&1
+tail -1 gpurun_out/r02u/bench.txt | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_ms'], d['kernels']['histogram_ms_per_step'])"
+timeout 1800 bash tools/profile_bench.sh r02 all > gpurun_out/r02u/profile.log 2>&1
+tail -12 gpurun_out/r02u/profile.log
