@@ -1,13 +1,11 @@
 #!/bin/bash
-# scratch: the commands of the current gpurun call
+# scratch: the commands of the current gpurun call (here: what the driver runs at the end of a round)
 set -x
 cd /root/repo
-mkdir -p gpurun_out/r02u
-timeout 600 python tools/bench_configs.py --out gpurun_out/r02u/bench_configs.json 2>&1 | grep "^{" | python3 -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l); print('  ', d['config'][:44].ljust(44), round(d['ms_per_sort'],3), round(d['Gkeys_per_s'],1))"
-timeout 600 python bench.py > gpurun_out/r02u/bench.txt 2>&1
-tail -1 gpurun_out/r02u/bench.txt | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_ms'], d['kernels']['histogram_ms_per_step'])"
-timeout 1800 bash tools/profile_bench.sh r02 all > gpurun_out/r02u/profile.log 2>&1
-tail -12 gpurun_out/r02u/profile.log
+mkdir -p gpurun_out/final
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/final/pytest_gpu.txt 2>&1
+tail -3 gpurun_out/final/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.txt 2>&1
+tail -1 gpurun_out/final/smoke.txt
+timeout 600 python bench.py > gpurun_out/final/bench.txt 2>&1
+tail -1 gpurun_out/final/bench.txt | cut -c1-400
