@@ -21,7 +21,7 @@ def _dev(bits):
 
 def _size(rng):
     anchors = [1, 64, 1024, 4096, 8192, 16384, 32768, 65536, 131072, 98304, 262144, 786432, 1048576, 1572864, 3145728, 4194304,
-               5000000]   # (2^20: 2-byte keys become one 16-bit digit; 2^22: one kept column is chosen on the device)
+               5000000]   # (2^20: 2-byte keys become one 16-bit digit)
     kind = rng.integers(0, 4)
     if kind == 0:
         return int(rng.integers(2, 3000))

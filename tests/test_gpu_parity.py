@@ -473,7 +473,7 @@ def test_keys_that_differ_in_one_byte_are_written_from_the_histogram(dt, mask, c
     import torch
     bits = ol.NP_BITS[dt]
     tdt = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[ol.DTYPE_SIZE[dt]]
-    for n in (100003, (1 << 22) + 5):
+    for n in (100003, (1 << 24) + 5):
         a = (ol.splitmix_fill(n, dt, 31 + n % 7, mask=mask) | np.array(const, dtype=bits)).astype(bits)
         for order in (rsa.ASCENDING, rsa.DESCENDING):
             want, want_aux, winfo = ol.oracle_sort(a, dt, order)
