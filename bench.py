@@ -285,6 +285,26 @@ def main():
         sys.stdout.flush()
         dist.barrier()
         torch.cuda.synchronize()
+    # how the last step went through its columns (rsx_info.hybrid): 0 one pass per kept column, 1 / 2 one / two MSB passes
+    # and LDS leaves (README.md:647-650), 3 MSB pass + LSB passes inside its buckets
+    how = int(last[1].hybrid) if (not sharded and hasattr(last[1], "hybrid")) else 0
+    lsd_only = None
+    if not sharded and how != 0 and rank == 0:
+        # the same workload with one pass per kept column (RSX_NO_HYBRID=1), a few steps, for comparison; not `value`
+        os.environ["RSX_NO_HYBRID"] = "1"
+        rsa.reload_env()
+        reps = min(K, 5)
+        for b in range(1 + reps):      # (the timed steps have sorted their batches in place: fresh ones)
+            rsa.fill_splitmix(batches[b], seed=1001 + b, first_index=rank * n)
+        step(0)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(1, 1 + reps):
+            step(i)
+        fence()
+        lsd_only = (time.perf_counter() - t1) / reps
+        del os.environ["RSX_NO_HYBRID"]
+        rsa.reload_env()
     if rank == 0:
         total_keys = float(K) * n * world
         launches = max(int(prof.scatter_launches), 1)
@@ -305,12 +325,16 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": ("2^%d uniform-random u32 keys, 4x8-bit LSD passes, keys only (BASELINE.json configs[1])" % log2n)
+                "workload": ("2^%d uniform-random u32 keys, 4 kept 8-bit columns, keys only (BASELINE.json configs[1])" % log2n)
                 if not sharded else
                 ("%d x 2^%d u32 keys sharded by MSD digit, RCCL all-to-all-v, local LSD (BASELINE.json configs[4])"
                  % (world, log2n)),
                 "keys_per_gpu": n, "total_keys": n * world, "generator": "splitmix64 seed 1+batch",
                 "parallelism": "msd%d" % world if sharded else "1 gpu", "output_sorted": ok,
+                "passes": {0: "one scatter pass per kept column, LSB first (radix_sort.hpp:82-90)",
+                           1: "one MSB scatter pass, then the other kept columns per bucket in LDS (README.md:647-650)",
+                           2: "two MSB scatter passes, then the other kept columns per bucket in LDS (README.md:647-650)",
+                           3: "one MSB scatter pass, then one pass per remaining column inside its buckets"}[how],
             },
             "roofline": {
                 "kernel": "rsx_scatter2_kernel<u32,NoVal,u32>",
@@ -323,7 +347,14 @@ def main():
                 "scatter_ms_per_step": prof.scatter_ms / K,
                 "histogram_ms_per_step": prof.hist_ms / K,
                 "histogram_GBps": (prof.hist_bytes / max(prof.hist_ms, 1e-9) / 1e6) if prof.hist_ms > 0 else None,
-                "sort_algorithmic_GBps": None if sharded else total_keys / world * 36 / elapsed / 1e9,
+                "leaf_ms_per_step": prof.leaf_ms / K,
+                "leaf_GBps": (prof.leaf_bytes / max(prof.leaf_ms, 1e-9) / 1e6) if prof.leaf_ms > 0 else None,
+                # algorithmic bytes per key of the whole sort: 4 (histogram) + 4 passes x 8 = 36 with one pass
+                # per kept column; two MSB passes + leaves: 4 + 4 (per-bucket counts) + 2 x 8 + 8 = 32
+                "sort_algorithmic_bytes_per_key": None if sharded else (36 if how in (0, 3) else 32 if how == 2 else 20),
+                "sort_algorithmic_GBps": None if sharded else total_keys / world * (36 if how in (0, 3) else 32 if how == 2 else 20) / elapsed / 1e9,
+                "lsd_only_ms_per_step": None if lsd_only is None else lsd_only * 1e3,
+                "lsd_only_Gkeys_per_s": None if lsd_only is None else n / lsd_only / 1e9,
             },
         }
         if sharded and isinstance(last[1], dict) and "host_ms_submit_exchange_and_sorts" in last[1]:

@@ -76,6 +76,10 @@ typedef struct rsx_info {
 	uint32_t cols[8];       /* their indices, LSB first                          */
 	uint32_t early_exit;    /* 0 none; 1 n<2 (:37-38); 2 pre-sorted (:60-62)    */
 	uint32_t result_in_aux; /* 1 iff the result is the second buffer / half     */
+	uint32_t hybrid;        /* how the passes were made: 0 one per kept column (:82-90); 1 / 2: one / two passes by the
+	                           highest kept column(s), then the remaining columns per bucket in LDS (README.md:647-650);
+	                           3: one pass by the highest kept column, then one pass per remaining column inside its
+	                           buckets.  The result and the returned buffer are the same whichever it is. */
 } rsx_info;
 
 /* ---- environment ---------------------------------------------------------- */
@@ -92,6 +96,11 @@ void        rsx_release(void);
  * program that creates many short-lived streams releases them one by one: frees the
  * workspace of (current device, stream) after synchronising the stream. */
 void        rsx_release_stream(void *stream);
+
+/* The RSX_* switches of the environment (diagnostics and A/B switches; every one is named where it acts, in
+ * DESIGN.md) are read once, at the library's first call.  A process that changes them afterwards -- tests do -- calls
+ * this to have them read again; RSX_FORCE_TABLE_RANK is only honoured before the first sort on a device. */
+void        rsx_reload_env(void);
 
 /* ---- radix_sort<T>(src, aux, n) -- radix_sort.hpp:98-115 ------------------ */
 
@@ -263,6 +272,9 @@ typedef struct rsx_profile {
 	uint64_t scatter_launches;
 	uint64_t hist_bytes;
 	uint64_t scatter_bytes;
+	double   leaf_ms;        /* rsx_leaf_sort_kernel (sorts that take one MSB pass and leaves): n * 2 * key bytes per launch */
+	uint64_t leaf_launches;
+	uint64_t leaf_bytes;
 } rsx_profile;
 int rsx_profile_begin(void);
 int rsx_profile_end(rsx_profile *out);

@@ -31,13 +31,14 @@ class RsxError(RuntimeError):
 class Profile(C.Structure):
     """rsx_profile: HIP-event kernel timings collected between profile_begin() and profile_end()."""
     _fields_ = [("hist_ms", C.c_double), ("scatter_ms", C.c_double), ("hist_launches", C.c_uint64),
-                ("scatter_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("scatter_bytes", C.c_uint64)]
+                ("scatter_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("scatter_bytes", C.c_uint64),
+                ("leaf_ms", C.c_double), ("leaf_launches", C.c_uint64), ("leaf_bytes", C.c_uint64)]
 
 
 class Info(C.Structure):
     """rsx_info: what the front half of rs_sort_main decided (radix_sort.hpp:48-80)."""
     _fields_ = [("key_bytes", C.c_uint32), ("ncols", C.c_uint32), ("cols", C.c_uint32 * 8),
-                ("early_exit", C.c_uint32), ("result_in_aux", C.c_uint32)]
+                ("early_exit", C.c_uint32), ("result_in_aux", C.c_uint32), ("hybrid", C.c_uint32)]
 
     def kept_columns(self):
         return [int(self.cols[i]) for i in range(self.ncols)]
@@ -53,6 +54,7 @@ ABI = [
     ("rsx_dtype_size", _SZ, [_I]),
     ("rsx_workspace_bytes", _SZ, [_SZ, _I, _SZ]),
     ("rsx_release", None, []),
+    ("rsx_reload_env", None, []),
     ("rsx_sort", _I, [_VP, _VP, _SZ, _I, _I, _PVP, _PINFO]),
     ("rsx_release_stream", None, [_VP]),
     ("rsx_sort_inplace_async", _I, [_VP, _VP, _SZ, _I, _I, _VP]),
@@ -107,6 +109,11 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RsxError("rsx error %d: %s" % (rc, lib().rsx_last_error().decode()))
+
+
+def reload_env():
+    """Have the library read its RSX_* environment switches again (it reads them once, at its first call)."""
+    lib().rsx_reload_env()
 
 
 def device_count():

@@ -10,6 +10,7 @@
 #include "rsx_kernels.hpp"
 #include "rsx_scatter2.hpp"
 #include "rsx_small.hpp"
+#include "rsx_hybrid.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -80,6 +81,54 @@ KdfArgs<KT> make_kdf(int dtype, int order)
 	return a;
 }
 
+// ---- the RSX_* switches of the environment, read ONCE per process (rsx_reload_env() reads them again: tests) ----------------
+// "set" switches are on when the variable exists, "=1" switches when its value starts with '1' (as documented in rsx.h).
+struct Env {
+	bool host_register = false;      // RSX_HOST_REGISTER=1
+	bool force_table_rank = false;   // RSX_FORCE_TABLE_RANK=1
+	bool verify = false;             // RSX_VERIFY=1
+	bool verify_inject = false;      // RSX_VERIFY_INJECT (set)
+	bool no_hot = false;             // RSX_NO_HOT (set)
+	bool elem_loads = false;         // RSX_ELEM_LOADS=1
+	bool no_small_tiles = false;     // RSX_NO_SMALL_TILES (set)
+	bool no_hybrid = false;          // RSX_NO_HYBRID=1
+	bool no_small_sort = false;      // RSX_NO_SMALL_SORT (set)
+	bool no_fill_runs = false;       // RSX_NO_FILL_RUNS (set)
+	bool no_speculation = false;     // RSX_NO_SPECULATION (set)
+	bool compact_bits = false;       // RSX_COMPACT_BITS=1
+	bool no_narrow_keys = false;     // RSX_NO_NARROW_KEYS (set)
+	bool no_host_small = false;      // RSX_NO_HOST_SMALL (set)
+	void load()
+	{
+		auto is_set = [](const char *name) { return getenv(name) != nullptr; };
+		auto is_one = [](const char *name) {
+			const char *e = getenv(name);
+			return e && e[0] == '1';
+		};
+		host_register = is_one("RSX_HOST_REGISTER");
+		force_table_rank = is_one("RSX_FORCE_TABLE_RANK");
+		verify = is_one("RSX_VERIFY");
+		verify_inject = is_set("RSX_VERIFY_INJECT");
+		no_hot = is_set("RSX_NO_HOT");
+		elem_loads = is_one("RSX_ELEM_LOADS");
+		no_small_tiles = is_set("RSX_NO_SMALL_TILES");
+		no_hybrid = is_one("RSX_NO_HYBRID");
+		no_small_sort = is_set("RSX_NO_SMALL_SORT");
+		no_fill_runs = is_set("RSX_NO_FILL_RUNS");
+		no_speculation = is_set("RSX_NO_SPECULATION");
+		compact_bits = is_one("RSX_COMPACT_BITS");
+		no_narrow_keys = is_set("RSX_NO_NARROW_KEYS");
+		no_host_small = is_set("RSX_NO_HOST_SMALL");
+	}
+};
+Env g_env;
+std::once_flag g_env_once;
+inline const Env &env()
+{
+	std::call_once(g_env_once, [] { g_env.load(); });
+	return g_env;
+}
+
 // ---- a growable device allocation -------------------------------------------
 struct DevBuf {
 	void *p = nullptr;
@@ -143,6 +192,10 @@ struct Ctx {
 	DevBuf tkeys;       // keys extracted from records (rsx_sort_records_tagged*)
 	DevBuf ckeys;       // rank sorts: the keys' varying bits packed together (RSX_COMPACT_BITS)
 	DevBuf joint;       // 2-byte keys: [65536 u32 counts][65537 u64 offsets] of the 16-bit digit (rsx_joint16_kernel)
+	DevBuf seg;         // two-level sorts (rsx_hybrid.hpp): [SegCtl][per-bucket digit counts][status regions][leaf segments][tiles]
+	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0;
+	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
+	hipEvent_t seg_ev = nullptr;
 	Plan *host_plan = nullptr;   // pinned, written by the kernels themselves (dev_host_plan: its device address)
 	Plan *dev_host_plan = nullptr;
 	hipEvent_t plan_ev = nullptr;   // recorded behind the plan's copy to the host
@@ -164,7 +217,8 @@ struct Ctx {
 	u32 *hotd() const { return (u32 *)((char *)small.p + 16); }   // [8] hot digits per column + [1] valid bits (rsx_plan_kernel)
 	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
 	u32 *kept() const { return (u32 *)((char *)small.p + 128); }
-	static constexpr size_t SMALL_BYTES = 192;
+	u32 *colmax() const { return (u32 *)((char *)small.p + 192); }   // [8] largest bin per column (rsx_plan_kernel, kept[16..])
+	static constexpr size_t SMALL_BYTES = 256;
 
 	int init()
 	{
@@ -176,6 +230,10 @@ struct Ctx {
 		}
 		if (!host_hist)
 			HIP_TRY(hipHostMalloc((void **)&host_hist, 256 * sizeof(u64), hipHostMallocDefault));
+		if (!host_segctl) {
+			HIP_TRY(hipHostMalloc((void **)&host_segctl, sizeof(SegCtl), hipHostMallocMapped));
+			HIP_TRY(hipHostGetDevicePointer((void **)&dev_host_segctl, host_segctl, 0));
+		}
 		return RSX_OK;
 	}
 	int ensure_hstage()
@@ -203,6 +261,13 @@ struct Ctx {
 		tkeys.release();
 		ckeys.release();
 		joint.release();
+		seg.release();
+		if (host_segctl)
+			(void)hipHostFree(host_segctl);
+		host_segctl = dev_host_segctl = nullptr;
+		if (seg_ev)
+			(void)hipEventDestroy(seg_ev);
+		seg_ev = nullptr;
 		if (plan_ev)
 			(void)hipEventDestroy(plan_ev);
 		plan_ev = nullptr;
@@ -230,14 +295,7 @@ struct HostReg {
 std::vector<HostReg> g_host_regs;
 std::mutex g_host_reg_mu;
 
-bool host_register_mode()
-{
-	static const bool on = [] {
-		const char *e = getenv("RSX_HOST_REGISTER");
-		return e && e[0] == '1';
-	}();
-	return on;
-}
+bool host_register_mode() { return env().host_register; }
 
 void host_register(void *p, size_t bytes)
 {
@@ -272,7 +330,7 @@ void host_unregister_all()
 
 // ---- optional HIP-event bracketing of the kernels (rsx_profile_begin/end) ------
 struct ProfRec {
-	int kind;   // 0 histogram, 1 scatter
+	int kind;   // 0 histogram, 1 scatter, 2 leaves (rsx_hybrid.hpp)
 	hipEvent_t start, stop;
 	u64 bytes;
 };
@@ -338,9 +396,8 @@ int lds_order_selfcheck(int dev)
 	if (it != g_lds_order_ok.end())
 		return it->second;
 	int ok = 0;
-	const char *force = getenv("RSX_FORCE_TABLE_RANK");
 	u64 *d_bad = nullptr;
-	if (!(force && force[0] == '1') && hipMalloc((void **)&d_bad, sizeof(u64)) == hipSuccess) {
+	if (!env().force_table_rank && hipMalloc((void **)&d_bad, sizeof(u64)) == hipSuccess) {
 		u64 bad = ~0ull;
 		if (hipMemset(d_bad, 0, sizeof(u64)) == hipSuccess) {
 			// two shapes: eight waves of bare atomics on collision-heavy digits, and the production shape of
@@ -390,14 +447,7 @@ int capture_hist(Ctx &c, size_t n, size_t kb)
 // chosen tile is re-ranked without LDS atomics (rsx_verify_tile_kernel) and compared with what the pass wrote; a
 // mismatch fails the call with RSX_EVERIFY.  Passes are then serialised by the check's read-back and no pass is
 // speculative; the *_inplace_async entry points, which never synchronise, are not verified.
-bool verify_mode()
-{
-	static const bool on = [] {
-		const char *e = getenv("RSX_VERIFY");
-		return e && e[0] == '1';
-	}();
-	return on;
-}
+bool verify_mode() { return env().verify; }
 u32 g_verify_seq = 0;
 
 int get_ctx(void *stream, Ctx **out)
@@ -487,24 +537,25 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 }
 
 template <typename KT>
-int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, size_t status_total = 0)
+int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, size_t status_total = 0,
+               HybCaps caps = HybCaps{0, 0, 0, 0})
 {
 	const size_t hist_bytes = sizeof(KT) * 256 * sizeof(u64);
 	RSX_TRY(c.hist.ensure(hist_bytes));
 	if (status_total) {
 		// flags, histogram and the status words of every pass of this sort in one launch
 		RSX_TRY(c.status.ensure(status_total));
-		const u64 total16 = (192 + hist_bytes + status_total) / 16;
+		const u64 total16 = (256 + hist_bytes + status_total) / 16;
 		const unsigned blocks = (unsigned)std::min<u64>((total16 + 255) / 256, 2048);
-		hipLaunchKernelGGL(rsx_zero3_kernel, dim3(blocks), dim3(256), 0, c.stream, (u32x4 *)c.small.p, (u64)(192 / 16),
+		hipLaunchKernelGGL(rsx_zero3_kernel, dim3(blocks), dim3(256), 0, c.stream, (u32x4 *)c.small.p, (u64)(256 / 16),
 		                   (u32x4 *)c.hist.p, (u64)(hist_bytes / 16), (u32x4 *)c.status.p, (u64)(status_total / 16));
 	} else {
 		HIP_TRY(hipMemsetAsync(c.hist.p, 0, hist_bytes, c.stream));
-		HIP_TRY(hipMemsetAsync(c.small.p, 0, 192, c.stream));
+		HIP_TRY(hipMemsetAsync(c.small.p, 0, 256, c.stream));
 	}
 	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted()));
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), ka,
-	                   c.kept(), c.hotd(), c.plan_done(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan);   // (+ the finish)
+	                   c.kept(), c.hotd(), c.plan_done(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, caps);   // (+ the finish)
 	HIP_TRY(hipGetLastError());
 	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
 		if (c.small.external)
@@ -529,7 +580,7 @@ int plan_wait(Ctx &c, Plan *out)
 // the flags of a pass over a column with hot digits (Plan::hot): the HOT kernel + the column, for its hotd word
 inline u32 hot_flags(u32 hotmask, u32 col)
 {
-	if (getenv("RSX_NO_HOT"))   // (diagnostic: the plain kernels on columns with hot digits)
+	if (env().no_hot)   // (diagnostic: the plain kernels on columns with hot digits)
 		return 0u;
 	return (hotmask >> col & 1u) ? ((u32)SCATTER_HOT | (col << SCATTER_COL_SHIFT)) : 0u;
 }
@@ -564,11 +615,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 	flags &= ~(u32)SCATTER_HOT;
 	// RSX_ELEM_LOADS=1: whole tiles are read with element loads instead of 16-byte loads + a transposition through the LDS
 	// (measured on 2^28 u32 keys: 0.490-0.505 against 0.503-0.513 ms per pass in the probe; off by default)
-	static const bool elem_loads = [] {
-		const char *e = getenv("RSX_ELEM_LOADS");
-		return e && e[0] == '1';
-	}();
-	if (elem_loads)
+	if (env().elem_loads)
 		flags |= SCATTER_ELEM_LOADS;
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
@@ -617,7 +664,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 		hipLaunchKernelGGL((rsx_verify_tile_kernel<KT, ST>), dim3(1), dim3(64), 0, c.stream, kin, (const void *)kout, vi,       \
 		                   (const void *)vout, (u64)n, shift, gbase, (const ST *)st, vt, (u32)C2::TILE, ka, (u32)sizeof(KTO),  \
 		                   oshift, (u32)val_bytes<VT>::value, (u32)((flags & SCATTER_SKIP_KEYS) ? 1 : 0), c.verify_bad(),           \
-		                   (u32)(getenv("RSX_VERIFY_INJECT") ? 1 : 0))
+		                   (u32)(env().verify_inject ? 1 : 0))
 		if (wide)
 			RSX_VERIFY_TILE(u64);
 		else
@@ -640,7 +687,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 template <typename KT, typename VT> bool use_small_tiles(size_t n)
 {
 	if constexpr (Sc2SmallCfg<KT, VT>::AVAILABLE)
-		return n < (size_t)96 * Sc2Cfg<KT, VT>::TILE && !getenv("RSX_NO_SMALL_TILES");
+		return n < (size_t)96 * Sc2Cfg<KT, VT>::TILE && !env().no_small_tiles;
 	return false;
 }
 
@@ -727,12 +774,156 @@ int scatter_pass_to(Ctx &c, const KT *kin, void *kout, u32 out_bytes, const VT *
 	return fail(RSX_EINVAL, "scatter_pass_to: %u-byte keys out of %zu-byte keys", out_bytes, sizeof(KT));
 }
 
+// ---- one MSB pass and leaves (rsx_hybrid.hpp; README.md:647-650) ---------------------------------------------------------
+template <typename KT> struct LeafShapes {
+	typedef LeafCfg<KT, 4, 32, sizeof(KT) == 8 ? 2 : 4, true, false> Small;   // 8 Ki keys: several workgroups per CU
+	typedef LeafCfg<KT, 16, sizeof(KT) == 8 ? 16 : 32> Big;      // as many keys as the LDS stages at once: one workgroup per CU
+};
+
+// RSX_NO_HYBRID=1: one pass per kept column whatever the keys look like (the reference's loop, radix_sort.hpp:82-90)
+bool hybrid_enabled() { return !env().no_hybrid; }
+
+template <typename KT> HybCaps hybrid_caps(size_t n)
+{
+	HybCaps caps{0, 0, 0, 0};
+	if constexpr (sizeof(KT) >= 4) {
+		if (hybrid_enabled() && n < ((size_t)1 << 30)) {
+			caps.cap1 = (u32)LeafShapes<KT>::Big::CAP;
+			caps.min_cols1 = 3;
+			if (n >= ((size_t)1 << 22)) {
+				caps.cap2 = (u32)LeafShapes<KT>::Small::CAP;
+				caps.min_cols2 = 4;
+			}
+		}
+	}
+	return caps;
+}
+
+// The leaves of a level (rsx_leaf_sort_kernel).  `shapes`: bit 0 the shape for leaves of up to 8 Ki keys, bit 1 the one that
+// fills the LDS; a launched shape does nothing unless the device-side plan has leaves of its size, so both may be enqueued
+// before the host knows (nothing then waits for the host).
+template <typename KT>
+int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level, u32 shapes)
+{
+	typedef typename LeafShapes<KT>::Small S;
+	typedef typename LeafShapes<KT>::Big B;
+	// persistent workgroups over the level-2 leaves (as many as the CUs hold at once); one per bucket at level 1
+	const unsigned grid_s = level == HYB_TWO_LEVEL ? 8192u : 256u;
+	const unsigned grid_b = 256u;
+	const LeafSeg *segtab = level == HYB_TWO_LEVEL ? (const LeafSeg *)((char *)c.seg.p + c.seg_segtab_off) : nullptr;
+	const SegCtl *ctl = (const SegCtl *)c.seg.p;
+	ProfScope prof(2, (u64)n * 2 * sizeof(KT), c.stream);
+	if (shapes & 1u)
+		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(grid_s), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
+		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP);
+	if (shapes & 2u)
+		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, B>), dim3(grid_b), dim3(B::BLOCK), 0, c.stream, src, aux, (u64)n,
+		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)B::CAP);
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
+// a pass inside the level-1 buckets (SEG instantiation of the pass kernel): j < 0 the one by the level-2 column (runs in
+// SEG_MODE_LEAVES), j >= 0 LSB-first pass j (runs in SEG_MODE_LSD).  aux -> src, src -> aux for odd j.
+template <typename KT>
+int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, int j)
+{
+	typedef Sc2Cfg<KT, NoVal> C2;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const size_t st_bytes = 256 + rows * 256 * 4;
+	char *base = (char *)c.seg.p + c.seg_status_off + (size_t)(j < 0 ? 0 : j) * st_bytes;
+	SegArgs sa;
+	sa.ctl = (const SegCtl *)c.seg.p;
+	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
+	sa.tiles = (const SegTile *)((char *)c.seg.p + c.seg_tiles_off);
+	sa.slots = (u32)sizeof(KT) - 1;
+	ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
+	const bool plain = ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0;
+	const u32 flags = j < 0 ? (u32)SCATTER_SEG_LEAVES : 0u;
+	const u32 pi = j < 0 ? 0u : (u32)j;
+#define RSX_LAUNCH_SEG(DIGV)                                                                                               \
+	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, KT, true>), dim3((unsigned)rows),       \
+	                   dim3(C2::BLOCK), 0, c.stream, aux, src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, 0u,         \
+	                   (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,             \
+	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
+	if (plain)
+		RSX_LAUNCH_SEG(DIG_PLAIN);
+	else
+		RSX_LAUNCH_SEG(DIG_GENERIC);
+#undef RSX_LAUNCH_SEG
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
+// The second level of a two-level sort.  Pass 1 (by the highest kept column, src -> aux) is on its way; `plan` says so.
+// Ends with the sorted keys in the buffer the reference's parity rule names (radix_sort.hpp:92); *result says which.
+template <typename KT>
+int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, const Plan &plan, KT **result, u32 *how)
+{
+	typedef Sc2Cfg<KT, NoVal> C2;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const size_t st_bytes = 256 + rows * 256 * 4;
+	const size_t hist_bytes = (size_t)256 * (sizeof(KT) - 1) * 256 * sizeof(u32);
+	c.seg_hist_off = 256;
+	c.seg_status_off = c.seg_hist_off + hist_bytes;
+	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
+	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
+	RSX_TRY(c.seg.ensure(c.seg_tiles_off + rows * sizeof(SegTile)));
+	// control block, digit counts and the status words of the first segmented pass, zeroed together
+	HIP_TRY(hipMemsetAsync(c.seg.p, 0, c.seg_status_off + st_bytes, c.stream));
+	SegCtl *ctl = (SegCtl *)c.seg.p;
+	u32 *seghist = (u32 *)((char *)c.seg.p + c.seg_hist_off);
+	SegTile *tiles = (SegTile *)((char *)c.seg.p + c.seg_tiles_off);
+	LeafSeg *segtab = (LeafSeg *)((char *)c.seg.p + c.seg_segtab_off);
+	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
+	                   (u32)C2::TILE, tiles, ctl);
+	{
+		ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
+		hipLaunchKernelGGL((rsx_seg_hist1_kernel<KT>), dim3(512), dim3(1024), 0, c.stream, (const KT *)aux, (const SegTile *)tiles,
+		                   (const SegCtl *)ctl, (const Plan *)c.plan(), ka, seghist);
+	}
+	hipLaunchKernelGGL((rsx_seg_plan_kernel<KT>), dim3(256), dim3(256), 0, c.stream, seghist, (const u64 *)c.ghist(), (u64)n,
+	                   (const Plan *)c.plan(), ctl, segtab, (u32)LeafShapes<KT>::Big::CAP, c.dev_host_segctl, 0u);
+	HIP_TRY(hipGetLastError());
+	if (!c.seg_ev)
+		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
+	// the pass by the level-2 column and the small leaves are enqueued before the host knows whether the (digit, digit)
+	// buckets fit leaves: they do nothing if not
+	RSX_TRY(launch_seg_pass<KT>(c, aux, src, n, ka, -1));
+	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, 1u));
+	HIP_TRY(hipEventSynchronize(c.seg_ev));
+	const SegCtl hc = *c.host_segctl;
+	KT *final = (plan.ncols & 1) ? aux : src;
+	if (hc.mode == SEG_MODE_LEAVES) {
+		if (hc.maxleaf > (u32)LeafShapes<KT>::Small::CAP)   // (rare: the leaves need the large shape)
+			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, 2u));
+	} else {
+		// keys clustered in their top two columns: one pass per remaining column inside the level-1 buckets, LSB first
+		// (the counts of the columns below the level-2 one are only made now)
+		if (plan.ncols > 2) {
+			ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
+			hipLaunchKernelGGL((rsx_seg_hist_kernel<KT>), dim3(512), dim3(1024), 0, c.stream, (const KT *)aux, (const SegTile *)tiles,
+			                   (const SegCtl *)ctl, (const Plan *)c.plan(), ka, seghist);
+		}
+		hipLaunchKernelGGL((rsx_seg_plan_kernel<KT>), dim3(256), dim3(256), 0, c.stream, seghist, (const u64 *)c.ghist(), (u64)n,
+		                   (const Plan *)c.plan(), ctl, segtab, 0u, (SegCtl *)nullptr, 1u);
+		if (plan.ncols > 2)
+			HIP_TRY(hipMemsetAsync((char *)c.seg.p + c.seg_status_off + st_bytes, 0, (plan.ncols - 2) * st_bytes, c.stream));
+		for (u32 j = 0; j + 1 < plan.ncols; ++j)
+			RSX_TRY(launch_seg_pass<KT>(c, aux, src, n, ka, (int)j));
+	}
+	*result = final;
+	*how = hc.mode == SEG_MODE_LEAVES ? 2u : 3u;
+	return RSX_OK;
+}
+
 // ---- keys only -------------------------------------------------------------------
 template <typename KT>
 int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	if (c.fast && n * sizeof(KT) <= SMALL_SORT_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed()) {
+	if (c.fast && n * sizeof(KT) <= SMALL_SORT_BYTES && !env().no_small_sort && !capture_armed()) {
 		// the whole sort in one workgroup and one launch (rsx_small.hpp)
 		ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
 		hipLaunchKernelGGL((rsx_small_sort_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, src, aux, (u32)n, ka, c.dev_host_plan);
@@ -751,7 +942,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	if constexpr (sizeof(KT) == 1) {
 		// 1-byte keys: at most one column, so the sorted array is the histogram written out (rsx_fill_runs_kernel) -- a read
 		// and a write of the keys instead of a read, a read and a scatter
-		if (!getenv("RSX_NO_FILL_RUNS") && (((uintptr_t)aux) & 15) == 0) {
+		if (!env().no_fill_runs && (((uintptr_t)aux) & 15) == 0) {
 			RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, 0));
 			const unsigned blocks = (unsigned)std::min<u64>((n / 16 + 255) / 256 + 1, 8192);
 			hipLaunchKernelGGL((rsx_fill_runs_kernel<KT>), dim3(blocks), dim3(256), 0, c.stream, aux, (u64)n, (const u64 *)c.ghist(),
@@ -776,14 +967,14 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	}
 	// The first pass is enqueued before the host knows the plan (it reads the device's copy and does nothing on
 	// sorted input): the host's wait for the plan, 20-25 us of idle GPU otherwise, hides behind it.
-	const bool spec = c.fast && !getenv("RSX_NO_SPECULATION") && !verify_mode();
+	const bool spec = c.fast && !env().no_speculation && !verify_mode();
 	// with the fast kernel every pass has its own region of status words, all zeroed together with the histogram
 	const size_t status_total = c.fast ? status_bytes<KT, NoVal>(n) * sizeof(KT) : 0;
 	if constexpr (sizeof(KT) == 2) {
 		// 2-byte keys, large arrays: one 16-bit digit.  The sorted array is written from the joint histogram of the two bytes
 		// (rsx_joint16_kernel ... rsx_fill16_kernel) into `src` -- where two passes end (radix_sort.hpp:92) --, from one
 		// byte's histogram into `aux` if only one column is kept; the device-side plan decides, no kernel scatters.
-		if (!getenv("RSX_NO_FILL_RUNS") && n >= ((size_t)1 << 20) && ((((uintptr_t)aux) | ((uintptr_t)src)) & 15) == 0) {
+		if (!env().no_fill_runs && n >= ((size_t)1 << 20) && ((((uintptr_t)aux) | ((uintptr_t)src)) & 15) == 0) {
 			RSX_TRY(c.joint.ensure(65536 * sizeof(u32) + 65537 * sizeof(u64) + 8));
 			u32 *jt = (u32 *)c.joint.p;
 			u64 *offs = (u64 *)((char *)c.joint.p + 65536 * sizeof(u32));
@@ -819,18 +1010,29 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	// One kept column (keys that differ in one byte only): the sorted array is written from the histogram instead of
 	// scattered (rsx_fill_runs_kernel).  With a speculative first pass both kernels are enqueued and the device-side plan
 	// decides which of them works, which costs an empty launch (3 us) in the usual case: only from 16 Mi keys on, where that is 1 %.
-	const bool fill_one = sizeof(KT) > 1 && !getenv("RSX_NO_FILL_RUNS") && (((uintptr_t)aux) & 15) == 0 && (!spec || n >= ((size_t)1 << 24));
+	const bool fill_one = sizeof(KT) > 1 && !env().no_fill_runs && (((uintptr_t)aux) & 15) == 0 && (!spec || n >= ((size_t)1 << 24));
 	auto launch_fill = [&]() {
 		const unsigned blocks = (unsigned)std::min<u64>((n * sizeof(KT) / 16 + 255) / 256 + 1, 8192);
 		hipLaunchKernelGGL((rsx_fill_runs_kernel<KT>), dim3(blocks), dim3(256), 0, c.stream, aux, (u64)n, (const u64 *)c.ghist(),
 		                   (const KT *)src, ka, (const Plan *)c.plan());
 		return hipGetLastError();
 	};
+	u32 spec_leaves = 0;
 	if (spec) {
-		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total));
+		// (the device may choose one MSB pass and leaves, rsx_hybrid.hpp: pass 0 then goes by the highest kept column)
+		const HybCaps caps = capture_armed() ? HybCaps{0, 0, 0, 0} : hybrid_caps<KT>(n);
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total, caps));
 		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, fill_one ? SCATTER_ONE_COL_FILLED : 0, c.plan(), 0)));
 		if (fill_one)
 			HIP_TRY(launch_fill());
+		if constexpr (sizeof(KT) >= 4) {
+			// one MSB pass and leaves, if the device-side plan says so: enqueued now, so that nothing waits for the host
+			// (the large shape only where even spread keys would come near the small one's capacity; else after the wait)
+			if (caps.cap1 && n <= (size_t)256 * caps.cap1) {
+				spec_leaves = n / 256 > (size_t)LeafShapes<KT>::Small::CAP / 2 ? 3u : 1u;
+				RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, spec_leaves));
+			}
+		}
 		RSX_TRY(plan_wait(c, &plan));
 	} else {
 		RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan, status_total));
@@ -852,6 +1054,27 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 		if (info)
 			info->result_in_aux = 1;
 		return RSX_OK;
+	}
+	if constexpr (sizeof(KT) >= 4) {
+		if (plan.hyb == HYB_ONE_LEVEL || plan.hyb == HYB_TWO_LEVEL) {
+			// pass 0 went by the highest kept column; the leaves put the result where an LSB-first sort of plan.ncols passes ends
+			KT *final = (plan.ncols & 1) ? aux : src;
+			u32 how = 1;
+			if (plan.hyb == HYB_TWO_LEVEL) {
+				RSX_TRY(sort_keys_two_level<KT>(c, src, aux, n, ka, plan, &final, &how));
+			} else {
+				// one level: the leaves are on their way, unless they need a shape that was not enqueued
+				const u32 need = plan.max1 > (u32)LeafShapes<KT>::Small::CAP ? 2u : 1u;
+				if (!(spec_leaves & need))
+					RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, need));
+			}
+			*result = final;                     // radix_sort.hpp:92
+			if (info) {
+				info->result_in_aux = final == aux;
+				info->hybrid = how;
+			}
+			return RSX_OK;
+		}
 	}
 	KT *cur = src, *oth = aux;
 	if (spec)
@@ -921,7 +1144,7 @@ template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	if (c.fast && n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed()) {
+	if (c.fast && n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES && !env().no_small_sort && !capture_armed()) {
 		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, VT, false>), dim3(1), dim3(1024), 0, c.stream, (const KT *)k0, k1, v0, v1,
 		                   (u32)n, ka, c.dev_host_plan);
@@ -1009,7 +1232,7 @@ template <typename KT, typename IT>
 int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info, int want_half = -1)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
-	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !getenv("RSX_NO_SMALL_SORT") && !capture_armed() &&
+	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !env().no_small_sort && !capture_armed() &&
 	    want_half < 0) {
 		ProfScope prof(1, (u64)n * (sizeof(KT) + 2 * sizeof(IT)), c.stream);
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, IT, true>), dim3(1), dim3(1024), 0, c.stream, src, (KT *)nullptr, ib, ib + n,
@@ -1046,10 +1269,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 	// narrower keys.  The ranks are the same (all other bits are equal in every key) and they are left in the half the
 	// reference's number of passes dictates.
 	if (want_half < 0 && c.fast && sizeof(IT) == 4 && P > 1) {
-		static const bool compact_on = [] {
-			const char *e = getenv("RSX_COMPACT_BITS");
-			return e && e[0] == '1';
-		}();
+		const bool compact_on = env().compact_bits;
 		const u64 vary = ((u64)plan.vary_hi << 32) | plan.vary_lo;
 		const u32 bits = (u32)__builtin_popcountll(vary), P2 = (bits + 7) / 8;
 		BitRuns runs;
@@ -1087,7 +1307,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 	// want_half: the halves swap roles when the number of passes would leave the ranks in the other one
 	const bool swap_halves = want_half >= 0 && (int)(P & 1) != want_half;
 	IT *H[2] = {swap_halves ? ib + n : ib, swap_halves ? ib : ib + n};
-	if (c.fast && sizeof(IT) == 4 && !getenv("RSX_NO_NARROW_KEYS")) {
+	if (c.fast && sizeof(IT) == 4 && !env().no_narrow_keys) {
 		// The ranks are the only output, so a pass hands on just the key bytes that later passes look at: once those fit a
 		// narrower type the keys are written as kdf(key) >> (8 * next column) in that type, and the passes after it read
 		// it with the identity KDF.  `base_col`: the column that sits in the low byte of the current representation.
@@ -1608,7 +1828,7 @@ int rsx_sort_rank_device(const void *d_src, void *d_index_buffer, size_t n, rsx_
 // host arrays the one-launch kernels take (sort_keys_device, sort_rank_device: the same conditions)
 static bool host_small_path(const Ctx &c, size_t key_bytes)
 {
-	return c.fast && key_bytes <= SMALL_SORT_BYTES && !getenv("RSX_NO_SMALL_SORT") && !getenv("RSX_NO_HOST_SMALL") && !capture_armed();
+	return c.fast && key_bytes <= SMALL_SORT_BYTES && !env().no_small_sort && !env().no_host_small && !capture_armed();
 }
 
 int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, void **result, rsx_info *info)
@@ -2194,9 +2414,16 @@ int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 	const size_t hist_bytes = kb * 256 * sizeof(u64);
 	RSX_TRY(c->hist.ensure(hist_bytes));
 	HIP_TRY(hipMemsetAsync(c->hist.p, 0, hist_bytes, c->stream));
-	HIP_TRY(hipMemsetAsync(c->small.p, 0, 192, c->stream));
+	HIP_TRY(hipMemsetAsync(c->small.p, 0, 256, c->stream));
 	RSX_DISPATCH_KT(dtype, return msd_split<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, top_hist));
 	return RSX_OK;
+}
+
+void rsx_reload_env(void)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	(void)env();
+	g_env.load();
 }
 
 int rsx_profile_begin(void)
@@ -2226,6 +2453,10 @@ int rsx_profile_end(rsx_profile *out)
 			out->hist_ms += ms;
 			out->hist_launches += 1;
 			out->hist_bytes += r.bytes;
+		} else if (r.kind == 2) {
+			out->leaf_ms += ms;
+			out->leaf_launches += 1;
+			out->leaf_bytes += r.bytes;
 		} else {
 			out->scatter_ms += ms;
 			out->scatter_launches += 1;

@@ -1,0 +1,615 @@
+// rsx_hybrid.hpp -- "one MSB pass and then LSB sort the sub-results" (README.md:647-650), gfx950.
+//
+// The reference's loop at radix_sort.hpp:82-90 makes one trip through memory per kept column.  The result of those P stable
+// passes is the stable order by the kept columns, and that order can be reached with fewer trips when the keys spread over
+// the digits of their TOP kept columns:
+//
+//   level 1  ONE ordinary stable scatter pass by the highest kept column (the pass kernel of rsx_scatter2.hpp, unchanged)
+//            leaves 256 buckets; if every bucket fits a workgroup (leaf capacity), rsx_leaf_sort_kernel sorts each bucket by
+//            the remaining kept columns, LSB first, with the keys in registers and one LDS staging area: read once, written
+//            once, in place or into the other buffer -- whichever the reference's parity rule names (radix_sort.hpp:92).
+//   level 2  larger arrays: a second pass by the next kept column INSIDE each bucket (the same pass kernel, SEG: its tiles are
+//            cut at bucket boundaries and the look-back chain restarts in every bucket) leaves 65536 buckets for the leaves.
+//            The per-bucket digit counts that pass needs come from rsx_seg_hist_kernel (one read of the pass-1 output).
+//            If a (digit, digit) bucket turns out larger than a leaf -- keys clustered in their top sixteen bits -- the
+//            segmented passes simply go on LSB first over the remaining columns inside each level-1 bucket (mode B): the
+//            same result with one trip per column, as the reference.
+//
+// Stable: every pass and every leaf pass is; a bucket holds all keys with its digits in their order of arrival.  The element
+// images are moved untouched (the KDF only picks digits), so the output is bit-identical to the P-pass sort.
+//
+// Which way a sort goes is decided on the device (rsx_plan_kernel -> Plan::hyb, from the column histograms it has anyway;
+// rsx_seg_plan_kernel -> SegCtl::mode) and read by the host where it has to enqueue different kernels.
+#pragma once
+
+#include "rsx_kernels.hpp"
+
+namespace rsx {
+
+enum : u32 { HYB_NONE = 0, HYB_ONE_LEVEL = 1, HYB_TWO_LEVEL = 2 };
+enum : u32 { SEG_MODE_NONE = 0, SEG_MODE_LEAVES = 1, SEG_MODE_LSD = 2 };
+
+// One tile of a segmented pass: [beg, beg + cnt) lies inside level-1 bucket `bucket`; `first` is the index of the bucket's
+// first tile (where the look-back chain of the bucket ends).
+struct SegTile {
+	u32 beg, cnt, bucket, first;
+};
+
+// Device-side control block of the level-2 part of a sort (zeroed by the host before rsx_seg_tiles_kernel).
+struct SegCtl {
+	u32 ntiles;     // rsx_seg_tiles_kernel
+	u32 mode;       // rsx_seg_plan_kernel: SEG_MODE_LEAVES (all (digit, digit) buckets fit a leaf) or SEG_MODE_LSD
+	u32 maxleaf;    // the largest (digit, digit) bucket
+	u32 done;       // blocks of rsx_seg_plan_kernel that are through
+	u32 nleaf;      // leaves in segtab (rsx_seg_plan_kernel)
+	u32 pad[11];
+};
+
+// A leaf's keys: [beg, beg + cnt), sorted by the `ncols` lowest kept columns.  Level 2: a (digit, digit) bucket (ncols = all
+// columns below the level-2 one) or a run of small neighbouring ones of the same level-1 bucket (one column more).
+struct LeafSeg {
+	u32 beg, cnt, ncols, pad;
+};
+
+constexpr u32 LEAF_MERGE_CAP = 4096;   // neighbouring (digit, digit) buckets are sorted together while they hold no more keys than this
+
+// exclusive scan of one u32 per thread over a workgroup of 256 threads (4 waves); `tot` = the sum
+__device__ __forceinline__ u32 block_scan_256(u32 v, u32 *s_w, u32 &tot)
+{
+	const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	u32 x = v;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const u32 y = __shfl_up(x, off);
+		if (lane >= (u32)off)
+			x += y;
+	}
+	if (lane == 63)
+		s_w[wid] = x;
+	__syncthreads();
+	u32 base = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		if (k < (int)wid)
+			base += s_w[k];
+	}
+	tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+	__syncthreads();
+	return base + x - v;
+}
+
+// ---- tiles of the segmented passes ----------------------------------------------------------------------------------
+// off1 = the exclusive offsets of the level-1 column (ghist + 256 * c1, after rsx_plan_kernel).  Every workgroup scans the 256
+// bucket sizes (cheap) and writes its share of the tiles.
+__global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restrict__ ghist, u64 n, const Plan *__restrict__ plan,
+                                                            u32 tile, SegTile *__restrict__ tiles, SegCtl *__restrict__ ctl)
+{
+	if (plan->hyb != HYB_TWO_LEVEL)
+		return;
+	__shared__ u32 s_size[256], s_tb[257], s_beg[256], s_w[4];
+	const u32 d = threadIdx.x;
+	const u64 *off1 = ghist + 256 * plan->cols[plan->ncols - 1];
+	const u64 b = off1[d], e = d == 255 ? n : off1[d + 1];
+	const u32 size = (u32)(e - b);
+	s_size[d] = size;
+	s_beg[d] = (u32)b;
+	u32 total;
+	const u32 tb = block_scan_256((size + tile - 1) / tile, s_w, total);
+	s_tb[d] = tb;
+	if (d == 0) {
+		s_tb[256] = total;
+		if (blockIdx.x == 0)
+			ctl->ntiles = total;
+	}
+	__syncthreads();
+	for (u32 t = blockIdx.x * 256 + d; t < total; t += gridDim.x * 256) {
+		u32 lo = 0, hi = 256;   // the bucket k with s_tb[k] <= t < s_tb[k + 1] (empty buckets have s_tb[k] == s_tb[k + 1])
+		while (hi - lo > 1) {
+			const u32 mid = (lo + hi) >> 1;
+			if (s_tb[mid] <= t)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		while (s_tb[lo + 1] <= t)   // (skip empty buckets that share the boundary)
+			++lo;
+		const u32 k = lo, j = t - s_tb[k];
+		SegTile st;
+		st.beg = s_beg[k] + j * tile;
+		const u32 left = s_size[k] - j * tile;
+		st.cnt = left < tile ? left : tile;
+		st.bucket = k;
+		st.first = s_tb[k];
+		tiles[t] = st;
+	}
+}
+
+// ---- digit counts per level-1 bucket ------------------------------------------------------------------------------------
+// seghist[bucket][slot][256], slot k = the k-th kept column (all kept columns but the level-1 one).  A workgroup takes a
+// contiguous range of tiles (tiles never straddle a bucket), counts into LDS and adds its counts to the bucket's rows when the
+// bucket changes.
+// This kernel: the slots below the level-2 column, wanted only in SEG_MODE_LSD (launched once the host knows);
+// rsx_seg_hist1_kernel below: the level-2 column alone, which every two-level sort needs.
+template <typename KT>
+__global__ __launch_bounds__(1024) void rsx_seg_hist_kernel(const KT *__restrict__ keys, const SegTile *__restrict__ tiles,
+                                                            const SegCtl *__restrict__ ctl, const Plan *__restrict__ plan,
+                                                            KdfArgs<KT> ka, u32 *__restrict__ seghist)
+{
+	if (plan->hyb != HYB_TWO_LEVEL || ctl->mode != SEG_MODE_LSD)
+		return;
+	constexpr int MAXS = sizeof(KT) - 1;
+	__shared__ u32 h[MAXS][256];
+	const u32 tid = threadIdx.x;
+	const u32 nslots = plan->ncols - 2;   // (the level-2 column's row is there already)
+	u32 shifts[MAXS];
+#pragma unroll
+	for (int k = 0; k < MAXS; ++k)
+		shifts[k] = 8 * plan->cols[k < (int)nslots ? k : 0];
+	const u32 nt = ctl->ntiles;
+	const u32 t0 = (u32)((u64)nt * blockIdx.x / gridDim.x), t1 = (u32)((u64)nt * (blockIdx.x + 1) / gridDim.x);
+	if (t0 == t1)
+		return;
+	for (u32 i = tid; i < MAXS * 256; i += 1024)
+		(&h[0][0])[i] = 0;
+	__syncthreads();
+	u32 bucket = tiles[t0].bucket;
+	auto flush = [&]() {
+		__syncthreads();
+		for (u32 i = tid; i < nslots * 256; i += 1024) {
+			const u32 v = (&h[0][0])[i];
+			if (v)
+				atomicAdd(&seghist[(u64)bucket * (MAXS * 256) + i], v);
+			(&h[0][0])[i] = 0;
+		}
+		__syncthreads();
+	};
+	for (u32 t = t0; t < t1; ++t) {
+		const SegTile st = tiles[t];
+		if (st.bucket != bucket) {
+			flush();
+			bucket = st.bucket;
+		}
+		const KT *p = keys + st.beg;
+		constexpr int U = 8;
+		for (u32 i0 = 0; i0 < st.cnt; i0 += 1024 * U) {
+			KT v[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const u32 i = i0 + u * 1024 + tid;
+				v[u] = i < st.cnt ? p[i] : (KT)0;
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const u32 i = i0 + u * 1024 + tid;
+				if (i < st.cnt) {
+					const KT k = kdf_apply(v[u], ka);
+#pragma unroll
+					for (int s = 0; s < MAXS; ++s)
+						if (s < (int)nslots)
+							atomicAdd(&h[s][(u32)(k >> shifts[s]) & 0xFFu], 1u);
+				}
+			}
+		}
+	}
+	flush();
+}
+
+// The level-2 column's digit counts per level-1 bucket: one LDS atomic per key on the wave's own row of 256 counters.
+template <typename KT>
+__global__ __launch_bounds__(1024) void rsx_seg_hist1_kernel(const KT *__restrict__ keys, const SegTile *__restrict__ tiles,
+                                                             const SegCtl *__restrict__ ctl, const Plan *__restrict__ plan,
+                                                             KdfArgs<KT> ka, u32 *__restrict__ seghist)
+{
+	if (plan->hyb != HYB_TWO_LEVEL)
+		return;
+	constexpr int MAXS = sizeof(KT) - 1, NW = 16;
+	__shared__ u32 h[NW][256];
+	const u32 tid = threadIdx.x, wid = tid >> 6;
+	const u32 slot = plan->ncols - 2;
+	const u32 shift = 8 * plan->cols[slot];
+	const u32 nt = ctl->ntiles;
+	const u32 t0 = (u32)((u64)nt * blockIdx.x / gridDim.x), t1 = (u32)((u64)nt * (blockIdx.x + 1) / gridDim.x);
+	if (t0 == t1)
+		return;
+	for (u32 i = tid; i < NW * 256; i += 1024)
+		(&h[0][0])[i] = 0;
+	__syncthreads();
+	u32 bucket = tiles[t0].bucket;
+	auto flush = [&]() {
+		__syncthreads();
+		if (tid < 256) {
+			u32 v = 0;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				v += h[w][tid];
+				h[w][tid] = 0;
+			}
+			if (v)
+				atomicAdd(&seghist[((u64)bucket * MAXS + slot) * 256 + tid], v);
+		}
+		__syncthreads();
+	};
+	u32 *hw = h[wid];
+	for (u32 t = t0; t < t1; ++t) {
+		const SegTile st = tiles[t];
+		if (st.bucket != bucket) {
+			flush();
+			bucket = st.bucket;
+		}
+		const KT *p = keys + st.beg;
+		constexpr int U = 8;
+		for (u32 i0 = 0; i0 < st.cnt; i0 += 1024 * U) {
+			KT v[U];
+			if (i0 + 1024 * U <= st.cnt) {
+#pragma unroll
+				for (int u = 0; u < U; ++u)
+					v[u] = p[i0 + u * 1024 + tid];
+#pragma unroll
+				for (int u = 0; u < U; ++u)
+					atomicAdd(&hw[digit_of(v[u], ka, shift)], 1u);
+			} else {
+#pragma unroll
+				for (int u = 0; u < U; ++u) {
+					const u32 i = i0 + u * 1024 + tid;
+					v[u] = i < st.cnt ? p[i] : (KT)0;
+				}
+#pragma unroll
+				for (int u = 0; u < U; ++u) {
+					const u32 i = i0 + u * 1024 + tid;
+					if (i < st.cnt)
+						atomicAdd(&hw[digit_of(v[u], ka, shift)], 1u);
+				}
+			}
+		}
+	}
+	flush();
+}
+
+// ---- per-bucket exclusive scans, the leaves' segments, and the decision -----------------------------------------------------
+// One workgroup per level-1 bucket, thread = digit.  seghist rows become exclusive offsets relative to the bucket's start
+// (radix_sort.hpp:72-80 per bucket); segtab[bucket * 256 + digit] = the (digit, digit) bucket of the level-2 column.
+template <typename KT>
+__global__ __launch_bounds__(256) void rsx_seg_plan_kernel(u32 *__restrict__ seghist, const u64 *__restrict__ ghist, u64 n,
+                                                           const Plan *__restrict__ plan, SegCtl *__restrict__ ctl,
+                                                           LeafSeg *__restrict__ segtab, u32 leaf_cap, SegCtl *host_ctl,
+                                                           u32 phase)
+{
+	// phase 0: the level-2 column's row, the leaves and the decision; phase 1 (SEG_MODE_LSD only, enqueued once the host
+	// knows): the rows of the columns below it (rsx_seg_hist_kernel has counted them by then)
+	if (plan->hyb != HYB_TWO_LEVEL || (phase == 1 && ctl->mode != SEG_MODE_LSD))
+		return;
+	constexpr int MAXS = sizeof(KT) - 1;
+	__shared__ u64 tot[256];
+	__shared__ u64 lsum[64];
+	__shared__ u32 s_max;
+	const u32 d = threadIdx.x, b = blockIdx.x;
+	const u32 nslots = plan->ncols - 1;
+	const u64 *off1 = ghist + 256 * plan->cols[plan->ncols - 1];
+	const u64 bbeg = off1[b];
+	if (d == 0)
+		s_max = 0;
+	for (u32 s = phase ? 0 : nslots - 1; s < (phase ? nslots - 1 : nslots); ++s) {
+		u32 *row = seghist + ((u64)b * MAXS + s) * 256;
+		const u32 c = row[d];
+		__syncthreads();
+		tot[d] = c;
+		__syncthreads();
+		if (d < 64)
+			wave_scan_256(tot, lsum, d);
+		__syncthreads();
+		row[d] = (u32)tot[d];
+		if (s == nslots - 1) {   // the level-2 column: the highest of the remaining ones
+			// The leaves of this bucket: every (digit, digit) bucket, small neighbours taken together (a workgroup per
+			// 100-key bucket is all overhead).  A bucket opens a new leaf unless it and its predecessor are small (at most
+			// half the merge cap) and start in the same window of half the cap: a merged leaf then stays below the cap.
+			__shared__ u32 s_cnt[256], s_start[257], s_first[257], s_w[4];
+			constexpr u32 H = LEAF_MERGE_CAP / 2;
+			const u32 o = (u32)tot[d];
+			s_cnt[d] = c;
+			__syncthreads();
+			const bool opens = d == 0 || c > H || s_cnt[d - 1] > H || (o / H) != ((o - s_cnt[d - 1]) / H);
+			u32 nleaf;
+			const u32 idx = block_scan_256(opens ? 1u : 0u, s_w, nleaf);
+			if (opens) {
+				s_start[idx] = o;
+				s_first[idx] = d;
+			}
+			if (d == 0) {
+				s_start[nleaf] = o;   // (overwritten below by the thread that knows the total)
+				s_first[nleaf] = 256;
+			}
+			__syncthreads();
+			if (d == 255)
+				s_start[nleaf] = o + c;
+			__syncthreads();
+			// (the table is dense: a bucket's leaves take the next free slots; their order across buckets does not matter)
+			__shared__ u32 s_slot;
+			if (d == 0)
+				s_slot = atomicAdd(&ctl->nleaf, nleaf);
+			__syncthreads();
+			u32 mine = 0;
+			if (d < nleaf) {
+				LeafSeg ls;
+				ls.beg = (u32)(bbeg + s_start[d]);
+				ls.cnt = s_start[d + 1] - s_start[d];
+				ls.ncols = nslots - 1 + (s_first[d + 1] - s_first[d] > 1 ? 1u : 0u);
+				ls.pad = 0;
+				segtab[s_slot + d] = ls;
+				mine = ls.cnt;
+			}
+			atomicMax(&s_max, mine);
+		}
+	}
+	if (phase)
+		return;
+	__syncthreads();
+	__shared__ u32 s_last;
+	if (d == 0) {
+		atomicMax(&ctl->maxleaf, s_max);
+		__threadfence();
+		s_last = atomicAdd(&ctl->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+	}
+	__syncthreads();
+	if (s_last && d == 0) {
+		__threadfence();
+		const u32 mx = atomicMax(&ctl->maxleaf, 0u);
+		const u32 mode = mx <= leaf_cap ? SEG_MODE_LEAVES : SEG_MODE_LSD;
+		ctl->mode = mode;
+		if (host_ctl) {
+			host_ctl->ntiles = ctl->ntiles;
+			host_ctl->maxleaf = mx;
+			host_ctl->nleaf = ctl->nleaf;
+			host_ctl->mode = mode;
+			__threadfence_system();
+		}
+	}
+}
+
+// ---- the leaves ---------------------------------------------------------------------------------------------------------
+// A workgroup sorts a leaf at a time: the leaf's keys go into registers (wave w owns a contiguous slice, round r of lane l is
+// the slice's element 64 r + l: memory order, as in rsx_scatter2_kernel), then per remaining kept column, LSB first: a
+// returning LDS atomic on the (wave, digit) cell is the key's rank in its run, the cells become run starts, the key is staged
+// at start + rank, and the slice is read back for the next column.  After the last column the staged leaf is written out in
+// 16-byte pieces.  Workgroups are persistent (leaf s, s + grid, ...) and request the NEXT leaf's keys before they sort the
+// current one, so that a CU always has loads in flight (without that, 2^28 keys in 65536 leaves: 0.77 ms; a leaf's life was
+// mostly the latency of its own loads).  Rests on the LDS resolving same-address lanes of a returning atomic in lane order,
+// as the pass kernel does (checked on the device before either is used: lds_order_selfcheck, rsx.hip).
+template <typename KT, int NW_, int KPT_, int WPE_ = 1, bool RANK1_ = true, bool PREFETCH_ = false> struct LeafCfg {
+	static constexpr int NW = NW_, KPT = KPT_, BLOCK = NW_ * 64, CAP = NW_ * 64 * KPT_;
+	static constexpr int WPE = WPE_;   // waves per SIMD the register allocation must leave room for
+	static constexpr bool RANK1 = RANK1_;       // one returning atomic per key and column (its rank, kept in 16 bits) or two
+	static constexpr bool PREFETCH = PREFETCH_; // the next leaf's keys requested before the current one is sorted
+	static_assert(CAP <= 32768, "ranks and positions are kept in 16 bits");
+};
+
+// level 1: the 256 buckets of the highest kept column, bounds from its offsets; level 2: segtab[0 .. ctl->nleaf).
+// Enqueued before the host knows what the plan says: does nothing unless the plan is `level` and the largest leaf lies in
+// (lo, hi] -- the host launches the shape for small leaves and, where it may be needed, the one that fills the LDS; the
+// device picks.  Reads the buffer the last pass wrote (level 1: aux, level 2: src) and writes where plan.ncols passes would
+// end (radix_sort.hpp:92).
+template <typename KT, typename C>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__restrict__ src, KT *__restrict__ aux, u64 n,
+                                                                  const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
+                                                                  const LeafSeg *__restrict__ segtab,
+                                                                  const SegCtl *__restrict__ ctl, KdfArgs<KT> ka, u32 level,
+                                                                  u32 lo, u32 hi)
+{
+	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK;
+	constexpr int CHUNK = 16 / sizeof(KT);
+	constexpr int G = 4;
+	static_assert(KPT % G == 0, "whole groups of rounds");
+	// everything the decision needs is requested at once (scalar loads), not one dependent round trip after the other
+	const u32 hyb = plan->hyb, ncols = plan->ncols, max1 = plan->max1;
+	u32 colpack = 0;   // 4 bits per kept column
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		colpack |= (plan->cols[k] & 15u) << (4 * k);
+	const u32 mode = level == HYB_TWO_LEVEL ? ctl->mode : (u32)SEG_MODE_LEAVES;
+	const u32 maxleaf = level == HYB_TWO_LEVEL ? ctl->maxleaf : max1;
+	const u32 nseg = level == HYB_TWO_LEVEL ? ctl->nleaf : 256u;
+	if (hyb != level || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi)
+		return;
+	const u64 *off1 = ghist + 256 * ((colpack >> (4 * (ncols - 1))) & 15u);
+	const KT *in = level == HYB_TWO_LEVEL ? src : aux;
+	KT *out = (ncols & 1) ? aux : src;
+
+	__shared__ __attribute__((aligned(16))) KT stage[C::CAP];
+	__shared__ u32 cell[NW][256];
+	__shared__ u32 wsum[4];
+	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	auto opaque = [](u32 x) {
+		asm volatile("" : "+v"(x));
+		return x;
+	};
+	// A wave's slice is a whole number of groups of G rounds; what lies behind the leaf's end is padded with keys whose
+	// derived key is all ones: they have digit 255 in every column and come last in memory order, so every (stable) pass
+	// leaves them behind the leaf's keys -- no lane ever tests whether its element exists.
+	// Inside a leaf the keys live in registers and LDS as their DERIVED keys (kdf_apply once when they arrive, kdf_invert once
+	// when they leave: the element images that reach memory are the caller's, bit for bit), so that a digit is one bit-field
+	// extract; with the KDF's arithmetic per column and phase the leaves were bound by vector instructions, not by the LDS.
+	const KT pad = (KT)~(KT)0;
+	auto bounds = [&](u32 s, u32 &beg, u32 &cnt, u32 &nc) {
+		if (level == HYB_TWO_LEVEL) {
+			const LeafSeg ls = segtab[s];
+			beg = ls.beg;
+			cnt = ls.cnt;
+			nc = ls.ncols;
+		} else {
+			const u64 b = off1[s], e = s == 255 ? n : off1[s + 1];
+			beg = (u32)b;
+			cnt = (u32)(e - b);
+			nc = ncols - 1;
+		}
+	};
+	// groups of rounds of this wave that hold any of the leaf's keys: what lies wholly behind the leaf's end is not touched
+	// (a round of nothing but padding is 64 lanes on ONE counter: the slowest thing an LDS atomic can be asked to do)
+	const u32 swid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
+	auto wave_groups = [&](u32 cnt, u32 ng) {
+		const u32 first = swid * ng * (64 * G);
+		const u32 mine = cnt > first ? cnt - first : 0u;
+		const u32 g = (mine + 64 * G - 1) / (64 * G);
+		return g < ng ? g : ng;
+	};
+	auto request = [&](auto &dst, u32 beg, u32 cnt) {
+		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);
+		const u32 ng = wave_groups(cnt, ngall);
+		const u32 wo = opaque(wid * (ngall * 64 * G) + lane);
+		const KT *p = in + beg;
+#pragma unroll
+		for (int g = 0; g < KPT / G; ++g) {
+			if (g < (int)ng) {
+#pragma unroll
+				for (int r = g * G; r < (g + 1) * G; ++r) {
+					const u32 i = wo + r * 64;
+					dst[r] = i < cnt ? p[i] : kdf_invert(pad, ka);
+				}
+			}
+		}
+	};
+	u32 s = blockIdx.x;
+	if (s >= nseg)
+		return;
+	u32 nbeg, ncnt, nnc;
+	bounds(s, nbeg, ncnt, nnc);
+	KT nxt[C::PREFETCH ? KPT : 1];
+	if constexpr (C::PREFETCH)
+		request(nxt, nbeg, ncnt);
+	for (;;) {
+		const u32 beg = nbeg, cnt = ncnt, nrem = nnc;
+		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);   // groups of rounds in a wave's slice
+		const u32 per = ngall * (64 * G);
+		const u32 ng = wave_groups(cnt, ngall);                  // ... and those this wave has keys in (wave-uniform)
+		const u32 wo0 = wid * per + lane;
+		KT keep[KPT];
+		if constexpr (C::PREFETCH) {
+#pragma unroll
+			for (int r = 0; r < KPT; ++r)
+				keep[r] = nxt[r];
+		} else {
+			request(keep, beg, cnt);
+		}
+#pragma unroll
+		for (int r = 0; r < KPT; ++r)
+			keep[r] = kdf_apply(keep[r], ka);
+		s += gridDim.x;
+		const bool more = s < nseg;
+		if (more) {
+			bounds(s, nbeg, ncnt, nnc);
+			if constexpr (C::PREFETCH)
+				request(nxt, nbeg, ncnt);
+		}
+		for (u32 c = 0; c < nrem; ++c) {
+			const u32 shift = 8 * ((colpack >> (4 * c)) & 15u);
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				cell[wid][lane + 64 * k] = 0;
+			// (a wave's DS operations execute in order: no barrier between zeroing and counting its own row)
+			u32 *wc = cell[wid];
+			u32 rk[C::RANK1 ? KPT / 2 : 1];
+			if constexpr (C::RANK1) {
+#pragma unroll
+				for (int i = 0; i < KPT / 2; ++i)
+					rk[i] = 0;
+			}
+#pragma unroll
+			for (int g = 0; g < KPT / G; ++g) {
+				if (g < (int)ng) {
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r) {
+						const u32 old = __hip_atomic_fetch_add(&wc[(u32)(keep[r] >> shift) & 0xFFu], 1u, __ATOMIC_RELAXED,
+						                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+						if constexpr (C::RANK1)
+							rk[r >> 1] |= old << (16 * (r & 1));   // the key's rank in its (wave, digit) run
+					}
+				}
+			}
+			__syncthreads();
+			u32 tot = 0, incl = 0;
+			if (tid < 256) {
+#pragma unroll
+				for (int w = 0; w < NW; ++w)
+					tot += cell[w][tid];
+				u32 x = tot;
+#pragma unroll
+				for (int off = 1; off < 64; off <<= 1) {
+					const u32 y = __shfl_up(x, off);
+					if (lane >= (u32)off)
+						x += y;
+				}
+				incl = x;
+				if (lane == 63)
+					wsum[wid] = x;
+			}
+			__syncthreads();
+			if (tid < 256) {
+				u32 acc = incl - tot;   // radix_sort.hpp:72-80, the exclusive scan over the digits
+				for (u32 w = 0; w < wid; ++w)
+					acc += wsum[w];
+#pragma unroll
+				for (int w = 0; w < NW; ++w) {
+					const u32 k = cell[w][tid];
+					cell[w][tid] = acc;
+					acc += k;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int g = 0; g < KPT / G; ++g) {
+				if (g < (int)ng) {
+					// the key's place: its run's start + its rank (or the returning atomic on the run's cursor): rounds in memory
+					// order, lanes in lane order
+					u32 pos[G];
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r) {
+						if constexpr (C::RANK1)
+							pos[r - g * G] = wc[(u32)(keep[r] >> shift) & 0xFFu] + ((rk[r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
+						else
+							pos[r - g * G] = __hip_atomic_fetch_add(&wc[(u32)(keep[r] >> shift) & 0xFFu], 1u, __ATOMIC_RELAXED,
+							                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r)
+						stage[pos[r - g * G]] = keep[r];
+				}
+			}
+			__syncthreads();
+			if (c + 1 < nrem) {
+				const u32 wo = opaque(wo0);
+#pragma unroll
+				for (int g = 0; g < KPT / G; ++g) {
+					if (g < (int)ng) {
+#pragma unroll
+						for (int r = g * G; r < (g + 1) * G; ++r)
+							keep[r] = stage[wo + r * 64];
+					}
+				}
+				// (the next column stages only behind two more barriers: every slice has been read back by then)
+			}
+		}
+		// write out: 16 bytes per lane (the leaf's start is only element-aligned)
+		if (nrem) {
+			KT *o = out + beg;
+			for (u32 i0 = tid * CHUNK; i0 < cnt; i0 += BLOCK * CHUNK) {
+				typedef KT kvec_t __attribute__((ext_vector_type(CHUNK)));
+				const kvec_t x = *(const kvec_t *)&stage[i0];
+				KT kv[CHUNK];
+#pragma unroll
+				for (int e = 0; e < CHUNK; ++e)
+					kv[e] = kdf_invert((KT)x[e], ka);
+				if (i0 + CHUNK <= cnt) {
+					store_chunk<KT, CHUNK>(o + i0, kv);
+				} else {
+#pragma unroll
+					for (int e = 0; e < CHUNK; ++e)
+						if (i0 + e < cnt)
+							o[i0 + e] = kv[e];
+				}
+			}
+		}
+		if (!more)
+			break;
+		__syncthreads();   // the staged leaf has been read before the next one is staged
+	}
+}
+
+}  // namespace rsx

@@ -87,7 +87,16 @@ struct Plan {            // 64 bytes, copied to the host after the plan kernels
 	u32 cols[8];
 	u32 hot;             // bit c: one digit of column c holds an eighth of the keys or more
 	u32 vary_lo, vary_hi;   // the bits of the KDF key that are not the same in all keys (byte c from column c's histogram); 0: not computed
-	u32 pad[3];
+	u32 hyb;             // rsx_hybrid.hpp: HYB_NONE (one pass per kept column), HYB_ONE_LEVEL, HYB_TWO_LEVEL
+	u32 max1;            // the largest bin of the highest kept column (the largest level-1 bucket)
+	u32 pad;
+};
+
+// What rsx_plan_kernel may choose (rsx_hybrid.hpp); all zero: one pass per kept column, as the reference.
+struct HybCaps {
+	u32 cap1;            // one level: every bucket of the highest kept column holds at most this many keys (0: never)
+	u32 cap2;            // two levels: the estimate for the largest (digit, digit) bucket is at most this (0: never)
+	u32 min_cols1, min_cols2;   // kept columns needed for either
 };
 
 // Exclusive scan of 256 u64 values held in LDS, by ONE wavefront (lanes 0..63 of the caller):
@@ -120,14 +129,15 @@ __device__ __forceinline__ void wave_scan_256(u64 *vals, u64 *lsum, u32 lane)
 // One workgroup (256 threads, thread = digit) per column.  ghist[col][256] holds counts on entry; on exit the
 // exclusive offset of the digit: every key with a smaller digit -- the reference's exclusive scan
 // (radix_sort.hpp:72-80).  kept[col] answers the column-skip probe (:64-70).
-__device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan);
+__device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan, u64 n,
+                                            HybCaps caps);
 
 template <typename KT>
 __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist,
                                                        KdfArgs<KT> ka, u32 *__restrict__ kept,
                                                        u32 *__restrict__ hotd = nullptr, u32 *done = nullptr,
                                                        const u32 *unsorted = nullptr, Plan *plan = nullptr,
-                                                       Plan *host_plan = nullptr)
+                                                       Plan *host_plan = nullptr, HybCaps caps = HybCaps{0, 0, 0, 0})
 {
 	constexpr int WC = sizeof(KT);
 	__shared__ u64 tot[256];
@@ -143,20 +153,24 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 		atomicOr(&kept[8 + col], 1u);                              // a hot digit (see Plan::hot)
 	// the bits of this column that vary: a bit varies iff the digits that occur do not agree in it (README.md:716-758's
 	// bit mask, read off the histogram instead of the keys)
-	__shared__ u32 s_and, s_or;
+	__shared__ u32 s_and, s_or, s_max;
 	if (d == 0) {
 		s_and = 0xFFu;
 		s_or = 0;
+		s_max = 0;
 	}
 	tot[d] = total;
 	__syncthreads();
 	if (total) {
 		atomicAnd(&s_and, d);
 		atomicOr(&s_or, d);
+		atomicMax(&s_max, total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)total);
 	}
 	__syncthreads();
-	if (d == 0)
+	if (d == 0) {
 		atomicOr(&kept[8 + col], ((s_and ^ s_or) & 0xFFu) << 8);
+		kept[16 + col] = s_max;                                    // the column's largest bin (rsx_hybrid.hpp)
+	}
 	__syncthreads();
 	// hotd[col]: up to four digits that hold a sixteenth of the keys or more, most frequent first, a byte each; hotd[8]:
 	// bit 4 col + r = slot r of column col is valid (all zeroed by the caller).  The HOT scatter kernels rank these
@@ -186,14 +200,15 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 		__syncthreads();
 		if (s_last && d == 0) {
 			__threadfence();
-			plan_finish((const u32 *)kept, WC, unsorted, plan, host_plan);
+			plan_finish((const u32 *)kept, WC, unsorted, plan, host_plan, n, caps);
 		}
 	}
 }
 
 // `host_plan`: the same 64 bytes in pinned, device-visible host memory -- the host reads the plan there once this kernel
 // has completed, without a copy of its own (one launch less per sort).
-__device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan)
+__device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan, u64 n,
+                                            HybCaps caps)
 {
 	Plan p;
 	for (u32 i = 0; i < 8; ++i)
@@ -214,6 +229,22 @@ __device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *
 		else
 			p.vary_hi |= v << (8 * (i - 4));
 	}
+	// One MSB pass and leaves (rsx_hybrid.hpp) where the keys spread over the digits of their top kept column(s): decided
+	// here, from the histograms, so that the device-scheduled first pass already takes the right column.
+	p.hyb = 0;
+	p.max1 = nc ? kept[16 + p.cols[nc - 1]] : 0;
+	if (!p.sorted && n < (1ull << 30)) {
+		if (caps.cap1 && nc >= caps.min_cols1 && p.max1 <= caps.cap1) {
+			p.hyb = 1;
+		} else if (caps.cap2 && nc >= caps.min_cols2 && nc >= 2) {
+			// the largest (digit, digit) bucket if the two top columns were independent; rsx_seg_plan_kernel has the last word
+			const u64 est = (u64)p.max1 * kept[16 + p.cols[nc - 2]] / n;
+			if (est <= caps.cap2 - caps.cap2 / 4)
+				p.hyb = 2;
+		}
+	}
+	plan->hyb = host_plan->hyb = p.hyb;
+	plan->max1 = host_plan->max1 = p.max1;
 	plan->ncols = host_plan->ncols = p.ncols;
 	plan->sorted = host_plan->sorted = p.sorted;
 	plan->hot = host_plan->hot = p.hot;
@@ -251,7 +282,8 @@ enum : u32 {
 	SCATTER_DBG_NOSTORE = 128, // probe only: skip the global stores
 	SCATTER_DBG_NOLOADB = 256, // probe only: phase B fabricates keys instead of re-reading them
 	SCATTER_DBG_XCD_RUNS = 512, // probe only: tiles by workgroup index, runs of 2^(bits 16-19) consecutive tiles per XCD (no ticket)
-	SCATTER_XCD_RUN_SHIFT = 16
+	SCATTER_XCD_RUN_SHIFT = 16,
+	SCATTER_SEG_LEAVES = 1024   // segmented pass (rsx_hybrid.hpp): the one by the level-2 column
 };
 
 // Tile shape: NWAVES wavefronts per workgroup, KPT keys per lane => NWAVES*64*KPT keys per tile.

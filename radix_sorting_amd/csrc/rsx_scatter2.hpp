@@ -27,6 +27,7 @@
 #pragma once
 
 #include "rsx_kernels.hpp"
+#include "rsx_hybrid.hpp"
 
 namespace rsx {
 
@@ -109,16 +110,30 @@ __device__ __forceinline__ u32 digit2(KT raw, const KdfArgs<KT> ka, u32 shift)
 // still look at: a pass writes kdf(key) >> oshift, narrowed to the smallest type that holds the columns to come, and the
 // next pass reads that type with the identity KDF and its digit in the low byte (2^28 f32 keys -> u32 ranks: 60 -> 50 bytes
 // of traffic per key).
+// SEG: a pass INSIDE the level-1 buckets of a two-level sort (rsx_hybrid.hpp).  Tiles come from `seg.tiles` (cut at bucket
+// boundaries, in bucket order = ticket order), a digit's offset is the bucket's start + the bucket's own exclusive scan
+// (seg.hist, rsx_seg_plan_kernel), and the look-back chain ends at the bucket's first tile.  With SCATTER_SEG_LEAVES the pass
+// goes by the level-2 column and only runs in SEG_MODE_LEAVES; without, it is pass `pass_index` of the LSB-first passes inside
+// the buckets and only runs in SEG_MODE_LSD.
+struct SegArgs {
+	const SegTile *tiles;
+	const SegCtl *ctl;
+	const u32 *hist;   // [bucket][slot][256] exclusive offsets inside the bucket
+	u32 slots;         // rows per bucket in `hist` (key bytes - 1)
+};
+
 template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bool TL = false, int DIG = DIG_GENERIC,
-          bool HOT_ = false, typename KTO = KT>
+          bool HOT_ = false, typename KTO = KT, bool SEG = false>
 __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__restrict__ kin, KTO *__restrict__ kout,
                                                                  const VT *__restrict__ vin, VT *__restrict__ vout, u64 n,
                                                                  u32 shift, const u64 *__restrict__ gbase, u32 tps, ST *status,
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags, u64 *tl,
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
-                                                                 u32 oshift = 0, const u32 *__restrict__ hotd = nullptr)
+                                                                 u32 oshift = 0, const u32 *__restrict__ hotd = nullptr,
+                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0})
 {
 	constexpr bool NARROW = !std::is_same<KTO, KT>::value;
+	static_assert(!SEG || (!NARROW && C::TPS == 1 && !HOT_), "segmented passes: plain tiles, keys of one type");
 	typedef StatusBits<ST> SB_;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, TPS = C::TPS, SB = C::SB, CHUNK = C::CHUNK;
 	// Device-scheduled pass: launched before the host has seen the plan (the first pass of every sort, so that the host's
@@ -127,12 +142,36 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// its index is odd, and does nothing if the input is sorted (radix_sort.hpp:60-62: `aux` must stay untouched then)
 	// or has fewer kept columns.  `gbase` is the histogram's column 0 in this case.
 	u32 dcol = 0;
-	if (dplan) {
+	u32 seg_slot = 0;
+	if constexpr (SEG) {
+		if (dplan->hyb != HYB_TWO_LEVEL)
+			return;
+		const u32 mode = seg.ctl->mode;
+		if (flags & SCATTER_SEG_LEAVES) {   // the pass by the level-2 column, aux -> src; enqueued before the host knows the mode
+			if (mode != SEG_MODE_LEAVES)
+				return;
+			seg_slot = dplan->ncols - 2;
+		} else {                            // LSB-first pass number pass_index inside the buckets (even: aux -> src)
+			if (mode != SEG_MODE_LSD || pass_index >= dplan->ncols - 1)
+				return;
+			seg_slot = pass_index;
+			if (pass_index & 1) {
+				const KT *t = kin;
+				kin = (const KT *)kout;
+				kout = (KTO *)const_cast<KT *>(t);
+			}
+		}
+		shift = 8 * dplan->cols[seg_slot];
+		gbase += 256 * dplan->cols[dplan->ncols - 1];   // the level-1 column's offsets: bucket starts
+	} else if (dplan) {
 		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
 		if ((flags & SCATTER_ONE_COL_FILLED) && dplan->ncols == 1)
 			return;   // keys only, one kept column: the sorted array is written from the histogram (rsx_fill_runs_kernel)
-		const u32 col = dplan->cols[pass_index];
+		if (dplan->hyb && pass_index != 0)
+			return;   // (one MSB pass and leaves, rsx_hybrid.hpp: only pass 0 is device-scheduled)
+		// pass 0 of a hybrid sort goes by the HIGHEST kept column (README.md:647-650)
+		const u32 col = dplan->cols[dplan->hyb ? dplan->ncols - 1 : pass_index];
 		dcol = col;
 		shift = 8 * col;
 		gbase += 256 * col;
@@ -201,10 +240,20 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		const u32 x = blockIdx.x & 7u, k = blockIdx.x >> 3;
 		stile = ((k >> lr) * 8u + x) * R + (k & (R - 1u));
 	}
-	const u64 beg = (u64)stile * tps * C::TILE;
+	u64 beg = (u64)stile * tps * C::TILE;
 	u64 end = beg + (u64)tps * C::TILE;
 	if (end > n)
 		end = n;
+	u32 seg_first = 0, seg_bucket = 0;
+	if constexpr (SEG) {
+		if (stile >= seg.ctl->ntiles)
+			return;
+		const SegTile st = seg.tiles[stile];
+		beg = st.beg;
+		end = beg + st.cnt;
+		seg_first = st.first;
+		seg_bucket = st.bucket;
+	}
 	const u32 wofs = wid * (64 * KPT) + lane;   // wave w owns [w*64*KPT, +64*KPT) of a tile; round r: element 64 r + lane
 	// Element `base + wofs + 64 r` of an array: a uniform (scalar) address for (base, r) plus ONE 32-bit lane offset,
 	// instead of a 64-bit address per round kept in registers (or spilled) across the tile.
@@ -222,7 +271,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// ---- phase A: count, per tile and wave.  Order inside a wave's slice does not matter here, so the
 	// slice is streamed with 16-byte loads (when the keys are 16-byte aligned), all of them in flight.
 	constexpr int VEC = 16 / sizeof(KT);
-	const bool vec_ok = (((uintptr_t)kin) & 15) == 0 && !(flags & SCATTER_ELEM_LOADS);
+	const bool vec_ok = !SEG && (((uintptr_t)kin) & 15) == 0 && !(flags & SCATTER_ELEM_LOADS);   // (a bucket starts anywhere)
 #pragma unroll
 	for (int t = 0; t < TPS; ++t) {
 		const u64 base = beg + (u64)t * C::TILE;
@@ -392,7 +441,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		const u32 t = opaque(tid);   // (or the compiler keeps LB loop-invariant offsets in registers)
 #pragma unroll
 		for (int j = 0; j < LB; ++j) {
-			const int p = back - j > 0 ? back - j : 0;   // super-tile 0 always holds a prefix: safe filler
+			const int lo = SEG ? (int)seg_first : 0;
+			const int p = back - j > lo ? back - j : lo;   // the (bucket's) first tile always holds a prefix: safe filler
 			w[j] = __hip_atomic_load(status + ((u32)p * 256u + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	};
@@ -406,9 +456,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			tc[t] = c;
 			st_cnt += c;
 		}
-		const ST word = ((ST)(stile == 0 ? ST_PREFIX : ST_AGGREGATE) << SB_::SHIFT) | (ST)st_cnt;
+		const ST word = ((ST)(stile == (SEG ? seg_first : 0u) ? ST_PREFIX : ST_AGGREGATE) << SB_::SHIFT) | (ST)st_cnt;
 		__hip_atomic_store(my_status, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (stile != 0)
+		if (stile != (SEG ? seg_first : 0u))
 			look();
 		// prefix over digits, per tile (wave scan now, wave totals through LDS)
 #pragma unroll
@@ -457,7 +507,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		// the chain: aggregates are summed until the first inclusive prefix; an empty word ends the batch
 		u64 excl = 0;
 		u32 depth = 0;
-		if (stile != 0) {
+		if (stile != (SEG ? seg_first : 0u)) {
 			for (;;) {
 				bool done = false;
 				int used = 0;
@@ -481,7 +531,11 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			const ST pword = ((ST)ST_PREFIX << SB_::SHIFT) | (ST)(excl + st_cnt);
 			__hip_atomic_store(my_status, pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		u64 running = gbase[tid] + excl;
+		u64 running;
+		if constexpr (SEG)
+			running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;
+		else
+			running = gbase[tid] + excl;
 #pragma unroll
 		for (int t = 0; t < TPS; ++t) {
 			sm.delta[t][tid] = (ST)(running - tb[t]);   // modulo 2^32 when ST is 32-bit (n < 2^30 then)

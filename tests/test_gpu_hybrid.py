@@ -1,0 +1,155 @@
+"""One MSB pass (or two) and leaves (csrc/rsx_hybrid.hpp; README.md:647-650) against the oracle, through the C ABI.
+
+The hybrid changes HOW the kept columns are gone through, never the result: output bytes, returned buffer, kept-column
+list and early exits must equal the CPU restatement of rs_sort_main (radix_sort.hpp:31-93) exactly as on the
+one-pass-per-column path.  `info.hybrid` says which way a sort went (0 one pass per kept column, 1 one MSB pass + leaves,
+2 two MSB passes + leaves, 3 two levels whose (digit, digit) buckets were too large for leaves: LSB-first passes inside
+the level-1 buckets), so that every branch is known to have run.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+_CARRIER = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def gpu_sort(bits, dt, order=ol.ASC):
+    a = np.ascontiguousarray(bits)
+    src = torch.from_numpy(a.view(_CARRIER[a.itemsize]).copy()).cuda()
+    aux = torch.full_like(src, 0x5A5A5A5A5A5A5A5A >> (64 - 8 * a.itemsize))
+    res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)
+    torch.cuda.synchronize()
+    return res.cpu().numpy().view(ol.NP_BITS[dt]), info
+
+
+def check(a, dt, order, want_hybrid=None, what=""):
+    want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+    got, info = gpu_sort(a, dt, order)
+    assert info.result_in_aux == want_aux, (what, info.hybrid)
+    assert info.kept_columns() == list(winfo.cols[:winfo.ncols]), (what, info.hybrid)
+    assert info.early_exit == winfo.early_exit, (what, info.hybrid)
+    assert np.array_equal(got, want), (what, info.hybrid)
+    if want_hybrid is not None:
+        assert info.hybrid == want_hybrid, (what, info.hybrid, want_hybrid)
+    return info
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    rsa.require_gpu()
+
+
+WIDE = [ol.U32, ol.I32, ol.F32, ol.U64, ol.I64, ol.F64]
+
+
+@pytest.mark.parametrize("dt", WIDE, ids=[ol.DTYPE_NAMES[d] for d in WIDE])
+def test_one_level_vs_oracle(dt):
+    """Uniform keys of mid-size arrays: every bucket of the top byte fits a leaf."""
+    rng = np.random.default_rng(700 + dt)
+    size = ol.DTYPE_SIZE[dt]
+    full = (1 << (8 * size)) - 1
+    for n in (16385 * 4 // size + 1, 20000, 100000, 300001, 1000000, (1 << 21) + 3):
+        for trial in range(3):
+            mask = full
+            if trial == 1:   # one constant byte somewhere below the top: the leaves skip it (radix_sort.hpp:64-70)
+                mask &= ~(0xFF << (8 * int(rng.integers(0, size - 1))))
+            if trial == 2:   # the top byte constant: the MSB pass goes by the highest KEPT column
+                mask &= ~(0xFF << (8 * (size - 1)))
+            a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+            for order in (ol.ASC, ol.DESC):
+                info = check(a, dt, order, None, (n, hex(mask), order))
+                if info.ncols >= 3 and dt not in (ol.F32, ol.F64):
+                    assert info.hybrid == 1, (n, hex(mask), order, info.hybrid)
+
+
+def test_one_level_big_leaves():
+    """Buckets beyond the small leaf's 8 Ki keys take the leaf that fills the LDS (32 Ki four-byte keys)."""
+    for n, dt in ((5000000, ol.U32), (7000000, ol.I32), (3000000, ol.U64)):
+        a = ol.splitmix_fill(n, dt, 77, (1 << (8 * ol.DTYPE_SIZE[dt])) - 1)
+        for order in (ol.ASC, ol.DESC):
+            check(a, dt, order, 1, (n, dt, order))
+
+
+@pytest.mark.parametrize("dt", [ol.U32, ol.F32, ol.U64], ids=["u32", "f32", "u64"])
+def test_two_levels_vs_oracle(dt):
+    """Arrays whose top-byte buckets exceed a leaf: a second pass inside the buckets, then 65536 leaves."""
+    size = ol.DTYPE_SIZE[dt]
+    full = (1 << (8 * size)) - 1
+    for n in ((1 << 23) + 12345, (1 << 24) + 1):
+        masks = [full]
+        if size == 8:
+            masks.append(0x0000FFFFFFFFFFFF)       # six kept columns
+            masks.append(0x00FF00FFFF00FFFF)       # the two top KEPT columns are not adjacent
+        else:
+            masks.append(0xFFFF00FF if False else full)
+        for mask in masks:
+            if dt == ol.F32:
+                # floats with flat top bytes: random bit patterns (NaNs, infinities and denormals among them)
+                a = ol.splitmix_fill(n, dt, 6, mask)
+            else:
+                a = ol.splitmix_fill(n, dt, 5, mask)
+            for order in (ol.ASC, ol.DESC):
+                check(a, dt, order, 2, (n, hex(mask), order))
+
+
+def test_two_levels_with_clustered_top_bytes_fall_back_inside_the_buckets():
+    """Flat top-byte and second-byte histograms, but the two bytes are equal in every key: the (digit, digit) buckets are
+    256 times the estimate and do not fit a leaf -- the segmented passes go on LSB first inside the level-1 buckets."""
+    n = (1 << 23) + 777
+    a = ol.splitmix_fill(n, ol.U32, 11, 0xFFFFFFFF).view(np.uint32).copy()
+    a = (a & np.uint32(0xFF00FFFF)) | ((a >> np.uint32(8)) & np.uint32(0x00FF0000))
+    for order in (ol.ASC, ol.DESC):
+        check(a, ol.U32, order, 3, order)
+    b = ol.splitmix_fill(n, ol.U64, 12, 0xFFFFFFFFFFFFFFFF).view(np.uint64).copy()
+    b = (b & np.uint64(0xFF00FFFFFFFFFFFF)) | ((b >> np.uint64(8)) & np.uint64(0x00FF000000000000))
+    check(b, ol.U64, ol.ASC, 3, "u64")
+
+
+def test_skewed_top_bytes_take_one_pass_per_column():
+    """98 % of the keys on one top byte: no bucket fits anything, the plan must say so before the first pass."""
+    rng = np.random.default_rng(5)
+    for n in (100000, 1000000, (1 << 23) + 5):
+        a = ol.splitmix_fill(n, ol.U32, 9, 0xFFFFFFFF).view(np.uint32).copy()
+        heavy = rng.random(n) < 0.98
+        a[heavy] = (a[heavy] & np.uint32(0x00FFFFFF)) | np.uint32(0x42000000)
+        info = check(a, ol.U32, ol.ASC, None, n)
+        if n >= 1000000:
+            assert info.hybrid == 0, (n, info.hybrid)
+    # floats of one magnitude (cfg 4 (ii)-like): top byte skewed
+    f = (rng.random(1 << 22, dtype=np.float32) * 2 - 1).view(np.uint32)
+    check(f, ol.F32, ol.ASC, None, "floats in [-1, 1)")
+    check(f, ol.F32, ol.DESC, None, "floats in [-1, 1) descending")
+
+
+def test_hybrid_early_exits_and_few_columns():
+    """Sorted input, two kept columns, one kept column: the hybrid must not change the reference's exits (radix_sort.hpp:60-70)."""
+    n = 1000000
+    a = np.sort(ol.splitmix_fill(n, ol.U32, 3, 0xFFFFFFFF).view(np.uint32))
+    info = check(a, ol.U32, ol.ASC, 0, "sorted")
+    assert info.early_exit == 2
+    check(a[::-1].copy(), ol.U32, ol.ASC, None, "reversed")
+    check(ol.splitmix_fill(n, ol.U32, 4, 0x0000FFFF), ol.U32, ol.ASC, 0, "two columns")
+    check(ol.splitmix_fill(n, ol.U32, 4, 0x00FF0000), ol.U32, ol.ASC, 0, "one column")
+    check(ol.splitmix_fill(n, ol.U32, 4, 0xFF00FF0F), ol.U32, ol.DESC, 1, "three columns, top byte kept")
+
+
+def test_hybrid_off_is_the_same_sort(monkeypatch):
+    """RSX_NO_HYBRID=1 (one pass per kept column) and the default give the same bytes in the same buffer."""
+    a = ol.splitmix_fill(3000001, ol.U32, 21, 0xFFFFFFFF)
+    got1, info1 = gpu_sort(a, ol.U32)
+    monkeypatch.setenv("RSX_NO_HYBRID", "1")
+    rsa.reload_env()
+    try:
+        got0, info0 = gpu_sort(a, ol.U32)
+    finally:
+        monkeypatch.delenv("RSX_NO_HYBRID")
+        rsa.reload_env()
+    assert info1.hybrid == 1 and info0.hybrid == 0
+    assert info1.result_in_aux == info0.result_in_aux
+    assert np.array_equal(got0, got1)
