@@ -94,7 +94,8 @@ size_t      rsx_workspace_bytes(size_t n, rsx_dtype dtype, size_t payload_bytes)
 void        rsx_release(void);
 /* One context is kept per (device, stream) the library has been called with; a
  * program that creates many short-lived streams releases them one by one: frees the
- * workspace of (current device, stream) after synchronising the stream. */
+ * workspace of (current device, stream) after synchronising the stream.  No other thread may be inside the library
+ * on that (device, stream) while this runs, or start a call on it before it returns. */
 void        rsx_release_stream(void *stream);
 
 /* The RSX_* switches of the environment (diagnostics and A/B switches; every one is named where it acts, in
@@ -244,6 +245,12 @@ int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order
  * the byte to split by (a caller that knows the bytes above it to be constant). */
 int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype,
                          rsx_order order, int column, uint64_t *top_hist, void *stream);
+
+/* The same pass for a caller that already has the shard's column counts -- d_hist: the 256 * key_bytes uint64 counts
+ * rsx_histogram_device left in device memory (one read of the shard gives every column's, so the column to split by can be
+ * chosen from them without a trial pass).  Counts nothing, waits for nothing: everything is only enqueued on `stream`. */
+int rsx_msd_split_async(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order,
+                        int column, const uint64_t *d_hist, void *stream);
 
 /* radix_sort(src, aux, n, kdf) on HOST buffers with the work spread over `ndev`
  * devices of this one process (radix_sort.hpp:98-115 semantics: early exits,

@@ -13,6 +13,7 @@ Function names and argument meaning follow the reference
 ``radix_sort_rank(src, index_buffer, n, kdf)`` radix_sort_rank.hpp:97-98).
 """
 import ctypes as C
+import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -72,6 +73,7 @@ ABI = [
     ("rsx_sort_rank_keys", _I, [_VP, _SZ, _VP, _SZ, _SZ, _PVP, _PINFO]),
     ("rsx_histogram_device", _I, [_VP, _SZ, _I, _I, _VP, _VP, _VP]),
     ("rsx_msd_split_device", _I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP]),
+    ("rsx_msd_split_async", _I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP]),
     ("rsx_sort_multi", _I, [_VP, _VP, _SZ, _I, _I, _VP, _I, _PVP, _PINFO]),
     ("rsx_profile_begin", _I, []),
     ("rsx_profile_end", _I, [C.POINTER(Profile)]),
@@ -164,16 +166,40 @@ def _same_shape(a, b, what):
                        % (what, b.element_size(), a.element_size(), b.numel(), a.numel()))
 
 
+_armed_hist = threading.local()   # keeps the armed array alive: the library only holds its address
+
+
 def capture_histogram(hist):
     """rsx_capture_histogram: arm the calling thread's next blocking sort to write the counts of loop 1
-    (radix_sort.hpp:48-58) into `hist` (numpy uint64, >= 256 * key bytes entries); None disarms."""
+    (radix_sort.hpp:48-58) into `hist` (numpy uint64, >= 256 * key bytes entries); None disarms.
+
+    The library keeps the raw address until a sort reaches its histogram: prefer ``with capturing_histogram(hist):``,
+    which disarms on the way out whatever happened in between (an exception before the sort, an *_async call that
+    never captures), so that no later sort of this thread writes into an array that is gone."""
     if hist is None:
         check(lib().rsx_capture_histogram(None, 0))
+        _armed_hist.ref = None
     else:
         import numpy as np
         if hist.dtype != np.uint64 or not hist.flags["C_CONTIGUOUS"]:
             raise RsxError("capture_histogram wants a contiguous numpy uint64 array")
         check(lib().rsx_capture_histogram(hist.ctypes.data, hist.size))
+        _armed_hist.ref = hist
+
+
+class capturing_histogram:
+    """Context manager around capture_histogram: armed on entry, disarmed on exit (rsx_capture_histogram(NULL, 0))."""
+
+    def __init__(self, hist):
+        self.hist = hist
+
+    def __enter__(self):
+        capture_histogram(self.hist)
+        return self.hist
+
+    def __exit__(self, *exc):
+        capture_histogram(None)
+        return False
 
 
 def radix_sort(src, aux, dtype=None, order=ASCENDING, stream=None):

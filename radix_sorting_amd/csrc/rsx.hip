@@ -98,6 +98,7 @@ struct Env {
 	bool compact_bits = false;       // RSX_COMPACT_BITS=1
 	bool no_narrow_keys = false;     // RSX_NO_NARROW_KEYS (set)
 	bool no_host_small = false;      // RSX_NO_HOST_SMALL (set)
+	bool no_fused_hist = false;      // RSX_NO_FUSED_HIST=1
 	void load()
 	{
 		auto is_set = [](const char *name) { return getenv(name) != nullptr; };
@@ -119,6 +120,7 @@ struct Env {
 		compact_bits = is_one("RSX_COMPACT_BITS");
 		no_narrow_keys = is_set("RSX_NO_NARROW_KEYS");
 		no_host_small = is_set("RSX_NO_HOST_SMALL");
+		no_fused_hist = is_one("RSX_NO_FUSED_HIST");
 	}
 };
 Env g_env;
@@ -210,19 +212,29 @@ struct Ctx {
 	// (same device and stream) share its workspace, so every entry point holds this for its duration.
 	std::recursive_mutex mu;
 
-	u64 *ghist() const { return (u64 *)hist.p; }
-	u32 *unsorted() const { return (u32 *)small.p; }
-	u32 *plan_done() const { return (u32 *)((char *)small.p + 52); }   // blocks of rsx_plan_kernel that are through
-	u64 *verify_bad() const { return (u64 *)((char *)small.p + 56); }  // RSX_VERIFY: mismatches found by rsx_verify_tile_kernel
-	u32 *hotd() const { return (u32 *)((char *)small.p + 16); }   // [8] hot digits per column + [1] valid bits (rsx_plan_kernel)
-	Plan *plan() const { return (Plan *)((char *)small.p + 64); }
-	u32 *kept() const { return (u32 *)((char *)small.p + 128); }
-	u32 *colmax() const { return (u32 *)((char *)small.p + 192); }   // [8] largest bin per column (rsx_plan_kernel, kept[16..])
-	static constexpr size_t SMALL_BYTES = 256;
+	// The library's own contexts hold TWO sets of flags and histograms and alternate between them (`gen`): small sorts zero
+	// the set of the next sort inside this sort's histogram kernel instead of launching a kernel for it (plan_phase).  A
+	// context in a caller's workspace (external) has one set.
+	u32 gen = 0;
+	static constexpr size_t SMALL_BYTES = 256, HIST_SET_BYTES = 8 * 256 * sizeof(u64);
+	char *small_set() const { return (char *)small.p + (small.external ? 0 : gen * SMALL_BYTES); }
+	char *small_set_other() const { return (char *)small.p + (gen ^ 1u) * SMALL_BYTES; }
+	u64 *ghist() const { return (u64 *)((char *)hist.p + (hist.external ? 0 : gen * HIST_SET_BYTES)); }
+	u64 *ghist_other() const { return (u64 *)((char *)hist.p + (gen ^ 1u) * HIST_SET_BYTES); }
+	u32 *unsorted() const { return (u32 *)small_set(); }
+	u32 *plan_done() const { return (u32 *)(small_set() + 52); }   // blocks of rsx_plan_kernel that are through
+	u64 *verify_bad() const { return (u64 *)(small_set() + 56); }  // RSX_VERIFY: mismatches found by rsx_verify_tile_kernel
+	u32 *hotd() const { return (u32 *)(small_set() + 16); }   // [8] hot digits per column + [1] valid bits (rsx_plan_kernel)
+	Plan *plan() const { return (Plan *)(small_set() + 64); }
+	u32 *kept() const { return (u32 *)(small_set() + 128); }
+	u32 *colmax() const { return (u32 *)(small_set() + 192); }   // [8] largest bin per column (rsx_plan_kernel, kept[16..])
 
 	int init()
 	{
-		RSX_TRY(small.ensure(SMALL_BYTES));
+		RSX_TRY(small.ensure(2 * SMALL_BYTES));
+		RSX_TRY(hist.ensure(2 * HIST_SET_BYTES));
+		HIP_TRY(hipMemset(small.p, 0, 2 * SMALL_BYTES));   // (both sets start out zeroed: see `gen`)
+		HIP_TRY(hipMemset(hist.p, 0, 2 * HIST_SET_BYTES));
 		if (!host_plan)
 		{
 			HIP_TRY(hipHostMalloc((void **)&host_plan, sizeof(Plan), hipHostMallocMapped));
@@ -284,49 +296,30 @@ std::mutex g_mu;
 std::map<std::pair<int, void *>, Ctx *> g_ctx;
 std::map<int, int> g_lds_order_ok;   // device -> result of lds_order_selfcheck (1 ok, 0 not)
 
-// ---- RSX_HOST_REGISTER=1: the caller's host buffers are page-locked (hipHostRegister) the first time they are seen and
-// stay so, cached per (pointer, bytes), so that repeated sorts of the same buffers copy by DMA straight from / to them
-// instead of through the runtime's bounce buffers.  Opt-in: the registration outlives the call (until rsx_release or
-// until 16 younger buffers have pushed it out), which is only safe for buffers the caller keeps.
-struct HostReg {
-	void *p;
-	size_t bytes;
-};
-std::vector<HostReg> g_host_regs;
-std::mutex g_host_reg_mu;
-
-bool host_register_mode() { return env().host_register; }
-
-void host_register(void *p, size_t bytes)
-{
-	if (!host_register_mode() || bytes < ((size_t)1 << 20))
-		return;
-	std::lock_guard<std::mutex> lock(g_host_reg_mu);
-	for (auto &r : g_host_regs)
-		if (r.p == p && r.bytes >= bytes)
+// ---- RSX_HOST_REGISTER=1 (a measurement switch): the caller's host buffers are page-locked (hipHostRegister) FOR THE
+// DURATION OF THE CALL, so that the copies go by DMA straight from / to them instead of through the runtime's bounce buffers.
+// (Round 2 kept registrations cached per pointer across calls: a buffer freed and reallocated at the same address then
+// reused a stale mapping, and evicting an entry could pull the registration from under another thread's copy.  Measured
+// gain of keeping buffers registered: 1-2 %; a caller that wants it registers its own buffers with
+// hipHostRegister -- the library copies from registered memory as it finds it.)
+struct HostRegScope {
+	void *p = nullptr;
+	HostRegScope(void *ptr, size_t bytes)
+	{
+		if (!env().host_register || bytes < ((size_t)1 << 20))
 			return;
-	for (size_t i = 0; i < g_host_regs.size(); ++i)   // overlapping older registrations of other sizes: drop them
-		if ((char *)g_host_regs[i].p < (char *)p + bytes && (char *)p < (char *)g_host_regs[i].p + g_host_regs[i].bytes) {
-			(void)hipHostUnregister(g_host_regs[i].p);
-			g_host_regs.erase(g_host_regs.begin() + i--);
-		}
-	if (g_host_regs.size() >= 16) {
-		(void)hipHostUnregister(g_host_regs.front().p);
-		g_host_regs.erase(g_host_regs.begin());
+		if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess)
+			p = ptr;
+		(void)hipGetLastError();   // (a buffer that cannot be registered -- or already is -- is copied as it is)
 	}
-	if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess)
-		g_host_regs.push_back({p, bytes});
-	(void)hipGetLastError();   // (a buffer that cannot be registered is copied the ordinary way)
-}
-
-void host_unregister_all()
-{
-	std::lock_guard<std::mutex> lock(g_host_reg_mu);
-	for (auto &r : g_host_regs)
-		(void)hipHostUnregister(r.p);
-	g_host_regs.clear();
-	(void)hipGetLastError();
-}
+	~HostRegScope()
+	{
+		if (p)
+			(void)hipHostUnregister(p);
+	}
+	HostRegScope(const HostRegScope &) = delete;
+	HostRegScope &operator=(const HostRegScope &) = delete;
+};
 
 // ---- optional HIP-event bracketing of the kernels (rsx_profile_begin/end) ------
 struct ProfRec {
@@ -507,7 +500,8 @@ u32 choose_tps(size_t n, size_t tile)
 
 // ---- phase 1: histogram + plan (radix_sort.hpp:48-80) --------------------------
 template <typename KT>
-int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted, u32 colmask = ~0u)
+int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, u32 *d_unsorted, u32 colmask = ~0u,
+                const HistFuse *fuse = nullptr)
 {
 	typedef HistCfg<KT> C;
 	const u64 per_block = (u64)C::BLOCK * C::U * C::VEC;     // elements one workgroup covers per sweep
@@ -522,6 +516,15 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 	// up to 128 workgroups add their counts to the histogram themselves (one launch and its gap less: 7 of the 62 us of
 	// a 10^5-key sort); beyond that the rows are summed by a kernel of their own
 	const bool direct = blocks <= 128;
+	if (fuse) {
+		// the kernel also zeroes what the caller names (FUSED, rsx_hist.hpp)
+		if (ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0)
+			hipLaunchKernelGGL((rsx_hist_kernel<KT, C, HIST_PLAIN, true>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src,
+			                   (u64)n, (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr, *fuse);
+		else
+			hipLaunchKernelGGL((rsx_hist_kernel<KT, C, HIST_GENERIC, true>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src,
+			                   (u64)n, (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr, *fuse);
+	} else
 	// keys that are their own KDF (unsigned, ascending) take the instantiation without the KDF arithmetic
 	if (ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0)
 		hipLaunchKernelGGL((rsx_hist_kernel<KT, C, HIST_PLAIN>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
@@ -538,24 +541,49 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 
 template <typename KT>
 int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, size_t status_total = 0,
-               HybCaps caps = HybCaps{0, 0, 0, 0})
+               HybCaps caps = HybCaps{0, 0, 0, 0}, bool fuse_ok = false)
 {
 	const size_t hist_bytes = sizeof(KT) * 256 * sizeof(u64);
-	RSX_TRY(c.hist.ensure(hist_bytes));
+	if (c.hist.external)
+		RSX_TRY(c.hist.ensure(hist_bytes));
+	// (fuse_ok: the blocking entry points only.  A captured graph replays the SAME launch, so it cannot alternate between
+	// the two sets of flags: the device-scheduled *_async sorts keep the separate zeroing launch.)
+	if (fuse_ok && status_total && !out && !c.small.external && !env().no_fused_hist) {
+		// Small arrays: the histogram kernel also zeroes (no launch for that).  The set of flags / histogram this sort uses
+		// was zeroed by the previous sort (or at start-up); this sort's histogram kernel zeroes the other set for the next
+		// one, and the status words of its own passes (which run after it).  One workgroup then makes the plan.
+		RSX_TRY(c.status.ensure(status_total));
+		c.gen ^= 1u;
+		HistFuse f{};
+		f.z0 = (u32x4 *)c.small_set_other();
+		f.n0 = Ctx::SMALL_BYTES / 16;
+		f.z1 = (u32x4 *)c.ghist_other();
+		f.n1 = Ctx::HIST_SET_BYTES / 16;
+		f.z2 = (u32x4 *)c.status.p;
+		f.n2 = status_total / 16;
+		RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted(), ~0u, &f));
+		hipLaunchKernelGGL((rsx_plan_all_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, d_src, (u64)n, c.ghist(), ka, c.kept(),
+		                   c.hotd(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, caps);
+		HIP_TRY(hipGetLastError());
+		if (!c.plan_ev)
+			HIP_TRY(hipEventCreateWithFlags(&c.plan_ev, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(c.plan_ev, c.stream));
+		return RSX_OK;
+	}
 	if (status_total) {
 		// flags, histogram and the status words of every pass of this sort in one launch
 		RSX_TRY(c.status.ensure(status_total));
 		const u64 total16 = (256 + hist_bytes + status_total) / 16;
 		const unsigned blocks = (unsigned)std::min<u64>((total16 + 255) / 256, 2048);
-		hipLaunchKernelGGL(rsx_zero3_kernel, dim3(blocks), dim3(256), 0, c.stream, (u32x4 *)c.small.p, (u64)(256 / 16),
-		                   (u32x4 *)c.hist.p, (u64)(hist_bytes / 16), (u32x4 *)c.status.p, (u64)(status_total / 16));
+		hipLaunchKernelGGL(rsx_zero3_kernel, dim3(blocks), dim3(256), 0, c.stream, (u32x4 *)c.small_set(), (u64)(256 / 16),
+		                   (u32x4 *)c.ghist(), (u64)(hist_bytes / 16), (u32x4 *)c.status.p, (u64)(status_total / 16));
 	} else {
-		HIP_TRY(hipMemsetAsync(c.hist.p, 0, hist_bytes, c.stream));
-		HIP_TRY(hipMemsetAsync(c.small.p, 0, 256, c.stream));
+		HIP_TRY(hipMemsetAsync(c.ghist(), 0, hist_bytes, c.stream));
+		HIP_TRY(hipMemsetAsync(c.small_set(), 0, 256, c.stream));
 	}
 	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted()));
-	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, d_src, (u64)n, c.ghist(), ka,
-	                   c.kept(), c.hotd(), c.plan_done(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, caps);   // (+ the finish)
+	hipLaunchKernelGGL((rsx_plan_all_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, d_src, (u64)n, c.ghist(), ka, c.kept(),
+	                   c.hotd(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, caps);
 	HIP_TRY(hipGetLastError());
 	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
 		if (c.small.external)
@@ -974,7 +1002,9 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 		// 2-byte keys, large arrays: one 16-bit digit.  The sorted array is written from the joint histogram of the two bytes
 		// (rsx_joint16_kernel ... rsx_fill16_kernel) into `src` -- where two passes end (radix_sort.hpp:92) --, from one
 		// byte's histogram into `aux` if only one column is kept; the device-side plan decides, no kernel scatters.
-		if (!env().no_fill_runs && n >= ((size_t)1 << 20) && ((((uintptr_t)aux) | ((uintptr_t)src)) & 15) == 0) {
+		// (below 2^32 keys: the joint table counts in 32 bits, and one 16-bit value may occur n times; larger arrays take the
+		// two scatter passes, whose status words are 64-bit from 2^30 keys on -- counter width by n, radix_sort.hpp:102-114)
+		if (!env().no_fill_runs && n >= ((size_t)1 << 20) && n < ((size_t)1 << 32) && ((((uintptr_t)aux) | ((uintptr_t)src)) & 15) == 0) {
 			RSX_TRY(c.joint.ensure(65536 * sizeof(u32) + 65537 * sizeof(u64) + 8));
 			u32 *jt = (u32 *)c.joint.p;
 			u64 *offs = (u64 *)((char *)c.joint.p + 65536 * sizeof(u32));
@@ -1021,7 +1051,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 	if (spec) {
 		// (the device may choose one MSB pass and leaves, rsx_hybrid.hpp: pass 0 then goes by the highest kept column)
 		const HybCaps caps = capture_armed() ? HybCaps{0, 0, 0, 0} : hybrid_caps<KT>(n);
-		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total, caps));
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total, caps, true));
 		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, fill_one ? SCATTER_ONE_COL_FILLED : 0, c.plan(), 0)));
 		if (fill_one)
 			HIP_TRY(launch_fill());
@@ -1409,6 +1439,19 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u3
 	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, top, ka, flags);
 }
 
+// The same pass for a caller that HAS the shard's column counts (rsx_histogram_device: one read gave every column): nothing
+// is counted again and nothing waits for the host.
+template <typename KT>
+int msd_split_known(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u32 col, const u64 *d_counts)
+{
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	HIP_TRY(hipMemcpyAsync(c.ghist(), d_counts, sizeof(KT) * 256 * sizeof(u64), hipMemcpyDeviceToDevice, c.stream));
+	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), ka, c.kept(),
+	                   c.hotd());   // (the exclusive scans, radix_sort.hpp:72-80)
+	HIP_TRY(hipGetLastError());
+	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0u);
+}
+
 // ---- single-process multi-device sort (rsx_sort_multi) -----------------------------------------------------------------
 // A "rank" is a (device, stream) pair: its own workspace context, its own host thread while a phase runs.  The streams are
 // pooled per (device, slot) so that repeated calls reuse the contexts.
@@ -1594,7 +1637,6 @@ void rsx_release(void)
 		kv.second.misc.release();
 	}
 	g_multi_bufs.clear();
-	host_unregister_all();
 }
 
 namespace {
@@ -1709,22 +1751,29 @@ int rsx_sort_pairs_inplace_async_ws(void *d_keys, void *d_keys_scratch, void *d_
 
 void rsx_release_stream(void *stream)
 {
-	std::lock_guard<std::mutex> lock(g_mu);
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess) {
-		(void)hipGetLastError();
-		return;
-	}
-	auto it = g_ctx.find(std::make_pair(dev, stream));
-	if (it == g_ctx.end())
-		return;
+	// Lock order everywhere else: a context's mutex, then g_mu (the host wrappers hold the context and look contexts up
+	// again).  So the context is taken out of the table under g_mu alone, and only then locked, drained and freed.  The
+	// caller must not have another thread inside the library on this (device, stream) -- see rsx.h.
+	Ctx *c = nullptr;
 	{
-		std::lock_guard<std::recursive_mutex> ctx_lock(it->second->mu);
-		(void)hipStreamSynchronize(it->second->stream);
-		it->second->release();
+		std::lock_guard<std::mutex> lock(g_mu);
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess) {
+			(void)hipGetLastError();
+			return;
+		}
+		auto it = g_ctx.find(std::make_pair(dev, stream));
+		if (it == g_ctx.end())
+			return;
+		c = it->second;
+		g_ctx.erase(it);
 	}
-	delete it->second;
-	g_ctx.erase(it);
+	{
+		std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);   // (a call that was already running on it finishes first)
+		(void)hipStreamSynchronize(c->stream);
+		c->release();
+	}
+	delete c;
 }
 
 int rsx_sort_pairs_inplace_async(void *d_keys, void *d_keys_scratch, void *d_vals, void *d_vals_scratch, size_t n, rsx_dtype dtype,
@@ -1875,8 +1924,7 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, v
 	// buffer the returned-pointer rule names (the other one is left as it was)
 	RSX_TRY(c->keys[0].ensure(n * kb));
 	RSX_TRY(c->keys[1].ensure(n * kb));
-	host_register(src, n * kb);
-	host_register(aux, n * kb);
+	HostRegScope reg_src(src, n * kb), reg_aux(aux, n * kb);   // (RSX_HOST_REGISTER=1: pinned until this call returns)
 	HIP_TRY(hipMemcpyAsync(c->keys[0].p, src, n * kb, hipMemcpyHostToDevice, c->stream));
 	void *dres = nullptr;
 	rsx_info li;
@@ -2412,10 +2460,26 @@ int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	const size_t hist_bytes = kb * 256 * sizeof(u64);
-	RSX_TRY(c->hist.ensure(hist_bytes));
-	HIP_TRY(hipMemsetAsync(c->hist.p, 0, hist_bytes, c->stream));
-	HIP_TRY(hipMemsetAsync(c->small.p, 0, 256, c->stream));
+	HIP_TRY(hipMemsetAsync(c->ghist(), 0, hist_bytes, c->stream));
+	HIP_TRY(hipMemsetAsync(c->small_set(), 0, 256, c->stream));
 	RSX_DISPATCH_KT(dtype, return msd_split<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, top_hist));
+	return RSX_OK;
+}
+
+int rsx_msd_split_async(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order, int column,
+                        const uint64_t *d_hist, void *stream)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb || !d_hist || column >= (int)kb || (n && (!d_src || !d_dst)))
+		return fail(RSX_EINVAL, "rsx_msd_split_async: bad argument");
+	const u32 col = column < 0 ? (u32)kb - 1 : (u32)column;
+	if (n == 0)
+		return RSX_OK;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	HIP_TRY(hipMemsetAsync(c->small_set(), 0, 256, c->stream));
+	RSX_DISPATCH_KT(dtype, return msd_split_known<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, (const u64 *)d_hist));
 	return RSX_OK;
 }
 

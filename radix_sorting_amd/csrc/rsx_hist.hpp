@@ -92,15 +92,28 @@ template <typename C> __device__ __forceinline__ void hist_collect(HistSmem<C> &
 	}
 }
 
+// FUSED (the blocking sorts): before it counts, every workgroup zeroes its share of three regions -- the status words of THIS
+// sort's passes and the flags / histogram of the NEXT sort (the host alternates between two sets: the set this sort counts
+// into was zeroed by the previous sort) --, which is one launch less per sort (rsx_zero3_kernel); at 10^5 keys a launch
+// costs as much as any of the sort's kernels.
+// (Also tried: the plan made by the workgroup that finishes last.  Every workgroup then needs a device-scope release fence
+// before it signs off, which on this multi-die part writes the die's L2 back: 2-3 us each, 22 us instead of 5 for the
+// histogram kernel of 2^16 keys and 48 instead of 8 for 2^20.  rsx_plan_all_kernel, one workgroup, does it instead.)
+struct HistFuse {
+	u32x4 *z0, *z1, *z2;
+	u64 n0, n1, n2;        // 16-byte units
+};
+
 // colmask: the columns to count (the MSD split of the multi-GPU path wants one).
 // partial: [workgroup][WC * 256] u32 rows for rsx_hist_reduce_kernel; `direct` (few workgroups): the counts are added
 // to the histogram at once and no reduce launch follows.
-template <typename KT, typename C = HistCfg<KT>, int MODE = HIST_GENERIC>
+template <typename KT, typename C = HistCfg<KT>, int MODE = HIST_GENERIC, bool FUSED = false>
 __global__ __launch_bounds__(C::BLOCK, (C::OCC * C::BLOCK + 255) / 256) void rsx_hist_kernel(const KT *__restrict__ src, u64 n,
                                                                                              u32 *__restrict__ partial,
                                                                                              u32 *__restrict__ unsorted, KdfArgs<KT> ka,
                                                                                              u32 colmask = ~0u,
-                                                                                             u64 *__restrict__ direct = nullptr)
+                                                                                             u64 *__restrict__ direct = nullptr,
+                                                                                             HistFuse fuse = HistFuse{})
 {
 	constexpr int WC = C::WC, VEC = C::VEC, U = C::U, S = C::STRIPES;
 	constexpr int KD = WC >= 4 ? WC / 4 : 1;           // dwords per key
@@ -108,6 +121,16 @@ __global__ __launch_bounds__(C::BLOCK, (C::OCC * C::BLOCK + 255) / 256) void rsx
 	const u32 tid = threadIdx.x;
 	const u32 lane = tid & 63;
 	const u32 nblk = gridDim.x, blk = blockIdx.x;
+	if constexpr (FUSED) {
+		const u64 stride = (u64)nblk * C::BLOCK, t = (u64)blk * C::BLOCK + tid;
+		const u32x4 z = {0u, 0u, 0u, 0u};
+		for (u64 i = t; i < fuse.n0; i += stride)
+			fuse.z0[i] = z;
+		for (u64 i = t; i < fuse.n1; i += stride)
+			fuse.z1[i] = z;
+		for (u64 i = t; i < fuse.n2; i += stride)
+			fuse.z2[i] = z;
+	}
 	for (u32 i = tid; i < 16384; i += C::BLOCK)
 		sm.ctr[i] = 0;
 	for (u32 i = tid; i < (u32)C::BINS; i += C::BLOCK)

@@ -73,10 +73,6 @@ __device__ __forceinline__ u32 mbcnt64(u64 m)
 // Kernel 1: histogram of all columns + pre-sorted test: rsx_hist.hpp
 // =============================================================================
 
-}  // namespace rsx
-#include "rsx_hist.hpp"
-namespace rsx {
-
 // =============================================================================
 // Kernel 2: column-skip probe + exclusive scan
 // =============================================================================
@@ -98,6 +94,10 @@ struct HybCaps {
 	u32 cap2;            // two levels: the estimate for the largest (digit, digit) bucket is at most this (0: never)
 	u32 min_cols1, min_cols2;   // kept columns needed for either
 };
+
+}  // namespace rsx
+#include "rsx_hist.hpp"
+namespace rsx {
 
 // Exclusive scan of 256 u64 values held in LDS, by ONE wavefront (lanes 0..63 of the caller):
 // 4 bins per lane, lane totals combined with a Hillis-Steele pass through LDS.
@@ -210,51 +210,125 @@ __global__ __launch_bounds__(256) void rsx_plan_kernel(const KT *__restrict__ sr
 __device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *unsorted, Plan *plan, Plan *host_plan, u64 n,
                                             HybCaps caps)
 {
-	Plan p;
-	for (u32 i = 0; i < 8; ++i)
-		p.cols[i] = 0;
+	// (no local Plan: an array indexed by a run-time count would live in scratch memory, and a kernel with scratch is
+	// dispatched noticeably more slowly -- this runs at the end of the FUSED histogram kernel of every small sort)
+	u64 colpack = 0;   // 4 bits per kept column, LSB first (radix_sort.hpp:66-69)
 	u32 nc = 0;
 	for (u32 i = 0; i < wc; ++i)
-		if (kept[i])
-			p.cols[nc++] = i;                                  // LSB first, radix_sort.hpp:66-69
-	p.ncols = nc;
-	p.sorted = *unsorted == 0;                                 // radix_sort.hpp:60
-	p.hot = 0;
-	p.vary_lo = p.vary_hi = 0;
+		if (kept[i]) {
+			colpack |= (u64)i << (4 * nc);
+			++nc;
+		}
+	const u32 sorted = *unsorted == 0;                             // radix_sort.hpp:60
+	u32 hot = 0, vary_lo = 0, vary_hi = 0;
 	for (u32 i = 0; i < wc; ++i) {
-		p.hot |= (kept[8 + i] & 1u) << i;
+		hot |= (kept[8 + i] & 1u) << i;
 		const u32 v = (kept[8 + i] >> 8) & 0xFFu;
 		if (i < 4)
-			p.vary_lo |= v << (8 * i);
+			vary_lo |= v << (8 * i);
 		else
-			p.vary_hi |= v << (8 * (i - 4));
+			vary_hi |= v << (8 * (i - 4));
 	}
 	// One MSB pass and leaves (rsx_hybrid.hpp) where the keys spread over the digits of their top kept column(s): decided
 	// here, from the histograms, so that the device-scheduled first pass already takes the right column.
-	p.hyb = 0;
-	p.max1 = nc ? kept[16 + p.cols[nc - 1]] : 0;
-	if (!p.sorted && n < (1ull << 30)) {
-		if (caps.cap1 && nc >= caps.min_cols1 && p.max1 <= caps.cap1) {
-			p.hyb = 1;
+	u32 hyb = 0;
+	const u32 top = nc ? (u32)(colpack >> (4 * (nc - 1))) & 15u : 0u;
+	const u32 max1 = nc ? kept[16 + top] : 0;
+	if (!sorted && n < (1ull << 30)) {
+		if (caps.cap1 && nc >= caps.min_cols1 && max1 <= caps.cap1) {
+			hyb = 1;
 		} else if (caps.cap2 && nc >= caps.min_cols2 && nc >= 2) {
 			// the largest (digit, digit) bucket if the two top columns were independent; rsx_seg_plan_kernel has the last word
-			const u64 est = (u64)p.max1 * kept[16 + p.cols[nc - 2]] / n;
+			const u32 second = (u32)(colpack >> (4 * (nc - 2))) & 15u;
+			const u64 est = (u64)max1 * kept[16 + second] / n;
 			if (est <= caps.cap2 - caps.cap2 / 4)
-				p.hyb = 2;
+				hyb = 2;
 		}
 	}
-	plan->hyb = host_plan->hyb = p.hyb;
-	plan->max1 = host_plan->max1 = p.max1;
-	plan->ncols = host_plan->ncols = p.ncols;
-	plan->sorted = host_plan->sorted = p.sorted;
-	plan->hot = host_plan->hot = p.hot;
-	plan->vary_lo = host_plan->vary_lo = p.vary_lo;
-	plan->vary_hi = host_plan->vary_hi = p.vary_hi;
-	for (u32 i = 0; i < 8; ++i)
-		plan->cols[i] = host_plan->cols[i] = p.cols[i];
+	plan->hyb = host_plan->hyb = hyb;
+	plan->max1 = host_plan->max1 = max1;
+	plan->ncols = host_plan->ncols = nc;
+	plan->sorted = host_plan->sorted = sorted;
+	plan->hot = host_plan->hot = hot;
+	plan->vary_lo = host_plan->vary_lo = vary_lo;
+	plan->vary_hi = host_plan->vary_hi = vary_hi;
+	for (u32 i = 0; i < 8; ++i) {
+		const u32 c = i < nc ? (u32)(colpack >> (4 * i)) & 15u : 0u;
+		plan->cols[i] = c;
+		host_plan->cols[i] = c;
+	}
 	__threadfence_system();
 }
 
+
+// rsx_plan_kernel's work for every column in ONE workgroup of 1024 threads, four columns at a time, thread (g, d) = digit d
+// of column col0 + g; the plan is finished from LDS.  (rsx_plan_kernel, one workgroup per column, ends with "the workgroup
+// that finishes last writes the plan": a device-scope fence per workgroup and a chain of dependent global loads in one
+// thread -- 10 us for four columns; this kernel takes about 4.)
+template <typename KT>
+__global__ __launch_bounds__(1024) void rsx_plan_all_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist, KdfArgs<KT> ka,
+                                                            u32 *__restrict__ kept_out, u32 *__restrict__ hotd,
+                                                            const u32 *unsorted, Plan *plan, Plan *host_plan, HybCaps caps)
+{
+	constexpr int WC = sizeof(KT);
+	__shared__ u64 tot[4][256];
+	__shared__ u64 lsum[4][64];
+	__shared__ u32 s_and[4], s_or[4], s_max[4];
+	__shared__ u32 s_kept[24];     // [col] kept, [8 + col] hot bit | varying bits << 8, [16 + col] largest bin
+	const u32 g = threadIdx.x >> 8, d = threadIdx.x & 255u;
+	if (threadIdx.x < 24)
+		s_kept[threadIdx.x] = 0;
+	const KT key0 = kdf_apply(src[0], ka);                         // radix_sort.hpp:65
+	const u32 uns = *unsorted;
+	__syncthreads();
+	for (u32 col0 = 0; col0 < (u32)WC; col0 += 4) {
+		const u32 col = col0 + g;
+		const bool on = col < (u32)WC;
+		u64 *h = ghist + 256 * (on ? col : 0) + d;
+		const u64 total = on ? *h : 0;
+		if (on && d == ((u32)(key0 >> (8 * col)) & 0xFFu))
+			s_kept[col] = total != n;                              // radix_sort.hpp:67
+		if (on && total >= n / 8 + 1)
+			atomicOr(&s_kept[8 + col], 1u);                        // a hot digit (see Plan::hot)
+		if (d == 0) {
+			s_and[g] = 0xFFu;
+			s_or[g] = 0;
+			s_max[g] = 0;
+		}
+		tot[g][d] = total;
+		__syncthreads();
+		if (on && total) {
+			atomicAnd(&s_and[g], d);
+			atomicOr(&s_or[g], d);
+			atomicMax(&s_max[g], total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)total);
+		}
+		__syncthreads();
+		if (on && d == 0) {
+			atomicOr(&s_kept[8 + col], ((s_and[g] ^ s_or[g]) & 0xFFu) << 8);
+			s_kept[16 + col] = s_max[g];
+		}
+		if (on && hotd && total >= n / 16 + 1) {
+			u32 rank = 0;
+			for (u32 e = 0; e < 256; ++e)
+				rank += (tot[g][e] > total || (tot[g][e] == total && e < d)) ? 1u : 0u;
+			if (rank < 4) {
+				atomicOr(&hotd[col], d << (8 * rank));
+				atomicOr(&hotd[8], 1u << (4 * col + rank));
+			}
+		}
+		__syncthreads();
+		if (d < 64)
+			wave_scan_256(tot[g], lsum[g], d);                         // radix_sort.hpp:74-79
+		__syncthreads();
+		if (on)
+			*h = tot[g][d];
+		__syncthreads();
+	}
+	if (threadIdx.x < 24)
+		kept_out[threadIdx.x] = s_kept[threadIdx.x];
+	if (threadIdx.x == 0)
+		plan_finish((const u32 *)s_kept, WC, &uns, plan, host_plan, n, caps);
+}
 
 // =============================================================================
 // Kernel 3: one stable scatter pass (onesweep)

@@ -4,11 +4,12 @@ The reference is single-threaded; its README suggests exactly this hybrid for
 parallelism ("one MSB pass then LSB sort the sub-results", README.md:647-650).
 SURVEY.md section 8e is the contract implemented here, one process per GPU:
 
-  1. every rank runs ONE stable scatter pass by the top KDF byte of its shard
-     (rsx_msd_split_device) and gets the 256 counts of that byte;
-  2. the counts of all ranks are all-gathered (G x 256 numbers) and every rank
-     derives the same splitters -- contiguous top-digit ranges holding ~n/G keys
-     each -- and the whole G x G count matrix (no second count exchange);
+  1. every rank counts ALL byte columns of its shard in one read (rsx_histogram_device; the counts stay on the
+     device) and the counts of all ranks are all-gathered once (G x key bytes x 256 numbers): every rank then knows
+     which byte to split by -- the highest one that varies over all ranks -- without a trial pass;
+  2. every rank runs ONE stable scatter pass by that byte (rsx_msd_split_async: nothing is counted again, nothing
+     waits for the host) and derives, from the same gathered counts, the same splitters -- contiguous digit ranges
+     holding ~n/G keys each -- and the whole G x G count matrix (no second count exchange);
   3. a destination's keys are a contiguous range of the split shard, so the
      buckets go out as they lie (RCCL all-to-all-v over xGMI as grouped
      send/recv; each directed pair of GPUs has its own link) -- in CHUNKS: a
@@ -89,6 +90,16 @@ def heavy_digits(global_hist, world, column):
     return [int(d) for d in np.nonzero(h.astype(np.float64) > HEAVY_FACTOR * total / world)[0]]
 
 
+def heavy_bins(share, world, bytes_left):
+    """Indices of the bins (global counts `share`) that hold more than HEAVY_FACTOR fair shares, while there is a lower byte to
+    refine them by.  split_plan asks this once per refinement level."""
+    share = np.asarray(share, dtype=np.float64)
+    total = float(share.sum())
+    if bytes_left <= 0 or world < 2 or total == 0:
+        return []
+    return [int(i) for i in np.nonzero(share > HEAVY_FACTOR * total / world)[0]]
+
+
 class HipEngine:
     """Device steps of the distributed sort through librsx.so (the product path)."""
 
@@ -99,12 +110,30 @@ class HipEngine:
         self.order = order
         self.kb = DTYPE_SIZE[dtype]
 
+        self.split_passes = 0      # stable passes over a whole shard or a run of it (tests count them)
+
     def msd_split(self, shard, out, column=-1):
         """out = shard in stable order of KDF byte `column` (-1: the top one), enqueued; returns the byte's 256 counts (host)."""
         hist = np.zeros(256, dtype=np.uint64)
         check(lib().rsx_msd_split_device(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order, column,
                                          hist.ctypes.data, _stream_ptr()))
+        self.split_passes += 1
         return hist
+
+    def histogram(self, shard):
+        """Counts of every KDF byte column of the shard: an int64 tensor [key bytes * 256] on the shard's device, only
+        enqueued (rsx_histogram_device; column c's 256 counts are [256 c, 256 c + 256))."""
+        torch = self.torch
+        h = torch.empty(self.kb * 256 + 1, dtype=torch.int64, device=shard.device)     # (+ the pre-sorted flag's word)
+        check(lib().rsx_histogram_device(shard.data_ptr(), shard.numel(), self.dtype, self.order, h.data_ptr(),
+                                         h[self.kb * 256:].data_ptr(), _stream_ptr()))
+        return h[:self.kb * 256]
+
+    def msd_split_known(self, shard, out, column, hist_all):
+        """msd_split for a caller that holds the shard's counts (histogram()): no second count, no host synchronisation."""
+        check(lib().rsx_msd_split_async(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order, column,
+                                        hist_all.data_ptr(), _stream_ptr()))
+        self.split_passes += 1
 
     def local_sort(self, keys, aux):
         res, info = radix_sort(keys, aux, dtype=self.dtype, order=self.order)
@@ -186,51 +215,65 @@ def choose_chunks(global_hist, lut, world, chunks):
 def split_plan(shard, part, engine, group, world, tmp=None):
     """Steps 1-2 of the distributed sort: split the shard into BINS in key order and gather every rank's bin counts.
 
-    A bin is a digit of the split byte -- the highest byte that varies over all ranks -- or, for a digit that holds more
-    than HEAVY_FACTOR fair shares of all the keys (a dominant top byte cannot be divided among ranks as a whole), one of
-    the 256 (digit, next lower byte) pairs: such a digit's run of `part` gets a second stable pass by the next byte.
-    Returns (counts[world, bins] uint64, column, heavy): `part` holds the shard ordered by bin, every rank has the same
-    bins in the same order.  `tmp`: a scratch tensor for the second pass (allocated when absent).
+    A bin is a digit of the split byte -- the highest byte that varies over all ranks -- or, for a bin that holds more
+    than HEAVY_FACTOR fair shares of all the keys (a dominant digit cannot be divided among ranks as a whole), the 256
+    bins of its keys' next lower byte, and so on down the bytes while a bin stays too heavy: such a bin's run of `part`
+    gets another stable pass by the next byte.
+    Returns (counts[world, bins] uint64, column, heavy, levels): `part` holds the shard ordered by bin, every rank has the
+    same bins in the same order; `heavy` = the digits of the split byte that were refined, `levels` = how many bytes
+    deep the refinement went.  `tmp`: a scratch tensor for the refinement passes (allocated when absent).
     """
     import torch
     import torch.distributed as dist
 
     def gather(local):
-        mine = torch.from_numpy(np.ascontiguousarray(local).astype(np.int64)).to(shard.device)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine, group=group)
+        """all-gather one int64 tensor per rank (it stays where it is until the single copy to the host)"""
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local, group=group)
         return torch.stack(gathered).cpu().numpy().astype(np.uint64)
 
-    # one stable pass by the top KDF byte and its counts.  A byte that is constant over ALL ranks would send every key to
-    # one rank: split by the next byte down instead (every rank sees the same gathered counts and decides the same).
-    column = engine.kb - 1
-    while True:
-        local = engine.msd_split(shard, part, column)
-        hists = gather(local)
-        if column == 0 or np.count_nonzero(hists.sum(axis=0)) > 1:
+    # every byte column's counts in ONE read of the shard, one all-gather: the byte to split by is the highest one that
+    # varies over ALL ranks (a byte that is constant everywhere would send every key to one rank) -- every rank sees the
+    # same gathered counts and decides the same, without a trial pass per constant byte
+    hall = engine.histogram(shard)
+    every = gather(hall).reshape(world, engine.kb, 256)
+    column = 0
+    for c in range(engine.kb - 1, -1, -1):
+        if np.count_nonzero(every[:, c, :].sum(axis=0)) > 1:
+            column = c
             break
-        column -= 1
-    heavy = heavy_digits(hists.sum(axis=0), world, column)
-    if not heavy:
-        return hists, column, heavy
-    # second pass over the runs of the heavy digits, by the next byte (the run of digit d of `part` is contiguous)
-    first = np.concatenate([[0], np.cumsum(local.astype(np.int64))])
-    sub_local = np.zeros((len(heavy), 256), dtype=np.uint64)
-    for i, d in enumerate(heavy):
-        a, b = int(first[d]), int(first[d + 1])
-        if b > a:
-            run = part[a:b]
-            t = tmp[:b - a] if tmp is not None and tmp.numel() >= b - a else engine.empty(b - a, shard)
-            sub_local[i] = engine.msd_split(run, t, column - 1)
-            run.copy_(t)
-    sub_all = gather(sub_local.reshape(-1)).reshape(world, len(heavy), 256)
-    cols = []
-    for d in range(256):
-        if d in heavy:
-            cols.append(sub_all[:, heavy.index(d), :])
-        else:
-            cols.append(hists[:, d:d + 1])
-    return np.concatenate(cols, axis=1), column, heavy
+    engine.msd_split_known(shard, part, column, hall)
+    hists = every[:, column, :]                     # [world, 256]
+    rank = dist.get_rank(group)
+    heavy = heavy_bins(hists.sum(axis=0), world, column)
+    levels = 0
+    # refinement, level by level: bins that are still too heavy are split by the next lower byte (their runs of `part`
+    # are contiguous); one all-gather of the sub-counts per level
+    while column - levels > 0:
+        too = heavy_bins(hists.sum(axis=0), world, column - levels)
+        if not too:
+            break
+        levels += 1
+        local = hists[rank].astype(np.int64)
+        first = np.concatenate([[0], np.cumsum(local)])
+        sub_local = np.zeros((len(too), 256), dtype=np.int64)
+        for i, b in enumerate(too):
+            a, e = int(first[b]), int(first[b + 1])
+            if e > a:
+                run = part[a:e]
+                t = tmp[:e - a] if tmp is not None and tmp.numel() >= e - a else engine.empty(e - a, shard)
+                sub_local[i] = engine.msd_split(run, t, column - levels).astype(np.int64)
+                run.copy_(t)
+        sub_all = gather(torch.from_numpy(sub_local.reshape(-1)).to(shard.device)).reshape(world, len(too), 256)
+        cols, k = [], 0
+        for b in range(hists.shape[1]):
+            if k < len(too) and too[k] == b:
+                cols.append(sub_all[:, k, :])
+                k += 1
+            else:
+                cols.append(hists[:, b:b + 1])
+        hists = np.concatenate(cols, axis=1)
+    return hists, column, heavy, levels
 
 
 def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None, force_exchange=False, chunks=None):
@@ -261,7 +304,7 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # matrix on every rank, no second count exchange.  The receive buffer is sized from the counts, never from n / G:
     # preallocated scratch is used when it is large enough and replaced when it is not.
     part = scratch["part"][:n] if scratch else engine.empty(n, shard)
-    hists, column, heavy = split_plan(shard, part, engine, group, world, tmp=scratch.get("aux") if scratch else None)
+    hists, column, heavy, levels = split_plan(shard, part, engine, group, world, tmp=scratch.get("aux") if scratch else None)
     t_planned = time.perf_counter()     # (includes the split pass's one synchronisation and the gather of the counts)
     local_hist = hists[rank]
     lut = choose_splitters(hists.sum(axis=0), world)
@@ -292,8 +335,9 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
         if n_recv > 1:
             engine.sort_inplace_async(recv, aux)
         return recv, {"sent": int(send_counts.sum() - send_counts[rank]), "received": n_recv, "local_info": None, "lut": lut,
-                      "split_column": column, "heavy_digits": heavy, "chunks": 1, "send_counts": send_counts,
-                      "recv_counts": recv_counts}
+                      "split_column": column, "heavy_digits": heavy, "refine_levels": levels, "chunks": 1,
+                      "send_counts": send_counts, "recv_counts": recv_counts,
+                      "imbalance": float(matrix.sum(axis=0).max()) * world / max(float(matrix.sum()), 1.0)}
     chunk_of = choose_chunks(hists.sum(axis=0), lut, world, nchunks)
     first = np.concatenate([[0], np.cumsum(local_hist.astype(np.int64))])     # offset of a bin's run in `part`
     es = shard.element_size()
@@ -349,5 +393,7 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     t_submitted = time.perf_counter()
     return recv, {"host_ms_split_and_counts": (t_planned - t_enter) * 1e3, "host_ms_submit_exchange_and_sorts": (t_submitted - t_planned) * 1e3,
                   "sent": sent, "received": n_recv, "local_info": None, "lut": lut, "split_column": column,
-                  "heavy_digits": heavy, "chunks": nchunks, "overlap_stream": side is not None, "send_counts": send_counts,
-                  "recv_counts": recv_counts}
+                  "heavy_digits": heavy, "refine_levels": levels, "chunks": nchunks, "overlap_stream": side is not None,
+                  "send_counts": send_counts, "recv_counts": recv_counts,
+                  # the largest rank's share of the keys over the fair share (1.0 = balanced): what is left of the skew
+                  "imbalance": float(matrix.sum(axis=0).max()) * world / max(float(matrix.sum()), 1.0)}

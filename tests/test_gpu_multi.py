@@ -396,6 +396,7 @@ def test_skewed_exchange_over_rccl_in_a_one_rank_group():
                                          "a = ol.splitmix_fill(777777, dt, 31); a[::2] = (a[::2] & a.dtype.type((1 << (8 * a.itemsize - 8)) - 1)) "
                                          "| (a.dtype.type(0x42) << a.dtype.type(8 * a.itemsize - 8))")
     script = script.replace("multi.HEAVY_FACTOR", "multi.HEAVY_FACTOR")
-    script = "import radix_sorting_amd.multi as _m\n_m.heavy_digits = lambda h, world, column: ([0x42] if column > 0 else [])\n" + script
+    script = ("import radix_sorting_amd.multi as _m\n"
+              "_m.heavy_bins = lambda share, world, left: ([0x42] if left > 0 and len(share) == 256 else [])\n") + script
     out = subprocess.run([sys.executable, "-c", script, root], capture_output=True, text=True, timeout=600, env=_one_rank_env())
     assert out.returncode == 0 and "self-exchange OK" in out.stdout, out.stdout + out.stderr

@@ -26,6 +26,7 @@ class OracleEngine:
     def __init__(self, dtype, order=0):
         self.dtype, self.order = dtype, order
         self.kb = ol.DTYPE_SIZE[dtype]
+        self.split_passes = 0
 
     def _bits(self, t):
         return t.numpy().view(ol.NP_BITS[self.dtype])
@@ -36,7 +37,20 @@ class OracleEngine:
         column = self.kb - 1 if column < 0 else column
         top = ((k >> ol.NP_BITS[self.dtype](8 * column)) & ol.NP_BITS[self.dtype](0xFF)).astype(np.int64)
         out.numpy().view(bits.dtype)[:bits.size] = bits[np.argsort(top, kind="stable")]
+        self.split_passes += 1
         return np.bincount(top, minlength=256).astype(np.uint64)
+
+    def histogram(self, shard):
+        k = ol.kdf_keys(self._bits(shard), self.dtype, self.order)
+        h = np.zeros(self.kb * 256, dtype=np.int64)
+        for c in range(self.kb):
+            d = ((k >> ol.NP_BITS[self.dtype](8 * c)) & ol.NP_BITS[self.dtype](0xFF)).astype(np.int64)
+            h[256 * c:256 * c + 256] = np.bincount(d, minlength=256)
+        return torch.from_numpy(h)
+
+    def msd_split_known(self, shard, out, column, hist_all):
+        counts = self.msd_split(shard, out, column)
+        assert np.array_equal(counts.astype(np.int64), hist_all.numpy()[256 * column:256 * column + 256])
 
     def local_sort(self, keys, aux):
         res, in_aux, info = ol.oracle_sort(self._bits(keys), self.dtype, self.order)
@@ -73,7 +87,21 @@ def _skew(whole, dtype, skew):
     return out
 
 
-def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chunks=None, skew=0):
+def _skew2(whole, dtype, skew):
+    """`skew` percent of the keys get the top TWO KDF bytes 0x42, 0x17: a dominant (digit, next byte) pair, which one
+    level of refinement cannot divide."""
+    if not skew:
+        return whole
+    bits = 8 * ol.DTYPE_SIZE[dtype]
+    out = whole.copy()
+    sel = (np.arange(out.size) % 100) < skew
+    top = ol.NP_BITS[dtype](0x4217) << ol.NP_BITS[dtype](bits - 16)
+    low = ol.NP_BITS[dtype]((1 << (bits - 16)) - 1)
+    out[sel] = (out[sel] & low) | top
+    return out
+
+
+def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chunks=None, skew=0, skew2=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -81,14 +109,17 @@ def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chu
         carrier = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[ol.DTYPE_SIZE[dtype]]
         n = n_per_rank[rank]
         first = sum(n_per_rank[:rank])
-        whole = _skew(ol.splitmix_fill(sum(n_per_rank), dtype, seed, mask), dtype, skew)
+        whole = _skew2(_skew(ol.splitmix_fill(sum(n_per_rank), dtype, seed, mask), dtype, skew), dtype, skew2)
         shard = torch.from_numpy(whole[first:first + n].view(carrier).copy())
         scratch = None
         if skew:      # preallocated buffers that are too small for what this rank receives must be replaced, not trusted
             scratch = {"part": torch.empty(n, dtype=shard.dtype), "recv": torch.empty(n // 2, dtype=shard.dtype),
                        "aux": torch.empty(n // 2, dtype=shard.dtype)}
-        res, stats = multi.distributed_sort(shard, OracleEngine(dtype, order), chunks=chunks, scratch=scratch)
+        engine = OracleEngine(dtype, order)
+        res, stats = multi.distributed_sort(shard, engine, chunks=chunks, scratch=scratch)
         np.save(os.path.join(outdir, "out%d.npy" % rank), res.numpy().view(ol.NP_BITS[dtype]).copy())
+        np.save(os.path.join(outdir, "passes%d.npy" % rank), np.asarray([engine.split_passes, stats.get("refine_levels", 0),
+                                                                         stats.get("split_column", -1)]))
         np.save(os.path.join(outdir, "recv%d.npy" % rank), np.asarray(stats.get("recv_counts", [n])))
         np.save(os.path.join(outdir, "heavy%d.npy" % rank), np.asarray(stats.get("heavy_digits", []), dtype=np.int64))
     finally:
@@ -138,6 +169,39 @@ def test_distributed_sort_with_a_dominant_top_digit(tmp_path, world, dtype, orde
         assert max(sizes) < 1.35 * sum(sizes) / world           # ... and the ranks are balanced again
     else:
         assert heavy.size == 0                                  # one-byte keys: nothing below to refine by
+
+
+@pytest.mark.parametrize("world,dtype,mask,column", [(2, ol.U32, 0x00FFFFFF, 2), (3, ol.U64, 0x000000FFFFFFFFFF, 4),
+                                                     (2, ol.U64, 0x00000000000000FF, 0)])
+def test_constant_top_bytes_cost_one_split_pass(tmp_path, world, dtype, mask, column):
+    """The byte to split by comes from ONE read of the shard (every column's counts, one all-gather): keys whose top bytes
+    are constant over all ranks are split exactly once, by the highest byte that varies -- no trial pass per constant byte."""
+    n_per_rank = [20000 + 97 * r for r in range(world)]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dtype, 0, n_per_rank, mask, 5, str(tmp_path)), nprocs=world, join=True)
+    whole = ol.splitmix_fill(sum(n_per_rank), dtype, 5, mask)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got, ol.oracle_sort(whole, dtype)[0])
+    for r in range(world):
+        passes, levels, col = np.load(os.path.join(str(tmp_path), "passes%d.npy" % r))
+        assert passes == 1 and levels == 0 and col == column, (r, passes, levels, col)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_dominant_digit_and_byte_pair_is_refined_by_the_third_byte(tmp_path, world):
+    """80 % of the keys share their top TWO bytes: refining the heavy top digit by the next byte leaves one (digit, byte) bin
+    as heavy as before; the refinement goes on by the third byte, and the ranks end up balanced."""
+    dtype = ol.U32
+    n_per_rank = [12000 + 53 * r for r in range(world)]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dtype, 0, n_per_rank, 0xFFFFFFFF, 29, str(tmp_path), None, 0, 80), nprocs=world, join=True)
+    whole = _skew2(ol.splitmix_fill(sum(n_per_rank), dtype, 29, 0xFFFFFFFF), dtype, 80)
+    outs = [np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate(outs), ol.oracle_sort(whole, dtype)[0])
+    _, levels, _ = np.load(os.path.join(str(tmp_path), "passes0.npy"))
+    assert levels == 2
+    sizes = [o.size for o in outs]
+    assert max(sizes) < 1.35 * sum(sizes) / world
 
 
 @pytest.mark.parametrize("chunks", [1, 3, 16])
