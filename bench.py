@@ -334,7 +334,9 @@ def main():
                 "passes": {0: "one scatter pass per kept column, LSB first (radix_sort.hpp:82-90)",
                            1: "one MSB scatter pass, then the other kept columns per bucket in LDS (README.md:647-650)",
                            2: "two MSB scatter passes, then the other kept columns per bucket in LDS (README.md:647-650)",
-                           3: "one MSB scatter pass, then one pass per remaining column inside its buckets"}[how],
+                           3: "one MSB scatter pass, then one pass per remaining column inside its buckets",
+                           4: "two MSB scatter passes (the second into per-bucket slots, no second count), then the other kept "
+                              "columns per bucket in LDS (README.md:647-650)"}[how],
             },
             "roofline": {
                 "kernel": "rsx_scatter2_kernel<u32,NoVal,u32>",
@@ -349,10 +351,11 @@ def main():
                 "histogram_GBps": (prof.hist_bytes / max(prof.hist_ms, 1e-9) / 1e6) if prof.hist_ms > 0 else None,
                 "leaf_ms_per_step": prof.leaf_ms / K,
                 "leaf_GBps": (prof.leaf_bytes / max(prof.leaf_ms, 1e-9) / 1e6) if prof.leaf_ms > 0 else None,
-                # algorithmic bytes per key of the whole sort: 4 (histogram) + 4 passes x 8 = 36 with one pass
-                # per kept column; two MSB passes + leaves: 4 + 4 (per-bucket counts) + 2 x 8 + 8 = 32
-                "sort_algorithmic_bytes_per_key": None if sharded else (36 if how in (0, 3) else 32 if how == 2 else 20),
-                "sort_algorithmic_GBps": None if sharded else total_keys / world * (36 if how in (0, 3) else 32 if how == 2 else 20) / elapsed / 1e9,
+                # algorithmic bytes per key of the whole sort, summed over the kernels that ran: 4 (histogram) +
+                # 4 passes x 8 = 36 with one pass per kept column; two MSB passes + leaves: 4 + 2 x 8 + 8 = 28 (+ 4 when the
+                # second pass needs per-bucket counts first)
+                "sort_algorithmic_bytes_per_key": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes) / total_keys,
+                "sort_algorithmic_GBps": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes) / elapsed / 1e9,
                 "lsd_only_ms_per_step": None if lsd_only is None else lsd_only * 1e3,
                 "lsd_only_Gkeys_per_s": None if lsd_only is None else n / lsd_only / 1e9,
             },

@@ -79,7 +79,9 @@ typedef struct rsx_info {
 	uint32_t hybrid;        /* how the passes were made: 0 one per kept column (:82-90); 1 / 2: one / two passes by the
 	                           highest kept column(s), then the remaining columns per bucket in LDS (README.md:647-650);
 	                           3: one pass by the highest kept column, then one pass per remaining column inside its
-	                           buckets.  The result and the returned buffer are the same whichever it is. */
+	                           buckets; 4: as 2, the second pass written into per-bucket slots of a scratch array without
+	                           counting first (evenly spread keys).  The result and the returned buffer are the same
+	                           whichever it is. */
 } rsx_info;
 
 /* ---- environment ---------------------------------------------------------- */

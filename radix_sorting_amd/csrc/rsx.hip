@@ -99,6 +99,7 @@ struct Env {
 	bool no_narrow_keys = false;     // RSX_NO_NARROW_KEYS (set)
 	bool no_host_small = false;      // RSX_NO_HOST_SMALL (set)
 	bool no_fused_hist = false;      // RSX_NO_FUSED_HIST=1
+	bool no_slack = false;           // RSX_NO_SLACK=1
 	void load()
 	{
 		auto is_set = [](const char *name) { return getenv(name) != nullptr; };
@@ -121,6 +122,7 @@ struct Env {
 		no_narrow_keys = is_set("RSX_NO_NARROW_KEYS");
 		no_host_small = is_set("RSX_NO_HOST_SMALL");
 		no_fused_hist = is_one("RSX_NO_FUSED_HIST");
+		no_slack = is_one("RSX_NO_SLACK");
 	}
 };
 Env g_env;
@@ -195,7 +197,9 @@ struct Ctx {
 	DevBuf ckeys;       // rank sorts: the keys' varying bits packed together (RSX_COMPACT_BITS)
 	DevBuf joint;       // 2-byte keys: [65536 u32 counts][65537 u64 offsets] of the 16-bit digit (rsx_joint16_kernel)
 	DevBuf seg;         // two-level sorts (rsx_hybrid.hpp): [SegCtl][per-bucket digit counts][status regions][leaf segments][tiles]
-	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0;
+	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0, seg_btile_off = 0;
+	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
+	u32 slack_cap = 0;
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
 	hipEvent_t seg_ev = nullptr;
 	Plan *host_plan = nullptr;   // pinned, written by the kernels themselves (dev_host_plan: its device address)
@@ -274,6 +278,7 @@ struct Ctx {
 		ckeys.release();
 		joint.release();
 		seg.release();
+		slack.release();
 		if (host_segctl)
 			(void)hipHostFree(host_segctl);
 		host_segctl = dev_host_segctl = nullptr;
@@ -841,18 +846,22 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	const LeafSeg *segtab = level == HYB_TWO_LEVEL ? (const LeafSeg *)((char *)c.seg.p + c.seg_segtab_off) : nullptr;
 	const SegCtl *ctl = (const SegCtl *)c.seg.p;
 	ProfScope prof(2, (u64)n * 2 * sizeof(KT), c.stream);
+	const KT *slots = level == HYB_TWO_LEVEL ? (const KT *)c.slack.p : nullptr;   // (only leaves of a slack attempt name slots)
 	if (shapes & 1u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(grid_s), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
-		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP);
+		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
+		                   c.slack_cap);
 	if (shapes & 2u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, B>), dim3(grid_b), dim3(B::BLOCK), 0, c.stream, src, aux, (u64)n,
-		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)B::CAP);
+		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)B::CAP, slots,
+		                   c.slack_cap);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
 
 // a pass inside the level-1 buckets (SEG instantiation of the pass kernel): j < 0 the one by the level-2 column (runs in
 // SEG_MODE_LEAVES), j >= 0 LSB-first pass j (runs in SEG_MODE_LSD).  aux -> src, src -> aux for odd j.
+// j == -2: the slack attempt (aux -> the slots of c.slack, no counts needed).
 template <typename KT>
 int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, int j)
 {
@@ -865,9 +874,13 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
 	sa.tiles = (const SegTile *)((char *)c.seg.p + c.seg_tiles_off);
 	sa.slots = (u32)sizeof(KT) - 1;
+	sa.slack_cap = j == -2 ? c.slack_cap : 0u;
+	sa.overflow = &((SegCtl *)c.seg.p)->overflow;
+	if (j == -2)
+		src = (KT *)c.slack.p;
 	ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
 	const bool plain = ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0;
-	const u32 flags = j < 0 ? (u32)SCATTER_SEG_LEAVES : 0u;
+	const u32 flags = j == -2 ? (u32)SCATTER_SEG_SLACK : j < 0 ? (u32)SCATTER_SEG_LEAVES : 0u;
 	const u32 pi = j < 0 ? 0u : (u32)j;
 #define RSX_LAUNCH_SEG(DIGV)                                                                                               \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, KT, true>), dim3((unsigned)rows),       \
@@ -896,15 +909,54 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 	c.seg_status_off = c.seg_hist_off + hist_bytes;
 	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
 	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
-	RSX_TRY(c.seg.ensure(c.seg_tiles_off + rows * sizeof(SegTile)));
-	// control block, digit counts and the status words of the first segmented pass, zeroed together
-	HIP_TRY(hipMemsetAsync(c.seg.p, 0, c.seg_status_off + st_bytes, c.stream));
+	c.seg_btile_off = c.seg_tiles_off + rows * sizeof(SegTile);
+	RSX_TRY(c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32)));
 	SegCtl *ctl = (SegCtl *)c.seg.p;
 	u32 *seghist = (u32 *)((char *)c.seg.p + c.seg_hist_off);
 	SegTile *tiles = (SegTile *)((char *)c.seg.p + c.seg_tiles_off);
 	LeafSeg *segtab = (LeafSeg *)((char *)c.seg.p + c.seg_segtab_off);
+	u32 *btile = (u32 *)((char *)c.seg.p + c.seg_btile_off);
+	KT *final = (plan.ncols & 1) ? aux : src;
+	if (!c.seg_ev)
+		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
+	// control block, digit counts and the status words of the first segmented pass, zeroed together
+	HIP_TRY(hipMemsetAsync(c.seg.p, 0, c.seg_status_off + st_bytes, c.stream));
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
-	                   (u32)C2::TILE, tiles, ctl);
+	                   (u32)C2::TILE, tiles, ctl, btile);
+	HIP_TRY(hipGetLastError());
+	// The slack attempt: evenly spread keys need no counts for the second pass.  Every (digit, digit) bucket gets a slot of
+	// 1.25 times its expected size in a scratch array and the pass writes each key where the look-back chain puts it inside
+	// its bucket's slot; the bucket sizes are then read off the chain, and the leaves gather from the slots into the dense
+	// result.  One read of the keys less than the counted path below (rsx_seg_hist1_kernel: 0.25 of 2.1 ms at 2^28 keys).
+	// A slot that overflows (keys clustered after all) only costs the attempt: pass 1's output in `aux` is untouched.
+	c.slack_cap = 0;
+	if (!env().no_slack && n >= ((size_t)1 << 26)) {
+		const u32 mean = (u32)(n >> 16);
+		const u32 cap = ((mean + mean / 4 + 255) / 256) * 256;
+		if (cap <= (u32)LeafShapes<KT>::Big::CAP && c.slack.ensure(((size_t)65536 * cap + C2::TILE) * sizeof(KT)) == RSX_OK) {
+			c.slack_cap = cap;
+			RSX_TRY(launch_seg_pass<KT>(c, aux, src, n, ka, -2));
+			hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
+			                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
+			                   (const Plan *)c.plan(), ctl, segtab, cap, c.dev_host_segctl);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
+			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, cap <= (u32)LeafShapes<KT>::Small::CAP ? 1u : 2u));
+			HIP_TRY(hipEventSynchronize(c.seg_ev));
+			if (c.host_segctl->mode == SEG_MODE_LEAVES) {
+				*result = final;
+				*how = 4u;
+				return RSX_OK;
+			}
+			// a slot overflowed: the counted path, from `aux` again
+			c.slack_cap = 0;
+			HIP_TRY(hipMemsetAsync(c.seg.p, 0, c.seg_status_off + st_bytes, c.stream));
+			hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n,
+			                   (const Plan *)c.plan(), (u32)C2::TILE, tiles, ctl, btile);
+		} else {
+			(void)hipGetLastError();
+		}
+	}
 	{
 		ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
 		hipLaunchKernelGGL((rsx_seg_hist1_kernel<KT>), dim3(512), dim3(1024), 0, c.stream, (const KT *)aux, (const SegTile *)tiles,
@@ -913,8 +965,6 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 	hipLaunchKernelGGL((rsx_seg_plan_kernel<KT>), dim3(256), dim3(256), 0, c.stream, seghist, (const u64 *)c.ghist(), (u64)n,
 	                   (const Plan *)c.plan(), ctl, segtab, (u32)LeafShapes<KT>::Big::CAP, c.dev_host_segctl, 0u);
 	HIP_TRY(hipGetLastError());
-	if (!c.seg_ev)
-		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	// the pass by the level-2 column and the small leaves are enqueued before the host knows whether the (digit, digit)
 	// buckets fit leaves: they do nothing if not
@@ -922,7 +972,6 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, 1u));
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	const SegCtl hc = *c.host_segctl;
-	KT *final = (plan.ncols & 1) ? aux : src;
 	if (hc.mode == SEG_MODE_LEAVES) {
 		if (hc.maxleaf > (u32)LeafShapes<KT>::Small::CAP)   // (rare: the leaves need the large shape)
 			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, 2u));

@@ -27,7 +27,7 @@
 namespace rsx {
 
 enum : u32 { HYB_NONE = 0, HYB_ONE_LEVEL = 1, HYB_TWO_LEVEL = 2 };
-enum : u32 { SEG_MODE_NONE = 0, SEG_MODE_LEAVES = 1, SEG_MODE_LSD = 2 };
+enum : u32 { SEG_MODE_NONE = 0, SEG_MODE_LEAVES = 1, SEG_MODE_LSD = 2, SEG_MODE_RETRY = 3 };
 
 // One tile of a segmented pass: [beg, beg + cnt) lies inside level-1 bucket `bucket`; `first` is the index of the bucket's
 // first tile (where the look-back chain of the bucket ends).
@@ -42,13 +42,15 @@ struct SegCtl {
 	u32 maxleaf;    // the largest (digit, digit) bucket
 	u32 done;       // blocks of rsx_seg_plan_kernel that are through
 	u32 nleaf;      // leaves in segtab (rsx_seg_plan_kernel)
-	u32 pad[11];
+	u32 overflow;   // slack attempt: a slot was too small (rsx_scatter2_kernel, SCATTER_SEG_SLACK)
+	u32 pad[10];
 };
 
 // A leaf's keys: [beg, beg + cnt), sorted by the `ncols` lowest kept columns.  Level 2: a (digit, digit) bucket (ncols = all
 // columns below the level-2 one) or a run of small neighbouring ones of the same level-1 bucket (one column more).
 struct LeafSeg {
-	u32 beg, cnt, ncols, pad;
+	u32 beg, cnt, ncols;
+	u32 slot;   // 0: the keys lie at `beg` of the input buffer; s + 1: in slot s of the scratch array (slack attempt)
 };
 
 constexpr u32 LEAF_MERGE_CAP = 4096;   // neighbouring (digit, digit) buckets are sorted together while they hold no more keys than this
@@ -82,7 +84,8 @@ __device__ __forceinline__ u32 block_scan_256(u32 v, u32 *s_w, u32 &tot)
 // off1 = the exclusive offsets of the level-1 column (ghist + 256 * c1, after rsx_plan_kernel).  Every workgroup scans the 256
 // bucket sizes (cheap) and writes its share of the tiles.
 __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restrict__ ghist, u64 n, const Plan *__restrict__ plan,
-                                                            u32 tile, SegTile *__restrict__ tiles, SegCtl *__restrict__ ctl)
+                                                            u32 tile, SegTile *__restrict__ tiles, SegCtl *__restrict__ ctl,
+                                                            u32 *__restrict__ btile)   // [257]: bucket k's tiles are [btile[k], btile[k + 1])
 {
 	if (plan->hyb != HYB_TWO_LEVEL)
 		return;
@@ -98,9 +101,13 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
 	s_tb[d] = tb;
 	if (d == 0) {
 		s_tb[256] = total;
-		if (blockIdx.x == 0)
+		if (blockIdx.x == 0) {
 			ctl->ntiles = total;
+			btile[256] = total;
+		}
 	}
+	if (blockIdx.x == 0)
+		btile[d] = tb;
 	__syncthreads();
 	for (u32 t = blockIdx.x * 256 + d; t < total; t += gridDim.x * 256) {
 		u32 lo = 0, hi = 256;   // the bucket k with s_tb[k] <= t < s_tb[k + 1] (empty buckets have s_tb[k] == s_tb[k + 1])
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(256) void rsx_seg_plan_kernel(u32 *__restrict__ seg
 				ls.beg = (u32)(bbeg + s_start[d]);
 				ls.cnt = s_start[d + 1] - s_start[d];
 				ls.ncols = nslots - 1 + (s_first[d + 1] - s_first[d] > 1 ? 1u : 0u);
-				ls.pad = 0;
+				ls.slot = 0;
 				segtab[s_slot + d] = ls;
 				mine = ls.cnt;
 			}
@@ -359,6 +366,68 @@ __global__ __launch_bounds__(256) void rsx_seg_plan_kernel(u32 *__restrict__ seg
 			host_ctl->ntiles = ctl->ntiles;
 			host_ctl->maxleaf = mx;
 			host_ctl->nleaf = ctl->nleaf;
+			host_ctl->mode = mode;
+			__threadfence_system();
+		}
+	}
+}
+
+// ---- slack attempt: the (digit, digit) counts read off the finished chain ---------------------------------------------
+// After a SCATTER_SEG_SLACK pass the inclusive prefix of a bucket's LAST tile is the bucket's count of every level-2 digit.
+// One workgroup per level-1 bucket: the leaves (one per non-empty (digit, digit) bucket, read from its slot, written to its
+// place in the dense output) and the verdict: SEG_MODE_LEAVES if no slot overflowed, else SEG_MODE_RETRY (the host runs the
+// counted path from the untouched pass-1 output).
+template <typename ST>
+__global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__restrict__ status, const u32 *__restrict__ btile,
+                                                                 const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
+                                                                 SegCtl *__restrict__ ctl, LeafSeg *__restrict__ segtab,
+                                                                 u32 slack_cap, SegCtl *host_ctl)
+{
+	if (plan->hyb != HYB_TWO_LEVEL)
+		return;
+	typedef StatusBits<ST> SB_;
+	__shared__ u32 s_w[4], s_max, s_slot, s_last;
+	const u32 d = threadIdx.x, b = blockIdx.x;
+	const u64 *off1 = ghist + 256 * plan->cols[plan->ncols - 1];
+	const u32 t0 = btile[b], t1 = btile[b + 1];
+	u32 c = 0;
+	if (t1 > t0)
+		c = (u32)(__hip_atomic_load(status + ((u64)(t1 - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SB_::VALMASK);
+	if (d == 0)
+		s_max = 0;
+	u32 total;
+	const u32 o = block_scan_256(c, s_w, total);
+	u32 nleaf;
+	const u32 idx = block_scan_256(c ? 1u : 0u, s_w, nleaf);
+	if (d == 0)
+		s_slot = atomicAdd(&ctl->nleaf, nleaf);
+	__syncthreads();
+	if (c) {
+		LeafSeg ls;
+		ls.beg = (u32)(off1[b] + o);
+		ls.cnt = c;
+		ls.ncols = plan->ncols - 2;
+		ls.slot = b * 256 + d + 1;
+		segtab[s_slot + idx] = ls;
+		atomicMax(&s_max, c);
+	}
+	__syncthreads();
+	if (d == 0) {
+		atomicMax(&ctl->maxleaf, s_max);
+		__threadfence();
+		s_last = atomicAdd(&ctl->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+	}
+	__syncthreads();
+	if (s_last && d == 0) {
+		__threadfence();
+		const u32 mx = atomicMax(&ctl->maxleaf, 0u);
+		const u32 mode = (mx <= slack_cap && atomicOr(&ctl->overflow, 0u) == 0) ? SEG_MODE_LEAVES : SEG_MODE_RETRY;
+		ctl->mode = mode;
+		if (host_ctl) {
+			host_ctl->ntiles = ctl->ntiles;
+			host_ctl->maxleaf = mx;
+			host_ctl->nleaf = ctl->nleaf;
+			host_ctl->overflow = ctl->overflow;
 			host_ctl->mode = mode;
 			__threadfence_system();
 		}
@@ -392,7 +461,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
                                                                   const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
                                                                   const LeafSeg *__restrict__ segtab,
                                                                   const SegCtl *__restrict__ ctl, KdfArgs<KT> ka, u32 level,
-                                                                  u32 lo, u32 hi)
+                                                                  u32 lo, u32 hi, const KT *__restrict__ slots = nullptr,
+                                                                  u32 slack_cap = 0)
 {
 	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK;
 	constexpr int CHUNK = 16 / sizeof(KT);
@@ -428,12 +498,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	// when they leave: the element images that reach memory are the caller's, bit for bit), so that a digit is one bit-field
 	// extract; with the KDF's arithmetic per column and phase the leaves were bound by vector instructions, not by the LDS.
 	const KT pad = (KT)~(KT)0;
-	auto bounds = [&](u32 s, u32 &beg, u32 &cnt, u32 &nc) {
+	auto bounds = [&](u32 s, u32 &beg, u32 &cnt, u32 &nc, u32 &slot) {
+		slot = 0;
 		if (level == HYB_TWO_LEVEL) {
 			const LeafSeg ls = segtab[s];
 			beg = ls.beg;
 			cnt = ls.cnt;
 			nc = ls.ncols;
+			slot = ls.slot;
 		} else {
 			const u64 b = off1[s], e = s == 255 ? n : off1[s + 1];
 			beg = (u32)b;
@@ -450,11 +522,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		const u32 g = (mine + 64 * G - 1) / (64 * G);
 		return g < ng ? g : ng;
 	};
-	auto request = [&](auto &dst, u32 beg, u32 cnt) {
+	auto request = [&](auto &dst, u32 beg, u32 cnt, u32 slot) {
 		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);
 		const u32 ng = wave_groups(cnt, ngall);
 		const u32 wo = opaque(wid * (ngall * 64 * G) + lane);
-		const KT *p = in + beg;
+		const KT *p = slot ? slots + (u64)(slot - 1) * slack_cap : in + beg;
 #pragma unroll
 		for (int g = 0; g < KPT / G; ++g) {
 			if (g < (int)ng) {
@@ -469,13 +541,13 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	u32 s = blockIdx.x;
 	if (s >= nseg)
 		return;
-	u32 nbeg, ncnt, nnc;
-	bounds(s, nbeg, ncnt, nnc);
+	u32 nbeg, ncnt, nnc, nslot;
+	bounds(s, nbeg, ncnt, nnc, nslot);
 	KT nxt[C::PREFETCH ? KPT : 1];
 	if constexpr (C::PREFETCH)
-		request(nxt, nbeg, ncnt);
+		request(nxt, nbeg, ncnt, nslot);
 	for (;;) {
-		const u32 beg = nbeg, cnt = ncnt, nrem = nnc;
+		const u32 beg = nbeg, cnt = ncnt, nrem = nnc, slot = nslot;
 		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);   // groups of rounds in a wave's slice
 		const u32 per = ngall * (64 * G);
 		const u32 ng = wave_groups(cnt, ngall);                  // ... and those this wave has keys in (wave-uniform)
@@ -486,7 +558,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 			for (int r = 0; r < KPT; ++r)
 				keep[r] = nxt[r];
 		} else {
-			request(keep, beg, cnt);
+			request(keep, beg, cnt, slot);
 		}
 #pragma unroll
 		for (int r = 0; r < KPT; ++r)
@@ -494,9 +566,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		s += gridDim.x;
 		const bool more = s < nseg;
 		if (more) {
-			bounds(s, nbeg, ncnt, nnc);
+			bounds(s, nbeg, ncnt, nnc, nslot);
 			if constexpr (C::PREFETCH)
-				request(nxt, nbeg, ncnt);
+				request(nxt, nbeg, ncnt, nslot);
 		}
 		for (u32 c = 0; c < nrem; ++c) {
 			const u32 shift = 8 * ((colpack >> (4 * c)) & 15u);

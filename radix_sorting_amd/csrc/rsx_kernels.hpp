@@ -357,7 +357,8 @@ enum : u32 {
 	SCATTER_DBG_NOLOADB = 256, // probe only: phase B fabricates keys instead of re-reading them
 	SCATTER_DBG_XCD_RUNS = 512, // probe only: tiles by workgroup index, runs of 2^(bits 16-19) consecutive tiles per XCD (no ticket)
 	SCATTER_XCD_RUN_SHIFT = 16,
-	SCATTER_SEG_LEAVES = 1024   // segmented pass (rsx_hybrid.hpp): the one by the level-2 column
+	SCATTER_SEG_LEAVES = 1024,  // segmented pass (rsx_hybrid.hpp): the one by the level-2 column
+	SCATTER_SEG_SLACK = 2048    // ... written into per-bucket slots of a scratch array, without counts (SegArgs::slack_cap)
 };
 
 // Tile shape: NWAVES wavefronts per workgroup, KPT keys per lane => NWAVES*64*KPT keys per tile.

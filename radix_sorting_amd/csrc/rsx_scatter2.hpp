@@ -120,6 +120,11 @@ struct SegArgs {
 	const SegCtl *ctl;
 	const u32 *hist;   // [bucket][slot][256] exclusive offsets inside the bucket
 	u32 slots;         // rows per bucket in `hist` (key bytes - 1)
+	// SCATTER_SEG_SLACK: no counts are known; (digit, digit) bucket b * 256 + d is written into its own slot of slack_cap
+	// keys of the scratch array `kout` points to, at the position the look-back chain alone gives (the keys of earlier tiles
+	// of the bucket with the digit).  A slot that would overflow sets *overflow; the caller then discards the attempt.
+	u32 slack_cap;
+	u32 *overflow;
 };
 
 template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bool TL = false, int DIG = DIG_GENERIC,
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags, u64 *tl,
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
                                                                  u32 oshift = 0, const u32 *__restrict__ hotd = nullptr,
-                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0})
+                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr})
 {
 	constexpr bool NARROW = !std::is_same<KTO, KT>::value;
 	static_assert(!SEG || (!NARROW && C::TPS == 1 && !HOT_), "segmented passes: plain tiles, keys of one type");
@@ -147,7 +152,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		if (dplan->hyb != HYB_TWO_LEVEL)
 			return;
 		const u32 mode = seg.ctl->mode;
-		if (flags & SCATTER_SEG_LEAVES) {   // the pass by the level-2 column, aux -> src; enqueued before the host knows the mode
+		if (flags & SCATTER_SEG_SLACK) {    // the pass by the level-2 column into slots of the scratch array, before anything is decided
+			seg_slot = dplan->ncols - 2;
+		} else if (flags & SCATTER_SEG_LEAVES) {   // the pass by the level-2 column, aux -> src; enqueued before the host knows the mode
 			if (mode != SEG_MODE_LEAVES)
 				return;
 			seg_slot = dplan->ncols - 2;
@@ -532,10 +539,17 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			__hip_atomic_store(my_status, pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		u64 running;
-		if constexpr (SEG)
-			running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;
-		else
+		if constexpr (SEG) {
+			if (flags & SCATTER_SEG_SLACK) {
+				running = ((u64)seg_bucket * 256 + tid) * seg.slack_cap + excl;
+				if (excl + st_cnt > (u64)seg.slack_cap)
+					atomicOr(seg.overflow, 1u);
+			} else {
+				running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;
+			}
+		} else {
 			running = gbase[tid] + excl;
+		}
 #pragma unroll
 		for (int t = 0; t < TPS; ++t) {
 			sm.delta[t][tid] = (ST)(running - tb[t]);   // modulo 2^32 when ST is 32-bit (n < 2^30 then)

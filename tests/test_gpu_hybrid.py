@@ -4,7 +4,8 @@ The hybrid changes HOW the kept columns are gone through, never the result: outp
 list and early exits must equal the CPU restatement of rs_sort_main (radix_sort.hpp:31-93) exactly as on the
 one-pass-per-column path.  `info.hybrid` says which way a sort went (0 one pass per kept column, 1 one MSB pass + leaves,
 2 two MSB passes + leaves, 3 two levels whose (digit, digit) buckets were too large for leaves: LSB-first passes inside
-the level-1 buckets), so that every branch is known to have run.
+the level-1 buckets, 4 two MSB passes + leaves with the second pass written into slack slots without a second count), so
+that every branch is known to have run.
 """
 import numpy as np
 import pytest
@@ -153,3 +154,33 @@ def test_hybrid_off_is_the_same_sort(monkeypatch):
     assert info1.hybrid == 1 and info0.hybrid == 0
     assert info1.result_in_aux == info0.result_in_aux
     assert np.array_equal(got0, got1)
+
+
+@pytest.mark.parametrize("dt", [ol.U32, ol.I32, ol.U64], ids=["u32", "i32", "u64"])
+def test_slack_two_levels_vs_oracle(dt):
+    """From 2^26 keys on the second pass is tried WITHOUT counting first: every (digit, digit) bucket has a slot of 1.25
+    times its expected size in a scratch array, the bucket sizes come off the look-back chain, the leaves gather from the
+    slots (info.hybrid == 4)."""
+    n = (1 << 26) + 4321
+    a = ol.splitmix_fill(n, dt, 17, (1 << (8 * ol.DTYPE_SIZE[dt])) - 1)
+    for order in (ol.ASC, ol.DESC):
+        check(a, dt, order, 4, (dt, order))
+
+
+def test_slack_overflow_falls_back_to_the_counted_pass():
+    """Flat byte histograms (the plan chooses two levels) but one (digit, digit) bucket holds four times its share: its slot
+    overflows, the attempt is discarded and the counted second pass runs from the untouched pass-1 output (hybrid 2); and
+    with the top two bytes equal in every key the counted path finds its buckets too large for leaves as well (hybrid 3)."""
+    n = (1 << 26) + 99
+    a = ol.splitmix_fill(n, ol.U32, 23, 0xFFFFFFFF).view(np.uint32).copy()
+    a[1000:1000 + 3000 * 7:7] = (a[1000:1000 + 3000 * 7:7] & np.uint32(0x0000FFFF)) | np.uint32(0x12340000)
+    check(a, ol.U32, ol.ASC, 2, "one heavy (digit, digit) bucket")
+    b = ol.splitmix_fill(n, ol.U32, 24, 0xFFFFFFFF).view(np.uint32).copy()
+    b = (b & np.uint32(0xFF00FFFF)) | ((b >> np.uint32(8)) & np.uint32(0x00FF0000))
+    check(b, ol.U32, ol.DESC, 3, "top two bytes equal")
+
+
+def test_slack_off_is_the_counted_pass(monkeypatch):
+    a = ol.splitmix_fill((1 << 26) + 5, ol.U32, 31, 0xFFFFFFFF)
+    monkeypatch.setenv("RSX_NO_SLACK", "1")
+    check(a, ol.U32, ol.ASC, 2, "RSX_NO_SLACK=1")
