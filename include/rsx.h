@@ -149,6 +149,20 @@ int rsx_sort_pairs_inplace_async(void *d_keys, void *d_keys_scratch, void *d_val
                                  size_t n, rsx_dtype dtype, size_t payload_bytes, rsx_order order,
                                  void *stream);
 
+/* radix_sort_rank (radix_sort_rank.hpp:97-112) in the same manner: the stable argsort of d_src (untouched) without a
+ * host synchronisation, HIP-graph capturable.  The ranks ALWAYS end in the first half of d_index_buffer (2n entries of
+ * idx_bytes = 4 or 8 bytes): the number of passes is only known on the device, where the passes take their buffers from
+ * the plan so that the last one writes the first half; sorted keys give 0 .. n-1 there (:52,:55-57).  The keys' work
+ * copies live in the (device, stream) workspace: call it once outside a capture so that the workspace has its size.  Keys
+ * travel at full width here (the blocking rsx_sort_rank_device hands on only the bytes still to be sorted by). */
+int rsx_sort_rank_inplace_async(const void *d_src, void *d_index_buffer, size_t n, rsx_dtype dtype,
+                                size_t idx_bytes, rsx_order order, void *stream);
+
+/* RSX_VERIFY=1 also checks one tile of every pass of the *_inplace_async sorts (re-ranked with ballots on the device, as
+ * for the blocking sorts), but those never wait: their mismatches add up on the device.  This waits for `stream`, reports
+ * the count (RSX_EVERIFY if it is not zero) and resets it; the next blocking sort on the stream does the same. */
+int rsx_verify_poll(void *stream, uint64_t *mismatches);
+
 /* rs_sort_main / rs_sort_rank with a caller-supplied Hist (radix_sort.hpp:28-33,
  * radix_sort_rank.hpp:22-23): arms the CALLING THREAD's next blocking sort call
  * (rsx_sort, rsx_sort_device, rsx_sort_rank*, rsx_sort_pairs_device,

@@ -74,6 +74,8 @@ ABI = [
     ("rsx_histogram_device", _I, [_VP, _SZ, _I, _I, _VP, _VP, _VP]),
     ("rsx_msd_split_device", _I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP]),
     ("rsx_msd_split_async", _I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP]),
+    ("rsx_sort_rank_inplace_async", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _VP]),
+    ("rsx_verify_poll", _I, [_VP, C.POINTER(C.c_uint64)]),
     ("rsx_sort_multi", _I, [_VP, _VP, _SZ, _I, _I, _VP, _I, _PVP, _PINFO]),
     ("rsx_profile_begin", _I, []),
     ("rsx_profile_end", _I, [C.POINTER(Profile)]),
@@ -279,6 +281,27 @@ def radix_sort_pairs_inplace_async(keys, keys_scratch, vals, vals_scratch, dtype
     check(lib().rsx_sort_pairs_inplace_async(keys.data_ptr(), keys_scratch.data_ptr(), vals.data_ptr(), vals_scratch.data_ptr(),
                                              keys.numel(), code, vals.element_size(), order, _stream_ptr(stream)))
     return keys, vals
+
+
+def radix_sort_rank_inplace_async(src, index_buffer, dtype=None, order=ASCENDING, stream=None):
+    """rsx_sort_rank_inplace_async: the stable argsort of ``src`` without a host synchronisation; the ranks always end in
+    ``index_buffer[:n]`` (``index_buffer``: 2n int32 / int64 entries).  Returns that view."""
+    _check_dev(src, index_buffer)
+    code = _torch_dtype_code(src) if dtype is None else dtype
+    n = src.numel()
+    if src.element_size() != DTYPE_SIZE[code] or index_buffer.element_size() not in (4, 8) or index_buffer.numel() < 2 * n:
+        raise RsxError("index_buffer must hold 2n 4- or 8-byte entries")
+    check(lib().rsx_sort_rank_inplace_async(src.data_ptr(), index_buffer.data_ptr(), n, code, index_buffer.element_size(), order,
+                                            _stream_ptr(stream)))
+    return index_buffer[:n]
+
+
+def verify_poll(stream=None):
+    """rsx_verify_poll: wait for the stream and return the mismatches RSX_VERIFY=1 found in device-scheduled sorts since
+    the last poll (raises RsxError if there are any)."""
+    bad = C.c_uint64(0)
+    check(lib().rsx_verify_poll(_stream_ptr(stream), C.byref(bad)))
+    return int(bad.value)
 
 
 def radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=None, order=ASCENDING, stream=None):

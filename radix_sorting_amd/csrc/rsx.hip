@@ -100,6 +100,7 @@ struct Env {
 	bool no_host_small = false;      // RSX_NO_HOST_SMALL (set)
 	bool no_fused_hist = false;      // RSX_NO_FUSED_HIST=1
 	bool no_slack = false;           // RSX_NO_SLACK=1
+	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
 	{
 		auto is_set = [](const char *name) { return getenv(name) != nullptr; };
@@ -123,6 +124,12 @@ struct Env {
 		no_host_small = is_set("RSX_NO_HOST_SMALL");
 		no_fused_hist = is_one("RSX_NO_FUSED_HIST");
 		no_slack = is_one("RSX_NO_SLACK");
+		two_level_min_log2 = 27;
+		if (const char *e = getenv("RSX_TWO_LEVEL_MIN_LOG2")) {
+			const int v = atoi(e);
+			if (v >= 22 && v <= 30)
+				two_level_min_log2 = (unsigned)v;
+		}
 	}
 };
 Env g_env;
@@ -198,6 +205,8 @@ struct Ctx {
 	DevBuf joint;       // 2-byte keys: [65536 u32 counts][65537 u64 offsets] of the 16-bit digit (rsx_joint16_kernel)
 	DevBuf seg;         // two-level sorts (rsx_hybrid.hpp): [SegCtl][per-bucket digit counts][status regions][leaf segments][tiles]
 	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0, seg_btile_off = 0;
+	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
+	DevBuf vasync;      // RSX_VERIFY: mismatches found in device-scheduled passes, kept until rsx_verify_poll / the next blocking sort
 	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
 	u32 slack_cap = 0;
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
@@ -279,6 +288,7 @@ struct Ctx {
 		joint.release();
 		seg.release();
 		slack.release();
+		vasync.release();
 		if (host_segctl)
 			(void)hipHostFree(host_segctl);
 		host_segctl = dev_host_segctl = nullptr;
@@ -653,7 +663,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
 	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, (u64 *)nullptr, dplan, pass_index,  \
-	                   oshift, (const u32 *)c.hotd())
+	                   oshift, (const u32 *)c.hotd(), SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr}, c.pass_alt)
 	// quarter tiles are for arrays of a few million keys: never 2^30 of them, and hot digits cost little there -- those
 	// instantiations are left out of the build
 	constexpr bool SMALL_CFG = C2::KPT < Sc2Cfg<KT, VT>::KPT;
@@ -690,6 +700,28 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 #undef RSX_LAUNCH2_ST
 #undef RSX_LAUNCH2
 	HIP_TRY(hipGetLastError());
+	if (verify_mode() && dplan && tiles > 0 && !std::is_same<KTO, void>::value && sizeof(KTO) == sizeof(KT)) {
+		// a device-scheduled pass (the *_inplace_async sorts): the same check, resolved from the device-side plan like the pass
+		// itself; nothing is read back here -- the mismatches add up in a counter of their own until rsx_verify_poll() or the
+		// next blocking sort on this stream looks at it
+		if (!c.vasync.p) {
+			RSX_TRY(c.vasync.ensure(8));
+			HIP_TRY(hipMemsetAsync(c.vasync.p, 0, 8, c.stream));
+		}
+		const u32 vt = (u32)(((u64)(++g_verify_seq) * 2654435761ull) % tiles);
+		const u32 kind = (flags & SCATTER_RANK_ASYNC) ? 2u : 1u;
+#define RSX_VERIFY_ASYNC(ST)                                                                                            \
+		hipLaunchKernelGGL((rsx_verify_tile_kernel<KT, ST>), dim3(1), dim3(64), 0, c.stream, kin, (const void *)kout,         \
+		                   (const void *)vin, (const void *)vout, (u64)n, shift, gbase, (const ST *)st, vt, (u32)C2::TILE, ka,  \
+		                   (u32)sizeof(KTO), oshift, (u32)val_bytes<VT>::value, 0u, (u64 *)c.vasync.p,                        \
+		                   (u32)(env().verify_inject ? 1 : 0), dplan, pass_index, kind, c.pass_alt)
+		if (wide)
+			RSX_VERIFY_ASYNC(u64);
+		else
+			RSX_VERIFY_ASYNC(u32);
+#undef RSX_VERIFY_ASYNC
+		HIP_TRY(hipGetLastError());
+	}
 	if (verify_mode() && !dplan && tiles > 0) {
 		const u32 vt = (u32)(((u64)(++g_verify_seq) * 2654435761ull) % tiles);
 		const void *vi = (flags & SCATTER_GEN_INDEX) ? nullptr : (const void *)vin;
@@ -704,9 +736,17 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 			RSX_VERIFY_TILE(u32);
 #undef RSX_VERIFY_TILE
 		HIP_TRY(hipGetLastError());
-		u64 bad = 0;
+		u64 bad = 0, abad = 0;
 		HIP_TRY(hipMemcpyAsync(&bad, c.verify_bad(), sizeof(bad), hipMemcpyDeviceToHost, c.stream));
+		if (c.vasync.p)
+			HIP_TRY(hipMemcpyAsync(&abad, c.vasync.p, sizeof(abad), hipMemcpyDeviceToHost, c.stream));
 		HIP_TRY(hipStreamSynchronize(c.stream));
+		if (abad) {
+			HIP_TRY(hipMemsetAsync(c.vasync.p, 0, 8, c.stream));
+			return fail(RSX_EVERIFY, "RSX_VERIFY: an earlier device-scheduled sort on this stream (rsx_sort*_inplace_async) had a pass "
+			                         "whose checked tile differs from its ballot-ranked re-computation in %llu places",
+			            (unsigned long long)abad);
+		}
 		if (bad)
 			return fail(RSX_EVERIFY, "RSX_VERIFY: tile %u of a scatter pass (shift %u, %zu keys) differs from its ballot-ranked "
 			                         "re-computation in %llu places: the LDS did not return same-address atomics in lane order",
@@ -823,7 +863,11 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 		if (hybrid_enabled() && n < ((size_t)1 << 30)) {
 			caps.cap1 = (u32)LeafShapes<KT>::Big::CAP;
 			caps.min_cols1 = 3;
-			if (n >= ((size_t)1 << 22)) {
+			// Two levels pay from about 2^27 keys on (tools/size_sweep.py, profiles/r03/size_sweep.txt: 128 Mi keys 1.16 ms
+			// against 1.22 with one pass per column, 256 Mi 1.89 against 2.30; at 64 Mi 0.73 against 0.62 -- a dozen launches
+			// and two host round trips are a fixed cost).  Between the reach of one level (about 7 Mi evenly spread keys)
+			// and that, one pass per kept column.
+			if (n >= ((size_t)1 << env().two_level_min_log2)) {
 				caps.cap2 = (u32)LeafShapes<KT>::Small::CAP;
 				caps.min_cols2 = 4;
 			}
@@ -1451,6 +1495,38 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 	return RSX_OK;
 }
 
+// ---- stable argsort, no host synchronisation: every pass is device-scheduled, the ranks always end in the FIRST half -----------
+// radix_sort_rank.hpp:97-112 for callers that cannot wait (graphs, the multi-GPU chunk pipeline).  The number of passes is only
+// known on the device, so the passes take their buffers from the plan (SCATTER_RANK_ASYNC): the last one writes the first
+// half.  Keys travel at full width (which narrower type a pass could write is a choice of kernel, i.e. the host's).
+template <typename KT, typename IT>
+int sort_rank_inplace_async(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order)
+{
+	if (!c.fast)
+		return fail(RSX_EHIP, "rsx_sort_rank_inplace_async needs the fast scatter kernel (the device self-check failed on this device)");
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	if (n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES) {
+		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, IT, true>), dim3(1), dim3(1024), 0, c.stream, src, (KT *)nullptr, ib, ib + n,
+		                   (u32)n, ka, c.dev_host_plan, true);
+		HIP_TRY(hipGetLastError());
+		return RSX_OK;
+	}
+	RSX_TRY(c.keys[0].ensure(n * sizeof(KT)));
+	RSX_TRY(c.keys[1].ensure(n * sizeof(KT)));
+	const size_t status_total = status_bytes<KT, IT>(n) * sizeof(KT);
+	RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total));
+	c.pass_alt = c.keys[1].p;
+	int rc = RSX_OK;
+	for (u32 i = 0; i < sizeof(KT) && rc == RSX_OK; ++i)   // pass i = the i-th kept column, if there is one
+		rc = scatter_pass<KT, IT>(c, src, (KT *)c.keys[0].p, ib, ib + n, n, 0, c.ghist(), ka, SCATTER_RANK_ASYNC, c.plan(), (int)i, i);
+	c.pass_alt = nullptr;
+	RSX_TRY(rc);
+	// sorted keys: no pass ran, the ranks are 0 .. n-1 (radix_sort_rank.hpp:52,:55-57)
+	hipLaunchKernelGGL((rsx_iota_if_sorted_kernel<IT>), dim3(1024), dim3(256), 0, c.stream, ib, (u64)n, (const Plan *)c.plan());
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
 bool is_device_ptr(const void *p)
 {
 	hipPointerAttribute_t attr;
@@ -1886,6 +1962,52 @@ int rsx_sort_pairs_device(void *d_keys, void *d_keys_aux, void *d_vals, void *d_
 	} else {
 		RSX_DISPATCH_KT(dtype, return (sort_pairs_device<KT, u64>(*c, (KT *)d_keys, (KT *)d_keys_aux, (u64 *)d_vals,
 		                                                         (u64 *)d_vals_aux, n, dtype, order, info)));
+	}
+	return RSX_OK;
+}
+
+int rsx_sort_rank_inplace_async(const void *d_src, void *d_index_buffer, size_t n, rsx_dtype dtype, size_t idx_bytes,
+                                rsx_order order, void *stream)
+{
+	if (!dtype_size(dtype) || (idx_bytes != 4 && idx_bytes != 8) || (n && (!d_src || !d_index_buffer)))
+		return fail(RSX_EINVAL, "rsx_sort_rank_inplace_async: bad argument");
+	if (idx_bytes == 4 && n > (1ull << 32))
+		return fail(RSX_EINVAL, "rsx_sort_rank_inplace_async: n does not fit a 4-byte index");
+	if (n == 0)
+		return RSX_OK;                       // radix_sort_rank.hpp:28-32
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	if (n == 1) {
+		HIP_TRY(hipMemsetAsync(d_index_buffer, 0, idx_bytes, c->stream));
+		return RSX_OK;
+	}
+	if (idx_bytes == 4) {
+		RSX_DISPATCH_KT(dtype, return (sort_rank_inplace_async<KT, u32>(*c, (const KT *)d_src, (u32 *)d_index_buffer, n, dtype, order)));
+	} else {
+		RSX_DISPATCH_KT(dtype, return (sort_rank_inplace_async<KT, u64>(*c, (const KT *)d_src, (u64 *)d_index_buffer, n, dtype, order)));
+	}
+	return RSX_OK;
+}
+
+int rsx_verify_poll(void *stream, uint64_t *mismatches)
+{
+	if (mismatches)
+		*mismatches = 0;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (!c->vasync.p)
+		return RSX_OK;
+	u64 bad = 0;
+	HIP_TRY(hipMemcpy(&bad, c->vasync.p, sizeof(bad), hipMemcpyDeviceToHost));
+	if (mismatches)
+		*mismatches = bad;
+	if (bad) {
+		HIP_TRY(hipMemset(c->vasync.p, 0, 8));
+		return fail(RSX_EVERIFY, "RSX_VERIFY: a device-scheduled sort on this stream had a pass whose checked tile differs from its "
+		                         "ballot-ranked re-computation in %llu places", (unsigned long long)bad);
 	}
 	return RSX_OK;
 }

@@ -358,7 +358,8 @@ enum : u32 {
 	SCATTER_DBG_XCD_RUNS = 512, // probe only: tiles by workgroup index, runs of 2^(bits 16-19) consecutive tiles per XCD (no ticket)
 	SCATTER_XCD_RUN_SHIFT = 16,
 	SCATTER_SEG_LEAVES = 1024,  // segmented pass (rsx_hybrid.hpp): the one by the level-2 column
-	SCATTER_SEG_SLACK = 2048    // ... written into per-bucket slots of a scratch array, without counts (SegArgs::slack_cap)
+	SCATTER_SEG_SLACK = 2048,   // ... written into per-bucket slots of a scratch array, without counts (SegArgs::slack_cap)
+	SCATTER_RANK_ASYNC = 4096   // device-scheduled pass of rsx_sort_rank_inplace_async: buffers, index generation and the key-less last pass follow from the plan
 };
 
 // Tile shape: NWAVES wavefronts per workgroup, KPT keys per lane => NWAVES*64*KPT keys per tile.
@@ -961,10 +962,39 @@ __global__ __launch_bounds__(64) void rsx_verify_tile_kernel(const KT *__restric
                                                              const void *__restrict__ vin, const void *__restrict__ vout, u64 n,
                                                              u32 shift, const u64 *__restrict__ gbase, const ST *__restrict__ status,
                                                              u32 tile, u32 tile_elems, KdfArgs<KT> ka, u32 out_bytes, u32 oshift,
-                                                             u32 val_bytes, u32 skip_keys, u64 *bad, u32 inject = 0)
+                                                             u32 val_bytes, u32 skip_keys, u64 *bad, u32 inject = 0,
+                                                             const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
+                                                             u32 async_kind = 0, const void *__restrict__ kalt = nullptr)
 {
 	// (inject: test hook, XORed into every expected key: the mismatch path end to end)
 	typedef StatusBits<ST> SB_;
+	// A device-scheduled pass (async_kind 1: rsx_sort[_pairs]_inplace_async, 2: rsx_sort_rank_inplace_async): column and
+	// buffers follow from the device-side plan exactly as in rsx_scatter2_kernel; a pass that did not run is not checked.
+	if (dplan) {
+		if (dplan->sorted || pass_index >= dplan->ncols || dplan->hyb)
+			return;
+		const u32 col = dplan->cols[pass_index];
+		shift = 8 * col;
+		gbase += 256 * col;
+		if (async_kind == 2) {
+			const u32 P = dplan->ncols, i = pass_index;
+			const KT *k0 = (const KT *)kout, *k1 = (const KT *)kalt;
+			kin = i == 0 ? kin : (((i - 1) & 1u) ? k1 : k0);
+			kout = (i & 1u) ? (const void *)k1 : (const void *)k0;
+			const u32 w = (P - 1 - i) & 1u;
+			const void *h0 = vin, *h1 = vout;
+			vout = w ? h1 : h0;
+			vin = i == 0 ? nullptr : (w ? h0 : h1);
+			skip_keys = i == P - 1;
+		} else if (pass_index & 1u) {
+			const KT *t = kin;
+			kin = (const KT *)kout;
+			kout = t;
+			const void *u = vin;
+			vin = vout;
+			vout = u;
+		}
+	}
 	__shared__ u64 cursor[256];
 	const u32 lane = threadIdx.x;
 	for (u32 d = lane; d < 256; d += 64) {
@@ -1063,6 +1093,17 @@ __global__ void rsx_fill_splitmix_kernel(T *dst, u64 n, u64 seed, u64 mask, u64 
 		z ^= z >> 31;
 		dst[i] = (T)(z & mask);
 	}
+}
+
+// dst = 0 .. n-1 if the device-side plan says "sorted": what rs_sort_rank leaves in the first half then
+// (radix_sort_rank.hpp:52,:55-57); the last step of rsx_sort_rank_inplace_async.
+template <typename IT>
+__global__ void rsx_iota_if_sorted_kernel(IT *dst, u64 n, const Plan *__restrict__ plan)
+{
+	if (!plan->sorted)
+		return;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+		dst[i] = (IT)i;
 }
 
 template <typename IT>

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags, u64 *tl,
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
                                                                  u32 oshift = 0, const u32 *__restrict__ hotd = nullptr,
-                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr})
+                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr},
+                                                                 const void *__restrict__ kalt = nullptr)
 {
 	constexpr bool NARROW = !std::is_same<KTO, KT>::value;
 	static_assert(!SEG || (!NARROW && C::TPS == 1 && !HOT_), "segmented passes: plain tiles, keys of one type");
@@ -183,7 +184,23 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		shift = 8 * col;
 		gbase += 256 * col;
 		if constexpr (!NARROW) {
-			if (pass_index & 1) {
+			if (flags & SCATTER_RANK_ASYNC) {
+				// rsx_sort_rank_inplace_async: the caller's keys are read by pass 0 only (which also makes the indices), the
+				// work copies kout / kalt alternate after that, the last pass writes no keys, and the halves of the index
+				// buffer are taken so that the LAST pass writes the first one, however many passes the plan has.
+				const u32 P = dplan->ncols, i = pass_index;
+				KT *k0 = kout, *k1 = (KT *)const_cast<void *>(kalt);
+				kin = i == 0 ? kin : (((i - 1) & 1u) ? k1 : k0);
+				kout = (i & 1u) ? k1 : k0;
+				const u32 w = (P - 1 - i) & 1u;
+				VT *h0 = const_cast<VT *>(vin), *h1 = vout;
+				vout = w ? h1 : h0;
+				vin = w ? h0 : h1;
+				if (i == 0)
+					flags |= SCATTER_GEN_INDEX;
+				if (i == P - 1)
+					flags |= SCATTER_SKIP_KEYS;
+			} else if (pass_index & 1) {
 				const KT *t = kin;
 				kin = kout;
 				kout = const_cast<KT *>(t);

@@ -46,6 +46,14 @@ def _need_gpu():
     rsa.require_gpu()
 
 
+@pytest.fixture(autouse=True)
+def _two_levels_from_4mi(monkeypatch):
+    """Two levels pay from 2^27 keys on and that is where the library starts using them; the tests lower the threshold to
+    2^22 (RSX_TWO_LEVEL_MIN_LOG2) so that every branch runs at sizes the oracle sorts in a second."""
+    monkeypatch.setenv("RSX_TWO_LEVEL_MIN_LOG2", "22")
+    yield
+
+
 WIDE = [ol.U32, ol.I32, ol.F32, ol.U64, ol.I64, ol.F64]
 
 

@@ -711,6 +711,55 @@ def test_inplace_async_sort_in_a_hip_graph(n):
         assert np.array_equal(to_bits(buf, ol.U32), want), (n, seed)
 
 
+@pytest.mark.parametrize("dt,itype", [(ol.U32, "int32"), (ol.F32, "int32"), (ol.I64, "int64"), (ol.U16, "int32")])
+def test_rank_inplace_async_vs_oracle(dt, itype):
+    """rsx_sort_rank_inplace_async (radix_sort_rank.hpp:97-112 without a host synchronisation): the oracle's ranks, always in
+    the first half of the index buffer whatever the number of kept columns; sorted keys give 0 .. n-1; the keys untouched."""
+    size = ol.DTYPE_SIZE[dt]
+    full = (1 << (8 * size)) - 1
+    idx_bytes = 4 if itype == "int32" else 8
+    for n, mask in ((2, full), (1000, full), (5000, full & ~0xFF), (70001, full), (300001, full & ~(0xFF << 8)), (1200003, full)):
+        a = ol.splitmix_fill(n, dt, 41 + n % 13, mask)
+        for order in (ol.ASC, ol.DESC):
+            src = to_dev(a)
+            ib = torch.full((2 * n,), -7, dtype=getattr(torch, itype), device="cuda")
+            ranks = rsa.radix_sort_rank_inplace_async(src, ib, dtype=dt, order=order)
+            torch.cuda.synchronize()
+            want = ol.oracle_rank(a, dt, idx_bytes, order)[0]
+            assert np.array_equal(ranks.cpu().numpy().view(want.dtype), want), (n, hex(mask), order)
+            assert np.array_equal(to_bits(src, dt), a)
+    s = np.sort(ol.splitmix_fill(50000, dt, 3, full).view(ol.NP_BITS[dt]))
+    if dt in (ol.U32, ol.U16):       # (sorted bit patterns are sorted keys for the unsigned types)
+        ib = torch.full((100000,), -7, dtype=getattr(torch, itype), device="cuda")
+        ranks = rsa.radix_sort_rank_inplace_async(to_dev(s), ib, dtype=dt)
+        torch.cuda.synchronize()
+        assert np.array_equal(ranks.cpu().numpy(), np.arange(50000))
+
+
+@pytest.mark.parametrize("n", [5000, 300001])
+def test_rank_inplace_async_in_a_hip_graph(n):
+    """The device-scheduled rank sort captured once and replayed on new keys with 4, 3 and 1 kept columns: the ranks land in
+    the first half every time."""
+    s = torch.cuda.Stream()
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    ib = torch.empty(2 * n, dtype=torch.int32, device="cuda")
+    with torch.cuda.stream(s):
+        rsa.fill_splitmix(keys, seed=1, stream=s)
+        rsa.radix_sort_rank_inplace_async(keys, ib, dtype=ol.F32, stream=s)     # sizes the workspace outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        rsa.radix_sort_rank_inplace_async(keys, ib, dtype=ol.F32, stream=torch.cuda.current_stream())
+    for seed, mask in ((11, 0xFFFFFFFF), (12, 0x00FFFFFF), (13, 0x0000FF00)):
+        a = ol.splitmix_fill(n, ol.F32, seed, mask)
+        keys.copy_(to_dev(a))
+        ib.fill_(-3)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(ib[:n].cpu().numpy().view(np.uint32), ol.oracle_rank(a, ol.F32, 4)[0]), (n, seed)
+
+
 @pytest.mark.parametrize("n", [5000, 300001, 1 << 22])
 def test_graph_with_a_caller_owned_workspace_survives_larger_sorts(n):
     """a graph captured from rsx_sort_inplace_async refers to the library's cached workspace, which a later

@@ -83,3 +83,43 @@ def test_verification_failure_is_reported():
 def test_soak_with_verification():
     out = _run([os.path.join("tools", "soak.py"), "6", "--small"], {"RSX_VERIFY": "1"})
     assert out.returncode == 0 and "soak ok" in out.stdout and "RSX_VERIFY=1" in out.stdout, out.stdout + out.stderr
+
+
+ASYNC_VERIFY_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np, torch
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+carrier = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}
+def dev(a): return torch.from_numpy(np.ascontiguousarray(a).view(carrier[a.itemsize]).copy()).cuda()
+n_checked = 0
+for dt, n, mask in [(ol.U32, 3000001, 0xFFFFFFFF), (ol.U64, 1500001, 0xFFFFFFFFFF), (ol.F32, 2000003, 0xFFFFFFFF), (ol.I32, 400001, 0x00FF00FF)]:
+    a = ol.splitmix_fill(n, dt, 15 + dt, mask)
+    for order in (0, 1):
+        buf = dev(a); scratch = torch.zeros_like(buf)
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=dt, order=order)
+        ib = torch.zeros(2 * n, dtype=torch.int32, device="cuda")
+        ranks = rsa.radix_sort_rank_inplace_async(dev(a), ib, dtype=dt, order=order)
+        keys = dev(a); vals = torch.arange(n, dtype=torch.int64, device="cuda")
+        rsa.radix_sort_pairs_inplace_async(keys, torch.zeros_like(keys), vals, torch.zeros_like(vals), dtype=dt, order=order)
+        assert rsa.verify_poll() == 0
+        assert np.array_equal(buf.cpu().numpy().view(ol.NP_BITS[dt]), ol.oracle_sort(a, dt, order)[0])
+        assert np.array_equal(ranks.cpu().numpy().view(np.uint32), ol.oracle_rank(a, dt, 4, order)[0])
+        assert np.array_equal(vals.cpu().numpy().astype(np.uint32), ol.oracle_rank(a, dt, 4, order)[0])
+        n_checked += 3
+print("async verify ok", n_checked)
+""" % (ROOT, ROOT)
+
+
+def test_device_scheduled_sorts_are_verified_too():
+    """RSX_VERIFY=1 covers the *_inplace_async sorts (keys, key + payload, ranks): every device-scheduled pass has one tile
+    re-ranked with ballots on the device, the mismatches are collected by rsx_verify_poll."""
+    out = _run(["-c", ASYNC_VERIFY_SCRIPT], {"RSX_VERIFY": "1"})
+    assert out.returncode == 0 and "async verify ok 24" in out.stdout, out.stdout + out.stderr
+
+
+def test_async_verification_failure_is_reported_at_the_poll():
+    out = _run(["-c", ASYNC_VERIFY_SCRIPT], {"RSX_VERIFY": "1", "RSX_VERIFY_INJECT": "1"})
+    assert out.returncode != 0
+    assert "rsx error -5" in out.stderr and "device-scheduled" in out.stderr, out.stderr
