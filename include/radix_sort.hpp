@@ -16,7 +16,10 @@
 //     sort and the gather of the records on the GPU.
 //   * any other callable (radix_tests.cpp:41-43,:111-113,:175-177 shapes): kf is evaluated once per
 //     element on the host into an array of KeyType, the GPU rank-sorts those keys and gathers the
-//     (trivially copyable) elements: rsx_sort_records().
+//     (trivially copyable) elements: rsx_sort_records().  Elements that are movable but NOT trivially
+//     copyable (the reference only ever move-assigns T, radix_sort.hpp:85-87): the GPU rank-sorts the
+//     keys (rsx_sort_rank_keys) and the host moves the elements into that order, through `aux` as the
+//     reference does, so that the result lies where its parity rule says.
 // There is no CPU sorting path: without a usable MI355X the call throws std::runtime_error, where the
 // reference "cannot fail".  The buffer that is not returned has unspecified contents (the reference
 // leaves the previous pass's data there).
@@ -27,6 +30,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "radix_sort_basic_kdf.hpp"
@@ -152,10 +156,14 @@ struct hist_capture {
 	~hist_capture() { rsx_capture_histogram(nullptr, 0); }
 };
 
-template <typename T, typename KeyFunc, typename Hist = void>
+// KeyType: what the reference derives from the KDF's return type and lets the caller override (the fourth template
+// parameter of rs_sort_main, radix_sort.hpp:31): the keys are kf(element) converted to it, its size is the number of columns.
+template <typename T, typename KeyFunc>
+using derived_key_t = std::remove_cv_t<std::remove_reference_t<std::invoke_result_t<KeyFunc &, const T &>>>;
+
+template <typename T, typename KeyFunc, typename Hist = void, typename KeyType = derived_key_t<T, KeyFunc>>
 T *sort_dispatch(T *src, T *aux, size_t n, KeyFunc &&kf, Hist *histogram = nullptr)
 {
-	using KeyType = std::remove_cv_t<std::remove_reference_t<std::invoke_result_t<KeyFunc &, const T &>>>;
 	static_assert(sizeof(KeyType) <= 8, "KeyType must be 64-bits or less");        // reference radix_sort.hpp:34
 	static_assert(std::is_unsigned_v<KeyType>, "KeyType must be unsigned");         // reference radix_sort.hpp:35
 	if (n < 2)
@@ -166,13 +174,53 @@ T *sort_dispatch(T *src, T *aux, size_t n, KeyFunc &&kf, Hist *histogram = nullp
 	hist_capture cap(histogram != nullptr, sizeof(KeyType));
 	// the opaque-callable path: kf once per element on the host, rank sort + gather of the elements on the device
 	auto opaque = [&]() {
-		static_assert(std::is_trivially_copyable_v<T>, "the GPU path moves elements as raw bytes");
 		std::vector<KeyType> keys(n);
 		for (size_t i = 0; i < n; ++i)
-			keys[i] = kf(src[i]);
-		return rsx_sort_records(src, aux, n, sizeof(T), keys.data(), sizeof(KeyType), &result, &info);
+			keys[i] = static_cast<KeyType>(kf(src[i]));
+		if constexpr (std::is_trivially_copyable_v<T>) {
+			return rsx_sort_records(src, aux, n, sizeof(T), keys.data(), sizeof(KeyType), &result, &info);
+		} else {
+			// Elements with constructors / ownership (the reference move-assigns them, radix_sort.hpp:85-87): the device
+			// gives the stable order, the host moves.  aux[i] = move(src[rank[i]]) is the reference's last pass with the
+			// earlier ones folded in; an even number of kept columns ends in src (:92), so the elements move back.
+			void *ranks = nullptr;
+			int r;
+			if (n <= 0xFFFFFFFFull) {
+				std::vector<uint32_t> ib(2 * n);
+				r = rsx_sort_rank_keys(keys.data(), sizeof(KeyType), ib.data(), n, 4, &ranks, &info);
+				if (r == RSX_OK && !info.early_exit) {
+					const uint32_t *rk = static_cast<const uint32_t *>(ranks);
+					for (size_t i = 0; i < n; ++i)
+						aux[i] = std::move(src[rk[i]]);
+				}
+			} else {
+				std::vector<uint64_t> ib(2 * n);
+				r = rsx_sort_rank_keys(keys.data(), sizeof(KeyType), ib.data(), n, 8, &ranks, &info);
+				if (r == RSX_OK && !info.early_exit) {
+					const uint64_t *rk = static_cast<const uint64_t *>(ranks);
+					for (size_t i = 0; i < n; ++i)
+						aux[i] = std::move(src[rk[i]]);
+				}
+			}
+			if (r != RSX_OK)
+				return r;
+			if (info.early_exit) {                  // pre-sorted: src, aux untouched (radix_sort.hpp:60-62)
+				result = src;
+			} else if (info.ncols & 1) {
+				result = aux;
+			} else {
+				for (size_t i = 0; i < n; ++i)
+					src[i] = std::move(aux[i]);
+				result = src;
+			}
+			info.result_in_aux = result == static_cast<void *>(aux);
+			return (int)RSX_OK;
+		}
 	};
-	if constexpr (may_be_default_kdf_v<T, KeyFunc>) {
+	constexpr bool key_overridden = !std::is_same_v<KeyType, derived_key_t<T, KeyFunc>>;
+	if constexpr (key_overridden) {
+		rc = opaque();   // (an explicit KeyType: the keys are the KDF's values converted to it, evaluated on the host)
+	} else if constexpr (may_be_default_kdf_v<T, KeyFunc>) {
 		if (kdf_kind<T, KeyFunc>::is_default(kf))
 			rc = rsx_sort(src, aux, n, dtype_of<T>(), RSX_ASCENDING, &result, &info);
 		else
@@ -229,8 +277,10 @@ T *radix_sort_multi(T *RESTRICT src, T *RESTRICT aux, size_t n, const int *devic
 // operator[], pre-zeroed, 256 * sizeof(KeyType) entries: radix_sort.hpp:28-33).  The device keeps its own counters;
 // the counts of its histogram pass are brought back (rsx_capture_histogram) and `histogram` is left in the state the
 // reference leaves it in (rsx_detail::hist_post_state; pinned against the real rs_sort_main by tests/golden, hist_post).
-template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>), typename Hist>
+// The fourth template parameter is the reference's (radix_sort.hpp:31): KeyType, by default the KDF's return type.
+template <typename T, typename KeyFunc = decltype(basic_kdfs::kdf<T>), typename Hist,
+          typename KeyType = rsx_detail::derived_key_t<T, KeyFunc>>
 T *rs_sort_main(T *RESTRICT src, T *RESTRICT aux, size_t n, Hist &histogram, KeyFunc &&kf = basic_kdfs::kdf<T>)
 {
-	return rsx_detail::sort_dispatch<T>(src, aux, n, kf, &histogram);
+	return rsx_detail::sort_dispatch<T, KeyFunc, Hist, KeyType>(src, aux, n, std::forward<KeyFunc>(kf), &histogram);
 }

@@ -1577,126 +1577,7 @@ int msd_split_known(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int ord
 	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0u);
 }
 
-// ---- single-process multi-device sort (rsx_sort_multi) -----------------------------------------------------------------
-// A "rank" is a (device, stream) pair: its own workspace context, its own host thread while a phase runs.  The streams are
-// pooled per (device, slot) so that repeated calls reuse the contexts.
-std::mutex g_multi_mu;
-std::map<std::pair<int, int>, hipStream_t> g_multi_streams;
-// device buffers of a rank, kept per (device, slot) between calls (grown when a larger sort comes, freed by rsx_release)
-struct MultiBufs {
-	DevBuf shard, part, recv, aux, misc;   // misc: [key bytes][256] u64 histogram + 64 bytes for the flag
-};
-std::map<std::pair<int, int>, MultiBufs> g_multi_bufs;
-std::map<std::pair<int, int>, int> g_peer_enabled;   // (device, peer) -> 1 enabled, 0 not possible
-
-struct MultiRank {
-	int dev = 0;
-	MultiBufs *bufs = nullptr;
-	hipStream_t stream = nullptr;
-	size_t first = 0, count = 0;         // this rank's shard of the input
-	void *shard = nullptr, *part = nullptr, *recv = nullptr, *aux = nullptr;
-	u64 *d_hist = nullptr;
-	u32 *d_flag = nullptr;
-	std::vector<u64> hist;               // [key bytes][256]
-	u32 unsorted = 0;
-	size_t n_recv = 0, out_first = 0;    // this rank's range of the result
-	int rc = RSX_OK;
-	char err[512] = "";
-};
-
-u64 host_kdf(const void *p, size_t kb, int dtype, int order)
-{
-	u64 raw = 0;
-	memcpy(&raw, p, kb);
-	const u64 ones = kb == 8 ? ~0ull : ((1ull << (8 * kb)) - 1);
-	const u64 high = 1ull << (8 * kb - 1);
-	const bool is_signed = dtype == RSX_I8 || dtype == RSX_I16 || dtype == RSX_I32 || dtype == RSX_I64;
-	const bool is_float = dtype == RSX_F32 || dtype == RSX_F64;
-	u64 k = raw;
-	if (is_float)
-		k ^= (raw & high) ? ones : high;     // radix_sort_basic_kdf.hpp:32-46
-	else if (is_signed)
-		k ^= high;                           // :26-30
-	if (order == RSX_DESCENDING)
-		k ^= ones;                           // README.md:564-574
-	return k & ones;
-}
-
-// digit -> destination rank: contiguous, monotone ranges of ~total/G keys (the midpoint of a digit's run decides)
-void choose_splitters_host(const u64 *hist, int G, uint8_t *lut)
-{
-	long double total = 0;
-	for (int d = 0; d < 256; ++d)
-		total += (long double)hist[d];
-	long double before = 0;
-	int prev = 0;
-	for (int d = 0; d < 256; ++d) {
-		int r = 0;
-		if (total > 0 && G > 1) {
-			const long double mid = before + (long double)hist[d] / 2;
-			r = (int)(mid * G / total);
-			r = r < 0 ? 0 : (r > G - 1 ? G - 1 : r);
-		}
-		if (r < prev)
-			r = prev;
-		prev = r;
-		lut[d] = (uint8_t)r;
-		before += (long double)hist[d];
-	}
-}
-
-// one host thread per rank; the first failure (code + message) becomes the caller's
-int multi_phase(std::vector<MultiRank> &ranks, const std::function<int(MultiRank &)> &body)
-{
-	std::vector<std::thread> threads;
-	for (auto &r : ranks)
-		threads.emplace_back([&r, &body]() {
-			if (hipSetDevice(r.dev) != hipSuccess) {
-				r.rc = RSX_EHIP;
-				snprintf(r.err, sizeof(r.err), "hipSetDevice(%d) failed", r.dev);
-				return;
-			}
-			r.rc = body(r);
-			if (r.rc != RSX_OK)
-				snprintf(r.err, sizeof(r.err), "%s", g_err);
-		});
-	for (auto &t : threads)
-		t.join();
-	for (auto &r : ranks)
-		if (r.rc != RSX_OK)
-			return fail(r.rc, "rsx_sort_multi (device %d): %s", r.dev, r.err);
-	return RSX_OK;
-}
-
-// the ranks' buffers belong to g_multi_bufs; a call only has to be sure that nothing of it is still running
-void multi_quiesce(std::vector<MultiRank> &ranks)
-{
-	for (auto &r : ranks) {
-		(void)hipSetDevice(r.dev);
-		if (r.stream)
-			(void)hipStreamSynchronize(r.stream);
-	}
-}
-
-// direct peer-to-peer copies dev <- peer over xGMI where the topology allows them (without it hipMemcpyPeerAsync stages
-// through the host); enabled once per ordered pair of devices
-void enable_peer(int dev, int peer)
-{
-	if (dev == peer)
-		return;
-	std::lock_guard<std::mutex> lock(g_mu);
-	const auto key = std::make_pair(dev, peer);
-	if (g_peer_enabled.count(key))
-		return;
-	int can = 0;
-	int ok = 0;
-	if (hipDeviceCanAccessPeer(&can, dev, peer) == hipSuccess && can) {
-		const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);   // (for the current device, which is `dev` here)
-		ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
-	}
-	(void)hipGetLastError();
-	g_peer_enabled[key] = ok;
-}
+#include "rsx_multi_state.hpp"   // rsx_sort_multi: per-rank streams, buffers, phases, peer access
 
 #define RSX_DISPATCH_KT(dtype, CALL)                               \
 	switch (dtype_size(dtype)) {                                   \
@@ -2201,395 +2082,9 @@ int rsx_sort_rank(const void *src, void *index_buffer, size_t n, rsx_dtype dtype
 	return RSX_OK;
 }
 
-int rsx_sort_rank_keys(const void *keys, size_t key_bytes, void *index_buffer, size_t n, size_t idx_bytes, void **result,
-                       rsx_info *info)
-{
-	rsx_dtype dt;
-	switch (key_bytes) {
-	case 1: dt = RSX_U8; break;
-	case 2: dt = RSX_U16; break;
-	case 4: dt = RSX_U32; break;
-	case 8: dt = RSX_U64; break;
-	default: return fail(RSX_EINVAL, "rsx_sort_rank_keys: key_bytes must be 1, 2, 4 or 8");
-	}
-	return rsx_sort_rank(keys, index_buffer, n, dt, idx_bytes, RSX_ASCENDING, result, info);
-}
+#include "rsx_records.hpp"       // rsx_sort_rank_keys, rsx_sort_records, rsx_sort_records_tagged[_device]
 
-int rsx_sort_records(void *src, void *aux, size_t n, size_t rec_bytes, const void *keys, size_t key_bytes, void **result,
-                     rsx_info *info)
-{
-	rsx_dtype dt;
-	switch (key_bytes) {
-	case 1: dt = RSX_U8; break;
-	case 2: dt = RSX_U16; break;
-	case 4: dt = RSX_U32; break;
-	case 8: dt = RSX_U64; break;
-	default: return fail(RSX_EINVAL, "rsx_sort_records: key_bytes must be 1, 2, 4 or 8");
-	}
-	info_clear(info, dt);
-	if (!result || !rec_bytes || (n && (!src || !aux || !keys)))
-		return fail(RSX_EINVAL, "rsx_sort_records: bad argument");
-	*result = src;
-	if (n < 2) {
-		if (info)
-			info->early_exit = 1;
-		return RSX_OK;
-	}
-	Ctx *c;
-	RSX_TRY(get_ctx(nullptr, &c));
-	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
-	const size_t wide = n > (1ull << 32) ? 8 : 4;
-	RSX_TRY(c->keys[0].ensure(n * key_bytes));   // note: rank passes use keys[0]/keys[1] too; the uploaded keys live in recs[1]
-	RSX_TRY(c->recs[1].ensure(n * key_bytes > n * rec_bytes ? n * key_bytes : n * rec_bytes));
-	RSX_TRY(c->vals[0].ensure(2 * n * wide));
-	HIP_TRY(hipMemcpyAsync(c->recs[1].p, keys, n * key_bytes, hipMemcpyHostToDevice, c->stream));
-	void *dres = nullptr;
-	rsx_info li;
-	RSX_TRY(rsx_sort_rank_device(c->recs[1].p, c->vals[0].p, n, dt, wide, RSX_ASCENDING, nullptr, &dres, &li));
-	if (info)
-		*info = li;
-	if (li.early_exit) {                     // pre-sorted by key: records stay where they are
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		return RSX_OK;
-	}
-	// gather the records through the ranks (the keys in recs[1] are no longer needed)
-	RSX_TRY(c->recs[0].ensure(n * rec_bytes));
-	HIP_TRY(hipMemcpyAsync(c->recs[0].p, src, n * rec_bytes, hipMemcpyHostToDevice, c->stream));
-	const uintptr_t al = (uintptr_t)rec_bytes;
-	const unsigned grid = 2048, block = 256;
-#define RSX_GATHER(WORD)                                                                                          \
-	do {                                                                                                          \
-		if (wide == 4)                                                                                            \
-			hipLaunchKernelGGL((rsx_gather_kernel<WORD, u32>), dim3(grid), dim3(block), 0, c->stream,              \
-			                   (WORD *)c->recs[1].p, (const WORD *)c->recs[0].p, (const u32 *)dres, (u64)n,         \
-			                   (u32)(rec_bytes / sizeof(WORD)));                                                  \
-		else                                                                                                      \
-			hipLaunchKernelGGL((rsx_gather_kernel<WORD, u64>), dim3(grid), dim3(block), 0, c->stream,              \
-			                   (WORD *)c->recs[1].p, (const WORD *)c->recs[0].p, (const u64 *)dres, (u64)n,         \
-			                   (u32)(rec_bytes / sizeof(WORD)));                                                  \
-	} while (0)
-	if (al % 16 == 0)
-		RSX_GATHER(uint4);
-	else if (al % 8 == 0)
-		RSX_GATHER(u64);
-	else if (al % 4 == 0)
-		RSX_GATHER(u32);
-	else if (al % 2 == 0)
-		RSX_GATHER(uint16_t);
-	else
-		RSX_GATHER(uint8_t);
-#undef RSX_GATHER
-	HIP_TRY(hipGetLastError());
-	void *hres = li.result_in_aux ? aux : src;
-	HIP_TRY(hipMemcpyAsync(hres, c->recs[1].p, n * rec_bytes, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	*result = hres;
-	return RSX_OK;
-}
-
-// ---- records with a declared key: extraction, rank sort and gather on the device --------------------------------
-namespace {
-
-int gather_records(Ctx &c, void *d_out, const void *d_in, const void *d_idx, size_t idx_bytes, size_t n, size_t rec_bytes)
-{
-	const unsigned grid = 2048, block = 256;
-	const uintptr_t al = (uintptr_t)rec_bytes | (uintptr_t)d_out | (uintptr_t)d_in;
-#define RSX_GATHER(WORD)                                                                                              \
-	do {                                                                                                              \
-		if (idx_bytes == 4)                                                                                           \
-			hipLaunchKernelGGL((rsx_gather_kernel<WORD, u32>), dim3(grid), dim3(block), 0, c.stream, (WORD *)d_out,      \
-			                   (const WORD *)d_in, (const u32 *)d_idx, (u64)n, (u32)(rec_bytes / sizeof(WORD)));         \
-		else                                                                                                          \
-			hipLaunchKernelGGL((rsx_gather_kernel<WORD, u64>), dim3(grid), dim3(block), 0, c.stream, (WORD *)d_out,      \
-			                   (const WORD *)d_in, (const u64 *)d_idx, (u64)n, (u32)(rec_bytes / sizeof(WORD)));         \
-	} while (0)
-	if (al % 16 == 0)
-		RSX_GATHER(uint4);
-	else if (al % 8 == 0)
-		RSX_GATHER(u64);
-	else if (al % 4 == 0)
-		RSX_GATHER(u32);
-	else if (al % 2 == 0)
-		RSX_GATHER(uint16_t);
-	else
-		RSX_GATHER(uint8_t);
-#undef RSX_GATHER
-	HIP_TRY(hipGetLastError());
-	return RSX_OK;
-}
-
-// d_out = the records of d_in in stable key order (nothing is written when the keys are already sorted: li.early_exit)
-int records_tagged_core(Ctx &c, const void *d_in, void *d_out, size_t n, size_t rec_bytes, size_t key_off, rsx_dtype dt,
-                        rsx_order order, rsx_info *li)
-{
-	const size_t kb = dtype_size(dt);
-	const size_t wide = n > (1ull << 32) ? 8 : 4;
-	RSX_TRY(c.tkeys.ensure(n * kb));
-	RSX_TRY(c.vals[0].ensure(2 * n * wide));
-	RSX_DISPATCH_KT(dt, hipLaunchKernelGGL((rsx_extract_key_kernel<KT>), dim3(2048), dim3(256), 0, c.stream, (KT *)c.tkeys.p,
-	                                      (const unsigned char *)d_in, (u64)n, (u32)rec_bytes, (u32)key_off));
-	HIP_TRY(hipGetLastError());
-	void *dres = nullptr;
-	RSX_TRY(rsx_sort_rank_device(c.tkeys.p, c.vals[0].p, n, dt, wide, order, c.stream, &dres, li));
-	if (li->early_exit)
-		return RSX_OK;
-	return gather_records(c, d_out, d_in, dres, wide, n, rec_bytes);
-}
-
-int tagged_args_ok(const char *who, size_t n, size_t rec_bytes, size_t key_off, rsx_dtype dt, const void *a, const void *b,
-                   void **result)
-{
-	const size_t kb = dtype_size(dt);
-	if (!kb)
-		return fail(RSX_EINVAL, "%s: unknown key dtype", who);
-	if (!result || !rec_bytes || key_off + kb > rec_bytes || rec_bytes > 0xFFFFFFFFull || (n && (!a || !b)))
-		return fail(RSX_EINVAL, "%s: bad argument (the key must lie inside the record)", who);
-	return RSX_OK;
-}
-
-}  // namespace
-
-int rsx_sort_records_tagged_device(void *d_src, void *d_aux, size_t n, size_t rec_bytes, size_t key_offset, rsx_dtype key_dtype,
-                                   rsx_order order, void *stream, void **result, rsx_info *info)
-{
-	info_clear(info, key_dtype);
-	RSX_TRY(tagged_args_ok("rsx_sort_records_tagged_device", n, rec_bytes, key_offset, key_dtype, d_src, d_aux, result));
-	*result = d_src;
-	if (n < 2) {
-		if (info)
-			info->early_exit = 1;
-		return RSX_OK;
-	}
-	Ctx *c;
-	RSX_TRY(get_ctx(stream, &c));
-	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
-	rsx_info li;
-	RSX_TRY(records_tagged_core(*c, d_src, d_aux, n, rec_bytes, key_offset, key_dtype, order, &li));
-	if (info)
-		*info = li;
-	if (li.early_exit)
-		return RSX_OK;
-	if (li.result_in_aux)
-		*result = d_aux;                      // radix_sort.hpp:92: odd number of kept columns
-	else
-		HIP_TRY(hipMemcpyAsync(d_src, d_aux, n * rec_bytes, hipMemcpyDeviceToDevice, c->stream));
-	return RSX_OK;
-}
-
-int rsx_sort_records_tagged(void *src, void *aux, size_t n, size_t rec_bytes, size_t key_offset, rsx_dtype key_dtype,
-                            rsx_order order, void **result, rsx_info *info)
-{
-	info_clear(info, key_dtype);
-	RSX_TRY(tagged_args_ok("rsx_sort_records_tagged", n, rec_bytes, key_offset, key_dtype, src, aux, result));
-	*result = src;
-	if (n < 2) {
-		if (info)
-			info->early_exit = 1;
-		return RSX_OK;
-	}
-	Ctx *c;
-	RSX_TRY(get_ctx(nullptr, &c));
-	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
-	RSX_TRY(c->recs[0].ensure(n * rec_bytes));
-	RSX_TRY(c->recs[1].ensure(n * rec_bytes));
-	HIP_TRY(hipMemcpyAsync(c->recs[0].p, src, n * rec_bytes, hipMemcpyHostToDevice, c->stream));
-	rsx_info li;
-	RSX_TRY(records_tagged_core(*c, c->recs[0].p, c->recs[1].p, n, rec_bytes, key_offset, key_dtype, order, &li));
-	if (info)
-		*info = li;
-	if (!li.early_exit) {
-		void *hres = li.result_in_aux ? aux : src;
-		HIP_TRY(hipMemcpyAsync(hres, c->recs[1].p, n * rec_bytes, hipMemcpyDeviceToHost, c->stream));
-		*result = hres;
-	}
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	return RSX_OK;
-}
-
-// radix_sort(src, aux, n) on host buffers with the work spread over several devices of ONE process (SURVEY.md 8b item 5;
-// the one-process-per-GPU form of the same algorithm is radix_sorting_amd/multi.py).  The front half of rs_sort_main is
-// done globally -- column histograms summed over the shards, the ordered-neighbour test across shard boundaries, the
-// column probe on src[0] -- so early exit, kept columns and the returned pointer are exactly the reference's; then every
-// shard is split by the highest kept byte, the devices pull their digit ranges from each other, sort them and write them
-// to their place in the buffer the parity rule names.
-int rsx_sort_multi(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order, const int *devices, int ndev,
-                   void **result, rsx_info *info)
-{
-	info_clear(info, dtype);
-	const size_t kb = dtype_size(dtype);
-	if (!kb || !result || ndev < 1 || ndev > 64 || !devices || (n && (!src || !aux)))
-		return fail(RSX_EINVAL, "rsx_sort_multi: bad argument");
-	if (n < 2) {                             // radix_sort.hpp:100-101
-		*result = src;
-		if (info)
-			info->early_exit = 1;
-		return RSX_OK;
-	}
-	{
-		std::lock_guard<std::mutex> lock(g_mu);
-		if (probe_devices() <= 0)
-			return fail(RSX_ENODEVICE, "no gfx950 (MI355X) device visible to HIP; this library has no CPU path");
-	}
-	int visible = 0;
-	HIP_TRY(hipGetDeviceCount(&visible));
-	for (int i = 0; i < ndev; ++i)
-		if (devices[i] < 0 || devices[i] >= visible)
-			return fail(RSX_EINVAL, "rsx_sort_multi: device %d is not one of the %d visible", devices[i], visible);
-	std::lock_guard<std::mutex> multi_lock(g_multi_mu);
-	int home = 0;
-	HIP_TRY(hipGetDevice(&home));
-	const int G = ndev;
-	std::vector<MultiRank> ranks(G);
-	std::map<int, int> slot;
-	for (int r = 0; r < G; ++r) {
-		MultiRank &k = ranks[r];
-		k.dev = devices[r];
-		const auto key = std::make_pair(k.dev, slot[k.dev]++);
-		auto it = g_multi_streams.find(key);
-		if (it == g_multi_streams.end()) {
-			hipStream_t st = nullptr;
-			HIP_TRY(hipSetDevice(k.dev));
-			HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-			it = g_multi_streams.emplace(key, st).first;
-		}
-		k.stream = it->second;
-		k.bufs = &g_multi_bufs[key];
-		k.first = (size_t)((unsigned __int128)n * r / G);
-		k.count = (size_t)((unsigned __int128)n * (r + 1) / G) - k.first;
-		k.hist.assign(kb * 256, 0);
-	}
-	struct Cleanup {
-		std::vector<MultiRank> &ranks;
-		int home;
-		~Cleanup()
-		{
-			multi_quiesce(ranks);
-			(void)hipSetDevice(home);
-		}
-	} cleanup{ranks, home};
-	const char *hsrc = (const char *)src;
-
-	// ---- radix_sort.hpp:47-58 per shard: upload, histogram of every column, ordered-neighbour test
-	RSX_TRY(multi_phase(ranks, [&](MultiRank &k) -> int {
-		if (k.count == 0)
-			return RSX_OK;
-		RSX_TRY(k.bufs->shard.ensure(k.count * kb));
-		RSX_TRY(k.bufs->part.ensure(k.count * kb));
-		RSX_TRY(k.bufs->misc.ensure(kb * 256 * sizeof(u64) + 64));
-		k.shard = k.bufs->shard.p;
-		k.part = k.bufs->part.p;
-		k.d_hist = (u64 *)k.bufs->misc.p;
-		k.d_flag = (u32 *)((char *)k.bufs->misc.p + kb * 256 * sizeof(u64));
-		HIP_TRY(hipMemcpyAsync(k.shard, hsrc + k.first * kb, k.count * kb, hipMemcpyHostToDevice, k.stream));
-		RSX_TRY(rsx_histogram_device(k.shard, k.count, dtype, order, (uint64_t *)k.d_hist, (uint32_t *)k.d_flag, k.stream));
-		HIP_TRY(hipMemcpyAsync(k.hist.data(), k.d_hist, kb * 256 * sizeof(u64), hipMemcpyDeviceToHost, k.stream));
-		HIP_TRY(hipMemcpyAsync(&k.unsorted, k.d_flag, sizeof(u32), hipMemcpyDeviceToHost, k.stream));
-		HIP_TRY(hipStreamSynchronize(k.stream));
-		return RSX_OK;
-	}));
-	std::vector<u64> ghist(kb * 256, 0);
-	bool sorted = true;
-	for (int r = 0; r < G; ++r) {
-		for (size_t i = 0; i < kb * 256; ++i)
-			ghist[i] += ranks[r].hist[i];
-		sorted = sorted && ranks[r].unsorted == 0;
-	}
-	for (int r = 0; r + 1 < G && sorted; ++r) {   // neighbours on either side of a shard boundary
-		const size_t b = ranks[r + 1].first;
-		if (b > 0 && b < n && host_kdf(hsrc + (b - 1) * kb, kb, dtype, order) > host_kdf(hsrc + b * kb, kb, dtype, order))
-			sorted = false;
-	}
-	if (sorted) {                            // radix_sort.hpp:60-62
-		*result = src;
-		if (info)
-			info->early_exit = 2;
-		return RSX_OK;
-	}
-	const u64 key0 = host_kdf(hsrc, kb, dtype, order);   // radix_sort.hpp:64-70
-	u32 cols[8], ncols = 0;
-	for (u32 c = 0; c < kb; ++c)
-		if (ghist[c * 256 + ((key0 >> (8 * c)) & 0xFF)] != n)
-			cols[ncols++] = c;
-	if (ncols == 0)
-		return fail(RSX_EHIP, "rsx_sort_multi: unsorted input without a varying column");
-	void *hres = (ncols & 1) ? aux : src;    // radix_sort.hpp:92
-	if (info) {
-		info->ncols = ncols;
-		for (u32 i = 0; i < ncols; ++i)
-			info->cols[i] = cols[i];
-		info->result_in_aux = hres == aux;
-	}
-
-	// ---- destinations: contiguous digit ranges of the highest kept byte; matrix[s][d] keys go from shard s to rank d
-	const u32 cs = cols[ncols - 1];
-	uint8_t lut[256];
-	choose_splitters_host(&ghist[cs * 256], G, lut);
-	std::vector<u64> matrix((size_t)G * G, 0);
-	for (int s = 0; s < G; ++s)
-		for (int d = 0; d < 256; ++d)
-			matrix[(size_t)s * G + lut[d]] += ranks[s].hist[cs * 256 + d];
-	size_t running = 0;
-	for (int d = 0; d < G; ++d) {
-		ranks[d].out_first = running;
-		ranks[d].n_recv = 0;
-		for (int s = 0; s < G; ++s)
-			ranks[d].n_recv += (size_t)matrix[(size_t)s * G + d];
-		running += ranks[d].n_recv;
-	}
-	if (running != n)
-		return fail(RSX_EHIP, "rsx_sort_multi: the count matrix sums to %zu, n = %zu", running, n);
-
-	// ---- one stable pass by that byte per shard
-	RSX_TRY(multi_phase(ranks, [&](MultiRank &k) -> int {
-		if (k.count == 0)
-			return RSX_OK;
-		uint64_t top[256];
-		RSX_TRY(rsx_msd_split_device(k.shard, k.part, k.count, dtype, order, (int)cs, top, k.stream));
-		for (int d = 0; d < 256; ++d)
-			if (top[d] != k.hist[cs * 256 + d])
-				return fail(RSX_EHIP, "the split counted digit %d differently from the histogram", d);
-		HIP_TRY(hipStreamSynchronize(k.stream));
-		return RSX_OK;
-	}));
-
-	// ---- exchange (every rank pulls its digit range from every shard, in shard order), local sort, write-back
-	char *hdst = (char *)hres;
-	RSX_TRY(multi_phase(ranks, [&](MultiRank &k) -> int {
-		if (k.n_recv == 0)
-			return RSX_OK;
-		const int d = (int)(&k - &ranks[0]);
-		RSX_TRY(k.bufs->recv.ensure(k.n_recv * kb));   // sized from the count matrix, whatever the skew
-		RSX_TRY(k.bufs->aux.ensure(k.n_recv * kb));
-		k.recv = k.bufs->recv.p;
-		k.aux = k.bufs->aux.p;
-		for (int s = 0; s < G; ++s)
-			if (matrix[(size_t)s * G + d])
-				enable_peer(k.dev, ranks[s].dev);
-		size_t off = 0;
-		for (int s = 0; s < G; ++s) {
-			const size_t cnt = (size_t)matrix[(size_t)s * G + d];
-			if (cnt == 0)
-				continue;
-			size_t soff = 0;
-			for (int e = 0; e < d; ++e)
-				soff += (size_t)matrix[(size_t)s * G + e];
-			const char *from = (const char *)ranks[s].part + soff * kb;
-			if (ranks[s].dev == k.dev)
-				HIP_TRY(hipMemcpyAsync((char *)k.recv + off * kb, from, cnt * kb, hipMemcpyDeviceToDevice, k.stream));
-			else
-				HIP_TRY(hipMemcpyPeerAsync((char *)k.recv + off * kb, k.dev, from, ranks[s].dev, cnt * kb, k.stream));
-			off += cnt;
-		}
-		void *dres = nullptr;
-		rsx_info li;
-		RSX_TRY(rsx_sort_device(k.recv, k.aux, k.n_recv, dtype, order, k.stream, &dres, &li));
-		HIP_TRY(hipMemcpyAsync(hdst + k.out_first * kb, dres, k.n_recv * kb, hipMemcpyDeviceToHost, k.stream));
-		HIP_TRY(hipStreamSynchronize(k.stream));
-		return RSX_OK;
-	}));
-	*result = hres;
-	return RSX_OK;
-}
+#include "rsx_multi_entry.hpp"   // rsx_sort_multi
 
 int rsx_histogram_device(const void *d_src, size_t n, rsx_dtype dtype, rsx_order order, uint64_t *d_hist,
                          uint32_t *d_unsorted, void *stream)

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// the run's start + rank -- an LDS read where a second atomic used to be.  On uniform digits the pass is as long as with
 	// two atomics (the phase ends with the chain either way), on skewed digits, where lanes queue at one cell, 25-30 % shorter
 	// (tools/ubench/rsx_scatter10_one_atomic.hpp).
-	// (keys-only passes: in the pair passes sixteen more registers live across the layout make several instantiations spill)
+	// (keys-only passes: in the pair passes sixteen more registers live across the layout make several instantiations spill;
+	// round 3 tried it there again WITHOUT the early payload requests, which frees 32 registers: 52-76 bytes of scratch per
+	// lane remain and 2^28 f32 keys -> ranks take 3.16 / 3.30 / 3.42 ms against 3.10 / 3.39 / 3.32, pairs 4.49 against 4.26)
 	constexpr bool RANK1 = KEEP && !C::CELL16 && !HAS_VAL;
 	u32 rk[RANK1 ? KPT / 2 : 1];
 	if constexpr (RANK1) {

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <numeric>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -497,6 +498,57 @@ int main()
 		sortrec *res = rs_sort_main(src.data(), aux.data(), N, h, kdf_sortrec);
 		CHECK(res == aux.data());
 		CHECK(h[0] == 0 && h[1] == 1 && h[2] == 2 && h[3] == 3 && h[44] == 3 && h[45] == 6 && h[254] == 6 && h[255] == 8);   // end offsets
+	}
+	{
+		// Elements that are movable but not trivially copyable (the reference only move-assigns T, radix_sort.hpp:85-87):
+		// records that own a std::string.  Stable order, the reference's returned buffer (src for an even number of kept
+		// columns, aux for an odd one, :92), the pre-sorted exit with aux untouched (:60-62).
+		struct Owner {
+			uint32_t key;
+			std::string name;
+		};
+		for (uint32_t mask : {0xFFFFFFFFu, 0x00FFFFFFu, 0x000000FFu}) {
+			const size_t N = 30011;
+			std::vector<uint32_t> k = splitmix_fill<uint32_t>(N, 61, mask);
+			std::vector<Owner> src(N), aux(N), want(N);
+			for (size_t i = 0; i < N; ++i) {
+				src[i].key = k[i] & 0xFFFFFF0Fu;      // (duplicates: stability is observable through the names)
+				src[i].name = "element #" + std::to_string(i) + " of a sort of records that own their storage";
+			}
+			want = src;
+			std::stable_sort(want.begin(), want.end(), [](const Owner &a, const Owner &b) { return a.key < b.key; });
+			auto kf = [](const Owner &e) -> uint32_t { return e.key; };
+			Owner *res = radix_sort(src.data(), aux.data(), N, kf);
+			const int cols = (mask == 0xFFFFFFFFu) ? 4 : (mask == 0x00FFFFFFu ? 3 : 1);
+			CHECK(res == ((cols & 1) ? aux.data() : src.data()));
+			bool same = true;
+			for (size_t i = 0; i < N; ++i)
+				same = same && res[i].key == want[i].key && res[i].name == want[i].name;
+			CHECK(same);
+			// sorted now: the same buffer comes back, the other one is not touched
+			Owner *other = res == src.data() ? aux.data() : src.data();
+			for (size_t i = 0; i < N; ++i)
+				other[i].name = "untouched";
+			Owner *again = radix_sort(res, other, N, kf);
+			CHECK(again == res);
+			bool untouched = true;
+			for (size_t i = 0; i < N; ++i)
+				untouched = untouched && other[i].name == "untouched" && res[i].name == want[i].name;
+			CHECK(untouched);
+		}
+	}
+	{
+		// rs_sort_main's fourth template parameter (radix_sort.hpp:31): an explicit KeyType narrower than what the KDF
+		// returns -- the keys are the KDF's values converted to it, its size is the number of columns
+		const size_t N = 40001;
+		std::vector<uint32_t> src = splitmix_fill<uint32_t>(N, 71, ~0ull), aux(N), want = src;
+		std::stable_sort(want.begin(), want.end(), [](uint32_t a, uint32_t b) { return (uint16_t)a < (uint16_t)b; });
+		std::vector<uint32_t> h(256 * 2, 0);
+		auto kf = [](const uint32_t &v) -> uint32_t { return v; };
+		uint32_t *res = rs_sort_main<uint32_t, decltype(kf) &, std::vector<uint32_t>, uint16_t>(src.data(), aux.data(), N, h, kf);
+		CHECK(res == src.data());                 // two columns
+		CHECK(std::memcmp(res, want.data(), N * 4) == 0);
+		CHECK(h[255] == N && h[511] == N);        // end offsets of both columns
 	}
 	if (failures) {
 		printf("dropin_check: %d failures\n", failures);

@@ -1,0 +1,26 @@
+"""Beyond 2^32 keys: the counter width follows n (radix_sort.hpp:102-114 picks uint64_t counters from 2^32 elements on; here
+the status words of the look-back chain are 64-bit from 2^30 keys on and every offset is 64-bit).  2^32 + 4097 u32 keys,
+16 GiB per buffer, generated and checked on the device: sortedness, the key sum and the key xor (size-independent
+properties: nothing of this size goes through the oracle).  37 ms of GPU time for the sort itself."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import radix_sorting_amd as rsa
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sort_of_more_than_2p32_keys():
+    rsa.require_gpu()
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 44 * (1 << 30):
+        pytest.skip("needs 44 GiB of free HBM (two 16 GiB buffers and the checks' temporaries)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_sort_check.py"), "32", "4097"], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "sorted True" in out.stdout and "preserved True" in out.stdout, out.stdout + out.stderr
