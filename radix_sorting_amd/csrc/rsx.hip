@@ -891,10 +891,22 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	const SegCtl *ctl = (const SegCtl *)c.seg.p;
 	ProfScope prof(2, (u64)n * 2 * sizeof(KT), c.stream);
 	const KT *slots = level == HYB_TWO_LEVEL ? (const KT *)c.slack.p : nullptr;   // (only leaves of a slack attempt name slots)
+	u32 skip_narrowable = 0;
+	if constexpr (sizeof(KT) == 8) {
+		// 8-byte keys: leaves whose columns all lie in the low four bytes are carried as 4-byte values (rsx_hybrid.hpp, CT)
+		if (shapes & 1u) {
+			typedef LeafCfg<u32, 4, 32, 3, true, false> N;   // (131 registers: three workgroups per CU)
+			static_assert(N::CAP == S::CAP, "the narrow shape takes the small shape's leaves");
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, N, u32>), dim3(grid_s), dim3(N::BLOCK), 0, c.stream, src, aux, (u64)n,
+			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
+			                   c.slack_cap, 0u);
+			skip_narrowable = 1;
+		}
+	}
 	if (shapes & 1u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(grid_s), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
 		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
-		                   c.slack_cap);
+		                   c.slack_cap, skip_narrowable);
 	if (shapes & 2u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, B>), dim3(grid_b), dim3(B::BLOCK), 0, c.stream, src, aux, (u64)n,
 		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)B::CAP, slots,

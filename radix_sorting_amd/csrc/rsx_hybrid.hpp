@@ -456,16 +456,23 @@ template <typename KT, int NW_, int KPT_, int WPE_ = 1, bool RANK1_ = true, bool
 // (lo, hi] -- the host launches the shape for small leaves and, where it may be needed, the one that fills the LDS; the
 // device picks.  Reads the buffer the last pass wrote (level 1: aux, level 2: src) and writes where plan.ncols passes would
 // end (radix_sort.hpp:92).
-template <typename KT, typename C>
+// CT: the type a key is CARRIED in inside the leaf.  All keys of a leaf agree in the columns above the ones it sorts by (the
+// MSB passes' digits; skipped columns are the same in every key), so when those columns all lie in the low half of the key
+// -- 8-byte keys whose top bytes are zero, BASELINE.json's cfg 3 -- registers and LDS hold 4 bytes per key and the upper
+// half is put back when the keys leave (one copy per leaf): the leaf of 2^28 u64 keys with three low columns then costs what
+// a u32 leaf does instead of three times as much.  The instantiation with CT narrower than KT takes exactly the leaves that
+// allow it; `skip_narrowable` tells the KT-wide instantiation launched beside it to leave those alone.
+template <typename KT, typename C, typename CT = KT>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__restrict__ src, KT *__restrict__ aux, u64 n,
                                                                   const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
                                                                   const LeafSeg *__restrict__ segtab,
                                                                   const SegCtl *__restrict__ ctl, KdfArgs<KT> ka, u32 level,
                                                                   u32 lo, u32 hi, const KT *__restrict__ slots = nullptr,
-                                                                  u32 slack_cap = 0)
+                                                                  u32 slack_cap = 0, u32 skip_narrowable = 0)
 {
 	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK;
-	constexpr int CHUNK = 16 / sizeof(KT);
+	constexpr bool NARROW = sizeof(CT) < sizeof(KT);
+	constexpr int CHUNK = 16 / sizeof(CT);
 	constexpr int G = 4;
 	static_assert(KPT % G == 0, "whole groups of rounds");
 	// everything the decision needs is requested at once (scalar loads), not one dependent round trip after the other
@@ -483,9 +490,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	const KT *in = level == HYB_TWO_LEVEL ? src : aux;
 	KT *out = (ncols & 1) ? aux : src;
 
-	__shared__ __attribute__((aligned(16))) KT stage[C::CAP];
+	__shared__ __attribute__((aligned(16))) CT stage[C::CAP];
 	__shared__ u32 cell[NW][256];
 	__shared__ u32 wsum[4];
+	__shared__ KT s_upper;   // NARROW: what every key of the current leaf has above its carried bits (derived key)
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	auto opaque = [](u32 x) {
 		asm volatile("" : "+v"(x));
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	// Inside a leaf the keys live in registers and LDS as their DERIVED keys (kdf_apply once when they arrive, kdf_invert once
 	// when they leave: the element images that reach memory are the caller's, bit for bit), so that a digit is one bit-field
 	// extract; with the KDF's arithmetic per column and phase the leaves were bound by vector instructions, not by the LDS.
-	const KT pad = (KT)~(KT)0;
+	const CT pad = (CT)~(CT)0;
 	auto bounds = [&](u32 s, u32 &beg, u32 &cnt, u32 &nc, u32 &slot) {
 		slot = 0;
 		if (level == HYB_TWO_LEVEL) {
@@ -522,6 +530,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		const u32 g = (mine + 64 * G - 1) / (64 * G);
 		return g < ng ? g : ng;
 	};
+	// the keys arrive as the caller's images and are kept as derived keys, cut to the carried type
 	auto request = [&](auto &dst, u32 beg, u32 cnt, u32 slot) {
 		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);
 		const u32 ng = wave_groups(cnt, ngall);
@@ -530,10 +539,20 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 #pragma unroll
 		for (int g = 0; g < KPT / G; ++g) {
 			if (g < (int)ng) {
+				KT raw[G];
 #pragma unroll
 				for (int r = g * G; r < (g + 1) * G; ++r) {
 					const u32 i = wo + r * 64;
-					dst[r] = i < cnt ? p[i] : kdf_invert(pad, ka);
+					raw[r - g * G] = i < cnt ? p[i] : kdf_invert((KT)~(KT)0, ka);
+				}
+#pragma unroll
+				for (int r = g * G; r < (g + 1) * G; ++r) {
+					const KT k = kdf_apply(raw[r - g * G], ka);
+					dst[r] = (CT)k;
+					if constexpr (NARROW) {
+						if (r == 0 && tid == 0)   // the leaf's first key: its upper part is every key's
+							s_upper = (KT)(k >> (8 * sizeof(CT)) << (8 * sizeof(CT)));
+					}
 				}
 			}
 		}
@@ -543,16 +562,26 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		return;
 	u32 nbeg, ncnt, nnc, nslot;
 	bounds(s, nbeg, ncnt, nnc, nslot);
-	KT nxt[C::PREFETCH ? KPT : 1];
+	static_assert(!C::PREFETCH || !NARROW, "one upper part at a time");
+	CT nxt[C::PREFETCH ? KPT : 1];
 	if constexpr (C::PREFETCH)
 		request(nxt, nbeg, ncnt, nslot);
 	for (;;) {
 		const u32 beg = nbeg, cnt = ncnt, nrem = nnc, slot = nslot;
+		// is this leaf this instantiation's?  (all its columns -- ascending -- inside the carried type, or not)
+		const bool narrowable = nrem != 0 && ((colpack >> (4 * (nrem - 1))) & 15u) < 4u && sizeof(KT) == 8;
+		if ((NARROW && !narrowable) || (!NARROW && skip_narrowable && narrowable)) {
+			s += gridDim.x;
+			if (s >= nseg)
+				break;
+			bounds(s, nbeg, ncnt, nnc, nslot);
+			continue;
+		}
 		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);   // groups of rounds in a wave's slice
 		const u32 per = ngall * (64 * G);
 		const u32 ng = wave_groups(cnt, ngall);                  // ... and those this wave has keys in (wave-uniform)
 		const u32 wo0 = wid * per + lane;
-		KT keep[KPT];
+		CT keep[KPT];
 		if constexpr (C::PREFETCH) {
 #pragma unroll
 			for (int r = 0; r < KPT; ++r)
@@ -560,9 +589,6 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		} else {
 			request(keep, beg, cnt, slot);
 		}
-#pragma unroll
-		for (int r = 0; r < KPT; ++r)
-			keep[r] = kdf_apply(keep[r], ka);
 		s += gridDim.x;
 		const bool more = s < nseg;
 		if (more) {
@@ -662,14 +688,25 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		if (nrem) {
 			KT *o = out + beg;
 			for (u32 i0 = tid * CHUNK; i0 < cnt; i0 += BLOCK * CHUNK) {
-				typedef KT kvec_t __attribute__((ext_vector_type(CHUNK)));
+				typedef CT kvec_t __attribute__((ext_vector_type(CHUNK)));
 				const kvec_t x = *(const kvec_t *)&stage[i0];
 				KT kv[CHUNK];
 #pragma unroll
 				for (int e = 0; e < CHUNK; ++e)
-					kv[e] = kdf_invert((KT)x[e], ka);
+					kv[e] = kdf_invert(NARROW ? (KT)(s_upper | (KT)x[e]) : (KT)x[e], ka);
 				if (i0 + CHUNK <= cnt) {
-					store_chunk<KT, CHUNK>(o + i0, kv);
+					if constexpr (sizeof(KT) * CHUNK > 16) {   // (carried narrower than stored: two 16-byte stores)
+						KT lo2[CHUNK / 2], hi2[CHUNK / 2];
+#pragma unroll
+						for (int e = 0; e < CHUNK / 2; ++e) {
+							lo2[e] = kv[e];
+							hi2[e] = kv[CHUNK / 2 + e];
+						}
+						store_chunk<KT, CHUNK / 2>(o + i0, lo2);
+						store_chunk<KT, CHUNK / 2>(o + i0 + CHUNK / 2, hi2);
+					} else {
+						store_chunk<KT, CHUNK>(o + i0, kv);
+					}
 				} else {
 #pragma unroll
 					for (int e = 0; e < CHUNK; ++e)

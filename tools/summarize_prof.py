@@ -54,8 +54,10 @@ def algorithmic_bytes(name):
         val = SIZES.get(t[1], 0)
         kout = SIZES.get(t[-1], kin) if t[-1] in SIZES else kin
         return N * (kin + kout + 2 * val)
-    if "rsx_hist_kernel" in name and t:
+    if ("rsx_hist_kernel" in name or "rsx_seg_hist1_kernel" in name or "rsx_seg_hist_kernel" in name) and t:
         return N * SIZES.get(t[0], 0)
+    if "rsx_leaf_sort_kernel" in name and t:      # a leaf pass reads and writes every key once (rsx_hybrid.hpp)
+        return N * 2 * SIZES.get(t[0], 0)
     return None
 
 
