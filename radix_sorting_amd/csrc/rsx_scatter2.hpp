@@ -561,8 +561,13 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		if constexpr (SEG) {
 			if (flags & SCATTER_SEG_SLACK) {
 				running = ((u64)seg_bucket * 256 + tid) * seg.slack_cap + excl;
-				if (excl + st_cnt > (u64)seg.slack_cap)
+				if (excl + st_cnt > (u64)seg.slack_cap) {
+					// the slot is too small: the attempt will be discarded (rsx_seg_slack_plan_kernel sees the flag); this run
+					// goes to the dump area behind the last slot (a tile of padding), wherever the chain would have put it --
+					// a heavy bucket's runs must not walk over the end of the scratch array
 					atomicOr(seg.overflow, 1u);
+					running = (u64)65536 * seg.slack_cap;
+				}
 			} else {
 				running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;
 			}
@@ -768,6 +773,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			// payloads: same positions, through the same staging area
 			const bool gen_index = (flags & SCATTER_GEN_INDEX) != 0;
 			__syncthreads();
+			if (TL && tid == 0)
+				tl[(u64)stile * 16 + 8] = __builtin_readcyclecounter();   // keys written out
 #pragma unroll
 			for (int r0 = 0; r0 < KPT; r0 += SB) {
 				VT val[SB];
@@ -790,6 +797,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				}
 			}
 			__syncthreads();
+			if (TL && tid == 0)
+				tl[(u64)stile * 16 + 9] = __builtin_readcyclecounter();   // payloads staged
 #pragma unroll
 			for (int j = 0; j < KPT / CHUNK; ++j) {
 				if (j % 4 == 0)

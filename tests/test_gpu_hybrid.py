@@ -183,6 +183,11 @@ def test_slack_overflow_falls_back_to_the_counted_pass():
     a = ol.splitmix_fill(n, ol.U32, 23, 0xFFFFFFFF).view(np.uint32).copy()
     a[1000:1000 + 3000 * 7:7] = (a[1000:1000 + 3000 * 7:7] & np.uint32(0x0000FFFF)) | np.uint32(0x12340000)
     check(a, ol.U32, ol.ASC, 2, "one heavy (digit, digit) bucket")
+    # the LAST slot far too small (a hundred thousand keys with the top sixteen bits all ones): its runs must not be written
+    # behind the end of the scratch array
+    c = ol.splitmix_fill(n, ol.U32, 25, 0xFFFFFFFF).view(np.uint32).copy()
+    c[5:5 + 100000 * 3:3] |= np.uint32(0xFFFF0000)
+    check(c, ol.U32, ol.ASC, 3, "heavy last (digit, digit) bucket")
     b = ol.splitmix_fill(n, ol.U32, 24, 0xFFFFFFFF).view(np.uint32).copy()
     b = (b & np.uint32(0xFF00FFFF)) | ((b >> np.uint32(8)) & np.uint32(0x00FF0000))
     check(b, ol.U32, ol.DESC, 3, "top two bytes equal")

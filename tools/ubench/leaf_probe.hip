@@ -124,7 +124,7 @@ int main(int argc, char **argv)
 	for (u32 i = 0; i < nleaf; ++i) {
 		// ragged: sizes per +- 64 (what uniform keys give at 4096 per leaf), starts at any element
 		u32 sz = ragged ? per - 64 + (((i + 1) * 2654435761u) >> 25) : per;
-		if (i + 1 == nleaf || acc + sz > n)
+		if (acc + sz > n)   // (the sizes average a little below `per`: the array's tail stays unused in the ragged case)
 			sz = (u32)(n - acc);
 		seg[i] = LeafSeg{acc, sz, 2, 0};
 		acc += sz;
@@ -132,10 +132,15 @@ int main(int argc, char **argv)
 	}
 	CK(hipMemcpy(d_seg, seg.data(), (size_t)nleaf * sizeof(LeafSeg), hipMemcpyHostToDevice));
 	if (ragged) {
+		n = acc;   // what the leaves cover
+		CK(hipMemset(d_in, 0, ((size_t)1 << log2n) * 4));
 		hipLaunchKernelGGL(gen_ragged_kernel, dim3(nleaf), dim3(256), 0, 0, d_in, (const LeafSeg *)d_seg);
 		c.maxleaf = mx;
 		CK(hipMemcpy(d_ctl, &c, sizeof c, hipMemcpyHostToDevice));
 		printf("ragged leaves: %u - %u keys, starting at any element\n", per - 64, mx);
+		CK(hipMemset(d_chk, 0, 24));
+		hipLaunchKernelGGL(check_kernel, dim3(2048), dim3(256), 0, 0, (const u32 *)d_in, (u64)n, d_chk);
+		CK(hipMemcpy(ref_chk, d_chk, 24, hipMemcpyDeviceToHost));
 	}
 	CK(hipMemset(d_chk, 0, 24));
 	hipLaunchKernelGGL(check_kernel, dim3(2048), dim3(256), 0, 0, (const u32 *)d_in, (u64)n, d_chk);
