@@ -100,6 +100,7 @@ struct Env {
 	bool no_host_small = false;      // RSX_NO_HOST_SMALL (set)
 	bool no_fused_hist = false;      // RSX_NO_FUSED_HIST=1
 	bool no_slack = false;           // RSX_NO_SLACK=1
+	bool no_self_plan = false;       // RSX_NO_SELF_PLAN=1
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
 	{
@@ -124,6 +125,7 @@ struct Env {
 		no_host_small = is_set("RSX_NO_HOST_SMALL");
 		no_fused_hist = is_one("RSX_NO_FUSED_HIST");
 		no_slack = is_one("RSX_NO_SLACK");
+		no_self_plan = is_one("RSX_NO_SELF_PLAN");
 		two_level_min_log2 = 27;
 		if (const char *e = getenv("RSX_TWO_LEVEL_MIN_LOG2")) {
 			const int v = atoi(e);
@@ -205,6 +207,8 @@ struct Ctx {
 	DevBuf joint;       // 2-byte keys: [65536 u32 counts][65537 u64 offsets] of the 16-bit digit (rsx_joint16_kernel)
 	DevBuf seg;         // two-level sorts (rsx_hybrid.hpp): [SegCtl][per-bucket digit counts][status regions][leaf segments][tiles]
 	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0, seg_btile_off = 0;
+	SelfPlanArgs pass_sp{nullptr, nullptr, nullptr, nullptr, HybCaps{0, 0, 0, 0}};   // a self-planned pass 0 (SCATTER_SELF_PLAN)
+	DevBuf gscan;       // [256] u64: the highest kept column's offsets from a self-planned pass 0 (for the leaves)
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
 	DevBuf vasync;      // RSX_VERIFY: mismatches found in device-scheduled passes, kept until rsx_verify_poll / the next blocking sort
 	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
@@ -246,6 +250,7 @@ struct Ctx {
 	{
 		RSX_TRY(small.ensure(2 * SMALL_BYTES));
 		RSX_TRY(hist.ensure(2 * HIST_SET_BYTES));
+		RSX_TRY(gscan.ensure(256 * sizeof(u64)));
 		HIP_TRY(hipMemset(small.p, 0, 2 * SMALL_BYTES));   // (both sets start out zeroed: see `gen`)
 		HIP_TRY(hipMemset(hist.p, 0, 2 * HIST_SET_BYTES));
 		if (!host_plan)
@@ -289,6 +294,7 @@ struct Ctx {
 		seg.release();
 		slack.release();
 		vasync.release();
+		gscan.release();
 		if (host_segctl)
 			(void)hipHostFree(host_segctl);
 		host_segctl = dev_host_segctl = nullptr;
@@ -556,8 +562,10 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 
 template <typename KT>
 int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, size_t status_total = 0,
-               HybCaps caps = HybCaps{0, 0, 0, 0}, bool fuse_ok = false)
+               HybCaps caps = HybCaps{0, 0, 0, 0}, bool fuse_ok = false, bool *self_plan = nullptr)
 {
+	// self_plan (in: the caller would like pass 0 to derive the plan itself, SCATTER_SELF_PLAN; out: whether it has to):
+	// then only the histogram is enqueued here -- no plan kernel, no event
 	const size_t hist_bytes = sizeof(KT) * 256 * sizeof(u64);
 	if (c.hist.external)
 		RSX_TRY(c.hist.ensure(hist_bytes));
@@ -577,6 +585,8 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, siz
 		f.z2 = (u32x4 *)c.status.p;
 		f.n2 = status_total / 16;
 		RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted(), ~0u, &f));
+		if (self_plan && *self_plan)
+			return RSX_OK;
 		hipLaunchKernelGGL((rsx_plan_all_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, d_src, (u64)n, c.ghist(), ka, c.kept(),
 		                   c.hotd(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, caps);
 		HIP_TRY(hipGetLastError());
@@ -585,6 +595,8 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, siz
 		HIP_TRY(hipEventRecord(c.plan_ev, c.stream));
 		return RSX_OK;
 	}
+	if (self_plan)
+		*self_plan = false;
 	if (status_total) {
 		// flags, histogram and the status words of every pass of this sort in one launch
 		RSX_TRY(c.status.ensure(status_total));
@@ -663,7 +675,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
 	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, (u64 *)nullptr, dplan, pass_index,  \
-	                   oshift, (const u32 *)c.hotd(), SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr}, c.pass_alt)
+	                   oshift, (const u32 *)c.hotd(), SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr}, c.pass_alt, c.pass_sp)
 	// quarter tiles are for arrays of a few million keys: never 2^30 of them, and hot digits cost little there -- those
 	// instantiations are left out of the build
 	constexpr bool SMALL_CFG = C2::KPT < Sc2Cfg<KT, VT>::KPT;
@@ -880,7 +892,7 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 // fills the LDS; a launched shape does nothing unless the device-side plan has leaves of its size, so both may be enqueued
 // before the host knows (nothing then waits for the host).
 template <typename KT>
-int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level, u32 shapes)
+int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level, u32 shapes, const u64 *off1 = nullptr)
 {
 	typedef typename LeafShapes<KT>::Small S;
 	typedef typename LeafShapes<KT>::Big B;
@@ -899,18 +911,18 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			static_assert(N::CAP == S::CAP, "the narrow shape takes the small shape's leaves");
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, N, u32>), dim3(grid_s), dim3(N::BLOCK), 0, c.stream, src, aux, (u64)n,
 			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
-			                   c.slack_cap, 0u);
+			                   c.slack_cap, 0u, off1);
 			skip_narrowable = 1;
 		}
 	}
 	if (shapes & 1u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(grid_s), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
 		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
-		                   c.slack_cap, skip_narrowable);
+		                   c.slack_cap, skip_narrowable, off1);
 	if (shapes & 2u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, B>), dim3(grid_b), dim3(B::BLOCK), 0, c.stream, src, aux, (u64)n,
 		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)B::CAP, slots,
-		                   c.slack_cap);
+		                   c.slack_cap, 0u, off1);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
@@ -1153,11 +1165,27 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 		return hipGetLastError();
 	};
 	u32 spec_leaves = 0;
+	bool self_planned = false;
 	if (spec) {
 		// (the device may choose one MSB pass and leaves, rsx_hybrid.hpp: pass 0 then goes by the highest kept column)
 		const HybCaps caps = capture_armed() ? HybCaps{0, 0, 0, 0} : hybrid_caps<KT>(n);
-		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total, caps, true));
-		RSX_TRY((scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, fill_one ? SCATTER_ONE_COL_FILLED : 0, c.plan(), 0)));
+		// Mid-size arrays: pass 0 derives the plan itself (SCATTER_SELF_PLAN, rsx_scatter2.hpp) -- no plan launch.  (Not
+		// with a caller's histogram: its counts are read back from the scanned offsets a plan kernel leaves.)
+		self_planned = sizeof(KT) >= 4 && caps.cap1 != 0 && n <= ((size_t)1 << 23) && !fill_one && !env().no_self_plan;
+		RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total, caps, true, &self_planned));
+		u32 flags0 = fill_one ? (u32)SCATTER_ONE_COL_FILLED : 0u;
+		if (self_planned) {
+			flags0 |= SCATTER_SELF_PLAN;
+			c.pass_sp = SelfPlanArgs{(const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, (u64 *)c.gscan.p, caps};
+		}
+		const int rc0 = scatter_pass<KT, NoVal>(c, src, aux, nullptr, nullptr, n, 0, c.ghist(), ka, flags0, c.plan(), 0);
+		c.pass_sp = SelfPlanArgs{nullptr, nullptr, nullptr, nullptr, HybCaps{0, 0, 0, 0}};
+		RSX_TRY(rc0);
+		if (self_planned) {   // the plan is pass 0's workgroup 0's now
+			if (!c.plan_ev)
+				HIP_TRY(hipEventCreateWithFlags(&c.plan_ev, hipEventDisableTiming));
+			HIP_TRY(hipEventRecord(c.plan_ev, c.stream));
+		}
 		if (fill_one)
 			HIP_TRY(launch_fill());
 		if constexpr (sizeof(KT) >= 4) {
@@ -1165,7 +1193,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 			// (the large shape only where even spread keys would come near the small one's capacity; else after the wait)
 			if (caps.cap1 && n <= (size_t)256 * caps.cap1) {
 				spec_leaves = n / 256 > (size_t)LeafShapes<KT>::Small::CAP / 2 ? 3u : 1u;
-				RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, spec_leaves));
+				RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, spec_leaves, self_planned ? (const u64 *)c.gscan.p : nullptr));
 			}
 		}
 		RSX_TRY(plan_wait(c, &plan));
@@ -1201,7 +1229,7 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 				// one level: the leaves are on their way, unless they need a shape that was not enqueued
 				const u32 need = plan.max1 > (u32)LeafShapes<KT>::Small::CAP ? 2u : 1u;
 				if (!(spec_leaves & need))
-					RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, need));
+					RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, need, self_planned ? (const u64 *)c.gscan.p : nullptr));
 			}
 			*result = final;                     // radix_sort.hpp:92
 			if (info) {
@@ -1210,6 +1238,12 @@ int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, v
 			}
 			return RSX_OK;
 		}
+	}
+	if (self_planned && plan.ncols > 1) {
+		// one pass per kept column after a self-planned pass 0: the other columns' scans (and the hot digits) are made now
+		hipLaunchKernelGGL((rsx_plan_all_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, c.ghist(), ka, c.kept(),
+		                   c.hotd(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, HybCaps{0, 0, 0, 0});
+		HIP_TRY(hipGetLastError());
 	}
 	KT *cur = src, *oth = aux;
 	if (spec)

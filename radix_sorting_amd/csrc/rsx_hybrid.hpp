@@ -468,7 +468,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
                                                                   const LeafSeg *__restrict__ segtab,
                                                                   const SegCtl *__restrict__ ctl, KdfArgs<KT> ka, u32 level,
                                                                   u32 lo, u32 hi, const KT *__restrict__ slots = nullptr,
-                                                                  u32 slack_cap = 0, u32 skip_narrowable = 0)
+                                                                  u32 slack_cap = 0, u32 skip_narrowable = 0,
+                                                                  const u64 *__restrict__ off1_given = nullptr)
 {
 	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK;
 	constexpr bool NARROW = sizeof(CT) < sizeof(KT);
@@ -486,7 +487,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	const u32 nseg = level == HYB_TWO_LEVEL ? ctl->nleaf : 256u;
 	if (hyb != level || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi)
 		return;
-	const u64 *off1 = ghist + 256 * ((colpack >> (4 * (ncols - 1))) & 15u);
+	// the level-1 buckets' starts: the highest kept column's scanned offsets (from a self-planned pass 0: its own copy)
+	const u64 *off1 = off1_given ? off1_given : ghist + 256 * ((colpack >> (4 * (ncols - 1))) & 15u);
 	const KT *in = level == HYB_TWO_LEVEL ? src : aux;
 	KT *out = (ncols & 1) ? aux : src;
 

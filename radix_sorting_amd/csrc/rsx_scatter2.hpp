@@ -76,6 +76,8 @@ template <typename KT, typename VT, typename ST, typename C> struct Sc2Smem {
 	ST delta[C::TPS][256];              // global offset of a digit's run minus its tile-local offset
 	u32 wsum[C::TPS][4];
 	u32 ticket;
+	u32 smax;        // SCATTER_SELF_PLAN: the planned column's largest bin
+	u64 soff[256];   // SCATTER_SELF_PLAN: the planned column's exclusive offsets (instead of gbase[])
 };
 
 // DIG_PLAIN: the key is its own KDF (unsigned, ascending): the digit is one
@@ -127,6 +129,19 @@ struct SegArgs {
 	u32 *overflow;
 };
 
+// SCATTER_SELF_PLAN (pass 0 of a blocking keys-only sort of a mid-size array): no plan kernel has run.  `gbase` is the
+// histogram's RAW counts; every workgroup derives what it needs itself -- the kept columns from the bins of the first key's
+// digits (radix_sort.hpp:64-70), the largest bin of the highest kept column and with it the hybrid decision (rsx_hybrid.hpp),
+// the exclusive scan of the column it then sorts by (:72-80) -- a dozen scalar loads, 256 counts and one wave scan, while its
+// tile's keys are not needed yet; workgroup 0 also writes the plan (device + the host's pinned copy) and, for the leaves, the
+// scanned offsets.  A launch (and its gap) less: at 10^5 keys a sort is four launches of 5-7 us.
+struct SelfPlanArgs {
+	const u32 *unsorted;   // the histogram kernel's flag
+	Plan *plan, *host_plan;
+	u64 *gscan;            // [256] the highest kept column's exclusive offsets, when the plan is one MSB pass and leaves
+	HybCaps caps;
+};
+
 template <typename KT, typename VT, typename ST, typename C = Sc2Cfg<KT, VT>, bool TL = false, int DIG = DIG_GENERIC,
           bool HOT_ = false, typename KTO = KT, bool SEG = false>
 __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__restrict__ kin, KTO *__restrict__ kout,
@@ -136,7 +151,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
                                                                  u32 oshift = 0, const u32 *__restrict__ hotd = nullptr,
                                                                  SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr},
-                                                                 const void *__restrict__ kalt = nullptr)
+                                                                 const void *__restrict__ kalt = nullptr,
+                                                                 SelfPlanArgs sp = SelfPlanArgs{nullptr, nullptr, nullptr, nullptr,
+                                                                                                HybCaps{0, 0, 0, 0}})
 {
 	constexpr bool NARROW = !std::is_same<KTO, KT>::value;
 	static_assert(!SEG || (!NARROW && C::TPS == 1 && !HOT_), "segmented passes: plain tiles, keys of one type");
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		}
 		shift = 8 * dplan->cols[seg_slot];
 		gbase += 256 * dplan->cols[dplan->ncols - 1];   // the level-1 column's offsets: bucket starts
-	} else if (dplan) {
+	} else if (dplan && !(flags & SCATTER_SELF_PLAN)) {
 		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
 		if ((flags & SCATTER_ONE_COL_FILLED) && dplan->ncols == 1)
@@ -251,6 +268,88 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	__shared__ Sc2Smem<KT, VT, ST, C> sm;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const u64 t_start = TL ? __builtin_readcyclecounter() : 0;
+	bool self_planned = false;
+	if constexpr (!SEG && !NARROW && !HAS_VAL && !HOT_) {
+		if (flags & SCATTER_SELF_PLAN) {
+			constexpr u32 WC = sizeof(KT);
+			// everything that comes from memory is requested at once: the first key, the sorted flag, and every column's
+			// 256 counts (thread d < 256 holds digit d's) -- one round trip instead of three dependent ones
+			const KT key0raw = kin[0];
+			const u32 unsorted_flag = *sp.unsorted;
+			u64 cnts[WC];
+#pragma unroll
+			for (u32 c = 0; c < WC; ++c)
+				cnts[c] = tid < 256 ? gbase[256 * c + tid] : 0;
+			const KT key0 = kdf_apply(key0raw, ka);                     // radix_sort.hpp:65
+			u32 *const skept = (u32 *)&sm.cell[0][0][0] + 256;          // (scratch: the cells are zeroed further down)
+#pragma unroll
+			for (u32 c = 0; c < WC; ++c)
+				if (tid == ((u32)(key0 >> (8 * c)) & 0xFFu))
+					skept[c] = cnts[c] != n ? 1u : 0u;                  // :67
+			if (tid == 0)
+				sm.smax = 0;
+			__syncthreads();
+			u32 nc = 0;
+			u64 colpack = 0;                                            // 4 bits per kept column, LSB first (:66-69)
+#pragma unroll
+			for (u32 c = 0; c < WC; ++c)
+				if (skept[c]) {
+					colpack |= (u64)c << (4 * nc);
+					++nc;
+				}
+			const bool sorted = unsorted_flag == 0;                     // :60
+			const u32 top = nc ? (u32)(colpack >> (4 * (nc - 1))) & 15u : 0u;
+			u64 cnt_top = 0;
+#pragma unroll
+			for (u32 c = 0; c < WC; ++c)
+				if (c == top)
+					cnt_top = cnts[c];
+			if (tid < 256)
+				atomicMax(&sm.smax, cnt_top > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)cnt_top);
+			__syncthreads();
+			const u32 max1 = nc ? sm.smax : 0u;
+			const u32 hyb = (!sorted && n < (1ull << 30) && sp.caps.cap1 && nc >= sp.caps.min_cols1 && max1 <= sp.caps.cap1) ? 1u : 0u;
+			const u32 col = hyb ? top : (u32)colpack & 15u;              // one MSB pass and leaves go by the HIGHEST kept column
+			u64 cnt = 0;
+#pragma unroll
+			for (u32 c = 0; c < WC; ++c)
+				if (c == col)
+					cnt = cnts[c];
+			__syncthreads();                                            // (skept has been read by everybody)
+			if (tid < 256)
+				sm.soff[tid] = cnt;
+			__syncthreads();
+			if (tid < 64)
+				wave_scan_256(sm.soff, (u64 *)&sm.cell[0][0][0], tid);  // :72-80
+			__syncthreads();
+			if (blockIdx.x == 0) {
+				if (hyb && tid < 256)
+					sp.gscan[tid] = sm.soff[tid];
+				if (tid == 0) {
+					Plan *const out[2] = {sp.plan, sp.host_plan};
+#pragma unroll
+					for (int k = 0; k < 2; ++k) {
+						out[k]->ncols = nc;
+						out[k]->sorted = sorted ? 1u : 0u;
+						for (u32 i = 0; i < 8; ++i)
+							out[k]->cols[i] = i < nc ? (u32)(colpack >> (4 * i)) & 15u : 0u;
+						out[k]->hot = 0;
+						out[k]->vary_lo = out[k]->vary_hi = 0;
+						out[k]->hyb = hyb;
+						out[k]->max1 = max1;
+					}
+					__threadfence_system();
+				}
+			}
+			if (sorted || nc == 0)
+				return;                                                 // :60-62: `aux` stays untouched
+			if ((flags & SCATTER_ONE_COL_FILLED) && nc == 1)
+				return;
+			dcol = col;
+			shift = 8 * col;
+			self_planned = true;
+		}
+	}
 
 	if (tid == 0)
 		sm.ticket = atomicAdd(ticket, 1u);   // super-tiles are handed out in start order => look-back cannot deadlock
@@ -572,7 +671,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;
 			}
 		} else {
-			running = gbase[tid] + excl;
+			running = (self_planned ? sm.soff[tid] : gbase[tid]) + excl;
 		}
 #pragma unroll
 		for (int t = 0; t < TPS; ++t) {
