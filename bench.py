@@ -56,13 +56,15 @@ def load_baseline_metric():
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per scatter launch from the committed rocprofv3 --pmc passes, if any (profiles/pmc_scatter.json)."""
+    """HBM bytes per scatter launch from the committed rocprofv3 --pmc passes, if any (profiles/pmc_scatter.json), and
+    the commit those counters were measured at (PMC counters need rocprofv3 around the process: not a per-run reading)."""
     path = os.path.join(ROOT, "profiles", "pmc_scatter.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+            d = json.load(f)
+        return d["hbm_bytes_per_launch"], d.get("measured_at_commit")
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_model():
@@ -342,7 +344,8 @@ def main():
                 "kernel": "rsx_scatter2_kernel<u32,NoVal,u32>",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_per_launch(),
+                "traffic": pmc_traffic_per_launch()[0],
+                "traffic_measured_at_commit": pmc_traffic_per_launch()[1],
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(prof.scatter_launches),
             },
             "kernels": {
