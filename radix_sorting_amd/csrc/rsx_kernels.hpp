@@ -234,12 +234,21 @@ __device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *
 	u32 hyb = 0;
 	const u32 top = nc ? (u32)(colpack >> (4 * (nc - 1))) & 15u : 0u;
 	const u32 max1 = nc ? kept[16 + top] : 0;
+	// A column with a dominant digit (Plan::hot: one bin holds an eighth of the keys or more) among those the LEAVES would sort
+	// by keeps the sort on the pass kernels: 64 lanes on one LDS counter make a leaf column ten times slower, and the pass
+	// kernels have their ballot-ranked HOT form for such columns.  (A dominant digit in a column the MSB passes go by shows
+	// in the bucket sizes and is excluded by them.)
+	u32 keptmask = 0;
+	for (u32 i = 0; i < nc; ++i)
+		keptmask |= 1u << ((u32)(colpack >> (4 * i)) & 15u);   // (a skipped column is one bin with all n keys: not meant here)
+	const u32 hot_below1 = nc ? hot & keptmask & ~(1u << top) : 0u;
+	const u32 second = nc >= 2 ? (u32)(colpack >> (4 * (nc - 2))) & 15u : 0u;
+	const u32 hot_below2 = hot_below1 & ~(1u << second);
 	if (!sorted && n < (1ull << 30)) {
-		if (caps.cap1 && nc >= caps.min_cols1 && max1 <= caps.cap1) {
+		if (caps.cap1 && nc >= caps.min_cols1 && max1 <= caps.cap1 && !hot_below1) {
 			hyb = 1;
-		} else if (caps.cap2 && nc >= caps.min_cols2 && nc >= 2) {
+		} else if (caps.cap2 && nc >= caps.min_cols2 && nc >= 2 && !hot_below2) {
 			// the largest (digit, digit) bucket if the two top columns were independent; rsx_seg_plan_kernel has the last word
-			const u32 second = (u32)(colpack >> (4 * (nc - 2))) & 15u;
 			const u64 est = (u64)max1 * kept[16 + second] / n;
 			if (est <= caps.cap2 - caps.cap2 / 4)
 				hyb = 2;

@@ -286,8 +286,10 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			for (u32 c = 0; c < WC; ++c)
 				if (tid == ((u32)(key0 >> (8 * c)) & 0xFFu))
 					skept[c] = cnts[c] != n ? 1u : 0u;                  // :67
-			if (tid == 0)
+			if (tid == 0) {
 				sm.smax = 0;
+				skept[8] = 0;
+			}
 			__syncthreads();
 			u32 nc = 0;
 			u64 colpack = 0;                                            // 4 bits per kept column, LSB first (:66-69)
@@ -306,9 +308,16 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					cnt_top = cnts[c];
 			if (tid < 256)
 				atomicMax(&sm.smax, cnt_top > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)cnt_top);
+			// a dominant digit (an eighth of the keys or more, Plan::hot) in a column the leaves would sort by: no leaves
+			bool mine_hot = false;
+#pragma unroll
+			for (u32 c = 0; c < WC; ++c)
+				mine_hot |= c != top && skept[c] && cnts[c] >= n / 8 + 1;
+			if (mine_hot)
+				skept[8] = 1u;
 			__syncthreads();
 			const u32 max1 = nc ? sm.smax : 0u;
-			const u32 hyb = (!sorted && n < (1ull << 30) && sp.caps.cap1 && nc >= sp.caps.min_cols1 && max1 <= sp.caps.cap1) ? 1u : 0u;
+			const u32 hyb = (!sorted && n < (1ull << 30) && sp.caps.cap1 && nc >= sp.caps.min_cols1 && max1 <= sp.caps.cap1 && !skept[8]) ? 1u : 0u;
 			const u32 col = hyb ? top : (u32)colpack & 15u;              // one MSB pass and leaves go by the HIGHEST kept column
 			u64 cnt = 0;
 #pragma unroll

@@ -197,3 +197,17 @@ def test_slack_off_is_the_counted_pass(monkeypatch):
     a = ol.splitmix_fill((1 << 26) + 5, ol.U32, 31, 0xFFFFFFFF)
     monkeypatch.setenv("RSX_NO_SLACK", "1")
     check(a, ol.U32, ol.ASC, 2, "RSX_NO_SLACK=1")
+
+
+def test_a_dominant_digit_in_a_low_column_keeps_the_pass_kernels():
+    """Evenly spread top bytes, but 99 % of the keys share their LOW byte: a leaf would put 64 lanes on one LDS counter in
+    that column, the pass kernels rank such digits with ballots (HOT) -- the plan must keep the sort on them (hybrid 0)."""
+    rng = np.random.default_rng(8)
+    for n in (1000000, (1 << 23) + 9):
+        a = ol.splitmix_fill(n, ol.U32, 33, 0xFFFFFFFF).view(np.uint32).copy()
+        sel = rng.random(n) < 0.99
+        a[sel] &= np.uint32(0xFFFFFF00)
+        check(a, ol.U32, ol.ASC, 0, n)
+        b = a.copy()
+        b[sel] = (b[sel] & np.uint32(0xFFFF00FF)) | np.uint32(0x00004200)      # ... or their second byte
+        check(b, ol.U32, ol.DESC, 0, n)
