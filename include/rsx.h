@@ -27,15 +27,24 @@
  *   - Order is a stable sort by kdf(key): output element images are bit-exact
  *     copies of the input's (NaN payloads, -0.0), radix_sort.hpp:85-87.
  *
- * Environment switches (read by the library)
- *   RSX_VERIFY=1            after every host-scheduled scatter pass one tile is
- *                           re-ranked without LDS atomics and compared with the
- *                           pass's output; a mismatch fails the call (RSX_EVERIFY).
+ * Environment switches (read ONCE, at the library's first call; rsx_reload_env() reads them again)
+ *   RSX_VERIFY=1            after every scatter pass one tile is re-ranked without LDS
+ *                           atomics and compared with the pass's output; a mismatch fails
+ *                           the call (RSX_EVERIFY) -- at once for the blocking sorts (which
+ *                           then keep to one pass per kept column), at rsx_verify_poll() or
+ *                           the next blocking sort for the *_inplace_async ones.
+ *   RSX_VERIFY=2            every keys-only sort runs as usual (any route, see rsx_info.hybrid)
+ *                           and its RESULT is checked on the device: sorted, and the input's
+ *                           key sum and key mix (RSX_EVERIFY if not).
  *   RSX_FORCE_TABLE_RANK=1  use the table-ranked scatter kernel, which does not rely
  *                           on the lane order of returning LDS atomics (slower).
+ *   RSX_NO_HYBRID=1         one scatter pass per kept column always (the reference's loop);
+ *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
+ *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,
  *   RSX_NO_NARROW_KEYS
  *                           switch single optimisations off (tests).
+ *   RSX_COMPACT_BITS=1, RSX_HOST_REGISTER=1, RSX_ELEM_LOADS=1   opt-in variants.
  */
 #ifndef RSX_H
 #define RSX_H
@@ -66,7 +75,7 @@ enum {
 	RSX_ENODEVICE = -2,  /* no usable gfx950 device / HIP runtime failure  */
 	RSX_ENOMEM = -3,     /* device workspace allocation failed             */
 	RSX_EHIP = -4,       /* a HIP call failed (see rsx_last_error)         */
-	RSX_EVERIFY = -5     /* RSX_VERIFY=1: a pass disagreed with its re-computation */
+	RSX_EVERIFY = -5     /* RSX_VERIFY=1: a pass disagreed with its re-computation; RSX_VERIFY=2: a result is not the sorted input */
 };
 
 /* What the front half of rs_sort_main decided (radix_sort.hpp:48-80). */

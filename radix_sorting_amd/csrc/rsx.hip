@@ -87,6 +87,7 @@ struct Env {
 	bool host_register = false;      // RSX_HOST_REGISTER=1
 	bool force_table_rank = false;   // RSX_FORCE_TABLE_RANK=1
 	bool verify = false;             // RSX_VERIFY=1
+	bool verify_whole = false;       // RSX_VERIFY=2: keys-only sorts check their whole result (sortedness + checksums), any route
 	bool verify_inject = false;      // RSX_VERIFY_INJECT (set)
 	bool no_hot = false;             // RSX_NO_HOT (set)
 	bool elem_loads = false;         // RSX_ELEM_LOADS=1
@@ -112,6 +113,10 @@ struct Env {
 		host_register = is_one("RSX_HOST_REGISTER");
 		force_table_rank = is_one("RSX_FORCE_TABLE_RANK");
 		verify = is_one("RSX_VERIFY");
+		{
+			const char *e = getenv("RSX_VERIFY");
+			verify_whole = e && e[0] == '2';
+		}
 		verify_inject = is_set("RSX_VERIFY_INJECT");
 		no_hot = is_set("RSX_NO_HOT");
 		elem_loads = is_one("RSX_ELEM_LOADS");
@@ -210,6 +215,7 @@ struct Ctx {
 	SelfPlanArgs pass_sp{nullptr, nullptr, nullptr, nullptr, HybCaps{0, 0, 0, 0}};   // a self-planned pass 0 (SCATTER_SELF_PLAN)
 	DevBuf gscan;       // [256] u64: the highest kept column's offsets from a self-planned pass 0 (for the leaves)
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
+	DevBuf vsum;        // RSX_VERIFY=2: [descents, sum, mix] of the input and of the result
 	DevBuf vasync;      // RSX_VERIFY: mismatches found in device-scheduled passes, kept until rsx_verify_poll / the next blocking sort
 	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
 	u32 slack_cap = 0;
@@ -294,6 +300,7 @@ struct Ctx {
 		seg.release();
 		slack.release();
 		vasync.release();
+		vsum.release();
 		gscan.release();
 		if (host_segctl)
 			(void)hipHostFree(host_segctl);
@@ -1065,7 +1072,39 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 
 // ---- keys only -------------------------------------------------------------------
 template <typename KT>
+int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info);
+
+// RSX_VERIFY=2: the sort as it always runs (speculation, leaves, slack slots ...), bracketed by rsx_checksum_kernel on the
+// input and on the result: not sorted, or not the same keys -> RSX_EVERIFY.  (RSX_VERIFY=1 re-ranks a tile of every PASS and
+// therefore keeps to the pass kernels; this one is blind to where an error came from but covers every route.)
+template <typename KT>
 int sort_keys_device(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info)
+{
+	if (!env().verify_whole)
+		return sort_keys_device_impl<KT>(c, src, aux, n, dtype, order, result, info);
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	RSX_TRY(c.vsum.ensure(6 * sizeof(u64)));
+	u64 *vs = (u64 *)c.vsum.p;
+	HIP_TRY(hipMemsetAsync(vs, 0, 6 * sizeof(u64), c.stream));
+	hipLaunchKernelGGL((rsx_checksum_kernel<KT>), dim3(2048), dim3(256), 0, c.stream, (const KT *)src, (u64)n, ka, vs);
+	HIP_TRY(hipGetLastError());
+	RSX_TRY(sort_keys_device_impl<KT>(c, src, aux, n, dtype, order, result, info));
+	hipLaunchKernelGGL((rsx_checksum_kernel<KT>), dim3(2048), dim3(256), 0, c.stream, (const KT *)*result, (u64)n, ka, vs + 3);
+	HIP_TRY(hipGetLastError());
+	u64 h[6];
+	HIP_TRY(hipMemcpyAsync(h, vs, sizeof h, hipMemcpyDeviceToHost, c.stream));
+	HIP_TRY(hipStreamSynchronize(c.stream));
+	if (env().verify_inject)   // (test hook: the failure report end to end)
+		h[5] ^= 1;
+	if (h[3] != 0 || h[1] != h[4] || h[2] != h[5])
+		return fail(RSX_EVERIFY, "RSX_VERIFY=2: the result of a sort of %zu keys (route %u) is %s: %llu descents, key sum %s, key mix %s",
+		            n, info ? info->hybrid : 0u, h[3] ? "not sorted" : "not a permutation of the input", (unsigned long long)h[3],
+		            h[1] == h[4] ? "kept" : "changed", h[2] == h[5] ? "kept" : "changed");
+	return RSX_OK;
+}
+
+template <typename KT>
+int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	if (c.fast && n * sizeof(KT) <= SMALL_SORT_BYTES && !env().no_small_sort && !capture_armed()) {

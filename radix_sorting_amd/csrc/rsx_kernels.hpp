@@ -1116,6 +1116,35 @@ __global__ void rsx_iota_if_sorted_kernel(IT *dst, u64 n, const Plan *__restrict
 		dst[i] = (IT)i;
 }
 
+// RSX_VERIFY=2: the whole-result check of a keys-only sort.  out[0] += the descents of the derived keys (kdf(a[i]) > kdf(a[i+1])),
+// out[1] += their sum, out[2] ^= a mix of them: a sorted array with the input's sum and mix is the sorted input (keys-only:
+// equal keys are indistinguishable, so this is the whole contract) -- whichever route the sort took, leaves included.
+template <typename KT>
+__global__ __launch_bounds__(256) void rsx_checksum_kernel(const KT *__restrict__ a, u64 n, KdfArgs<KT> ka, u64 *out)
+{
+	u64 bad = 0, sum = 0, mix = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+		const KT k = kdf_apply(a[i], ka);
+		if (i + 1 < n && k > kdf_apply(a[i + 1], ka))
+			++bad;
+		sum += (u64)k;
+		mix ^= ((u64)k + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+	}
+	__shared__ u64 s[3];
+	if (threadIdx.x < 3)
+		s[threadIdx.x] = 0;
+	__syncthreads();
+	atomicAdd((unsigned long long *)&s[0], (unsigned long long)bad);
+	atomicAdd((unsigned long long *)&s[1], (unsigned long long)sum);
+	atomicXor((unsigned long long *)&s[2], (unsigned long long)mix);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicAdd((unsigned long long *)&out[0], (unsigned long long)s[0]);
+		atomicAdd((unsigned long long *)&out[1], (unsigned long long)s[1]);
+		atomicXor((unsigned long long *)&out[2], (unsigned long long)s[2]);
+	}
+}
+
 template <typename IT>
 __global__ void rsx_iota_kernel(IT *dst, u64 n)
 {

@@ -123,3 +123,40 @@ def test_async_verification_failure_is_reported_at_the_poll():
     out = _run(["-c", ASYNC_VERIFY_SCRIPT], {"RSX_VERIFY": "1", "RSX_VERIFY_INJECT": "1"})
     assert out.returncode != 0
     assert "rsx error -5" in out.stderr and "device-scheduled" in out.stderr, out.stderr
+
+
+WHOLE_VERIFY_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np, torch
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+carrier = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}
+def dev(a): return torch.from_numpy(np.ascontiguousarray(a).view(carrier[a.itemsize]).copy()).cuda()
+routes = set()
+for dt, n, mask in [(ol.U32, 100003, 0xFFFFFFFF), (ol.U32, 3000001, 0xFFFFFFFF), (ol.I32, 5000000, 0xFFFFFFFF), (ol.U32, (1 << 23) + 7, 0xFFFFFFFF),
+                    (ol.U64, (1 << 23) + 7, 0xFFFFFFFFFF), (ol.F32, 2000003, 0xFFFFFFFF), (ol.U32, (1 << 26) + 11, 0xFFFFFFFF),
+                    (ol.U16, 3000001, 0xFFFF), (ol.U32, 70000, 0x00FF00FF)]:
+    a = ol.splitmix_fill(n, dt, 25 + dt, mask)
+    for order in (0, 1):
+        src = dev(a); aux = torch.zeros_like(src)
+        res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)
+        torch.cuda.synchronize()
+        routes.add(int(info.hybrid))
+        if n <= 5000000:
+            assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), ol.oracle_sort(a, dt, order)[0])
+print("whole verify ok, routes", sorted(routes))
+""" % (ROOT, ROOT)
+
+
+def test_whole_result_verification_over_every_route():
+    """RSX_VERIFY=2: the sort as it always runs -- leaves, slack slots, speculation -- with its result checked on the device
+    (sorted, and the input's key sum and key mix): every route of csrc/rsx_hybrid.hpp under it."""
+    out = _run(["-c", WHOLE_VERIFY_SCRIPT], {"RSX_VERIFY": "2", "RSX_TWO_LEVEL_MIN_LOG2": "22"})
+    assert out.returncode == 0 and "whole verify ok, routes [0, 1, 2, 4]" in out.stdout, out.stdout + out.stderr
+
+
+def test_whole_result_verification_failure_is_reported():
+    out = _run(["-c", WHOLE_VERIFY_SCRIPT], {"RSX_VERIFY": "2", "RSX_VERIFY_INJECT": "1"})
+    assert out.returncode != 0
+    assert "rsx error -5" in out.stderr and "RSX_VERIFY=2" in out.stderr, out.stderr
