@@ -217,6 +217,7 @@ struct Ctx {
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
 	DevBuf vsum;        // RSX_VERIFY=2: [descents, sum, mix] of the input and of the result
 	DevBuf vasync;      // RSX_VERIFY: mismatches found in device-scheduled passes, kept until rsx_verify_poll / the next blocking sort
+	DevBuf slack_v;     // ... the payloads' slots (key + payload and rank sorts)
 	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
 	u32 slack_cap = 0;
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
@@ -299,6 +300,7 @@ struct Ctx {
 		joint.release();
 		seg.release();
 		slack.release();
+		slack_v.release();
 		vasync.release();
 		vsum.release();
 		gscan.release();
@@ -1347,6 +1349,86 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 	return RSX_OK;
 }
 
+// ---- two MSB passes and leaves for key + payload sorts and rank sorts (4-byte keys, 4-byte payloads; rsx_leaf_pairs_kernel) ----
+template <typename KT> HybCaps hybrid_caps_pairs(size_t n, size_t val_bytes_)
+{
+	HybCaps caps{0, 0, 0, 0};
+	// the slack route only, and only where a slot fits the pairs' leaf shape: 2^27 .. 2^28 pairs (cfg 4)
+	if (sizeof(KT) == 4 && val_bytes_ == 4 && hybrid_enabled() && !env().no_slack && n >= ((size_t)1 << env().two_level_min_log2) &&
+	    n <= ((size_t)1 << 28)) {
+		caps.cap2 = (u32)LeafShapes<KT>::Small::CAP;
+		caps.min_cols2 = 4;
+	}
+	return caps;
+}
+
+// Pass 1 (by the highest kept column) has written (k1, v1).  The second pass goes into slots, the leaves write the payloads
+// (and the keys, if kfinal) to (kfinal, vfinal).  *ok = false: a slot overflowed -- nothing the caller owns was written, it
+// sorts with one pass per column.
+template <typename KT, typename VT>
+int pairs_two_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, bool *ok)
+{
+	typedef Sc2Cfg<KT, VT> C2;
+	typedef LeafCfg<u32, 4, 20, 3> L;   // 5120 pairs: the slack slot of 2^28 pairs; three workgroups per CU
+	*ok = false;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const size_t st_bytes = 256 + rows * 256 * 4;
+	const size_t hist_bytes = (size_t)256 * (sizeof(KT) - 1) * 256 * sizeof(u32);
+	c.seg_hist_off = 256;
+	c.seg_status_off = c.seg_hist_off + hist_bytes;
+	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
+	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
+	c.seg_btile_off = c.seg_tiles_off + rows * sizeof(SegTile);
+	RSX_TRY(c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32)));
+	const u32 mean = (u32)(n >> 16);
+	const u32 cap = ((mean + mean / 4 + 255) / 256) * 256;
+	if (cap > (u32)L::CAP)
+		return RSX_OK;
+	if (c.slack.ensure(((size_t)65536 * cap + C2::TILE) * sizeof(KT)) != RSX_OK ||
+	    c.slack_v.ensure(((size_t)65536 * cap + C2::TILE) * sizeof(VT)) != RSX_OK) {
+		(void)hipGetLastError();
+		return RSX_OK;   // (no room for the slots: one pass per column)
+	}
+	SegCtl *ctl = (SegCtl *)c.seg.p;
+	SegTile *tiles = (SegTile *)((char *)c.seg.p + c.seg_tiles_off);
+	LeafSeg *segtab = (LeafSeg *)((char *)c.seg.p + c.seg_segtab_off);
+	u32 *btile = (u32 *)((char *)c.seg.p + c.seg_btile_off);
+	if (!c.seg_ev)
+		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
+	HIP_TRY(hipMemsetAsync(c.seg.p, 0, c.seg_status_off + st_bytes, c.stream));
+	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
+	                   (u32)C2::TILE, tiles, ctl, btile);
+	char *base = (char *)c.seg.p + c.seg_status_off;
+	SegArgs sa;
+	sa.ctl = ctl;
+	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
+	sa.tiles = tiles;
+	sa.slots = (u32)sizeof(KT) - 1;
+	sa.slack_cap = cap;
+	sa.overflow = &ctl->overflow;
+	{
+		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
+		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, KT, true>), dim3((unsigned)rows),
+		                   dim3(C2::BLOCK), 0, c.stream, k1, (KT *)c.slack.p, v1, (VT *)c.slack_v.p, (u64)n, 0u, (const u64 *)c.ghist(), 1u,
+		                   (u32 *)(base + 256), (u32 *)base, ka, (u32)SCATTER_SEG_SLACK, (u64 *)nullptr, (const Plan *)c.plan(), 0u, 0u,
+		                   (const u32 *)nullptr, sa);
+	}
+	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream, (const u32 *)(base + 256), (const u32 *)btile,
+	                   (const u64 *)c.ghist(), (const Plan *)c.plan(), ctl, segtab, cap, c.dev_host_segctl);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
+	{
+		ProfScope prof(2, (u64)n * (sizeof(KT) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
+		hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(8192), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+		                   (const VT *)c.slack_v.p, cap, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+		                   (const SegCtl *)ctl, ka);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventSynchronize(c.seg_ev));
+	*ok = c.host_segctl->mode == SEG_MODE_LEAVES;
+	return RSX_OK;
+}
+
 // ---- key + payload -----------------------------------------------------------------
 template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
@@ -1367,7 +1449,7 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 		return RSX_OK;
 	}
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, k0, n, ka, &plan));
+	RSX_TRY(plan_phase<KT>(c, k0, n, ka, &plan, 0, (c.fast && !capture_armed() && !verify_mode()) ? hybrid_caps_pairs<KT>(n, sizeof(VT)) : HybCaps{0, 0, 0, 0}));
 	info_from_plan(info, plan);
 	RSX_TRY(capture_hist(c, n, sizeof(KT)));
 	if (plan.sorted) {
@@ -1376,6 +1458,23 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 			info->ncols = 0;
 		}
 		return RSX_OK;
+	}
+	if constexpr (sizeof(KT) == 4 && sizeof(VT) == 4) {
+		if (plan.hyb == HYB_TWO_LEVEL) {
+			// two MSB passes (the second into slots) and leaves; on a slot's overflow: one pass per column, from (k0, v0) again
+			const u32 top = plan.cols[plan.ncols - 1];
+			RSX_TRY((scatter_pass<KT, VT>(c, k0, k1, v0, v1, n, 8 * top, c.ghist() + 256 * top, ka, 0u)));
+			const bool in_aux = (plan.ncols & 1) != 0;
+			bool ok = false;
+			RSX_TRY((pairs_two_level<KT, VT>(c, k1, v1, in_aux ? k1 : k0, in_aux ? v1 : v0, n, ka, &ok)));
+			if (ok) {
+				if (info) {
+					info->result_in_aux = in_aux;
+					info->hybrid = 4;
+				}
+				return RSX_OK;
+			}
+		}
 	}
 	KT *kc = k0, *ko = k1;
 	VT *vc = v0, *vo = v1;
@@ -1457,9 +1556,33 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		return RSX_OK;
 	}
 	Plan plan;
-	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan));
+	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan, 0,
+	                       (c.fast && want_half < 0 && !capture_armed() && !verify_mode() && !env().compact_bits)
+	                           ? hybrid_caps_pairs<KT>(n, sizeof(IT)) : HybCaps{0, 0, 0, 0}));
 	info_from_plan(info, plan);
 	RSX_TRY(capture_hist(c, n, sizeof(KT)));
+	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
+		if (!plan.sorted && plan.hyb == HYB_TWO_LEVEL && want_half < 0) {
+			// Keys spread over their top two columns (cfg 4 (i)): two MSB passes of (key, index) -- the first makes the indices,
+			// the second goes into slots -- and leaves that write the ranks where the parity rule says (radix_sort_rank.hpp:91).
+			// On a slot's overflow nothing has been written to that half: the ordinary passes follow.
+			const u32 P = plan.ncols, top = plan.cols[P - 1];
+			RSX_TRY(c.keys[0].ensure(n * sizeof(KT)));
+			IT *fin = (P & 1) ? ib + n : ib, *scratch = (P & 1) ? ib : ib + n;
+			RSX_TRY((scatter_pass<KT, IT>(c, src, (KT *)c.keys[0].p, (const IT *)fin, scratch, n, 8 * top, c.ghist() + 256 * top, ka,
+			                              (u32)SCATTER_GEN_INDEX)));
+			bool ok = false;
+			RSX_TRY((pairs_two_level<KT, IT>(c, (const KT *)c.keys[0].p, (const IT *)scratch, (KT *)nullptr, fin, n, ka, &ok)));
+			if (ok) {
+				*result = fin;
+				if (info) {
+					info->result_in_aux = fin != ib;
+					info->hybrid = 4;
+				}
+				return RSX_OK;
+			}
+		}
+	}
 	if (plan.sorted) {                       // radix_sort_rank.hpp:52,:55-57: first half = iota
 		hipLaunchKernelGGL((rsx_iota_kernel<IT>), dim3(1024), dim3(256), 0, c.stream, ib, (u64)n);
 		HIP_TRY(hipGetLastError());

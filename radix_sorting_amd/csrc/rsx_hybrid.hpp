@@ -743,4 +743,161 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	}
 }
 
+// ---- leaves of key + payload sorts (4-byte keys, 4-byte payloads: BASELINE.json's cfg 4) ------------------------------------
+// The slack route of a two-level sort for (key, payload) pairs and for rank sorts (payload = the element's index,
+// radix_sort_rank.hpp): two MSB passes of the key + payload pass kernel, the second into per-bucket slots of two scratch
+// arrays, then this kernel -- rsx_leaf_sort_kernel's algorithm with the pair carried as ONE 8-byte value, derived key in the
+// upper half (so a key column c is byte 4 + c of what is ranked) and the payload in the lower.  A leaf gathers from its slot
+// and writes the payloads (and, for pair sorts, the keys) to its place in the dense result.  Rank sorts do not want the keys.
+template <typename KT, typename VT, typename C>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const KT *__restrict__ kslots, const VT *__restrict__ vslots,
+                                                                           u32 slack_cap, KT *__restrict__ kout, VT *__restrict__ vout,
+                                                                           const Plan *__restrict__ plan,
+                                                                           const LeafSeg *__restrict__ segtab,
+                                                                           const SegCtl *__restrict__ ctl, KdfArgs<KT> ka)
+{
+	static_assert(sizeof(KT) == 4 && sizeof(VT) == 4, "pairs of 4-byte keys and 4-byte payloads");
+	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK, G = 4;
+	static_assert(KPT % G == 0, "whole groups of rounds");
+	if (plan->hyb != HYB_TWO_LEVEL || ctl->mode != SEG_MODE_LEAVES)
+		return;
+	u32 colpack = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		colpack |= (plan->cols[k] & 15u) << (4 * k);
+	const u32 nseg = ctl->nleaf;
+	__shared__ __attribute__((aligned(16))) u64 stage[C::CAP];
+	__shared__ u32 cell[NW][256];
+	__shared__ u32 wsum[4];
+	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const u32 swid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
+	auto opaque = [](u32 x) {
+		asm volatile("" : "+v"(x));
+		return x;
+	};
+	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+		const LeafSeg ls = segtab[s];
+		const u32 cnt = ls.cnt, nrem = ls.ncols;
+		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);
+		const u32 per = ngall * (64 * G);
+		const u32 first = swid * per;
+		const u32 mine = cnt > first ? cnt - first : 0u;
+		u32 ng = (mine + 64 * G - 1) / (64 * G);
+		ng = ng < ngall ? ng : ngall;
+		const u32 wo0 = wid * per + lane;
+		const KT *kp = kslots + (u64)(ls.slot - 1) * slack_cap;
+		const VT *vp = vslots + (u64)(ls.slot - 1) * slack_cap;
+		KT kr[KPT];
+		VT vr[KPT];
+		{
+			const u32 wo = opaque(wo0);
+#pragma unroll
+			for (int g = 0; g < KPT / G; ++g) {
+				if (g < (int)ng) {
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r) {
+						const u32 i = wo + r * 64;
+						kr[r] = i < cnt ? kp[i] : kdf_invert((KT)~(KT)0, ka);
+						vr[r] = i < cnt ? vp[i] : (VT)0;
+					}
+				}
+			}
+		}
+		u64 keep[KPT];   // derived key : payload (padding: all-ones keys, last in memory order: they stay behind the leaf's pairs)
+#pragma unroll
+		for (int r = 0; r < KPT; ++r)
+			keep[r] = ((u64)kdf_apply(kr[r], ka) << 32) | (u64)vr[r];
+		for (u32 c = 0; c < nrem; ++c) {
+			const u32 shift = 32 + 8 * ((colpack >> (4 * c)) & 15u);
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				cell[wid][lane + 64 * k] = 0;
+			u32 *wc = cell[wid];
+			u32 rk[KPT / 2];
+#pragma unroll
+			for (int i = 0; i < KPT / 2; ++i)
+				rk[i] = 0;
+#pragma unroll
+			for (int g = 0; g < KPT / G; ++g) {
+				if (g < (int)ng) {
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r) {
+						const u32 old = __hip_atomic_fetch_add(&wc[(u32)(keep[r] >> shift) & 0xFFu], 1u, __ATOMIC_RELAXED,
+						                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+						rk[r >> 1] |= old << (16 * (r & 1));
+					}
+				}
+			}
+			__syncthreads();
+			u32 tot = 0, incl = 0;
+			if (tid < 256) {
+#pragma unroll
+				for (int w = 0; w < NW; ++w)
+					tot += cell[w][tid];
+				u32 x = tot;
+#pragma unroll
+				for (int off = 1; off < 64; off <<= 1) {
+					const u32 y = __shfl_up(x, off);
+					if (lane >= (u32)off)
+						x += y;
+				}
+				incl = x;
+				if (lane == 63)
+					wsum[wid] = x;
+			}
+			__syncthreads();
+			if (tid < 256) {
+				u32 acc = incl - tot;
+				for (u32 w = 0; w < wid; ++w)
+					acc += wsum[w];
+#pragma unroll
+				for (int w = 0; w < NW; ++w) {
+					const u32 k = cell[w][tid];
+					cell[w][tid] = acc;
+					acc += k;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int g = 0; g < KPT / G; ++g) {
+				if (g < (int)ng) {
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r) {
+						const u32 pos = wc[(u32)(keep[r] >> shift) & 0xFFu] + ((rk[r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
+						stage[pos] = keep[r];
+					}
+				}
+			}
+			__syncthreads();
+			if (c + 1 < nrem) {
+				const u32 wo = opaque(wo0);
+#pragma unroll
+				for (int g = 0; g < KPT / G; ++g) {
+					if (g < (int)ng) {
+#pragma unroll
+						for (int r = g * G; r < (g + 1) * G; ++r)
+							keep[r] = stage[wo + r * 64];
+					}
+				}
+			}
+		}
+		// write out: two pairs (16 bytes of LDS) per lane and step; payloads (and keys) to the dense result
+		VT *vo = vout + ls.beg;
+		KT *ko = kout ? kout + ls.beg : nullptr;
+		for (u32 i0 = tid * 2; i0 < cnt; i0 += BLOCK * 2) {
+			typedef u64 pvec_t __attribute__((ext_vector_type(2)));
+			const pvec_t x = *(const pvec_t *)&stage[i0];
+			vo[i0] = (VT)(u32)x[0];
+			if (ko)
+				ko[i0] = kdf_invert((KT)(x[0] >> 32), ka);
+			if (i0 + 1 < cnt) {
+				vo[i0 + 1] = (VT)(u32)x[1];
+				if (ko)
+					ko[i0 + 1] = kdf_invert((KT)(x[1] >> 32), ka);
+			}
+		}
+		__syncthreads();   // the staged leaf has been read before the next one is staged
+	}
+}
+
 }  // namespace rsx

@@ -211,3 +211,56 @@ def test_a_dominant_digit_in_a_low_column_keeps_the_pass_kernels():
         b = a.copy()
         b[sel] = (b[sel] & np.uint32(0xFFFF00FF)) | np.uint32(0x00004200)      # ... or their second byte
         check(b, ol.U32, ol.DESC, 0, n)
+
+
+def _dev(a):
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(_CARRIER[a.itemsize]).copy()).cuda()
+
+
+@pytest.mark.parametrize("dt", [ol.F32, ol.U32, ol.I32], ids=["f32", "u32", "i32"])
+def test_rank_sort_two_levels_vs_oracle(dt):
+    """Rank sorts of 4-byte keys that spread over their top two bytes (cfg 4 (i)): two MSB passes of (key, index), the second
+    into slack slots, and leaves that carry the pair as one 8-byte value (rsx_leaf_pairs_kernel); ranks, returned half and
+    kept columns are the oracle's (radix_sort_rank.hpp:22-92, Listing 6 semantics)."""
+    n = (1 << 23) + 4567
+    for mask in (0xFFFFFFFF,):
+        a = ol.splitmix_fill(n, dt, 6, mask)
+        for order in (ol.ASC, ol.DESC):
+            ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+            ranks, info = rsa.radix_sort_rank(_dev(a), ib, dtype=dt, order=order)
+            torch.cuda.synchronize()
+            want, whalf, winfo, _ = ol.oracle_rank(a, dt, 4, order)
+            assert info.hybrid == 4, (dt, order, info.hybrid)
+            assert info.result_in_aux == whalf
+            assert info.kept_columns() == list(winfo.cols[:winfo.ncols])
+            assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), (dt, order)
+
+
+def test_pairs_sort_two_levels_vs_oracle():
+    """Key + payload sorts the same way: keys and payloads where the parity rule says, stable."""
+    n = (1 << 23) + 321
+    a = ol.splitmix_fill(n, ol.U32, 9, 0xFFFFFFFF).view(np.uint32).copy()
+    a &= np.uint32(0xFFFFFF0F)                      # duplicates: stability is observable through the payloads
+    for order in (ol.ASC, ol.DESC):
+        keys = _dev(a)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda") * 3 + 1
+        k, v, info = rsa.radix_sort_pairs(keys, torch.zeros_like(keys), vals, torch.zeros_like(vals), dtype=ol.U32, order=order)
+        torch.cuda.synchronize()
+        perm = ol.stable_argsort_by_kdf(a, ol.U32, order)
+        assert info.hybrid == 4, info.hybrid
+        assert np.array_equal(k.cpu().numpy().view(np.uint32), a[perm])
+        assert np.array_equal(v.cpu().numpy().astype(np.int64), perm.astype(np.int64) * 3 + 1)
+
+
+def test_rank_sort_slot_overflow_falls_back():
+    """One (digit, digit) bucket four times its share: the slot overflows, nothing has been written, the ordinary passes run."""
+    n = (1 << 23) + 99
+    a = ol.splitmix_fill(n, ol.U32, 23, 0xFFFFFFFF).view(np.uint32).copy()
+    a[1000:1000 + 1200 * 7:7] = (a[1000:1000 + 1200 * 7:7] & np.uint32(0x0000FFFF)) | np.uint32(0x12340000)
+    ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(_dev(a), ib, dtype=ol.U32)
+    torch.cuda.synchronize()
+    want, whalf, _, _ = ol.oracle_rank(a, ol.U32, 4)
+    assert info.hybrid == 0 and info.result_in_aux == whalf
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)
