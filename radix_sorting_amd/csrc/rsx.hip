@@ -872,6 +872,19 @@ int scatter_pass_to(Ctx &c, const KT *kin, void *kout, u32 out_bytes, const VT *
 template <typename KT> struct LeafShapes {
 	typedef LeafCfg<KT, 4, 32, sizeof(KT) == 8 ? 2 : 4, true, false> Small;   // 8 Ki keys: several workgroups per CU
 	typedef LeafCfg<KT, 16, sizeof(KT) == 8 ? 16 : 32> Big;      // as many keys as the LDS stages at once: one workgroup per CU
+	// 4-byte keys: a shape in between (16 Ki keys, two workgroups per CU) -- leaves of 8-16 Ki keys (2^29 keys in 65536 buckets)
+	// in the large shape were no faster than four passes.  8-byte keys: the small shape already holds 64 KiB.
+	static constexpr bool HAS_MEDIUM = sizeof(KT) == 4;
+	typedef LeafCfg<KT, 8, 32, 4, true, false> Medium;
+	// the shape (bit 0 small, bit 2 medium, bit 1 large) for leaves of up to `m` keys
+	static u32 shape_for(u32 m)
+	{
+		if (m <= (u32)Small::CAP)
+			return 1u;
+		if (HAS_MEDIUM && m <= (u32)Medium::CAP)
+			return 4u;
+		return 2u;
+	}
 };
 
 // RSX_NO_HYBRID=1: one pass per kept column whatever the keys look like (the reference's loop, radix_sort.hpp:82-90)
@@ -889,7 +902,7 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 			// and two host round trips are a fixed cost).  Between the reach of one level (about 7 Mi evenly spread keys)
 			// and that, one pass per kept column.
 			if (n >= ((size_t)1 << env().two_level_min_log2)) {
-				caps.cap2 = (u32)LeafShapes<KT>::Small::CAP;
+				caps.cap2 = (u32)LeafShapes<KT>::Big::CAP;   // (leaves beyond the small shape's 8 Ki keys take the large one)
 				caps.min_cols2 = 4;
 			}
 		}
@@ -928,9 +941,17 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(grid_s), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
 		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
 		                   c.slack_cap, skip_narrowable, off1);
+	typedef typename LeafShapes<KT>::Medium M;
+	const u32 big_lo = LeafShapes<KT>::HAS_MEDIUM ? (u32)M::CAP : (u32)S::CAP;
+	if constexpr (LeafShapes<KT>::HAS_MEDIUM) {
+		if (shapes & 4u)
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, M>), dim3(level == HYB_TWO_LEVEL ? 4096u : 256u), dim3(M::BLOCK), 0, c.stream, src,
+			                   aux, (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)M::CAP,
+			                   slots, c.slack_cap, 0u, off1);
+	}
 	if (shapes & 2u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, B>), dim3(grid_b), dim3(B::BLOCK), 0, c.stream, src, aux, (u64)n,
-		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)B::CAP, slots,
+		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, big_lo, (u32)B::CAP, slots,
 		                   c.slack_cap, 0u, off1);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
@@ -1018,7 +1039,7 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 			                   (const Plan *)c.plan(), ctl, segtab, cap, c.dev_host_segctl);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
-			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, cap <= (u32)LeafShapes<KT>::Small::CAP ? 1u : 2u));
+			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for(cap)));
 			HIP_TRY(hipEventSynchronize(c.seg_ev));
 			if (c.host_segctl->mode == SEG_MODE_LEAVES) {
 				*result = final;
@@ -1050,8 +1071,8 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	const SegCtl hc = *c.host_segctl;
 	if (hc.mode == SEG_MODE_LEAVES) {
-		if (hc.maxleaf > (u32)LeafShapes<KT>::Small::CAP)   // (rare: the leaves need the large shape)
-			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, 2u));
+		if (hc.maxleaf > (u32)LeafShapes<KT>::Small::CAP)   // (rare: the leaves need a larger shape)
+			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for(hc.maxleaf)));
 	} else {
 		// keys clustered in their top two columns: one pass per remaining column inside the level-1 buckets, LSB first
 		// (the counts of the columns below the level-2 one are only made now)
@@ -1233,7 +1254,7 @@ int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int ord
 			// one MSB pass and leaves, if the device-side plan says so: enqueued now, so that nothing waits for the host
 			// (the large shape only where even spread keys would come near the small one's capacity; else after the wait)
 			if (caps.cap1 && n <= (size_t)256 * caps.cap1) {
-				spec_leaves = n / 256 > (size_t)LeafShapes<KT>::Small::CAP / 2 ? 3u : 1u;
+				spec_leaves = n / 256 > (size_t)LeafShapes<KT>::Small::CAP / 2 ? (LeafShapes<KT>::HAS_MEDIUM ? 7u : 3u) : 1u;
 				RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, spec_leaves, self_planned ? (const u64 *)c.gscan.p : nullptr));
 			}
 		}
@@ -1268,7 +1289,7 @@ int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int ord
 				RSX_TRY(sort_keys_two_level<KT>(c, src, aux, n, ka, plan, &final, &how));
 			} else {
 				// one level: the leaves are on their way, unless they need a shape that was not enqueued
-				const u32 need = plan.max1 > (u32)LeafShapes<KT>::Small::CAP ? 2u : 1u;
+				const u32 need = LeafShapes<KT>::shape_for(plan.max1);
 				if (!(spec_leaves & need))
 					RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_ONE_LEVEL, need, self_planned ? (const u64 *)c.gscan.p : nullptr));
 			}

@@ -79,7 +79,7 @@ def test_one_level_vs_oracle(dt):
 
 def test_one_level_big_leaves():
     """Buckets beyond the small leaf's 8 Ki keys take the leaf that fills the LDS (32 Ki four-byte keys)."""
-    for n, dt in ((5000000, ol.U32), (7000000, ol.I32), (3000000, ol.U64)):
+    for n, dt in ((3000000, ol.U32), (5000000, ol.U32), (7000000, ol.I32), (3000000, ol.U64)):   # (the first: the 16 Ki-key shape)
         a = ol.splitmix_fill(n, dt, 77, (1 << (8 * ol.DTYPE_SIZE[dt])) - 1)
         for order in (ol.ASC, ol.DESC):
             check(a, dt, order, 1, (n, dt, order))

@@ -49,8 +49,8 @@ def main():
         c = res[o:o + CHUNK + 1] ^ SIGN   # unsigned order as signed
         ok &= bool((c[1:] >= c[:-1]).all().item())
     after = checksums(res)
-    print("n = %d: %.2f ms, %.1f Gkeys/s, ncols %d, sorted %s, sum/xor preserved %s" %
-          (n, dt * 1e3, n / dt / 1e9, info.ncols, ok, before == after))
+    print("n = %d: %.2f ms, %.1f Gkeys/s, ncols %d, route %d, sorted %s, sum/xor preserved %s" %
+          (n, dt * 1e3, n / dt / 1e9, info.ncols, info.hybrid, ok, before == after))
     sys.exit(0 if ok and before == after else 1)
 
 
