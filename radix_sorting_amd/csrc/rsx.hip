@@ -1374,9 +1374,13 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 template <typename KT> HybCaps hybrid_caps_pairs(size_t n, size_t val_bytes_)
 {
 	HybCaps caps{0, 0, 0, 0};
-	// the slack route only, and only where a slot fits the pairs' leaf shape: 2^27 .. 2^28 pairs (cfg 4)
-	if (sizeof(KT) == 4 && val_bytes_ == 4 && hybrid_enabled() && !env().no_slack && n >= ((size_t)1 << env().two_level_min_log2) &&
-	    n <= ((size_t)1 << 28)) {
+	if (sizeof(KT) != 4 || val_bytes_ != 4 || !hybrid_enabled())
+		return caps;
+	// one level where every bucket of the highest kept column fits the pairs' leaf (5120 pairs: up to about a million pairs)
+	caps.cap1 = 5120;
+	caps.min_cols1 = 3;
+	// two levels: the slack route only, and only where a slot fits the pairs' leaf shape: 2^27 .. 2^28 pairs (cfg 4)
+	if (!env().no_slack && n >= ((size_t)1 << env().two_level_min_log2) && n <= ((size_t)1 << 28)) {
 		caps.cap2 = (u32)LeafShapes<KT>::Small::CAP;
 		caps.min_cols2 = 4;
 	}
@@ -1450,6 +1454,19 @@ int pairs_two_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 	return RSX_OK;
 }
 
+// One MSB pass has written (k1, v1); the 256 buckets' pairs sorted by the remaining columns into (kfinal, vfinal).
+template <typename KT, typename VT>
+int pairs_one_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka)
+{
+	typedef LeafCfg<u32, 4, 20, 3> L;
+	ProfScope prof(2, (u64)n * (sizeof(KT) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
+	hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(256), dim3(L::BLOCK), 0, c.stream, k1, v1, 0u, kfinal, vfinal,
+	                   (const Plan *)c.plan(), (const LeafSeg *)nullptr, (const SegCtl *)nullptr, ka, (u32)HYB_ONE_LEVEL,
+	                   (const u64 *)c.ghist(), (u64)n);
+	HIP_TRY(hipGetLastError());
+	return RSX_OK;
+}
+
 // ---- key + payload -----------------------------------------------------------------
 template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
@@ -1481,6 +1498,18 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 		return RSX_OK;
 	}
 	if constexpr (sizeof(KT) == 4 && sizeof(VT) == 4) {
+		if (plan.hyb == HYB_ONE_LEVEL) {
+			// one MSB pass and the pairs' leaves (mid-size arrays)
+			const u32 top = plan.cols[plan.ncols - 1];
+			RSX_TRY((scatter_pass<KT, VT>(c, k0, k1, v0, v1, n, 8 * top, c.ghist() + 256 * top, ka, 0u)));
+			const bool in_aux = (plan.ncols & 1) != 0;
+			RSX_TRY((pairs_one_level<KT, VT>(c, k1, v1, in_aux ? k1 : k0, in_aux ? v1 : v0, n, ka)));
+			if (info) {
+				info->result_in_aux = in_aux;
+				info->hybrid = 1;
+			}
+			return RSX_OK;
+		}
 		if (plan.hyb == HYB_TWO_LEVEL) {
 			// two MSB passes (the second into slots) and leaves; on a slot's overflow: one pass per column, from (k0, v0) again
 			const u32 top = plan.cols[plan.ncols - 1];
@@ -1583,6 +1612,21 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 	info_from_plan(info, plan);
 	RSX_TRY(capture_hist(c, n, sizeof(KT)));
 	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
+		if (!plan.sorted && plan.hyb == HYB_ONE_LEVEL && want_half < 0) {
+			// mid-size arrays: one MSB pass of (key, index), which makes the indices, and the pairs' leaves write the ranks
+			const u32 P = plan.ncols, top = plan.cols[P - 1];
+			RSX_TRY(c.keys[0].ensure(n * sizeof(KT)));
+			IT *fin = (P & 1) ? ib + n : ib, *scratch = (P & 1) ? ib : ib + n;
+			RSX_TRY((scatter_pass<KT, IT>(c, src, (KT *)c.keys[0].p, (const IT *)fin, scratch, n, 8 * top, c.ghist() + 256 * top, ka,
+			                              (u32)SCATTER_GEN_INDEX)));
+			RSX_TRY((pairs_one_level<KT, IT>(c, (const KT *)c.keys[0].p, (const IT *)scratch, (KT *)nullptr, fin, n, ka)));
+			*result = fin;
+			if (info) {
+				info->result_in_aux = fin != ib;
+				info->hybrid = 1;
+			}
+			return RSX_OK;
+		}
 		if (!plan.sorted && plan.hyb == HYB_TWO_LEVEL && want_half < 0) {
 			// Keys spread over their top two columns (cfg 4 (i)): two MSB passes of (key, index) -- the first makes the indices,
 			// the second goes into slots -- and leaves that write the ranks where the parity rule says (radix_sort_rank.hpp:91).

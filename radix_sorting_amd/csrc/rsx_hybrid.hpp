@@ -565,10 +565,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		// never loaded is never looked at)
 		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);
 		const u32 wo = opaque(wid * (ngall * 64 * G) + lane);
-		const KT upper_raw = NARROW ? (KT)(first_raw >> (8 * sizeof(CT)) << (8 * sizeof(CT))) : (KT)0;
+		constexpr u32 CBITS = NARROW ? 8 * sizeof(CT) : 0;   // (0: nothing above the carried bits)
+		KT upper_raw = 0;
 		if constexpr (NARROW) {
+			upper_raw = (KT)(first_raw >> CBITS << CBITS);
 			if (tid == 0)   // what every derived key of this leaf has above its carried bits
-				s_upper = (KT)(kdf_apply(first_raw, ka) >> (8 * sizeof(CT)) << (8 * sizeof(CT)));
+				s_upper = (KT)(kdf_apply(first_raw, ka) >> CBITS << CBITS);
 		}
 #pragma unroll
 		for (int r = 0; r < KPT; ++r) {
@@ -749,23 +751,29 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 // arrays, then this kernel -- rsx_leaf_sort_kernel's algorithm with the pair carried as ONE 8-byte value, derived key in the
 // upper half (so a key column c is byte 4 + c of what is ranked) and the payload in the lower.  A leaf gathers from its slot
 // and writes the payloads (and, for pair sorts, the keys) to its place in the dense result.  Rank sorts do not want the keys.
+// level == HYB_ONE_LEVEL (mid-size arrays): the 256 buckets of ONE pass by the highest kept column, read where that pass wrote
+// them (kslots / vslots are then its dense output, the bounds the column's offsets in `ghist`).
 template <typename KT, typename VT, typename C>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const KT *__restrict__ kslots, const VT *__restrict__ vslots,
                                                                            u32 slack_cap, KT *__restrict__ kout, VT *__restrict__ vout,
                                                                            const Plan *__restrict__ plan,
                                                                            const LeafSeg *__restrict__ segtab,
-                                                                           const SegCtl *__restrict__ ctl, KdfArgs<KT> ka)
+                                                                           const SegCtl *__restrict__ ctl, KdfArgs<KT> ka,
+                                                                           u32 level = HYB_TWO_LEVEL,
+                                                                           const u64 *__restrict__ ghist = nullptr, u64 n = 0)
 {
 	static_assert(sizeof(KT) == 4 && sizeof(VT) == 4, "pairs of 4-byte keys and 4-byte payloads");
 	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK, G = 4;
 	static_assert(KPT % G == 0, "whole groups of rounds");
-	if (plan->hyb != HYB_TWO_LEVEL || ctl->mode != SEG_MODE_LEAVES)
+	if (plan->hyb != level || (level == HYB_TWO_LEVEL && ctl->mode != SEG_MODE_LEAVES))
 		return;
 	u32 colpack = 0;
 #pragma unroll
 	for (int k = 0; k < 8; ++k)
 		colpack |= (plan->cols[k] & 15u) << (4 * k);
-	const u32 nseg = ctl->nleaf;
+	const u32 ncols_all = plan->ncols;
+	const u32 nseg = level == HYB_TWO_LEVEL ? ctl->nleaf : 256u;
+	const u64 *off1 = ghist + 256 * ((colpack >> (4 * (ncols_all - 1))) & 15u);
 	__shared__ __attribute__((aligned(16))) u64 stage[C::CAP];
 	__shared__ u32 cell[NW][256];
 	__shared__ u32 wsum[4];
@@ -776,8 +784,19 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 		return x;
 	};
 	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
-		const LeafSeg ls = segtab[s];
+		LeafSeg ls;
+		if (level == HYB_TWO_LEVEL) {
+			ls = segtab[s];
+		} else {
+			const u64 b = off1[s], e = s == 255 ? n : off1[s + 1];
+			ls.beg = (u32)b;
+			ls.cnt = (u32)(e - b);
+			ls.ncols = ncols_all - 1;
+			ls.slot = 0;
+		}
 		const u32 cnt = ls.cnt, nrem = ls.ncols;
+		if (cnt == 0)
+			continue;
 		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);
 		const u32 per = ngall * (64 * G);
 		const u32 first = swid * per;
@@ -785,8 +804,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 		u32 ng = (mine + 64 * G - 1) / (64 * G);
 		ng = ng < ngall ? ng : ngall;
 		const u32 wo0 = wid * per + lane;
-		const KT *kp = kslots + (u64)(ls.slot - 1) * slack_cap;
-		const VT *vp = vslots + (u64)(ls.slot - 1) * slack_cap;
+		const KT *kp = ls.slot ? kslots + (u64)(ls.slot - 1) * slack_cap : kslots + ls.beg;
+		const VT *vp = ls.slot ? vslots + (u64)(ls.slot - 1) * slack_cap : vslots + ls.beg;
 		KT kr[KPT];
 		VT vr[KPT];
 		{

@@ -264,3 +264,28 @@ def test_rank_sort_slot_overflow_falls_back():
     want, whalf, _, _ = ol.oracle_rank(a, ol.U32, 4)
     assert info.hybrid == 0 and info.result_in_aux == whalf
     assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)
+
+
+@pytest.mark.parametrize("dt", [ol.U32, ol.F32, ol.I32], ids=["u32", "f32", "i32"])
+def test_rank_and_pairs_one_level_vs_oracle(dt):
+    """Mid-size rank sorts and key + payload sorts of 4-byte keys: one MSB pass of (key, payload) and the pairs' leaves."""
+    rng = np.random.default_rng(40 + dt)
+    for n in (20001, 100000, 500001, 1000000):
+        for mask in (0xFFFFFFFF, 0xFFFF00FF):
+            a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+            for order in (ol.ASC, ol.DESC):
+                ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+                ranks, info = rsa.radix_sort_rank(_dev(a), ib, dtype=dt, order=order)
+                torch.cuda.synchronize()
+                want, whalf, winfo, _ = ol.oracle_rank(a, dt, 4, order)
+                assert info.result_in_aux == whalf and info.kept_columns() == list(winfo.cols[:winfo.ncols]), (n, hex(mask), order)
+                assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), (n, hex(mask), order, info.hybrid)
+                if dt != ol.F32:
+                    assert info.hybrid == 1, (n, hex(mask), order, info.hybrid)
+        keys = _dev(a)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda") * 7 + 3
+        k, v, info = rsa.radix_sort_pairs(keys, torch.zeros_like(keys), vals, torch.zeros_like(vals), dtype=dt)
+        torch.cuda.synchronize()
+        perm = ol.stable_argsort_by_kdf(a, dt)
+        assert np.array_equal(k.cpu().numpy().view(np.uint32), a.view(np.uint32)[perm]), n
+        assert np.array_equal(v.cpu().numpy().astype(np.int64), perm.astype(np.int64) * 7 + 3), n
