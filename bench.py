@@ -338,6 +338,9 @@ def main():
                            2: "two MSB scatter passes, then the other kept columns per bucket in LDS (README.md:647-650)",
                            3: "one MSB scatter pass, then one pass per remaining column inside its buckets",
                            4: "two MSB scatter passes (the second into per-bucket slots, no second count), then the other kept "
+                              "columns per bucket in LDS (README.md:647-650)",
+                           5: "no histogram (a sample proves all columns kept and the input unsorted): two MSB scatter passes, both "
+                              "into per-bucket slots with the bucket sizes read off the look-back chains, then the other kept "
                               "columns per bucket in LDS (README.md:647-650)"}[how],
             },
             "roofline": {

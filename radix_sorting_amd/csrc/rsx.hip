@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <functional>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -83,6 +84,7 @@ KdfArgs<KT> make_kdf(int dtype, int order)
 
 // ---- the RSX_* switches of the environment, read ONCE per process (rsx_reload_env() reads them again: tests) ----------------
 // "set" switches are on when the variable exists, "=1" switches when its value starts with '1' (as documented in rsx.h).
+std::atomic<u32> g_env_epoch{0};   // bumped by rsx_reload_env()
 struct Env {
 	bool host_register = false;      // RSX_HOST_REGISTER=1
 	bool force_table_rank = false;   // RSX_FORCE_TABLE_RANK=1
@@ -102,6 +104,7 @@ struct Env {
 	bool no_fused_hist = false;      // RSX_NO_FUSED_HIST=1
 	bool no_slack = false;           // RSX_NO_SLACK=1
 	bool no_self_plan = false;       // RSX_NO_SELF_PLAN=1
+	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
 	{
@@ -131,6 +134,7 @@ struct Env {
 		no_fused_hist = is_one("RSX_NO_FUSED_HIST");
 		no_slack = is_one("RSX_NO_SLACK");
 		no_self_plan = is_one("RSX_NO_SELF_PLAN");
+		no_blind = is_one("RSX_NO_BLIND");
 		two_level_min_log2 = 27;
 		if (const char *e = getenv("RSX_TWO_LEVEL_MIN_LOG2")) {
 			const int v = atoi(e);
@@ -220,6 +224,10 @@ struct Ctx {
 	DevBuf slack_v;     // ... the payloads' slots (key + payload and rank sorts)
 	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
 	u32 slack_cap = 0;
+	DevBuf slack1;      // sorts without a histogram (sort_keys_blind): the level-1 pass's 256 slots of slack1_cap keys
+	u32 slack1_cap = 0;
+	u32 blind_skip = 0, blind_backoff = 0;   // ... sorts to go before the next attempt; doubled by every attempt that is called off
+	u32 env_epoch = 0;                       // ... forgotten when rsx_reload_env() has run since
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
 	hipEvent_t seg_ev = nullptr;
 	Plan *host_plan = nullptr;   // pinned, written by the kernels themselves (dev_host_plan: its device address)
@@ -300,6 +308,7 @@ struct Ctx {
 		joint.release();
 		seg.release();
 		slack.release();
+		slack1.release();
 		slack_v.release();
 		vasync.release();
 		vsum.release();
@@ -960,29 +969,39 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 // a pass inside the level-1 buckets (SEG instantiation of the pass kernel): j < 0 the one by the level-2 column (runs in
 // SEG_MODE_LEAVES), j >= 0 LSB-first pass j (runs in SEG_MODE_LSD).  aux -> src, src -> aux for odd j.
 // j == -2: the slack attempt (aux -> the slots of c.slack, no counts needed).
+// blind (a sort without a histogram, sort_keys_blind): 1 = its level-1 pass (`aux` = the caller's array -> the 256 slots of
+// c.slack1, by the top column, status region 1), 2 = its level-2 pass (j == -2, reading c.slack1 instead of `aux`).
 template <typename KT>
-int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, int j)
+int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, int j, int blind = 0)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
 	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
 	const size_t st_bytes = 256 + rows * 256 * 4;
-	char *base = (char *)c.seg.p + c.seg_status_off + (size_t)(j < 0 ? 0 : j) * st_bytes;
+	char *base = (char *)c.seg.p + c.seg_status_off + (size_t)(blind == 1 ? 1 : j < 0 ? 0 : j) * st_bytes;
 	SegArgs sa;
 	sa.ctl = (const SegCtl *)c.seg.p;
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
 	sa.tiles = (const SegTile *)((char *)c.seg.p + c.seg_tiles_off);
 	sa.slots = (u32)sizeof(KT) - 1;
-	sa.slack_cap = j == -2 ? c.slack_cap : 0u;
+	sa.slack_cap = blind == 1 ? c.slack1_cap : j == -2 ? c.slack_cap : 0u;
 	sa.overflow = &((SegCtl *)c.seg.p)->overflow;
 	if (j == -2)
 		src = (KT *)c.slack.p;
+	if (blind == 1)
+		src = (KT *)c.slack1.p;
+	if (blind == 2)
+		aux = (const KT *)c.slack1.p;
 	ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
 	const bool plain = ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0;
-	const u32 flags = j == -2 ? (u32)SCATTER_SEG_SLACK : j < 0 ? (u32)SCATTER_SEG_LEAVES : 0u;
+	u32 flags = j == -2 ? (u32)SCATTER_SEG_SLACK : j < 0 ? (u32)SCATTER_SEG_LEAVES : 0u;
+	if (blind)
+		flags |= SCATTER_BLIND | (blind == 1 ? (u32)SCATTER_BLIND_TOP : 0u);
 	const u32 pi = j < 0 ? 0u : (u32)j;
+	const unsigned grid = blind == 1 ? (unsigned)(rows - 256) : (unsigned)rows;
+	const u32 shift0 = blind == 1 ? 8 * ((u32)sizeof(KT) - 1) : 0u;
 #define RSX_LAUNCH_SEG(DIGV)                                                                                               \
-	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, KT, true>), dim3((unsigned)rows),       \
-	                   dim3(C2::BLOCK), 0, c.stream, aux, src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, 0u,         \
+	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, KT, true>), dim3(grid),                 \
+	                   dim3(C2::BLOCK), 0, c.stream, aux, src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift0,     \
 	                   (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,             \
 	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
 	if (plain)
@@ -994,10 +1013,8 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	return RSX_OK;
 }
 
-// The second level of a two-level sort.  Pass 1 (by the highest kept column, src -> aux) is on its way; `plan` says so.
-// Ends with the sorted keys in the buffer the reference's parity rule names (radix_sort.hpp:92); *result says which.
-template <typename KT>
-int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, const Plan &plan, KT **result, u32 *how)
+// where the parts of a two-level sort's device-side state lie in c.seg
+template <typename KT> int seg_layout(Ctx &c, size_t n)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
 	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
@@ -1008,7 +1025,18 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
 	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
 	c.seg_btile_off = c.seg_tiles_off + rows * sizeof(SegTile);
-	RSX_TRY(c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32)));
+	return c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32));
+}
+
+// The second level of a two-level sort.  Pass 1 (by the highest kept column, src -> aux) is on its way; `plan` says so.
+// Ends with the sorted keys in the buffer the reference's parity rule names (radix_sort.hpp:92); *result says which.
+template <typename KT>
+int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, const Plan &plan, KT **result, u32 *how)
+{
+	typedef Sc2Cfg<KT, NoVal> C2;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const size_t st_bytes = 256 + rows * 256 * 4;
+	RSX_TRY(seg_layout<KT>(c, n));
 	SegCtl *ctl = (SegCtl *)c.seg.p;
 	u32 *seghist = (u32 *)((char *)c.seg.p + c.seg_hist_off);
 	SegTile *tiles = (SegTile *)((char *)c.seg.p + c.seg_tiles_off);
@@ -1093,6 +1121,96 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 	return RSX_OK;
 }
 
+// ---- two MSB passes and leaves WITHOUT the histogram (rsx_hybrid.hpp, rsx_blind_precheck_kernel) -----------------------------
+// For the arrays a two-level sort is for (hybrid_caps: cap2), blocking keys-only sorts.  *done = 1: sorted, *result set.
+// *done = 0: called off (the sample did not prove what it has to, or a slot overflowed) -- `src` and `aux` are untouched and
+// the caller runs the ordinary path.  A context that has been called off skips the next attempts (1, 3, 7 ... 63 sorts).
+template <typename KT> bool blind_wanted(Ctx &c, size_t n)
+{
+	if constexpr (sizeof(KT) < 4)
+		return false;
+	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode())
+		return false;
+	const HybCaps caps = hybrid_caps<KT>(n);
+	if (caps.cap2 == 0 || n < ((size_t)1 << 22) || n >= ((size_t)1 << 30))
+		return false;
+	const u32 epoch = g_env_epoch.load();
+	if (c.env_epoch != epoch) {
+		c.env_epoch = epoch;
+		c.blind_skip = c.blind_backoff = 0;
+	}
+	if (c.blind_skip) {
+		--c.blind_skip;
+		return false;
+	}
+	return true;
+}
+
+template <typename KT>
+int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **result, rsx_info *info, int *done)
+{
+	typedef Sc2Cfg<KT, NoVal> C2;
+	*done = 0;
+	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
+	const u32 cap1 = ((mean1 + mean1 / 4 + 255) / 256) * 256;
+	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
+	if (cap2 > (u32)LeafShapes<KT>::Big::CAP)
+		return RSX_OK;
+	if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
+	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK) {
+		(void)hipGetLastError();   // (no room for the slots: the ordinary path)
+		return RSX_OK;
+	}
+	RSX_TRY(seg_layout<KT>(c, n));
+	RSX_TRY(c.gscan.ensure(256 * sizeof(u64)));
+	const u64 ntiles0 = (n + C2::TILE - 1) / C2::TILE;
+	const size_t st_bytes = 256 + (ntiles0 + 256) * 256 * 4;
+	SegCtl *ctl = (SegCtl *)c.seg.p;
+	SegTile *tiles = (SegTile *)((char *)c.seg.p + c.seg_tiles_off);
+	LeafSeg *segtab = (LeafSeg *)((char *)c.seg.p + c.seg_segtab_off);
+	u32 *btile = (u32 *)((char *)c.seg.p + c.seg_btile_off);
+	u64 *off1 = (u64 *)c.gscan.p;
+	if (!c.seg_ev)
+		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
+	c.host_segctl->mode = SEG_MODE_NONE;
+	c.slack1_cap = cap1;
+	c.slack_cap = cap2;
+	// control block, (unused) digit counts and the status words of both passes, zeroed together
+	HIP_TRY(hipMemsetAsync(c.seg.p, 0, c.seg_status_off + 2 * st_bytes, c.stream));
+	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl, c.plan(),
+	                   c.dev_host_plan);
+	RSX_TRY(launch_seg_pass<KT>(c, src, nullptr, n, ka, -2, 1));
+	hipLaunchKernelGGL((rsx_blind_counts_kernel<u32>), dim3(1), dim3(256), 0, c.stream,
+	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0, ctl, off1, cap1);
+	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
+	                   (u32)C2::TILE, tiles, ctl, btile, (const u64 *)off1, cap1);
+	RSX_TRY(launch_seg_pass<KT>(c, nullptr, nullptr, n, ka, -2, 2));
+	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
+	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
+	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, 1u);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
+	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for(cap2), (const u64 *)off1));
+	HIP_TRY(hipEventSynchronize(c.seg_ev));
+	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
+		c.blind_backoff = std::min<u32>(2 * c.blind_backoff + 1, 63);
+		c.blind_skip = c.blind_backoff;
+		c.slack_cap = 0;
+		return RSX_OK;
+	}
+	c.blind_backoff = 0;
+	const Plan plan = *c.host_plan;
+	info_from_plan(info, plan);
+	KT *final = (plan.ncols & 1) ? aux : src;   // radix_sort.hpp:92
+	*result = final;
+	if (info) {
+		info->result_in_aux = final == aux;
+		info->hybrid = 5u;
+	}
+	*done = 1;
+	return RSX_OK;
+}
+
 // ---- keys only -------------------------------------------------------------------
 template <typename KT>
 int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info);
@@ -1170,6 +1288,18 @@ int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int ord
 			if (info)
 				info->result_in_aux = 1;
 			return RSX_OK;
+		}
+	}
+	if constexpr (sizeof(KT) >= 4) {
+		// large arrays: two MSB passes and leaves without the histogram, where a sample of the keys allows it (rsx_hybrid.hpp)
+		if (!c.small.external && !env().no_speculation && blind_wanted<KT>(c, n)) {
+			int done = 0;
+			KT *res = nullptr;
+			RSX_TRY(sort_keys_blind<KT>(c, src, aux, n, ka, &res, info, &done));
+			if (done) {
+				*result = res;
+				return RSX_OK;
+			}
 		}
 	}
 	// The first pass is enqueued before the host knows the plan (it reads the device's copy and does nothing on
@@ -2427,6 +2557,7 @@ void rsx_reload_env(void)
 	std::lock_guard<std::mutex> lock(g_mu);
 	(void)env();
 	g_env.load();
+	g_env_epoch.fetch_add(1u);   // (contexts forget what they have learnt about their inputs: sort_keys_blind's back-off)
 }
 
 int rsx_profile_begin(void)

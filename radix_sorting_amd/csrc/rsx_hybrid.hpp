@@ -43,8 +43,10 @@ struct SegCtl {
 	u32 done;       // blocks of rsx_seg_plan_kernel that are through
 	u32 nleaf;      // leaves in segtab (rsx_seg_plan_kernel)
 	u32 overflow;   // slack attempt: a slot was too small (rsx_scatter2_kernel, SCATTER_SEG_SLACK)
-	u32 pad[10];
+	u32 blind;      // sorts without a histogram (rsx_blind_precheck_kernel): BLIND_GO while nothing speaks against going on
+	u32 pad[9];
 };
+enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
 
 // A leaf's keys: [beg, beg + cnt), sorted by the `ncols` lowest kept columns.  Level 2: a (digit, digit) bucket (ncols = all
 // columns below the level-2 one) or a run of small neighbouring ones of the same level-1 bucket (one column more).
@@ -85,17 +87,20 @@ __device__ __forceinline__ u32 block_scan_256(u32 v, u32 *s_w, u32 &tot)
 // bucket sizes (cheap) and writes its share of the tiles.
 __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restrict__ ghist, u64 n, const Plan *__restrict__ plan,
                                                             u32 tile, SegTile *__restrict__ tiles, SegCtl *__restrict__ ctl,
-                                                            u32 *__restrict__ btile)   // [257]: bucket k's tiles are [btile[k], btile[k + 1])
+                                                            u32 *__restrict__ btile,   // [257]: bucket k's tiles are [btile[k], btile[k + 1])
+                                                            const u64 *__restrict__ off1_given = nullptr, u32 blind_cap = 0)
 {
-	if (plan->hyb != HYB_TWO_LEVEL)
+	// blind_cap != 0 (a sort without a histogram): bucket k lies in ITS SLOT of blind_cap keys of the level-1 pass's output
+	// (rsx_scatter2_kernel, SCATTER_BLIND_TOP), its size from off1_given (rsx_blind_counts_kernel)
+	if (plan->hyb != HYB_TWO_LEVEL || (blind_cap && ctl->blind != BLIND_GO))
 		return;
 	__shared__ u32 s_size[256], s_tb[257], s_beg[256], s_w[4];
 	const u32 d = threadIdx.x;
-	const u64 *off1 = ghist + 256 * plan->cols[plan->ncols - 1];
+	const u64 *off1 = off1_given ? off1_given : ghist + 256 * plan->cols[plan->ncols - 1];
 	const u64 b = off1[d], e = d == 255 ? n : off1[d + 1];
 	const u32 size = (u32)(e - b);
 	s_size[d] = size;
-	s_beg[d] = (u32)b;
+	s_beg[d] = blind_cap ? d * blind_cap : (u32)b;
 	u32 total;
 	const u32 tb = block_scan_256((size + tile - 1) / tile, s_w, total);
 	s_tb[d] = tb;
@@ -381,14 +386,15 @@ template <typename ST>
 __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__restrict__ status, const u32 *__restrict__ btile,
                                                                  const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
                                                                  SegCtl *__restrict__ ctl, LeafSeg *__restrict__ segtab,
-                                                                 u32 slack_cap, SegCtl *host_ctl)
+                                                                 u32 slack_cap, SegCtl *host_ctl,
+                                                                 const u64 *__restrict__ off1_given = nullptr, u32 blind = 0)
 {
-	if (plan->hyb != HYB_TWO_LEVEL)
+	if (plan->hyb != HYB_TWO_LEVEL || (blind && ctl->blind != BLIND_GO))
 		return;
 	typedef StatusBits<ST> SB_;
 	__shared__ u32 s_w[4], s_max, s_slot, s_last;
 	const u32 d = threadIdx.x, b = blockIdx.x;
-	const u64 *off1 = ghist + 256 * plan->cols[plan->ncols - 1];
+	const u64 *off1 = off1_given ? off1_given : ghist + 256 * plan->cols[plan->ncols - 1];
 	const u32 t0 = btile[b], t1 = btile[b + 1];
 	u32 c = 0;
 	if (t1 > t0)
@@ -432,6 +438,115 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 			__threadfence_system();
 		}
 	}
+}
+
+// ---- sorts without a histogram ("blind") ------------------------------------------------------------------------------------
+// The histogram of radix_sort.hpp:47-58 serves three purposes: the pre-sorted exit (:60-62), the kept columns (:64-70) and the
+// offsets (:72-80).  For keys that spread evenly over ALL their columns -- BASELINE.json's headline, 2^28 uniform u32 keys --
+// a two-level sort needs none of its counts: both MSB passes write into slots of 1.25 times the expected bucket size and the
+// bucket sizes are read off the look-back chains.  What is left of the histogram's job is decided EXACTLY from a sample:
+//   * one descent among sampled neighbours proves the input unsorted (no early exit to honour);
+//   * two different bytes among the samples of a column prove the column kept (so all sizeof(KT) columns are, and the result
+//     lies where that many passes end, radix_sort.hpp:92).
+// If the sample proves both, and shows no sign of clustering (which would only cost the attempt: a slot that overflows sets
+// SegCtl::overflow and everything after it is skipped; the caller's array is only READ until the leaves, so the ordinary
+// histogram-first sort then starts from untouched input), the sort goes on without the 0.24 ms (of 1.85) the histogram's
+// read of 2^28 keys costs.  Otherwise the host runs the ordinary path and remembers not to try for a while.
+// One workgroup; 64 places spread over the array, 128 consecutive keys (8 per thread) at each: every place is an address
+// translation of its own, and 1024 scattered places took 14.6 us where this takes a third of that.
+template <typename KT>
+__global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka,
+                                                                  SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
+                                                                  Plan *host_plan)
+{
+	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
+	__shared__ u32 h[W][256];
+	__shared__ u32 s_desc, s_distinct[W], s_max[W];
+	const u32 tid = threadIdx.x;
+	for (u32 i = tid; i < W * 256; i += 1024)
+		(&h[0][0])[i] = 0;
+	if (tid < W) {
+		s_distinct[tid] = 0;
+		s_max[tid] = 0;
+	}
+	if (tid == 0)
+		s_desc = 0;
+	__syncthreads();
+	const u64 i0 = ((n - 16 * S) / 63) * (tid >> 4) + (tid & 15u) * S;   // (n >= 2^20: the places do not overlap)
+	KT k[S];
+#pragma unroll
+	for (u32 e = 0; e < S; ++e)
+		k[e] = kdf_apply(src[i0 + e], ka);
+	bool desc = false;
+#pragma unroll
+	for (u32 e = 0; e < S; ++e) {
+		if (e)
+			desc |= k[e] < k[e - 1];
+#pragma unroll
+		for (u32 c = 0; c < W; ++c)
+			atomicAdd(&h[c][(u32)(k[e] >> (8 * c)) & 0xFFu], 1u);
+	}
+	if (__ballot(desc) && (tid & 63) == 0)
+		s_desc = 1;
+	__syncthreads();
+	if (tid < 256) {
+#pragma unroll
+		for (u32 c = 0; c < W; ++c) {
+			const u32 v = h[c][tid];
+			const u64 m = __ballot(v != 0);
+			if ((tid & 63) == 0)
+				atomicAdd(&s_distinct[c], (u32)__popcll(m));
+			atomicMax(&s_max[c], v);
+		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		bool go = s_desc != 0;
+		for (u32 c = 0; c < W; ++c) {
+			go = go && s_distinct[c] >= 2;
+			// the two columns the MSB passes go by: no digit with twice its share of the sample (a slot holds 1.25 times the
+			// mean); the columns the leaves sort by: no digit with a tenth of the sample (Plan::hot: lanes queue at one counter)
+			go = go && s_max[c] <= (c + 2 >= W ? 2 * NS / 256 : NS / 10);
+		}
+		ctl->blind = go ? BLIND_GO : BLIND_FAILED;
+		if (go) {
+			Plan *const out[2] = {plan, host_plan};
+			for (int j = 0; j < 2; ++j) {
+				out[j]->ncols = W;
+				out[j]->sorted = 0;
+				for (u32 i = 0; i < 8; ++i)
+					out[j]->cols[i] = i < W ? i : 0u;
+				out[j]->hot = 0;
+				out[j]->vary_lo = out[j]->vary_hi = 0;
+				out[j]->hyb = HYB_TWO_LEVEL;
+				out[j]->max1 = 0;
+			}
+		}
+	}
+}
+
+// After the blind level-1 pass: the inclusive prefix of the LAST tile is the count of every digit of the top column.  Writes
+// their exclusive scan (the buckets' places in the dense result, what `ghist` would hold: radix_sort.hpp:72-80) to off1[256];
+// a slot that overflowed ends the attempt.
+template <typename ST>
+__global__ __launch_bounds__(256) void rsx_blind_counts_kernel(const ST *__restrict__ status, u32 ntiles, SegCtl *__restrict__ ctl,
+                                                               u64 *__restrict__ off1, u32 cap)
+{
+	if (ctl->blind != BLIND_GO)
+		return;
+	typedef StatusBits<ST> SB_;
+	__shared__ u32 s_w[4], s_max;
+	const u32 d = threadIdx.x;
+	if (d == 0)
+		s_max = 0;
+	const u32 c = (u32)(__hip_atomic_load(status + ((u64)(ntiles - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SB_::VALMASK);
+	u32 total;
+	const u32 o = block_scan_256(c, s_w, total);
+	off1[d] = o;
+	atomicMax(&s_max, c);
+	__syncthreads();
+	if (d == 0 && (s_max > cap || ctl->overflow != 0))
+		ctl->blind = BLIND_FAILED;
 }
 
 // ---- the leaves ---------------------------------------------------------------------------------------------------------

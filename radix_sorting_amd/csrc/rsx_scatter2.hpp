@@ -167,10 +167,15 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	u32 dcol = 0;
 	u32 seg_slot = 0;
 	if constexpr (SEG) {
-		if (dplan->hyb != HYB_TWO_LEVEL)
-			return;
+		if ((flags & SCATTER_BLIND) && seg.ctl->blind != BLIND_GO)
+			return;   // (a sort without a histogram that has been called off: rsx_hybrid.hpp)
 		const u32 mode = seg.ctl->mode;
-		if (flags & SCATTER_SEG_SLACK) {    // the pass by the level-2 column into slots of the scratch array, before anything is decided
+		if (flags & SCATTER_BLIND_TOP) {
+			// the level-1 pass of such a sort: by the column `shift` names (the top one), no plan, no offsets
+			seg_slot = 0;
+		} else if (dplan->hyb != HYB_TWO_LEVEL) {
+			return;
+		} else if (flags & SCATTER_SEG_SLACK) {    // the pass by the level-2 column into slots of the scratch array, before anything is decided
 			seg_slot = dplan->ncols - 2;
 		} else if (flags & SCATTER_SEG_LEAVES) {   // the pass by the level-2 column, aux -> src; enqueued before the host knows the mode
 			if (mode != SEG_MODE_LEAVES)
@@ -186,8 +191,10 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				kout = (KTO *)const_cast<KT *>(t);
 			}
 		}
-		shift = 8 * dplan->cols[seg_slot];
-		gbase += 256 * dplan->cols[dplan->ncols - 1];   // the level-1 column's offsets: bucket starts
+		if (!(flags & SCATTER_BLIND_TOP)) {
+			shift = 8 * dplan->cols[seg_slot];
+			gbase += 256 * dplan->cols[dplan->ncols - 1];   // the level-1 column's offsets: bucket starts
+		}
 	} else if (dplan && !(flags & SCATTER_SELF_PLAN)) {
 		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
@@ -360,8 +367,11 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		}
 	}
 
-	if (tid == 0)
+	if (tid == 0) {
 		sm.ticket = atomicAdd(ticket, 1u);   // super-tiles are handed out in start order => look-back cannot deadlock
+		if constexpr (SEG)   // (blind level-1 pass: has a slot overflowed already?  one answer for the whole workgroup)
+			sm.smax = (flags & SCATTER_BLIND_TOP) ? __hip_atomic_load(seg.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+	}
 	constexpr int CW = C::CELL16 ? 128 : 256;   // words per (tile, wave)
 	for (u32 i = tid; i < TPS * NWAVES * CW; i += BLOCK)
 		(&sm.cell[0][0][0])[i] = 0;
@@ -380,13 +390,25 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		end = n;
 	u32 seg_first = 0, seg_bucket = 0;
 	if constexpr (SEG) {
-		if (stile >= seg.ctl->ntiles)
-			return;
-		const SegTile st = seg.tiles[stile];
-		beg = st.beg;
-		end = beg + st.cnt;
-		seg_first = st.first;
-		seg_bucket = st.bucket;
+		if (flags & SCATTER_BLIND_TOP) {
+			// plain tiles, one bucket (the whole array), the chain ends at tile 0
+			if (beg >= n)
+				return;
+			if (sm.smax) {
+				// the attempt is lost (a slot overflowed): pass the chain on and leave -- what this pass writes is discarded
+				if (tid < 256)
+					__hip_atomic_store(status + (stile * 256u + tid), (ST)ST_PREFIX << SB_::SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+		} else {
+			if (stile >= seg.ctl->ntiles)
+				return;
+			const SegTile st = seg.tiles[stile];
+			beg = st.beg;
+			end = beg + st.cnt;
+			seg_first = st.first;
+			seg_bucket = st.bucket;
+		}
 	}
 	const u32 wofs = wid * (64 * KPT) + lane;   // wave w owns [w*64*KPT, +64*KPT) of a tile; round r: element 64 r + lane
 	// Element `base + wofs + 64 r` of an array: a uniform (scalar) address for (base, r) plus ONE 32-bit lane offset,
@@ -674,7 +696,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					// goes to the dump area behind the last slot (a tile of padding), wherever the chain would have put it --
 					// a heavy bucket's runs must not walk over the end of the scratch array
 					atomicOr(seg.overflow, 1u);
-					running = (u64)65536 * seg.slack_cap;
+					running = (u64)((flags & SCATTER_BLIND_TOP) ? 256u : 65536u) * seg.slack_cap;
 				}
 			} else {
 				running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;

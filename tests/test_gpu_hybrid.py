@@ -51,6 +51,8 @@ def _two_levels_from_4mi(monkeypatch):
     """Two levels pay from 2^27 keys on and that is where the library starts using them; the tests lower the threshold to
     2^22 (RSX_TWO_LEVEL_MIN_LOG2) so that every branch runs at sizes the oracle sorts in a second."""
     monkeypatch.setenv("RSX_TWO_LEVEL_MIN_LOG2", "22")
+    # (the routes these tests name start with the histogram; the sorts without one have their own tests at the end)
+    monkeypatch.setenv("RSX_NO_BLIND", "1")
     yield
 
 
@@ -289,3 +291,64 @@ def test_rank_and_pairs_one_level_vs_oracle(dt):
         perm = ol.stable_argsort_by_kdf(a, dt)
         assert np.array_equal(k.cpu().numpy().view(np.uint32), a.view(np.uint32)[perm]), n
         assert np.array_equal(v.cpu().numpy().astype(np.int64), perm.astype(np.int64) * 7 + 3), n
+
+
+# ---- sorts without a histogram (rsx_blind_precheck_kernel ... ; info.hybrid == 5) -------------------------------------------
+@pytest.fixture
+def blind_on(monkeypatch):
+    monkeypatch.setenv("RSX_NO_BLIND", "0")   # (also makes the context forget earlier attempts: rsx_reload_env)
+    yield monkeypatch
+
+
+@pytest.mark.parametrize("dt", WIDE, ids=lambda d: ol.DTYPE_NAMES[d] if hasattr(ol, "DTYPE_NAMES") else str(d))
+def test_blind_two_levels_vs_oracle(dt, blind_on):
+    """Keys that spread over all their columns: no histogram kernel runs, the sample proves what the plan needs, both MSB
+    passes write into slots; result, returned buffer, kept columns as the oracle's."""
+    for n in ((1 << 22) + 777, 6000001):
+        for order in (ol.ASC, ol.DESC):
+            a = ol.splitmix_fill(n, dt, 1000 + n % 97 + order, (1 << (8 * ol.DTYPE_SIZE[dt])) - 1)
+            check(a, dt, order, 5, (n, dt, order))
+
+
+def test_blind_called_off_by_the_sample(blind_on):
+    """What the sample cannot prove sends the sort down the ordinary path: sorted input (early exit, `aux` untouched), a
+    constant column (a different returned buffer), a dominant top digit, a hot low column."""
+    n = (1 << 22) + 4321
+    base = ol.splitmix_fill(n, ol.U32, 77, 0xFFFFFFFF).view(np.uint32)
+    srt = np.sort(base)
+    info = check(srt, ol.U32, ol.ASC, 0, "sorted")
+    assert info.early_exit == 2
+    for name, a in (("low byte constant", base & np.uint32(0xFFFFFF00)),
+                    ("column 2 constant", base & np.uint32(0xFF00FFFF)),
+                    ("half the keys in top digit 0", np.where(base & 1 == 1, base & np.uint32(0x00FFFFFF), base)),
+                    ("low byte 7/8 zero", np.where(base & 0x700 != 0, base & np.uint32(0xFFFFFF00), base))):
+        for _ in range(3):   # (the attempt, the skipped sort after it, the next attempt)
+            info = check(np.ascontiguousarray(a.astype(np.uint32)), ol.U32, ol.ASC, None, name)
+            assert info.hybrid != 5, (name, info.hybrid)
+
+
+def test_blind_called_off_by_an_overflowing_slot(blind_on):
+    """Clustering the sample does not see: a top digit with 1.6 times its share overflows its level-1 slot, a (digit, digit)
+    pair with five times its share its level-2 slot.  The attempt has only read the caller's array: the ordinary sort follows
+    and the next sort of this context does not try."""
+    n = (1 << 22) + 99
+    base = ol.splitmix_fill(n, ol.U32, 78, 0xFFFFFFFF).view(np.uint32).copy()
+    a = base.copy()
+    extra = np.flatnonzero((a >> 24) == 0x11)[: int(0.6 * n / 256)]
+    a[extra] = (a[extra] & np.uint32(0x00FFFFFF)) | np.uint32(0x77000000)
+    b = base.copy()
+    b[5000:5000 + 300 * 11:11] = (b[5000:5000 + 300 * 11:11] & np.uint32(0x0000FFFF)) | np.uint32(0x43210000)
+    for name, x in (("level 1", a), ("level 2", b)):
+        blind_on.setenv("RSX_NO_BLIND", "0")
+        info = check(x, ol.U32, ol.ASC, None, name)
+        assert info.hybrid != 5, (name, info.hybrid)
+        u = ol.splitmix_fill(n, ol.U32, 79, 0xFFFFFFFF)
+        assert check(u, ol.U32, ol.ASC, None, "after").hybrid != 5     # (skipped: one sort after the first failure)
+        assert check(u, ol.U32, ol.ASC, None, "after").hybrid == 5     # (tried again, and kept)
+
+
+def test_blind_whole_result_verification(blind_on):
+    """RSX_VERIFY=2 brackets the sort with checksums whatever its route."""
+    blind_on.setenv("RSX_VERIFY", "2")
+    a = ol.splitmix_fill((1 << 22) + 5, ol.U32, 80, 0xFFFFFFFF)
+    check(a, ol.U32, ol.ASC, 5, "verify=2")
