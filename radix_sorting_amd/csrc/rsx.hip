@@ -224,9 +224,12 @@ struct Ctx {
 	DevBuf slack_v;     // ... the payloads' slots (key + payload and rank sorts)
 	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
 	u32 slack_cap = 0;
+	DevBuf slack1_v;    // ... and of as many payloads (pairs_blind)
 	DevBuf slack1;      // sorts without a histogram (sort_keys_blind): the level-1 pass's 256 slots of slack1_cap keys
 	u32 slack1_cap = 0;
-	u32 blind_skip = 0, blind_backoff = 0;   // ... sorts to go before the next attempt; doubled by every attempt that is called off
+	// ... sorts to go before the next attempt, doubled by every attempt that is called off; per kind of sort (4- / 8-byte keys,
+	// keys + payload): what one kind's inputs look like says nothing about another's
+	u32 blind_skip[4] = {0, 0, 0, 0}, blind_backoff[4] = {0, 0, 0, 0};
 	u32 env_epoch = 0;                       // ... forgotten when rsx_reload_env() has run since
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
 	hipEvent_t seg_ev = nullptr;
@@ -309,6 +312,7 @@ struct Ctx {
 		seg.release();
 		slack.release();
 		slack1.release();
+		slack1_v.release();
 		slack_v.release();
 		vasync.release();
 		vsum.release();
@@ -1124,23 +1128,33 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 // ---- two MSB passes and leaves WITHOUT the histogram (rsx_hybrid.hpp, rsx_blind_precheck_kernel) -----------------------------
 // For the arrays a two-level sort is for (hybrid_caps: cap2), blocking keys-only sorts.  *done = 1: sorted, *result set.
 // *done = 0: called off (the sample did not prove what it has to, or a slot overflowed) -- `src` and `aux` are untouched and
-// the caller runs the ordinary path.  A context that has been called off skips the next attempts (1, 3, 7 ... 63 sorts).
-template <typename KT> bool blind_wanted(Ctx &c, size_t n)
+// the caller runs the ordinary path.  A context that has been called off skips the next attempts of its kind (1, 3, 7 ... 31 sorts).
+template <typename KT> HybCaps hybrid_caps_pairs(size_t n, size_t val_bytes_);
+template <typename KT> constexpr int blind_kind(size_t payload_bytes) { return (payload_bytes ? 2 : 0) + (sizeof(KT) == 8 ? 1 : 0); }
+inline void blind_called_off(Ctx &c, int kind)
+{
+	c.blind_backoff[kind] = std::min<u32>(2 * c.blind_backoff[kind] + 1, 31);
+	c.blind_skip[kind] = c.blind_backoff[kind];
+}
+template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes = 0)
 {
 	if constexpr (sizeof(KT) < 4)
 		return false;
-	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode())
+	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() ||
+	    c.small.external || env().no_speculation)
 		return false;
-	const HybCaps caps = hybrid_caps<KT>(n);
+	const HybCaps caps = payload_bytes ? hybrid_caps_pairs<KT>(n, payload_bytes) : hybrid_caps<KT>(n);
 	if (caps.cap2 == 0 || n < ((size_t)1 << 22) || n >= ((size_t)1 << 30))
 		return false;
 	const u32 epoch = g_env_epoch.load();
 	if (c.env_epoch != epoch) {
 		c.env_epoch = epoch;
-		c.blind_skip = c.blind_backoff = 0;
+		for (int k = 0; k < 4; ++k)
+			c.blind_skip[k] = c.blind_backoff[k] = 0;
 	}
-	if (c.blind_skip) {
-		--c.blind_skip;
+	const int kind = blind_kind<KT>(payload_bytes);
+	if (c.blind_skip[kind]) {
+		--c.blind_skip[kind];
 		return false;
 	}
 	return true;
@@ -1175,15 +1189,14 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	c.host_segctl->mode = SEG_MODE_NONE;
 	c.slack1_cap = cap1;
 	c.slack_cap = cap2;
-	// control block, (unused) digit counts and the status words of both passes, zeroed together
-	HIP_TRY(hipMemsetAsync(c.seg.p, 0, c.seg_status_off + 2 * st_bytes, c.stream));
-	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl, c.plan(),
-	                   c.dev_host_plan);
+	// the sample (workgroup 0: control block, plan) and the zeroing of both passes' status words, one launch
+	static_assert(sizeof(SegCtl) <= 256, "the control block is not part of what is zeroed");
+	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl,
+	                   c.plan(), c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16));
 	RSX_TRY(launch_seg_pass<KT>(c, src, nullptr, n, ka, -2, 1));
-	hipLaunchKernelGGL((rsx_blind_counts_kernel<u32>), dim3(1), dim3(256), 0, c.stream,
-	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0, ctl, off1, cap1);
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
-	                   (u32)C2::TILE, tiles, ctl, btile, (const u64 *)off1, cap1);
+	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
+	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0);
 	RSX_TRY(launch_seg_pass<KT>(c, nullptr, nullptr, n, ka, -2, 2));
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
@@ -1193,12 +1206,11 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for(cap2), (const u64 *)off1));
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
-		c.blind_backoff = std::min<u32>(2 * c.blind_backoff + 1, 63);
-		c.blind_skip = c.blind_backoff;
+		blind_called_off(c, blind_kind<KT>(0));
 		c.slack_cap = 0;
 		return RSX_OK;
 	}
-	c.blind_backoff = 0;
+	c.blind_backoff[blind_kind<KT>(0)] = 0;
 	const Plan plan = *c.host_plan;
 	info_from_plan(info, plan);
 	KT *final = (plan.ncols & 1) ? aux : src;   // radix_sort.hpp:92
@@ -1292,7 +1304,7 @@ int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int ord
 	}
 	if constexpr (sizeof(KT) >= 4) {
 		// large arrays: two MSB passes and leaves without the histogram, where a sample of the keys allows it (rsx_hybrid.hpp)
-		if (!c.small.external && !env().no_speculation && blind_wanted<KT>(c, n)) {
+		if (blind_wanted<KT>(c, n)) {
 			int done = 0;
 			KT *res = nullptr;
 			RSX_TRY(sort_keys_blind<KT>(c, src, aux, n, ka, &res, info, &done));
@@ -1597,6 +1609,94 @@ int pairs_one_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 	return RSX_OK;
 }
 
+// Rank sorts and key + payload sorts without the histogram (sort_keys_blind's scheme with the (key, payload) pass kernel and
+// the pairs' leaves): both MSB passes into slots -- the first reads the caller's (kin, vin), or makes the indices (vin ==
+// nullptr) --, the leaves write to (kfinal, vfinal).  *done = 0: called off, nothing the caller owns has been written.
+template <typename KT, typename VT>
+int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, rsx_info *info, int *done)
+{
+	typedef Sc2Cfg<KT, VT> C2;
+	typedef LeafCfg<u32, 4, 20, 3> L;
+	*done = 0;
+	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
+	const u32 cap1 = ((mean1 + mean1 / 4 + 255) / 256) * 256;
+	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
+	if (cap2 > (u32)L::CAP)
+		return RSX_OK;
+	if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
+	    c.slack1_v.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(VT)) != RSX_OK ||
+	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK ||
+	    c.slack_v.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(VT)) != RSX_OK) {
+		(void)hipGetLastError();
+		return RSX_OK;
+	}
+	RSX_TRY(seg_layout<KT>(c, n));   // (Sc2Cfg<KT, NoVal> and <KT, VT> have the same tile: 32 Ki elements)
+	static_assert((int)C2::TILE == (int)Sc2Cfg<KT, NoVal>::TILE, "one layout for both");
+	RSX_TRY(c.gscan.ensure(256 * sizeof(u64)));
+	const u64 ntiles0 = (n + C2::TILE - 1) / C2::TILE;
+	const u64 rows = ntiles0 + 256;
+	const size_t st_bytes = 256 + rows * 256 * 4;
+	SegCtl *ctl = (SegCtl *)c.seg.p;
+	SegTile *tiles = (SegTile *)((char *)c.seg.p + c.seg_tiles_off);
+	LeafSeg *segtab = (LeafSeg *)((char *)c.seg.p + c.seg_segtab_off);
+	u32 *btile = (u32 *)((char *)c.seg.p + c.seg_btile_off);
+	u64 *off1 = (u64 *)c.gscan.p;
+	if (!c.seg_ev)
+		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
+	c.host_segctl->mode = SEG_MODE_NONE;
+	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, kin, (u64)n, ka, ctl, c.plan(),
+	                   c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16));
+	SegArgs sa;
+	sa.ctl = ctl;
+	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
+	sa.tiles = tiles;
+	sa.slots = (u32)sizeof(KT) - 1;
+	sa.overflow = &ctl->overflow;
+	char *base0 = (char *)c.seg.p + c.seg_status_off, *base1 = base0 + st_bytes;
+	{
+		ProfScope prof(1, (u64)n * (2 * sizeof(KT) + (vin ? 2 : 1) * sizeof(VT)), c.stream);
+		sa.slack_cap = cap1;
+		const u32 flags = (u32)SCATTER_SEG_SLACK | (u32)SCATTER_BLIND | (u32)SCATTER_BLIND_TOP | (vin ? 0u : (u32)SCATTER_GEN_INDEX);
+		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, KT, true>), dim3((unsigned)ntiles0),
+		                   dim3(C2::BLOCK), 0, c.stream, kin, (KT *)c.slack1.p, vin, (VT *)c.slack1_v.p, (u64)n, 8 * ((u32)sizeof(KT) - 1),
+		                   (const u64 *)c.ghist(), 1u, (u32 *)(base1 + 256), (u32 *)base1, ka, flags, (u64 *)nullptr,
+		                   (const Plan *)c.plan(), 0u, 0u, (const u32 *)nullptr, sa);
+	}
+	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
+	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1, (const u32 *)(base1 + 256), (u32)ntiles0);
+	{
+		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
+		sa.slack_cap = cap2;
+		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, KT, true>), dim3((unsigned)rows),
+		                   dim3(C2::BLOCK), 0, c.stream, (const KT *)c.slack1.p, (KT *)c.slack.p, (const VT *)c.slack1_v.p,
+		                   (VT *)c.slack_v.p, (u64)n, 0u, (const u64 *)c.ghist(), 1u, (u32 *)(base0 + 256), (u32 *)base0, ka,
+		                   (u32)SCATTER_SEG_SLACK | (u32)SCATTER_BLIND, (u64 *)nullptr, (const Plan *)c.plan(), 0u, 0u,
+		                   (const u32 *)nullptr, sa);
+	}
+	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream, (const u32 *)(base0 + 256), (const u32 *)btile,
+	                   (const u64 *)c.ghist(), (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, 1u);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
+	{
+		ProfScope prof(2, (u64)n * (sizeof(KT) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
+		hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(8192), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+		                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+		                   (const SegCtl *)ctl, ka);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventSynchronize(c.seg_ev));
+	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
+		blind_called_off(c, blind_kind<KT>(sizeof(VT)));
+		return RSX_OK;
+	}
+	c.blind_backoff[blind_kind<KT>(sizeof(VT))] = 0;
+	info_from_plan(info, *c.host_plan);
+	if (info)
+		info->hybrid = 5u;
+	*done = 1;
+	return RSX_OK;
+}
+
 // ---- key + payload -----------------------------------------------------------------
 template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
@@ -1615,6 +1715,18 @@ int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtyp
 			info->result_in_aux = p.ncols & 1;
 		}
 		return RSX_OK;
+	}
+	if constexpr (sizeof(KT) == 4 && sizeof(VT) == 4) {
+		if (blind_wanted<KT>(c, n, sizeof(VT))) {
+			// all sizeof(KT) columns kept (pairs_blind: the sample proves it): the result lies where an even number of passes ends
+			int done = 0;
+			RSX_TRY((pairs_blind<KT, VT>(c, k0, v0, k0, v0, n, ka, info, &done)));
+			if (done) {
+				if (info)
+					info->result_in_aux = 0;
+				return RSX_OK;
+			}
+		}
 	}
 	Plan plan;
 	RSX_TRY(plan_phase<KT>(c, k0, n, ka, &plan, 0, (c.fast && !capture_armed() && !verify_mode()) ? hybrid_caps_pairs<KT>(n, sizeof(VT)) : HybCaps{0, 0, 0, 0}));
@@ -1734,6 +1846,18 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		}
 		*result = (p.ncols & 1) ? ib + n : ib;   // radix_sort_rank.hpp:91 (sorted: first half = iota)
 		return RSX_OK;
+	}
+	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
+		if (want_half < 0 && !env().compact_bits && blind_wanted<KT>(c, n, sizeof(IT))) {
+			int done = 0;
+			RSX_TRY((pairs_blind<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, info, &done)));
+			if (done) {   // four kept columns: the ranks are in the first half (radix_sort_rank.hpp:91)
+				*result = ib;
+				if (info)
+					info->result_in_aux = 0;
+				return RSX_OK;
+			}
+		}
 	}
 	Plan plan;
 	RSX_TRY(plan_phase<KT>(c, src, n, ka, &plan, 0,

@@ -88,19 +88,38 @@ __device__ __forceinline__ u32 block_scan_256(u32 v, u32 *s_w, u32 &tot)
 __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restrict__ ghist, u64 n, const Plan *__restrict__ plan,
                                                             u32 tile, SegTile *__restrict__ tiles, SegCtl *__restrict__ ctl,
                                                             u32 *__restrict__ btile,   // [257]: bucket k's tiles are [btile[k], btile[k + 1])
-                                                            const u64 *__restrict__ off1_given = nullptr, u32 blind_cap = 0)
+                                                            u64 *__restrict__ off1_out = nullptr, u32 blind_cap = 0,
+                                                            const u32 *__restrict__ status0 = nullptr, u32 ntiles0 = 0)
 {
-	// blind_cap != 0 (a sort without a histogram): bucket k lies in ITS SLOT of blind_cap keys of the level-1 pass's output
-	// (rsx_scatter2_kernel, SCATTER_BLIND_TOP), its size from off1_given (rsx_blind_counts_kernel)
+	// blind_cap != 0 (a sort without a histogram): no offsets exist.  The inclusive prefix of the LAST tile of the level-1 pass
+	// (rsx_scatter2_kernel, SCATTER_BLIND_TOP; status0) is the size of every bucket; bucket k lies in ITS SLOT of blind_cap keys
+	// of that pass's output.  The sizes' exclusive scan -- the buckets' places in the dense result, what `ghist` would hold
+	// (radix_sort.hpp:72-80) -- goes to off1_out[256]; a slot that overflowed ends the attempt.
 	if (plan->hyb != HYB_TWO_LEVEL || (blind_cap && ctl->blind != BLIND_GO))
 		return;
 	__shared__ u32 s_size[256], s_tb[257], s_beg[256], s_w[4];
 	const u32 d = threadIdx.x;
-	const u64 *off1 = off1_given ? off1_given : ghist + 256 * plan->cols[plan->ncols - 1];
-	const u64 b = off1[d], e = d == 255 ? n : off1[d + 1];
-	const u32 size = (u32)(e - b);
+	u32 size;
+	if (blind_cap) {
+		size = __hip_atomic_load(status0 + ((u64)(ntiles0 - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & StatusBits<u32>::VALMASK;
+		const bool over = size > blind_cap || ctl->overflow != 0;
+		u32 tot1;
+		const u32 o = block_scan_256(size, s_w, tot1);
+		if (blockIdx.x == 0)
+			off1_out[d] = o;
+		if (__syncthreads_or(over ? 1 : 0)) {
+			if (blockIdx.x == 0 && d == 0)
+				ctl->blind = BLIND_FAILED;
+			return;
+		}
+		s_beg[d] = d * blind_cap;
+	} else {
+		const u64 *off1 = ghist + 256 * plan->cols[plan->ncols - 1];
+		const u64 b = off1[d], e = d == 255 ? n : off1[d + 1];
+		size = (u32)(e - b);
+		s_beg[d] = (u32)b;
+	}
 	s_size[d] = size;
-	s_beg[d] = blind_cap ? d * blind_cap : (u32)b;
 	u32 total;
 	const u32 tb = block_scan_256((size + tile - 1) / tile, s_w, total);
 	s_tb[d] = tb;
@@ -379,9 +398,12 @@ __global__ __launch_bounds__(256) void rsx_seg_plan_kernel(u32 *__restrict__ seg
 
 // ---- slack attempt: the (digit, digit) counts read off the finished chain ---------------------------------------------
 // After a SCATTER_SEG_SLACK pass the inclusive prefix of a bucket's LAST tile is the bucket's count of every level-2 digit.
-// One workgroup per level-1 bucket: the leaves (one per non-empty (digit, digit) bucket, read from its slot, written to its
-// place in the dense output) and the verdict: SEG_MODE_LEAVES if no slot overflowed, else SEG_MODE_RETRY (the host runs the
-// counted path from the untouched pass-1 output).
+// One workgroup per level-1 bucket: the leaves (one per (digit, digit) bucket, read from its slot, written to its place in the
+// dense output; table entry b * 256 + d, empty buckets stay in the table with no keys) and the verdict: SEG_MODE_LEAVES if no
+// slot overflowed, else SEG_MODE_RETRY (the host runs the counted path from the untouched pass-1 output).  The pass itself
+// flags every run that leaves its slot, so the verdict is there when this kernel starts and no workgroup waits for another
+// (with a table compacted through a global counter and a last-workgroup-decides counter this kernel took 14.6 us: three
+// serialised same-address atomics per workgroup).
 template <typename ST>
 __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__restrict__ status, const u32 *__restrict__ btile,
                                                                  const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
@@ -392,52 +414,36 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 	if (plan->hyb != HYB_TWO_LEVEL || (blind && ctl->blind != BLIND_GO))
 		return;
 	typedef StatusBits<ST> SB_;
-	__shared__ u32 s_w[4], s_max, s_slot, s_last;
+	__shared__ u32 s_w[4];
 	const u32 d = threadIdx.x, b = blockIdx.x;
 	const u64 *off1 = off1_given ? off1_given : ghist + 256 * plan->cols[plan->ncols - 1];
 	const u32 t0 = btile[b], t1 = btile[b + 1];
+	const u32 ncols = plan->ncols;
+	const u64 bbeg = off1[b];
 	u32 c = 0;
 	if (t1 > t0)
 		c = (u32)(__hip_atomic_load(status + ((u64)(t1 - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SB_::VALMASK);
-	if (d == 0)
-		s_max = 0;
-	u32 total;
-	const u32 o = block_scan_256(c, s_w, total);
-	u32 nleaf;
-	const u32 idx = block_scan_256(c ? 1u : 0u, s_w, nleaf);
-	if (d == 0)
-		s_slot = atomicAdd(&ctl->nleaf, nleaf);
-	__syncthreads();
-	if (c) {
-		LeafSeg ls;
-		ls.beg = (u32)(off1[b] + o);
-		ls.cnt = c;
-		ls.ncols = plan->ncols - 2;
-		ls.slot = b * 256 + d + 1;
-		segtab[s_slot + idx] = ls;
-		atomicMax(&s_max, c);
-	}
-	__syncthreads();
-	if (d == 0) {
-		atomicMax(&ctl->maxleaf, s_max);
-		__threadfence();
-		s_last = atomicAdd(&ctl->done, 1u) == gridDim.x - 1 ? 1u : 0u;
-	}
-	__syncthreads();
-	if (s_last && d == 0) {
-		__threadfence();
-		const u32 mx = atomicMax(&ctl->maxleaf, 0u);
-		const u32 mode = (mx <= slack_cap && atomicOr(&ctl->overflow, 0u) == 0) ? SEG_MODE_LEAVES : SEG_MODE_RETRY;
+	if (b == 0 && d == 0) {
+		const u32 mode = ctl->overflow == 0 ? SEG_MODE_LEAVES : SEG_MODE_RETRY;
 		ctl->mode = mode;
+		ctl->nleaf = 65536;
+		ctl->maxleaf = slack_cap;   // (no leaf is larger: a run that leaves its slot sets the flag)
 		if (host_ctl) {
 			host_ctl->ntiles = ctl->ntiles;
-			host_ctl->maxleaf = mx;
-			host_ctl->nleaf = ctl->nleaf;
+			host_ctl->maxleaf = slack_cap;
+			host_ctl->nleaf = 65536;
 			host_ctl->overflow = ctl->overflow;
 			host_ctl->mode = mode;
-			__threadfence_system();
 		}
 	}
+	u32 total;
+	const u32 o = block_scan_256(c, s_w, total);
+	LeafSeg ls;
+	ls.beg = (u32)(bbeg + o);
+	ls.cnt = c <= slack_cap ? c : 0u;   // (an overflowed slot: the attempt is discarded anyway)
+	ls.ncols = ncols - 2;
+	ls.slot = b * 256 + d + 1;
+	segtab[b * 256 + d] = ls;   // (the buckets' order in the table makes no difference to the leaves: tools/blind_ab.py)
 }
 
 // ---- sorts without a histogram ("blind") ------------------------------------------------------------------------------------
@@ -454,15 +460,22 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 // read of 2^28 keys costs.  Otherwise the host runs the ordinary path and remembers not to try for a while.
 // One workgroup; 64 places spread over the array, 128 consecutive keys (8 per thread) at each: every place is an address
 // translation of its own, and 1024 scattered places took 14.6 us where this takes a third of that.
+// Workgroups 1 .. : zero the status words of the two passes (z, nz 16-byte words) -- one launch for both jobs.
 template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka,
                                                                   SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
-                                                                  Plan *host_plan)
+                                                                  Plan *host_plan, u32x4 *__restrict__ z, u64 nz)
 {
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
 	__shared__ u32 s_desc, s_distinct[W], s_max[W];
 	const u32 tid = threadIdx.x;
+	if (blockIdx.x != 0) {
+		const u32x4 zero = {0, 0, 0, 0};
+		for (u64 i = (u64)(blockIdx.x - 1) * 1024 + tid; i < nz; i += (u64)(gridDim.x - 1) * 1024)
+			z[i] = zero;
+		return;
+	}
 	for (u32 i = tid; i < W * 256; i += 1024)
 		(&h[0][0])[i] = 0;
 	if (tid < W) {
@@ -494,9 +507,16 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		for (u32 c = 0; c < W; ++c) {
 			const u32 v = h[c][tid];
 			const u64 m = __ballot(v != 0);
-			if ((tid & 63) == 0)
+			u32 mx = v;   // (the wave's maximum first: 64 lanes on one LDS word take their turns one by one)
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) {
+				const u32 y = __shfl_xor(mx, off);
+				mx = y > mx ? y : mx;
+			}
+			if ((tid & 63) == 0) {
 				atomicAdd(&s_distinct[c], (u32)__popcll(m));
-			atomicMax(&s_max[c], v);
+				atomicMax(&s_max[c], mx);
+			}
 		}
 	}
 	__syncthreads();
@@ -508,6 +528,7 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 			// mean); the columns the leaves sort by: no digit with a tenth of the sample (Plan::hot: lanes queue at one counter)
 			go = go && s_max[c] <= (c + 2 >= W ? 2 * NS / 256 : NS / 10);
 		}
+		ctl->ntiles = ctl->mode = ctl->maxleaf = ctl->done = ctl->nleaf = ctl->overflow = 0;   // (nobody else zeroes the control block)
 		ctl->blind = go ? BLIND_GO : BLIND_FAILED;
 		if (go) {
 			Plan *const out[2] = {plan, host_plan};
@@ -523,30 +544,6 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 			}
 		}
 	}
-}
-
-// After the blind level-1 pass: the inclusive prefix of the LAST tile is the count of every digit of the top column.  Writes
-// their exclusive scan (the buckets' places in the dense result, what `ghist` would hold: radix_sort.hpp:72-80) to off1[256];
-// a slot that overflowed ends the attempt.
-template <typename ST>
-__global__ __launch_bounds__(256) void rsx_blind_counts_kernel(const ST *__restrict__ status, u32 ntiles, SegCtl *__restrict__ ctl,
-                                                               u64 *__restrict__ off1, u32 cap)
-{
-	if (ctl->blind != BLIND_GO)
-		return;
-	typedef StatusBits<ST> SB_;
-	__shared__ u32 s_w[4], s_max;
-	const u32 d = threadIdx.x;
-	if (d == 0)
-		s_max = 0;
-	const u32 c = (u32)(__hip_atomic_load(status + ((u64)(ntiles - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SB_::VALMASK);
-	u32 total;
-	const u32 o = block_scan_256(c, s_w, total);
-	off1[d] = o;
-	atomicMax(&s_max, c);
-	__syncthreads();
-	if (d == 0 && (s_max > cap || ctl->overflow != 0))
-		ctl->blind = BLIND_FAILED;
 }
 
 // ---- the leaves ---------------------------------------------------------------------------------------------------------
@@ -708,7 +705,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		const u32 beg = nbeg, cnt = ncnt, nrem = nnc, slot = nslot;
 		// is this leaf this instantiation's?  (all its columns -- ascending -- inside the carried type, or not)
 		const bool narrowable = nrem != 0 && ((colpack >> (4 * (nrem - 1))) & 15u) < 4u && sizeof(KT) == 8;
-		if ((NARROW && !narrowable) || (!NARROW && skip_narrowable && narrowable)) {
+		if (cnt == 0 || (NARROW && !narrowable) || (!NARROW && skip_narrowable && narrowable)) {   // (cnt 0: an empty bucket's table entry)
 			s += gridDim.x;
 			if (s >= nseg)
 				break;

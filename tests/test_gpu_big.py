@@ -26,15 +26,16 @@ def test_sort_of_more_than_2p32_keys():
     assert out.returncode == 0 and "sorted True" in out.stdout and "preserved True" in out.stdout, out.stdout + out.stderr
 
 
-def test_two_levels_with_medium_leaves_at_2p29_keys():
-    """2^29 + 12345 u32 keys: 65536 (digit, digit) buckets of 8 Ki keys -- the slack route with the 16 Ki-key leaf shape
-    (rsx_info.hybrid == 4); sortedness and checksums on the device."""
+@pytest.mark.parametrize("no_blind,route", [("1", 4), ("0", 5)], ids=["histogram-first", "without-histogram"])
+def test_two_levels_with_medium_leaves_at_2p29_keys(no_blind, route):
+    """2^29 + 12345 u32 keys: 65536 (digit, digit) buckets of 8 Ki keys -- the slack route with the 16 Ki-key leaf shape, with
+    the histogram first (rsx_info.hybrid == 4) and without one (5); sortedness and checksums on the device."""
     rsa.require_gpu()
     import torch
     free, _ = torch.cuda.mem_get_info()
-    if free < 16 * (1 << 30):
-        pytest.skip("needs 16 GiB of free HBM")
+    if free < 20 * (1 << 30):
+        pytest.skip("needs 20 GiB of free HBM")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_sort_check.py"), "29", "12345"], capture_output=True,
-                         text=True, timeout=900)
-    assert out.returncode == 0 and "route 4" in out.stdout and "sorted True" in out.stdout and "preserved True" in out.stdout, \
-        out.stdout + out.stderr
+                         text=True, timeout=900, env=dict(os.environ, RSX_NO_BLIND=no_blind))
+    assert out.returncode == 0 and ("route %d" % route) in out.stdout and "sorted True" in out.stdout and \
+        "preserved True" in out.stdout, out.stdout + out.stderr

@@ -352,3 +352,41 @@ def test_blind_whole_result_verification(blind_on):
     blind_on.setenv("RSX_VERIFY", "2")
     a = ol.splitmix_fill((1 << 22) + 5, ol.U32, 80, 0xFFFFFFFF)
     check(a, ol.U32, ol.ASC, 5, "verify=2")
+
+
+@pytest.mark.parametrize("dt", [ol.U32, ol.F32, ol.I32], ids=["u32", "f32", "i32"])
+def test_blind_rank_and_pairs_vs_oracle(dt, blind_on):
+    """Rank sorts and key + payload sorts of 4-byte keys the same way: the first MSB pass makes the indices (or reads the
+    caller's payloads) and writes into slots like the second; ranks / pairs where the parity rule says."""
+    n = (1 << 23) + 4097
+    a = ol.splitmix_fill(n, dt, 91 + dt, 0xFFFFFFFF)
+    for order in (ol.ASC, ol.DESC):
+        ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+        ranks, info = rsa.radix_sort_rank(_dev(a), ib, dtype=dt, order=order)
+        torch.cuda.synchronize()
+        want, whalf, winfo, _ = ol.oracle_rank(a, dt, 4, order)
+        assert info.hybrid == 5, (dt, order, info.hybrid)
+        assert info.result_in_aux == whalf and info.kept_columns() == list(winfo.cols[:winfo.ncols])
+        assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), (dt, order)
+        keys = _dev(a)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda") * 5 + 2
+        k, v, info = rsa.radix_sort_pairs(keys, torch.zeros_like(keys), vals, torch.zeros_like(vals), dtype=dt, order=order)
+        torch.cuda.synchronize()
+        perm = ol.stable_argsort_by_kdf(a, dt, order)
+        assert info.hybrid == 5 and not info.result_in_aux, (dt, order, info.hybrid)
+        assert np.array_equal(k.cpu().numpy().view(np.uint32), a.view(np.uint32)[perm])
+        assert np.array_equal(v.cpu().numpy().astype(np.int64), perm.astype(np.int64) * 5 + 2)
+
+
+def test_blind_rank_called_off(blind_on):
+    """A slot overflows under a rank sort: the index buffer has not been written, the ordinary passes follow."""
+    n = (1 << 23) + 99
+    a = ol.splitmix_fill(n, ol.U32, 23, 0xFFFFFFFF).view(np.uint32).copy()
+    a[1000:1000 + 1200 * 7:7] = (a[1000:1000 + 1200 * 7:7] & np.uint32(0x0000FFFF)) | np.uint32(0x12340000)
+    want, whalf, _, _ = ol.oracle_rank(a, ol.U32, 4)
+    for _ in range(2):
+        ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+        ranks, info = rsa.radix_sort_rank(_dev(a), ib, dtype=ol.U32)
+        torch.cuda.synchronize()
+        assert info.hybrid != 5 and info.result_in_aux == whalf
+        assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)

@@ -145,6 +145,14 @@ for dt, n, mask in [(ol.U32, 100003, 0xFFFFFFFF), (ol.U32, 3000001, 0xFFFFFFFF),
         routes.add(int(info.hybrid))
         if n <= 5000000:
             assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), ol.oracle_sort(a, dt, order)[0])
+import os
+os.environ["RSX_NO_BLIND"] = "1"        # (the same sizes with the histogram first: the slack route that starts from its counts)
+rsa.reload_env()
+a = ol.splitmix_fill((1 << 26) + 11, ol.U32, 27, 0xFFFFFFFF)
+src = dev(a); aux = torch.zeros_like(src)
+res, info = rsa.radix_sort(src, aux, dtype=ol.U32)
+torch.cuda.synchronize()
+routes.add(int(info.hybrid))
 print("whole verify ok, routes", sorted(routes))
 """ % (ROOT, ROOT)
 
@@ -153,7 +161,7 @@ def test_whole_result_verification_over_every_route():
     """RSX_VERIFY=2: the sort as it always runs -- leaves, slack slots, speculation -- with its result checked on the device
     (sorted, and the input's key sum and key mix): every route of csrc/rsx_hybrid.hpp under it."""
     out = _run(["-c", WHOLE_VERIFY_SCRIPT], {"RSX_VERIFY": "2", "RSX_TWO_LEVEL_MIN_LOG2": "22"})
-    assert out.returncode == 0 and "whole verify ok, routes [0, 1, 2, 4]" in out.stdout, out.stdout + out.stderr
+    assert out.returncode == 0 and "whole verify ok, routes [0, 1, 2, 4, 5]" in out.stdout, out.stdout + out.stderr
 
 
 def test_whole_result_verification_failure_is_reported():
