@@ -39,6 +39,7 @@
  *   RSX_FORCE_TABLE_RANK=1  use the table-ranked scatter kernel, which does not rely
  *                           on the lane order of returning LDS atomics (slower).
  *   RSX_NO_HYBRID=1         one scatter pass per kept column always (the reference's loop);
+ *   RSX_NO_BLIND=1          every sort starts with the histogram (rsx_info.hybrid never 5);
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,
@@ -89,8 +90,11 @@ typedef struct rsx_info {
 	                           highest kept column(s), then the remaining columns per bucket in LDS (README.md:647-650);
 	                           3: one pass by the highest kept column, then one pass per remaining column inside its
 	                           buckets; 4: as 2, the second pass written into per-bucket slots of a scratch array without
-	                           counting first (evenly spread keys).  The result and the returned buffer are the same
-	                           whichever it is. */
+	                           counting first (evenly spread keys); 5: as 4 without the histogram -- a sample of the keys
+	                           has PROVED the input unsorted and every column kept (the two facts radix_sort.hpp:60-70
+	                           takes from the histogram), both passes write into slots, the bucket sizes come off the
+	                           look-back chains (large arrays; blocking keys-only, rank and key + payload sorts).  The
+	                           result and the returned buffer are the same whichever it is. */
 } rsx_info;
 
 /* ---- environment ---------------------------------------------------------- */
