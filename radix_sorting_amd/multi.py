@@ -19,6 +19,8 @@ SURVEY.md section 8e is the contract implemented here, one process per GPU:
   4. each rank LSD-sorts every sub-range it received, in place and without a host
      synchronisation (rsx_sort_inplace_async).  Sub-ranges are in digit order, so
      the receive buffer ends up sorted as a whole.
+  (split_slices > 1: step 2's pass runs in consecutive parts of the shard and the first sub-range's pieces of part 0 are
+  on the links while the other parts are split; see split_plan.)
 
 Splitting by the byte itself (256 digits) and not by destination (G buckets)
 keeps the pass on the plain-digit kernel: with G = 2..8 buckets every LDS counter
@@ -212,7 +214,15 @@ def choose_chunks(global_hist, lut, world, chunks):
     return chunk_of
 
 
-def split_plan(shard, part, engine, group, world, tmp=None):
+def slice_bounds(n, slices):
+    """[a_0 = 0, a_1, ..., a_slices = n]: the shard in `slices` consecutive parts that start on multiples of 4096 elements
+    (16-byte loads stay aligned); a short shard leaves the later parts empty -- every rank has the same NUMBER of parts."""
+    b = [min(n, ((n * s // slices + 4095) // 4096) * 4096) for s in range(slices)] + [n]
+    b[0] = 0
+    return b
+
+
+def split_plan(shard, part, engine, group, world, tmp=None, slices=1):
     """Steps 1-2 of the distributed sort: split the shard into BINS in key order and gather every rank's bin counts.
 
     A bin is a digit of the split byte -- the highest byte that varies over all ranks -- or, for a bin that holds more
@@ -222,6 +232,11 @@ def split_plan(shard, part, engine, group, world, tmp=None):
     Returns (counts[world, bins] uint64, column, heavy, levels): `part` holds the shard ordered by bin, every rank has the
     same bins in the same order; `heavy` = the digits of the split byte that were refined, `levels` = how many bytes
     deep the refinement went.  `tmp`: a scratch tensor for the refinement passes (allocated when absent).
+
+    slices > 1 (and no bin too heavy): the shard is split in `slices` consecutive parts, each into its own part of
+    `part` -- part 0 here, the others by the closures returned as sliced["pending"], which the caller enqueues AFTER it has
+    put part 0's first pieces on the links: the split of the rest then runs under that exchange.  A fifth value is
+    returned: None, or {"bounds", "hists": [world, slices, bins] counts, "pending"}.
     """
     import torch
     import torch.distributed as dist
@@ -235,17 +250,32 @@ def split_plan(shard, part, engine, group, world, tmp=None):
     # every byte column's counts in ONE read of the shard, one all-gather: the byte to split by is the highest one that
     # varies over ALL ranks (a byte that is constant everywhere would send every key to one rank) -- every rank sees the
     # same gathered counts and decides the same, without a trial pass per constant byte
-    hall = engine.histogram(shard)
-    every = gather(hall).reshape(world, engine.kb, 256)
+    slices = max(1, int(slices))
+    bounds = slice_bounds(shard.numel(), slices)
+    halls = [engine.histogram(shard[bounds[i]:bounds[i + 1]]) if bounds[i + 1] > bounds[i]
+             else torch.zeros(engine.kb * 256, dtype=torch.int64, device=shard.device) for i in range(slices)]
+    every_s = gather(torch.cat(halls) if slices > 1 else halls[0]).reshape(world, slices, engine.kb, 256)
+    every = every_s.sum(axis=1)
     column = 0
     for c in range(engine.kb - 1, -1, -1):
         if np.count_nonzero(every[:, c, :].sum(axis=0)) > 1:
             column = c
             break
-    engine.msd_split_known(shard, part, column, hall)
     hists = every[:, column, :]                     # [world, 256]
     rank = dist.get_rank(group)
     heavy = heavy_bins(hists.sum(axis=0), world, column)
+    if slices > 1 and not heavy:
+        # part by part; nothing is refined (a heavy bin's run must be contiguous in `part`), so this is the whole plan
+        def split_one(i):
+            if bounds[i + 1] > bounds[i]:
+                engine.msd_split_known(shard[bounds[i]:bounds[i + 1]], part[bounds[i]:bounds[i + 1]], column, halls[i])
+        split_one(0)
+        pending = [lambda i=i: split_one(i) for i in range(1, slices)]
+        return hists, column, heavy, 0, {"bounds": bounds, "hists": every_s[:, :, column, :], "pending": pending}
+    hall = halls[0]
+    for h in halls[1:]:
+        hall = hall + h
+    engine.msd_split_known(shard, part, column, hall)
     levels = 0
     # refinement, level by level: bins that are still too heavy are split by the next lower byte (their runs of `part`
     # are contiguous); one all-gather of the sub-counts per level
@@ -273,10 +303,11 @@ def split_plan(shard, part, engine, group, world, tmp=None):
             else:
                 cols.append(hists[:, b:b + 1])
         hists = np.concatenate(cols, axis=1)
-    return hists, column, heavy, levels
+    return hists, column, heavy, levels, None
 
 
-def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None, force_exchange=False, chunks=None):
+def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None, force_exchange=False, chunks=None,
+                     split_slices=None):
     """Sort the concatenation of every rank's ``shard`` (rank order = global index order).
 
     Returns (sorted_local, stats): rank r ends up with the r-th contiguous slice of
@@ -286,6 +317,9 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     rank then sends to itself): that is how the RCCL path is exercised on a one-GPU box.  ``chunks``: sub-ranges a
     destination's digit range is cut into; the exchange of sub-range j+1 overlaps the local sort of sub-range j
     (default: RSX_MULTI_CHUNKS or 4; 1 = one ``all_to_all_single`` and one local sort, nothing overlapped).
+    ``split_slices`` (default: RSX_MULTI_SPLIT_SLICES or 1): the split pass itself in that many consecutive parts of the
+    shard, so that the first sub-range's pieces of part 0 are on the links while the rest of the shard is still being split
+    (only with chunks > 1 and no bin heavy enough to be refined; a piece is then one run per part).
     """
     import time
     import torch
@@ -304,7 +338,16 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # matrix on every rank, no second count exchange.  The receive buffer is sized from the counts, never from n / G:
     # preallocated scratch is used when it is large enough and replaced when it is not.
     part = scratch["part"][:n] if scratch else engine.empty(n, shard)
-    hists, column, heavy, levels = split_plan(shard, part, engine, group, world, tmp=scratch.get("aux") if scratch else None)
+    if chunks is None:
+        chunks = int(os.environ.get("RSX_MULTI_CHUNKS", "4"))
+    nchunks = max(1, min(int(chunks), 64))
+    if split_slices is None:
+        split_slices = int(os.environ.get("RSX_MULTI_SPLIT_SLICES", "1"))
+    nslices = max(1, min(int(split_slices), 16)) if nchunks > 1 else 1
+    hists, column, heavy, levels, sliced = split_plan(shard, part, engine, group, world,
+                                                      tmp=scratch.get("aux") if scratch else None, slices=nslices)
+    if sliced is None:
+        nslices = 1
     t_planned = time.perf_counter()     # (includes the split pass's one synchronisation and the gather of the counts)
     local_hist = hists[rank]
     lut = choose_splitters(hists.sum(axis=0), world)
@@ -324,9 +367,6 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # every key width works on every backend), and as soon as they are in, they are sorted in place while the next
     # sub-range is on the links.  The split shard is in digit order: piece (destination d, sub-range j) of this rank is
     # part[first[a] : first[b]] for the digits [a, b) of that sub-range.  Receive layout: sub-range major, source minor.
-    if chunks is None:
-        chunks = int(os.environ.get("RSX_MULTI_CHUNKS", "4"))
-    nchunks = max(1, min(int(chunks), 64))
     if nchunks == 1:
         es = shard.element_size()
         dist.all_to_all_single(recv.view(torch.uint8), part.view(torch.uint8),
@@ -339,42 +379,64 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
                       "send_counts": send_counts, "recv_counts": recv_counts,
                       "imbalance": float(matrix.sum(axis=0).max()) * world / max(float(matrix.sum()), 1.0)}
     chunk_of = choose_chunks(hists.sum(axis=0), lut, world, nchunks)
-    first = np.concatenate([[0], np.cumsum(local_hist.astype(np.int64))])     # offset of a bin's run in `part`
+    # per part of the split (one part unless the split pass was sliced): every rank's bin counts and, for this rank, where
+    # the part and its bins' runs start in `part`.  A piece (destination, sub-range) is one run per part.
+    sl_hists = sliced["hists"] if sliced else hists[:, None, :]                  # [world, parts, bins]
+    sl_begin = sliced["bounds"] if sliced else [0, n]
+    first = [np.concatenate([[0], np.cumsum(sl_hists[rank][i].astype(np.int64))]) + sl_begin[i] for i in range(nslices)]
     es = shard.element_size()
     part_b, recv_b = part.view(torch.uint8), recv.view(torch.uint8)
-    mine_digits = lut.astype(np.int64) == rank
+    lut64 = lut.astype(np.int64)
+    mine_digits = lut64 == rank
     side = engine.overlap_stream(group, force_exchange) if hasattr(engine, "overlap_stream") else None
     main = torch.cuda.current_stream() if side is not None else None
-
-    def exchange(j, roff):
-        """enqueue sub-range j's pieces; returns (works, begin, end) in elements of recv"""
-        ops, begin = [], roff
+    # receive layout: sub-range major, then source rank, then part (= global index order inside a source rank)
+    roffs = np.zeros((nchunks, world, nslices + 1), dtype=np.int64)
+    acc = 0
+    for j in range(nchunks):
+        sel_r = np.nonzero(mine_digits & (chunk_of == j))[0]
         for p in range(world):
-            sel_r = np.nonzero(mine_digits & (chunk_of == j))[0]               # what rank p sends me for sub-range j
-            rcnt = int(hists[p][sel_r].sum()) if sel_r.size else 0
-            sel_s = np.nonzero((lut.astype(np.int64) == p) & (chunk_of == j))[0]   # what I send rank p
-            scnt = int(local_hist[sel_s].sum()) if sel_s.size else 0
-            soff = int(first[sel_s[0]]) if sel_s.size else 0
-            dst = recv_b[roff * es:(roff + rcnt) * es]
-            src = part_b[soff * es:(soff + scnt) * es]
-            if p == rank and not force_exchange:
-                if rcnt:
-                    dst.copy_(src)
-            else:
-                if scnt:
-                    ops.append(dist.P2POp(dist.isend, src, p, group))
-                if rcnt:
-                    ops.append(dist.P2POp(dist.irecv, dst, p, group))
-            roff += rcnt
-        return (dist.batch_isend_irecv(ops) if ops else []), begin, roff
+            for i in range(nslices):
+                roffs[j, p, i] = acc
+                acc += int(sl_hists[p][i][sel_r].sum()) if sel_r.size else 0
+            roffs[j, p, nslices] = acc
+    chunk_end = [int(roffs[j, world - 1, nslices]) for j in range(nchunks)]
+
+    def exchange(j, parts):
+        """enqueue sub-range j's pieces of the given parts of the split; returns the works"""
+        ops = []
+        for p in range(world):
+            sel_s = np.nonzero((lut64 == p) & (chunk_of == j))[0]                 # the bins I send rank p for sub-range j
+            for i in parts:
+                roff = int(roffs[j, p, i])
+                rcnt = int(roffs[j, p, i + 1]) - roff                               # what rank p's part i sends me
+                scnt = int(sl_hists[rank][i][sel_s].sum()) if sel_s.size else 0
+                soff = int(first[i][sel_s[0]]) if sel_s.size else 0
+                dst = recv_b[roff * es:(roff + rcnt) * es]
+                src = part_b[soff * es:(soff + scnt) * es]
+                if p == rank and not force_exchange:
+                    if rcnt:
+                        dst.copy_(src)
+                else:
+                    if scnt:
+                        ops.append(dist.P2POp(dist.isend, src, p, group))
+                    if rcnt:
+                        ops.append(dist.P2POp(dist.irecv, dst, p, group))
+        return dist.batch_isend_irecv(ops) if ops else []
 
     # sub-range j+1 is submitted before sub-range j is sorted: with the sorts on a stream of their own (another hardware
-    # queue than RCCL's) the two overlap; on a shared queue the order of submission is simply the order of execution
-    nxt = exchange(0, 0)
+    # queue than RCCL's) the two overlap; on a shared queue the order of submission is simply the order of execution.
+    # A sliced split: part 0's pieces of sub-range 0 go out first, THEN the rest of the shard is split (under them).
+    works0 = exchange(0, [0])
+    if sliced:
+        for fn in sliced["pending"]:
+            fn()
+        works0 = list(works0) + list(exchange(0, list(range(1, nslices))))
+    nxt = (works0, 0, chunk_end[0])
     for j in range(nchunks):
         works, begin, end = nxt
         if j + 1 < nchunks:
-            nxt = exchange(j + 1, end)
+            nxt = (exchange(j + 1, list(range(nslices))), end, chunk_end[j + 1])
         if side is not None:
             side.wait_stream(main)                     # this rank's own piece was copied on the main stream
             with torch.cuda.stream(side):
@@ -393,7 +455,8 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     t_submitted = time.perf_counter()
     return recv, {"host_ms_split_and_counts": (t_planned - t_enter) * 1e3, "host_ms_submit_exchange_and_sorts": (t_submitted - t_planned) * 1e3,
                   "sent": sent, "received": n_recv, "local_info": None, "lut": lut, "split_column": column,
-                  "heavy_digits": heavy, "refine_levels": levels, "chunks": nchunks, "overlap_stream": side is not None,
+                  "heavy_digits": heavy, "refine_levels": levels, "chunks": nchunks, "split_slices": nslices,
+                  "overlap_stream": side is not None,
                   "send_counts": send_counts, "recv_counts": recv_counts,
                   # the largest rank's share of the keys over the fair share (1.0 = balanced): what is left of the skew
                   "imbalance": float(matrix.sum(axis=0).max()) * world / max(float(matrix.sum()), 1.0)}

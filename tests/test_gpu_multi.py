@@ -183,6 +183,12 @@ for dt, carrier in ((ol.U32, np.int32), (ol.U64, np.int64), (ol.I16, np.int16)):
         torch.cuda.synchronize()
         assert stats["received"] == a.size and stats["sent"] == 0 and stats["chunks"] == chunks, stats
         assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), want), (dt, chunks)
+    for slices in (2, 5):          # the split pass in consecutive parts of the shard: a piece is one run per part
+        eng = multi.HipEngine(dt)
+        res, stats = multi.distributed_sort(shard, eng, force_exchange=True, chunks=4, split_slices=slices)
+        torch.cuda.synchronize()
+        assert stats["split_slices"] == slices and eng.split_passes == slices, (stats, eng.split_passes)
+        assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), want), (dt, slices)
 dist.barrier()
 dist.destroy_process_group()
 print("self-exchange OK")

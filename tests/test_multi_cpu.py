@@ -101,7 +101,7 @@ def _skew2(whole, dtype, skew):
     return out
 
 
-def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chunks=None, skew=0, skew2=0):
+def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chunks=None, skew=0, skew2=0, slices=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -116,10 +116,11 @@ def _worker(rank, world, port, dtype, order, n_per_rank, mask, seed, outdir, chu
             scratch = {"part": torch.empty(n, dtype=shard.dtype), "recv": torch.empty(n // 2, dtype=shard.dtype),
                        "aux": torch.empty(n // 2, dtype=shard.dtype)}
         engine = OracleEngine(dtype, order)
-        res, stats = multi.distributed_sort(shard, engine, chunks=chunks, scratch=scratch)
+        res, stats = multi.distributed_sort(shard, engine, chunks=chunks, scratch=scratch, split_slices=slices)
         np.save(os.path.join(outdir, "out%d.npy" % rank), res.numpy().view(ol.NP_BITS[dtype]).copy())
         np.save(os.path.join(outdir, "passes%d.npy" % rank), np.asarray([engine.split_passes, stats.get("refine_levels", 0),
                                                                          stats.get("split_column", -1)]))
+        np.save(os.path.join(outdir, "slices%d.npy" % rank), np.asarray([stats.get("split_slices", 1)]))
         np.save(os.path.join(outdir, "recv%d.npy" % rank), np.asarray(stats.get("recv_counts", [n])))
         np.save(os.path.join(outdir, "heavy%d.npy" % rank), np.asarray(stats.get("heavy_digits", []), dtype=np.int64))
     finally:
@@ -214,6 +215,47 @@ def test_distributed_sort_chunk_counts(tmp_path, chunks):
     whole = ol.splitmix_fill(sum(n_per_rank), dtype, 13, 0xFFFFFFFF)
     got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
     assert np.array_equal(got, ol.oracle_sort(whole, dtype)[0])
+
+
+@pytest.mark.parametrize("world,n_per_rank,slices,chunks,dtype", [
+    (2, [30000, 41111], 2, 4, ol.U32),
+    (3, [50000, 20001, 9000], 3, 3, ol.I32),
+    (2, [70000, 3000], 4, 2, ol.U64),        # the second rank's shard is shorter than one part: its later parts are empty
+])
+def test_split_pass_in_slices(tmp_path, world, n_per_rank, slices, chunks, dtype):
+    """The split pass in consecutive parts of the shard (the first sub-range's pieces of part 0 leave before the rest is
+    split): a piece is one run per part, the receive layout keeps (sub-range, source rank, part) order, the result is the
+    single sort's; every non-empty part costs one split pass."""
+    port = _free_port()
+    mask = (1 << (8 * ol.DTYPE_SIZE[dtype])) - 1
+    mp.spawn(_worker, args=(world, port, dtype, 0, n_per_rank, mask, 17, str(tmp_path), chunks, 0, 0, slices), nprocs=world, join=True)
+    whole = ol.splitmix_fill(sum(n_per_rank), dtype, 17, mask)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got, ol.oracle_sort(whole, dtype)[0])
+    for r in range(world):
+        assert int(np.load(os.path.join(str(tmp_path), "slices%d.npy" % r))[0]) == slices
+        b = multi.slice_bounds(n_per_rank[r], slices)
+        nonempty = sum(1 for i in range(slices) if b[i + 1] > b[i])
+        assert int(np.load(os.path.join(str(tmp_path), "passes%d.npy" % r))[0]) == nonempty
+
+
+def test_sliced_split_steps_aside_for_heavy_bins(tmp_path):
+    """A dominant top digit needs its run contiguous for the refinement: the split is then made in one piece."""
+    world, dtype, n_per_rank = 2, ol.U32, [40000, 40000]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dtype, 0, n_per_rank, 0xFFFFFFFF, 19, str(tmp_path), 4, 70, 0, 3), nprocs=world, join=True)
+    whole = _skew(ol.splitmix_fill(sum(n_per_rank), dtype, 19, 0xFFFFFFFF), dtype, 70)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got, ol.oracle_sort(whole, dtype)[0])
+    assert int(np.load(os.path.join(str(tmp_path), "slices0.npy"))[0]) == 1
+
+
+def test_slice_bounds():
+    assert multi.slice_bounds(100000, 1) == [0, 100000]
+    b = multi.slice_bounds(100000, 3)
+    assert b[0] == 0 and b[-1] == 100000 and all(x % 4096 == 0 for x in b[:-1]) and b == sorted(b)
+    assert multi.slice_bounds(3000, 4) == [0, 3000, 3000, 3000, 3000]
+    assert multi.slice_bounds(0, 2) == [0, 0, 0]
 
 
 def test_heavy_digits():
