@@ -1192,7 +1192,8 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	// the sample (workgroup 0: control block, plan) and the zeroing of both passes' status words, one launch
 	static_assert(sizeof(SegCtl) <= 256, "the control block is not part of what is zeroed");
 	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl,
-	                   c.plan(), c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16));
+	                   c.plan(), c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
+	                   hybrid_caps<KT>(n).min_cols2);
 	RSX_TRY(launch_seg_pass<KT>(c, src, nullptr, n, ka, -2, 1));
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
@@ -1645,7 +1646,8 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
 	c.host_segctl->mode = SEG_MODE_NONE;
 	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, kin, (u64)n, ka, ctl, c.plan(),
-	                   c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16));
+	                   c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
+	                   (u32)sizeof(KT));   // (every column kept: the callers' parity rule below counts on it)
 	SegArgs sa;
 	sa.ctl = ctl;
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);

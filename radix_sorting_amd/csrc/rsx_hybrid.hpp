@@ -44,7 +44,10 @@ struct SegCtl {
 	u32 nleaf;      // leaves in segtab (rsx_seg_plan_kernel)
 	u32 overflow;   // slack attempt: a slot was too small (rsx_scatter2_kernel, SCATTER_SEG_SLACK)
 	u32 blind;      // sorts without a histogram (rsx_blind_precheck_kernel): BLIND_GO while nothing speaks against going on
-	u32 pad[9];
+	// ... the byte columns the sample found constant (0xFF per column, derived-key space) and the first key's derived key: the
+	// level-1 pass checks EVERY key against them (a column is skipped only if all keys share its byte, radix_sort.hpp:64-70)
+	u32 cmask_lo, cmask_hi, key0_lo, key0_hi;
+	u32 pad[5];
 };
 enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
 
@@ -452,8 +455,10 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 // a two-level sort needs none of its counts: both MSB passes write into slots of 1.25 times the expected bucket size and the
 // bucket sizes are read off the look-back chains.  What is left of the histogram's job is decided EXACTLY from a sample:
 //   * one descent among sampled neighbours proves the input unsorted (no early exit to honour);
-//   * two different bytes among the samples of a column prove the column kept (so all sizeof(KT) columns are, and the result
-//     lies where that many passes end, radix_sort.hpp:92).
+//   * two different bytes among the samples of a column prove the column kept; a column whose samples all agree is taken
+//     for constant, and the level-1 pass -- which sees every key anyway -- compares that byte of every key with the first
+//     key's (SegCtl::cmask / key0): one key that differs calls the attempt off like an overflowing slot does.  So the list
+//     of kept columns (radix_sort.hpp:64-70), and with it the buffer the result lies in (:92), is exact.
 // If the sample proves both, and shows no sign of clustering (which would only cost the attempt: a slot that overflows sets
 // SegCtl::overflow and everything after it is skipped; the caller's array is only READ until the leaves, so the ordinary
 // histogram-first sort then starts from untouched input), the sort goes on without the 0.24 ms (of 1.85) the histogram's
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka,
                                                                   SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
-                                                                  Plan *host_plan, u32x4 *__restrict__ z, u64 nz)
+                                                                  Plan *host_plan, u32x4 *__restrict__ z, u64 nz, u32 min_cols)
 {
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
@@ -522,21 +527,33 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 	__syncthreads();
 	if (tid == 0) {
 		bool go = s_desc != 0;
+		u32 nk = 0, cols[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		u64 cmask = 0;
 		for (u32 c = 0; c < W; ++c) {
-			go = go && s_distinct[c] >= 2;
+			if (s_distinct[c] >= 2)
+				cols[nk++] = c;                      // proved kept
+			else
+				cmask |= (u64)0xFFu << (8 * c);      // taken for constant; the level-1 pass will know
+		}
+		go = go && nk >= min_cols;
+		for (u32 i = 0; i < nk; ++i) {
 			// the two columns the MSB passes go by: no digit with twice its share of the sample (a slot holds 1.25 times the
 			// mean); the columns the leaves sort by: no digit with a tenth of the sample (Plan::hot: lanes queue at one counter)
-			go = go && s_max[c] <= (c + 2 >= W ? 2 * NS / 256 : NS / 10);
+			go = go && s_max[cols[i]] <= (i + 2 >= nk ? 2 * NS / 256 : NS / 10);
 		}
 		ctl->ntiles = ctl->mode = ctl->maxleaf = ctl->done = ctl->nleaf = ctl->overflow = 0;   // (nobody else zeroes the control block)
 		ctl->blind = go ? BLIND_GO : BLIND_FAILED;
+		ctl->cmask_lo = (u32)cmask;
+		ctl->cmask_hi = (u32)(cmask >> 32);
+		ctl->key0_lo = (u32)(u64)k[0];               // (thread 0's first sample is the array's first key)
+		ctl->key0_hi = (u32)((u64)k[0] >> 32);
 		if (go) {
 			Plan *const out[2] = {plan, host_plan};
 			for (int j = 0; j < 2; ++j) {
-				out[j]->ncols = W;
+				out[j]->ncols = nk;
 				out[j]->sorted = 0;
 				for (u32 i = 0; i < 8; ++i)
-					out[j]->cols[i] = i < W ? i : 0u;
+					out[j]->cols[i] = i < nk ? cols[i] : 0u;
 				out[j]->hot = 0;
 				out[j]->vary_lo = out[j]->vary_hi = 0;
 				out[j]->hyb = HYB_TWO_LEVEL;

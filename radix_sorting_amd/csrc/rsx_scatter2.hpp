@@ -166,13 +166,17 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// or has fewer kept columns.  `gbase` is the histogram's column 0 in this case.
 	u32 dcol = 0;
 	u32 seg_slot = 0;
+	KT bl_cmask = 0, bl_key0 = 0;   // SCATTER_BLIND_TOP: the columns taken for constant and the first key (derived): checked on every key
 	if constexpr (SEG) {
 		if ((flags & SCATTER_BLIND) && seg.ctl->blind != BLIND_GO)
 			return;   // (a sort without a histogram that has been called off: rsx_hybrid.hpp)
 		const u32 mode = seg.ctl->mode;
 		if (flags & SCATTER_BLIND_TOP) {
-			// the level-1 pass of such a sort: by the column `shift` names (the top one), no plan, no offsets
+			// the level-1 pass of such a sort: by the highest column the sample proved kept, no offsets
 			seg_slot = 0;
+			shift = 8 * dplan->cols[dplan->ncols - 1];
+			bl_cmask = (KT)(((u64)seg.ctl->cmask_hi << 32) | seg.ctl->cmask_lo);
+			bl_key0 = (KT)(((u64)seg.ctl->key0_hi << 32) | seg.ctl->key0_lo);
 		} else if (dplan->hyb != HYB_TWO_LEVEL) {
 			return;
 		} else if (flags & SCATTER_SEG_SLACK) {    // the pass by the level-2 column into slots of the scratch array, before anything is decided
@@ -519,6 +523,16 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 #pragma unroll
 					for (int r = 0; r < KPT; ++r)
 						keep[r] = p[r * 64];
+					if constexpr (SEG) {
+						if (bl_cmask) {   // (uniform) a key that differs from the first one in a column taken for constant ends the attempt
+							KT bad = 0;
+#pragma unroll
+							for (int r = 0; r < KPT; ++r)
+								bad |= ((DIG == DIG_PLAIN ? keep[r] : kdf_apply(keep[r], ka)) ^ bl_key0) & bl_cmask;
+							if (__ballot(bad != 0) && lane == 0)
+								atomicOr(seg.overflow, 1u);
+						}
+					}
 #pragma unroll
 					for (int r = 0; r < KPT; ++r) {
 						const u32 d = digit2<DIG>(keep[r], ka, shift);
@@ -538,6 +552,17 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				for (int r = 0; r < KPT; ++r) {
 					const u32 o = wo + r * 64;
 					keep[r] = o < cnt ? elem(kin, base, r, wo) : (KT)0;
+				}
+				if constexpr (SEG) {
+					if (bl_cmask) {
+						KT bad = 0;
+#pragma unroll
+						for (int r = 0; r < KPT; ++r)
+							if (wo + r * 64 < cnt)
+								bad |= ((DIG == DIG_PLAIN ? keep[r] : kdf_apply(keep[r], ka)) ^ bl_key0) & bl_cmask;
+						if (__ballot(bad != 0) && lane == 0)
+							atomicOr(seg.overflow, 1u);
+					}
 				}
 #pragma unroll
 				for (int r = 0; r < KPT; ++r) {

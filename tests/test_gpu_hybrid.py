@@ -390,3 +390,27 @@ def test_blind_rank_called_off(blind_on):
         torch.cuda.synchronize()
         assert info.hybrid != 5 and info.result_in_aux == whalf
         assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)
+
+
+@pytest.mark.parametrize("mask,ncols", [(0xFFFFFFFFFF, 5), (0xFFFFFFFF, 4), (0x00FFFFFFFFFF00FF, 6)])
+def test_blind_with_constant_columns(mask, ncols, blind_on):
+    """8-byte keys with constant byte columns (BASELINE.json's cfg 3): the sample proves the kept ones, the level-1 pass checks
+    the others on every key; kept columns and returned buffer as the oracle's (an odd number of kept columns ends in aux)."""
+    n = (1 << 22) + 555
+    for dt, order in ((ol.U64, ol.ASC), (ol.U64, ol.DESC), (ol.I64, ol.ASC)):
+        a = ol.splitmix_fill(n, dt, 300 + ncols, mask)
+        info = check(a, dt, order, 5, (hex(mask), dt, order))
+        assert info.ncols == ncols
+
+
+def test_blind_constant_column_disproved_by_one_key(blind_on):
+    """One key, nowhere near the sampled places, differs in a column the sample took for constant: the level-1 pass finds
+    it, the attempt is called off, the ordinary sort keeps that column."""
+    n = (1 << 22) + 555
+    a = ol.splitmix_fill(n, ol.U64, 310, 0xFFFFFFFFFF).copy()
+    for where in (1000, n // 2 + 777, n - 3):
+        b = a.copy()
+        b[where] |= np.uint64(0x0100000000000000)
+        info = check(b, ol.U64, ol.ASC, None, where)
+        assert info.hybrid != 5 and info.ncols == 6, (where, info.hybrid, info.ncols)
+        blind_on.setenv("RSX_NO_BLIND", "0")   # (forget the back-off)

@@ -187,7 +187,8 @@ for dt, carrier in ((ol.U32, np.int32), (ol.U64, np.int64), (ol.I16, np.int16)):
         eng = multi.HipEngine(dt)
         res, stats = multi.distributed_sort(shard, eng, force_exchange=True, chunks=4, split_slices=slices)
         torch.cuda.synchronize()
-        assert stats["split_slices"] == slices and eng.split_passes == slices, (stats, eng.split_passes)
+        if not stats["heavy_digits"]:   # (a refined digit's run must be contiguous: the split is then made in one piece)
+            assert stats["split_slices"] == slices and eng.split_passes == slices, (stats, eng.split_passes)
         assert np.array_equal(res.cpu().numpy().view(ol.NP_BITS[dt]), want), (dt, slices)
 dist.barrier()
 dist.destroy_process_group()
