@@ -105,6 +105,7 @@ struct Env {
 	bool no_slack = false;           // RSX_NO_SLACK=1
 	bool no_self_plan = false;       // RSX_NO_SELF_PLAN=1
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
+	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
 	{
@@ -135,6 +136,7 @@ struct Env {
 		no_slack = is_one("RSX_NO_SLACK");
 		no_self_plan = is_one("RSX_NO_SELF_PLAN");
 		no_blind = is_one("RSX_NO_BLIND");
+		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
 		two_level_min_log2 = 27;
 		if (const char *e = getenv("RSX_TWO_LEVEL_MIN_LOG2")) {
 			const int v = atoi(e);
@@ -938,7 +940,8 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	const SegCtl *ctl = (const SegCtl *)c.seg.p;
 	ProfScope prof(2, (u64)n * 2 * sizeof(KT), c.stream);
 	const KT *slots = level == HYB_TWO_LEVEL ? (const KT *)c.slack.p : nullptr;   // (only leaves of a slack attempt name slots)
-	u32 skip_narrowable = 0;
+	const u32 nopre = env().no_leaf_prefix ? 2u : 0u;   // RSX_NO_LEAF_PREFIX=1: 8-byte-key leaves go through all their columns
+	u32 skip_narrowable = nopre;
 	if constexpr (sizeof(KT) == 8) {
 		// 8-byte keys: leaves whose columns all lie in the low four bytes are carried as 4-byte values (rsx_hybrid.hpp, CT)
 		if (shapes & 1u) {
@@ -946,8 +949,8 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			static_assert(N::CAP == S::CAP, "the narrow shape takes the small shape's leaves");
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, N, u32>), dim3(grid_s), dim3(N::BLOCK), 0, c.stream, src, aux, (u64)n,
 			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
-			                   c.slack_cap, 0u, off1);
-			skip_narrowable = 1;
+			                   c.slack_cap, nopre, off1);
+			skip_narrowable |= 1u;
 		}
 	}
 	if (shapes & 1u)
@@ -960,12 +963,12 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 		if (shapes & 4u)
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, M>), dim3(level == HYB_TWO_LEVEL ? 4096u : 256u), dim3(M::BLOCK), 0, c.stream, src,
 			                   aux, (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)M::CAP,
-			                   slots, c.slack_cap, 0u, off1);
+			                   slots, c.slack_cap, nopre, off1);
 	}
 	if (shapes & 2u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, B>), dim3(grid_b), dim3(B::BLOCK), 0, c.stream, src, aux, (u64)n,
 		                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, big_lo, (u32)B::CAP, slots,
-		                   c.slack_cap, 0u, off1);
+		                   c.slack_cap, nopre, off1);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		const u32 beg = nbeg, cnt = ncnt, nrem = nnc, slot = nslot;
 		// is this leaf this instantiation's?  (all its columns -- ascending -- inside the carried type, or not)
 		const bool narrowable = nrem != 0 && ((colpack >> (4 * (nrem - 1))) & 15u) < 4u && sizeof(KT) == 8;
-		if (cnt == 0 || (NARROW && !narrowable) || (!NARROW && skip_narrowable && narrowable)) {   // (cnt 0: an empty bucket's table entry)
+		if (cnt == 0 || (NARROW && !narrowable) || (!NARROW && (skip_narrowable & 1u) && narrowable)) {   // (cnt 0: an empty bucket's table entry)
 			s += gridDim.x;
 			if (s >= nseg)
 				break;
@@ -749,7 +749,22 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 			if constexpr (C::PREFETCH)
 				request(nxt, nbeg, ncnt, nslot);
 		}
-		for (u32 c = 0; c < nrem; ++c) {
+		// 8-byte keys with five or more columns left (BASELINE.json's cfg 3, all eight columns kept: six per leaf).  Keys-only,
+		// so equal keys are the same bits and ANY sorted order is the reference's output: the leaf is sorted by its TOP three
+		// columns only (LSB first among them), after which evenly spread keys are in order but for the few that share those
+		// 24 bits -- 4096 keys: half a pair per leaf -- and odd-even transposition on whole keys puts those right in one
+		// sweep and finds nothing to do in the next.  Keys that cluster in these columns (the sweeps do not come to rest
+		// within four rounds) get what every leaf got before: all columns, LSB first, from wherever the keys lie now.
+		// (2^28 u64 keys, six columns per leaf, one box: the sort takes 3.79 instead of 4.55 ms; with the top TWO columns and
+		// the three sweeps those need: 3.87 against 4.58 -- a sweep costs more than a third of a column.)
+		constexpr bool PREFIX_OK = sizeof(CT) == 8;
+		u32 c0 = 0;
+		if constexpr (PREFIX_OK) {
+			if (nrem >= 5 && !(skip_narrowable & 2u))
+				c0 = nrem - 3;
+		}
+		for (;;) {
+		for (u32 c = c0; c < nrem; ++c) {
 			const u32 shift = 8 * ((colpack >> (4 * c)) & 15u);
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
@@ -836,6 +851,48 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 				}
 				// (the next column stages only behind two more barriers: every slice has been read back by then)
 			}
+		}
+		if constexpr (!PREFIX_OK) {
+			break;
+		} else {
+			if (c0 == 0)
+				break;
+			bool rest = false;
+			for (u32 it = 0; it < 4 && !rest; ++it) {
+				u32 sw = 0;
+				for (u32 i = 2 * tid; i + 1 < cnt; i += 2 * BLOCK) {          // pairs (2 i, 2 i + 1)
+					const CT a = stage[i], b = stage[i + 1];
+					if (a > b) {
+						stage[i] = b;
+						stage[i + 1] = a;
+						sw = 1;
+					}
+				}
+				__syncthreads();
+				for (u32 i = 2 * tid + 1; i + 1 < cnt; i += 2 * BLOCK) {      // pairs (2 i + 1, 2 i + 2)
+					const CT a = stage[i], b = stage[i + 1];
+					if (a > b) {
+						stage[i] = b;
+						stage[i + 1] = a;
+						sw = 1;
+					}
+				}
+				rest = __syncthreads_or((int)sw) == 0;
+			}
+			if (rest)
+				break;
+			c0 = 0;   // clustered after all: every column
+			const u32 wo = opaque(wo0);
+#pragma unroll
+			for (int g = 0; g < KPT / G; ++g) {
+				if (g < (int)ng) {
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r)
+						keep[r] = stage[wo + r * 64];
+				}
+			}
+			__syncthreads();
+		}
 		}
 		// write out: 16 bytes per lane (the leaf's start is only element-aligned)
 		if (nrem) {

@@ -414,3 +414,21 @@ def test_blind_constant_column_disproved_by_one_key(blind_on):
         info = check(b, ol.U64, ol.ASC, None, where)
         assert info.hybrid != 5 and info.ncols == 6, (where, info.hybrid, info.ncols)
         blind_on.setenv("RSX_NO_BLIND", "0")   # (forget the back-off)
+
+
+@pytest.mark.parametrize("blind", ["0", "1"], ids=["histogram-first", "without-histogram"])
+def test_leaves_of_8_byte_keys_sorted_by_their_top_columns(blind, monkeypatch):
+    """Leaves of 8-byte keys with five or more columns left sort by the top three of them and finish with odd-even
+    transposition on whole keys (rsx_hybrid.hpp); keys that cluster in exactly those columns (sixteen values per byte:
+    thousands of equal 24-bit prefixes per leaf) must fall back to all columns.  Both against the oracle, with the
+    shortcut on and off."""
+    monkeypatch.setenv("RSX_NO_BLIND", "0" if blind == "1" else "1")
+    for n in (1000003, (1 << 22) + 999):
+        for mask in (0xFFFFFFFFFFFFFFFF, 0xFFFF0F0F0FFFFFFF, 0xFF0F0F0FFFFFFFFF, 0xFFFF000103FFFFFF):
+            for dt, order in ((ol.U64, ol.ASC), (ol.F64, ol.DESC)):
+                a = ol.splitmix_fill(n, dt, 400 + (mask & 0xFF00) // 256, mask)
+                info = check(a, dt, order, None, (n, hex(mask), dt, order))
+                monkeypatch.setenv("RSX_NO_LEAF_PREFIX", "1")
+                info2 = check(a, dt, order, None, (n, hex(mask), dt, order, "no prefix"))
+                monkeypatch.delenv("RSX_NO_LEAF_PREFIX")
+                assert info.hybrid == info2.hybrid

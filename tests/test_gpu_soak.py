@@ -148,11 +148,12 @@ for dt, n, mask in [(ol.U32, 100003, 0xFFFFFFFF), (ol.U32, 3000001, 0xFFFFFFFF),
 import os
 os.environ["RSX_NO_BLIND"] = "1"        # (the same sizes with the histogram first: the slack route that starts from its counts)
 rsa.reload_env()
-a = ol.splitmix_fill((1 << 26) + 11, ol.U32, 27, 0xFFFFFFFF)
-src = dev(a); aux = torch.zeros_like(src)
-res, info = rsa.radix_sort(src, aux, dtype=ol.U32)
-torch.cuda.synchronize()
-routes.add(int(info.hybrid))
+for dt, n, mask in [(ol.U32, (1 << 26) + 11, 0xFFFFFFFF), (ol.U64, (1 << 23) + 7, 0xFFFFFFFFFF)]:   # (slots from counts; counted second pass)
+    a = ol.splitmix_fill(n, dt, 27, mask)
+    src = dev(a); aux = torch.zeros_like(src)
+    res, info = rsa.radix_sort(src, aux, dtype=dt)
+    torch.cuda.synchronize()
+    routes.add(int(info.hybrid))
 print("whole verify ok, routes", sorted(routes))
 """ % (ROOT, ROOT)
 
