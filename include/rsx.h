@@ -40,6 +40,7 @@
  *                           on the lane order of returning LDS atomics (slower).
  *   RSX_NO_HYBRID=1         one scatter pass per kept column always (the reference's loop);
  *   RSX_NO_BLIND=1          every sort starts with the histogram (rsx_info.hybrid never 5);
+ *   RSX_NO_LEAF_PREFIX=1    leaves of 8-byte keys sort by every column they have left;
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,
@@ -91,9 +92,10 @@ typedef struct rsx_info {
 	                           3: one pass by the highest kept column, then one pass per remaining column inside its
 	                           buckets; 4: as 2, the second pass written into per-bucket slots of a scratch array without
 	                           counting first (evenly spread keys); 5: as 4 without the histogram -- a sample of the keys
-	                           has PROVED the input unsorted and every column kept (the two facts radix_sort.hpp:60-70
-	                           takes from the histogram), both passes write into slots, the bucket sizes come off the
-	                           look-back chains (large arrays; blocking keys-only, rank and key + payload sorts).  The
+	                           has PROVED the input unsorted and which columns are kept (the two facts radix_sort.hpp:60-70
+	                           takes from the histogram; columns the sample found constant are checked on every key by
+	                           the first pass), both passes write into slots, the bucket sizes come off the look-back
+	                           chains (large arrays; blocking keys-only, rank and key + payload sorts).  The
 	                           result and the returned buffer are the same whichever it is. */
 } rsx_info;
 
