@@ -1005,7 +1005,7 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 		flags |= SCATTER_BLIND | (blind == 1 ? (u32)SCATTER_BLIND_TOP : 0u);
 	const u32 pi = j < 0 ? 0u : (u32)j;
 	const unsigned grid = blind == 1 ? (unsigned)(rows - 256) : (unsigned)rows;
-	const u32 shift0 = blind == 1 ? 8 * ((u32)sizeof(KT) - 1) : 0u;
+	const u32 shift0 = 0u;   // (every segmented pass reads its column from the device-side plan)
 #define RSX_LAUNCH_SEG(DIGV)                                                                                               \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, KT, true>), dim3(grid),                 \
 	                   dim3(C2::BLOCK), 0, c.stream, aux, src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift0,     \
@@ -1663,7 +1663,7 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 		sa.slack_cap = cap1;
 		const u32 flags = (u32)SCATTER_SEG_SLACK | (u32)SCATTER_BLIND | (u32)SCATTER_BLIND_TOP | (vin ? 0u : (u32)SCATTER_GEN_INDEX);
 		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, KT, true>), dim3((unsigned)ntiles0),
-		                   dim3(C2::BLOCK), 0, c.stream, kin, (KT *)c.slack1.p, vin, (VT *)c.slack1_v.p, (u64)n, 8 * ((u32)sizeof(KT) - 1),
+		                   dim3(C2::BLOCK), 0, c.stream, kin, (KT *)c.slack1.p, vin, (VT *)c.slack1_v.p, (u64)n, 0u,
 		                   (const u64 *)c.ghist(), 1u, (u32 *)(base1 + 256), (u32 *)base1, ka, flags, (u64 *)nullptr,
 		                   (const Plan *)c.plan(), 0u, 0u, (const u32 *)nullptr, sa);
 	}

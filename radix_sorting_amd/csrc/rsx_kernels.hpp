@@ -370,7 +370,7 @@ enum : u32 {
 	SCATTER_SEG_SLACK = 2048,   // ... written into per-bucket slots of a scratch array, without counts (SegArgs::slack_cap)
 	SCATTER_SELF_PLAN = 1u << 21,   // (bits 12-14 are the column, 16-19 the probe's run length) pass 0 derives the plan itself from the raw counts (SelfPlanArgs, rsx_scatter2.hpp)
 	SCATTER_BLIND = 1u << 22,       // segmented pass of a sort WITHOUT a histogram (rsx_hybrid.hpp, rsx_blind_*): runs only while SegCtl::blind says go
-	SCATTER_BLIND_TOP = 1u << 23,   // ... its first pass: by the column `shift` names, plain tiles, ONE bucket whose 256 digits have a slot each
+	SCATTER_BLIND_TOP = 1u << 23,   // ... its first pass: by the highest column of the plan the sample made, plain tiles, ONE bucket whose 256 digits have a slot each
 	SCATTER_RANK_ASYNC = 1u << 20   // device-scheduled pass of rsx_sort_rank_inplace_async: buffers, index generation and the key-less last pass follow from the plan
 };
 
