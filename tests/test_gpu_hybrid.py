@@ -432,3 +432,44 @@ def test_leaves_of_8_byte_keys_sorted_by_their_top_columns(blind, monkeypatch):
                 info2 = check(a, dt, order, None, (n, hex(mask), dt, order, "no prefix"))
                 monkeypatch.delenv("RSX_NO_LEAF_PREFIX")
                 assert info.hybrid == info2.hybrid
+
+
+def test_blind_fuzz(blind_on):
+    """Seeded random inputs at the sizes where sorts may skip the histogram: constant byte columns (several, anywhere), random
+    bit masks, duplicates, nearly sorted arrays, a few stray keys in otherwise constant columns.  Every result against the
+    oracle; the route must have been taken by a good share of the cases (the others were called off, which is the point)."""
+    rng = np.random.default_rng(2026)
+    taken = 0
+    cases = 48
+    for k in range(cases):
+        dt = [ol.U32, ol.I32, ol.F32, ol.U64, ol.I64, ol.F64, ol.U64, ol.U64][k % 8]
+        size = ol.DTYPE_SIZE[dt]
+        full = (1 << (8 * size)) - 1
+        n = int(rng.integers(1 << 22, 6000000))
+        mask = full
+        style = int(rng.integers(0, 6))
+        if style in (1, 5):                       # constant byte columns
+            for b in range(size):
+                if rng.random() < 0.35:
+                    mask &= ~(0xFF << (8 * b))
+        elif style == 2:                          # random bit mask
+            mask &= int(rng.integers(0, full, dtype=np.uint64, endpoint=True))
+        a = ol.splitmix_fill(n, dt, int(rng.integers(1, 1 << 30)), mask)
+        if style == 3:                            # nearly sorted
+            a = np.sort(a)
+            for _ in range(int(rng.integers(0, 3))):
+                i, j = rng.integers(0, n, size=2)
+                a[i], a[j] = a[j], a[i]
+        elif style == 4:                          # a tenth of the keys from a small pool
+            pool = a[:64].copy()
+            sel = rng.random(n) < 0.1
+            a[sel] = pool[rng.integers(0, 64, size=int(sel.sum()))]
+        elif style == 5:                          # strays in the constant columns
+            bits = a.view(ol.NP_BITS[dt])
+            for _ in range(int(rng.integers(1, 4))):
+                bits[int(rng.integers(0, n))] ^= ol.NP_BITS[dt](~mask & full) & ol.NP_BITS[dt](int(rng.integers(0, full, dtype=np.uint64, endpoint=True)))
+        order = int(rng.integers(0, 2))
+        blind_on.setenv("RSX_NO_BLIND", "0")      # (no back-off between cases)
+        info = check(a, dt, order, None, (k, n, dt, order, style, hex(mask)))
+        taken += info.hybrid == 5
+    assert taken >= cases // 6, taken
