@@ -171,5 +171,12 @@ int main(int argc, char **argv)
 	SHAPE(8, 16, 8, true, false, nleaf);
 	SHAPE(8, 16, 4, true, false, nleaf);
 	SHAPE(8, 32, 4, true, false, nleaf);
+	// shapes that hold just the 5120 keys a slot of 2^28 keys can (more workgroups per CU: 24.5 KiB of LDS each)
+	SHAPE(4, 20, 4, true, false, 8192);
+	SHAPE(4, 20, 5, true, false, 8192);
+	SHAPE(4, 20, 6, true, false, 8192);
+	SHAPE(4, 20, 6, true, false, 16384);
+	SHAPE(4, 24, 5, true, false, 8192);
+	SHAPE(2, 40, 6, true, false, 16384);
 	return 0;
 }
