@@ -891,6 +891,19 @@ template <typename KT> struct LeafShapes {
 	// in the large shape were no faster than four passes.  8-byte keys: the small shape already holds 64 KiB.
 	static constexpr bool HAS_MEDIUM = sizeof(KT) == 4;
 	typedef LeafCfg<KT, 8, 32, 4, true, false> Medium;
+	// 4-byte keys, leaves read from slots of at most 5120 keys (2^28 keys in 65536 slots: BASELINE.json's headline): the small
+	// shape cut to that size -- twenty rounds per lane instead of thirty-two, 24.5 instead of 37 KiB of LDS: the leaves of 2^28
+	// keys take 0.587 instead of 0.640 ms (tools/ubench/leaf_probe, profiles/r03/leaf_probe.txt; with room for a fifth
+	// workgroup's registers the compiler spills: 1.5 ms)
+	static constexpr bool HAS_FIT = sizeof(KT) == 4;
+	typedef LeafCfg<KT, 4, 20, 4, true, false> Fit;
+	// ... the shape (bit 3: Fit) for leaves that lie in slots of `cap` keys
+	static u32 shape_for_slots(u32 cap)
+	{
+		if (HAS_FIT && cap <= (u32)Fit::CAP)
+			return 8u;
+		return shape_for(cap);
+	}
 	// the shape (bit 0 small, bit 2 medium, bit 1 large) for leaves of up to `m` keys
 	static u32 shape_for(u32 m)
 	{
@@ -952,6 +965,13 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			                   c.slack_cap, nopre, off1);
 			skip_narrowable |= 1u;
 		}
+	}
+	if constexpr (LeafShapes<KT>::HAS_FIT) {
+		typedef typename LeafShapes<KT>::Fit F;
+		if (shapes & 8u)
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F>), dim3(grid_s), dim3(F::BLOCK), 0, c.stream, src, aux, (u64)n,
+			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)F::CAP, slots,
+			                   c.slack_cap, nopre, off1);
 	}
 	if (shapes & 1u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(grid_s), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
@@ -1074,7 +1094,7 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 			                   (const Plan *)c.plan(), ctl, segtab, cap, c.dev_host_segctl);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
-			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for(cap)));
+			RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for_slots(cap)));
 			HIP_TRY(hipEventSynchronize(c.seg_ev));
 			if (c.host_segctl->mode == SEG_MODE_LEAVES) {
 				*result = final;
@@ -1207,7 +1227,7 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, 1u);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
-	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for(cap2), (const u64 *)off1));
+	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for_slots(cap2), (const u64 *)off1));
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
 		blind_called_off(c, blind_kind<KT>(0));
