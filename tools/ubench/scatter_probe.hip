@@ -953,6 +953,35 @@ int main(int argc, char **argv)
 	g_flags = SCATTER_ELEM_LOADS;
 	bench2<Sc2Cfg<u32, NoVal>>("v2 elem loads", 1);
 	g_flags = 0;
+	if (getenv("RSX_PROBE_NARROW")) {
+		// what a pass costs that writes only the two low bytes of every key (a level-2 pass whose leaves need nothing else)
+		typedef Sc2Cfg<u32, NoVal> C;
+		const u64 tiles = (n + C::TILE - 1) / C::TILE;
+		for (int rep = 0; rep < 6; ++rep) {
+			CK(hipMemsetAsync(d_status, 0, 256 + tiles * 256 * 4, 0));
+			hipEvent_t e0, e1;
+			CK(hipEventCreate(&e0));
+			CK(hipEventCreate(&e1));
+			CK(hipEventRecord(e0, 0));
+			if (rep & 1)
+				hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, false, DIG_PLAIN, false, uint16_t>), dim3((unsigned)tiles), dim3(C::BLOCK),
+				                   0, 0, d_in, (uint16_t *)d_out, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, 16u, d_hist + 256 * 2, 1u,
+				                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, (u32)SCATTER_ELEM_LOADS, (u64 *)nullptr,
+				                   (const Plan *)nullptr, 0u, 0u, (const u32 *)nullptr);
+			else
+				hipLaunchKernelGGL((rsx_scatter2_kernel<u32, NoVal, u32, C, false, DIG_PLAIN, false>), dim3((unsigned)tiles), dim3(C::BLOCK),
+				                   0, 0, d_in, d_out, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, 16u, d_hist + 256 * 2, 1u,
+				                   (u32 *)((char *)d_status + 256), (u32 *)d_status, ka, (u32)SCATTER_ELEM_LOADS, (u64 *)nullptr,
+				                   (const Plan *)nullptr, 0u, 0u, (const u32 *)nullptr);
+			CK(hipGetLastError());
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			printf("pass by column 2, keys written as %s: %.3f ms\n", (rep & 1) ? "their low 16 bits (u16)" : "u32", ms);
+		}
+		return 0;
+	}
 	if (getenv("RSX_PROBE_ALL"))
 		bench7<Sc7Cfg<u32>>("v7 2 WG/CU, re-ranked windows");
 	if (getenv("RSX_PROBE_ONE_ATOMIC") || getenv("RSX_PROBE_ALL")) {
