@@ -603,6 +603,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK;
 	constexpr bool NARROW = sizeof(CT) < sizeof(KT);
 	constexpr int CHUNK = 16 / sizeof(CT);
+	// rounds per guarded group (a wave's slice is a whole number of groups).  Groups of two rounds balance the waves of a
+	// 4100-key leaf better (18 instead of 20 rounds in the longest wave) and change nothing: 0.585 against 0.589 ms in the
+	// 20-round shape, single rounds 0.630 (tools/ubench/leaf_probe); the 32-round shapes spill with either.
 	constexpr int G = 4;
 	static_assert(KPT % G == 0, "whole groups of rounds");
 	// everything the decision needs is requested at once (scalar loads), not one dependent round trip after the other
