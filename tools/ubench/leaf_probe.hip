@@ -177,6 +177,11 @@ int main(int argc, char **argv)
 	SHAPE(4, 20, 6, true, false, 8192);
 	SHAPE(4, 20, 6, true, false, 16384);
 	SHAPE(4, 24, 5, true, false, 8192);
-	SHAPE(2, 40, 6, true, false, 16384);
+	SHAPE(8, 12, 8, true, false, 8192);
+	SHAPE(8, 12, 6, true, false, 8192);
+	SHAPE(6, 16, 6, true, false, 8192);
+	SHAPE(6, 16, 4, true, false, 8192);
+	SHAPE(4, 20, 4, true, false, 4096);
+	SHAPE(4, 20, 4, true, false, 65536);
 	return 0;
 }
