@@ -106,6 +106,7 @@ struct Env {
 	bool no_self_plan = false;       // RSX_NO_SELF_PLAN=1
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
+	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
 	{
@@ -137,6 +138,9 @@ struct Env {
 		no_self_plan = is_one("RSX_NO_SELF_PLAN");
 		no_blind = is_one("RSX_NO_BLIND");
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
+		leaf_grid = 65536;
+		if (const char *e = getenv("RSX_LEAF_GRID"))
+			leaf_grid = std::max(256, std::min(65536, atoi(e)));
 		two_level_min_log2 = 27;
 		if (const char *e = getenv("RSX_TWO_LEVEL_MIN_LOG2")) {
 			const int v = atoi(e);
@@ -948,7 +952,7 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	typedef typename LeafShapes<KT>::Big B;
 	// persistent workgroups over the level-2 leaves (as many as the CUs hold at once); one per bucket at level 1
 	// (level 2: a workgroup per table entry -- 0.569 against 0.585 ms for 2^28 keys with 8192 persistent ones, tools/ubench/leaf_probe)
-	const unsigned grid_s = level == HYB_TWO_LEVEL ? 65536u : 256u;
+	const unsigned grid_s = level == HYB_TWO_LEVEL ? env().leaf_grid : 256u;
 	const unsigned grid_b = 256u;
 	const LeafSeg *segtab = level == HYB_TWO_LEVEL ? (const LeafSeg *)((char *)c.seg.p + c.seg_segtab_off) : nullptr;
 	const SegCtl *ctl = (const SegCtl *)c.seg.p;
@@ -1611,7 +1615,7 @@ int pairs_two_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	{
 		ProfScope prof(2, (u64)n * (sizeof(KT) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
-		hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(8192), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+		hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
 		                   (const VT *)c.slack_v.p, cap, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
 		                   (const SegCtl *)ctl, ka);
 	}
@@ -1705,7 +1709,7 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	{
 		ProfScope prof(2, (u64)n * (sizeof(KT) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
-		hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(8192), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+		hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
 		                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
 		                   (const SegCtl *)ctl, ka);
 	}
