@@ -986,7 +986,7 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	const u32 big_lo = LeafShapes<KT>::HAS_MEDIUM ? (u32)M::CAP : (u32)S::CAP;
 	if constexpr (LeafShapes<KT>::HAS_MEDIUM) {
 		if (shapes & 4u)
-			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, M>), dim3(level == HYB_TWO_LEVEL ? 4096u : 256u), dim3(M::BLOCK), 0, c.stream, src,
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, M>), dim3(level == HYB_TWO_LEVEL ? env().leaf_grid : 256u), dim3(M::BLOCK), 0, c.stream, src,
 			                   aux, (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, (u32)S::CAP, (u32)M::CAP,
 			                   slots, c.slack_cap, nopre, off1);
 	}
