@@ -950,8 +950,8 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 {
 	typedef typename LeafShapes<KT>::Small S;
 	typedef typename LeafShapes<KT>::Big B;
-	// persistent workgroups over the level-2 leaves (as many as the CUs hold at once); one per bucket at level 1
-	// (level 2: a workgroup per table entry -- 0.569 against 0.585 ms for 2^28 keys with 8192 persistent ones, tools/ubench/leaf_probe)
+	// one workgroup per bucket at level 1; level 2: a workgroup per table entry (0.569 against 0.585 ms for 2^28 keys with
+	// 8192 persistent ones, tools/ubench/leaf_probe; RSX_LEAF_GRID to probe other grids)
 	const unsigned grid_s = level == HYB_TWO_LEVEL ? env().leaf_grid : 256u;
 	const unsigned grid_b = 256u;
 	const LeafSeg *segtab = level == HYB_TWO_LEVEL ? (const LeafSeg *)((char *)c.seg.p + c.seg_segtab_off) : nullptr;

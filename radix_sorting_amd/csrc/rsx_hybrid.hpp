@@ -568,10 +568,11 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 // the slice's element 64 r + l: memory order, as in rsx_scatter2_kernel), then per remaining kept column, LSB first: a
 // returning LDS atomic on the (wave, digit) cell is the key's rank in its run, the cells become run starts, the key is staged
 // at start + rank, and the slice is read back for the next column.  After the last column the staged leaf is written out in
-// 16-byte pieces.  Workgroups are persistent (leaf s, s + grid, ...) and request the NEXT leaf's keys before they sort the
-// current one, so that a CU always has loads in flight (without that, 2^28 keys in 65536 leaves: 0.77 ms; a leaf's life was
-// mostly the latency of its own loads).  Rests on the LDS resolving same-address lanes of a returning atomic in lane order,
-// as the pass kernel does (checked on the device before either is used: lds_order_selfcheck, rsx.hip).
+// 16-byte pieces.  A workgroup takes leaf s, s + grid, ... of the table; the launches of the level-2 leaves give every table
+// entry a workgroup of its own (several fit a CU, so its loads overlap the others' sorting: 0.569 against 0.585 ms for 2^28
+// keys with 8192 persistent workgroups).  PREFETCH_ (the next leaf's keys requested before the current one is sorted) is
+// kept for the probe; no shipped shape uses it.  Rests on the LDS resolving same-address lanes of a returning atomic in lane
+// order, as the pass kernel does (checked on the device before either is used: lds_order_selfcheck, rsx.hip).
 template <typename KT, int NW_, int KPT_, int WPE_ = 1, bool RANK1_ = true, bool PREFETCH_ = false> struct LeafCfg {
 	static constexpr int NW = NW_, KPT = KPT_, BLOCK = NW_ * 64, CAP = NW_ * 64 * KPT_;
 	static constexpr int WPE = WPE_;   // waves per SIMD the register allocation must leave room for
