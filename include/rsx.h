@@ -41,6 +41,7 @@
  *   RSX_NO_HYBRID=1         one scatter pass per kept column always (the reference's loop);
  *   RSX_NO_BLIND=1          every sort starts with the histogram (rsx_info.hybrid never 5);
  *   RSX_NO_LEAF_PREFIX=1    leaves of 8-byte keys sort by every column they have left;
+ *   RSX_NO_DENSE_SLOTS=1    the second pass of such a sort writes whole keys into its slots;
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,

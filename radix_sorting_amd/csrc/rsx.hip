@@ -106,6 +106,7 @@ struct Env {
 	bool no_self_plan = false;       // RSX_NO_SELF_PLAN=1
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
+	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
@@ -138,6 +139,7 @@ struct Env {
 		no_self_plan = is_one("RSX_NO_SELF_PLAN");
 		no_blind = is_one("RSX_NO_BLIND");
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
+		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		leaf_grid = 65536;
 		if (const char *e = getenv("RSX_LEAF_GRID"))
 			leaf_grid = std::max(256, std::min(65536, atoi(e)));
@@ -942,6 +944,14 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 	return caps;
 }
 
+// Sorts without a histogram of 4-byte keys (all four columns kept): the level-2 pass writes only the low two bytes of the
+// derived keys into its slots and the leaves put the rest back from the slot's digits (RSX_NO_DENSE_SLOTS=1: whole keys).
+// (where the slots fit the leaf shape that reads them: up to 5120 keys each, 2^28 keys in all)
+template <typename KT> bool dense_slots(const Ctx &c)
+{
+	return sizeof(KT) == 4 && !env().no_dense_slots && c.slack_cap != 0 && c.slack_cap <= (u32)LeafShapes<KT>::Fit::CAP;
+}
+
 // The leaves of a level (rsx_leaf_sort_kernel).  `shapes`: bit 0 the shape for leaves of up to 8 Ki keys, bit 1 the one that
 // fills the LDS; a launched shape does nothing unless the device-side plan has leaves of its size, so both may be enqueued
 // before the host knows (nothing then waits for the host).
@@ -973,6 +983,10 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	}
 	if constexpr (LeafShapes<KT>::HAS_FIT) {
 		typedef typename LeafShapes<KT>::Fit F;
+		if (shapes & 16u)   // slots of 2-byte values (dense_slots)
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F, uint16_t, true>), dim3(grid_s), dim3(F::BLOCK), 0, c.stream, src, aux,
+			                   (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)F::CAP, slots,
+			                   c.slack_cap, nopre, off1);
 		if (shapes & 8u)
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F>), dim3(grid_s), dim3(F::BLOCK), 0, c.stream, src, aux, (u64)n,
 			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)F::CAP, slots,
@@ -1036,6 +1050,24 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	                   dim3(C2::BLOCK), 0, c.stream, aux, src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, shift0,     \
 	                   (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,             \
 	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
+	if constexpr (sizeof(KT) == 4) {
+		if (blind == 2 && dense_slots<KT>(c)) {
+			// 4-byte keys, every column kept: the leaves sort by the two low bytes and the slot says the rest -- the pass writes
+			// the low half of every DERIVED key (rsx_leaf_sort_kernel, DENSE)
+#define RSX_LAUNCH_SEG16(DIGV)                                                                                             \
+	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, uint16_t, true>), dim3(grid),           \
+	                   dim3(C2::BLOCK), 0, c.stream, aux, (uint16_t *)src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n, \
+	                   shift0, (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,      \
+	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
+			if (plain)
+				RSX_LAUNCH_SEG16(DIG_PLAIN);
+			else
+				RSX_LAUNCH_SEG16(DIG_GENERIC);
+#undef RSX_LAUNCH_SEG16
+			HIP_TRY(hipGetLastError());
+			return RSX_OK;
+		}
+	}
 	if (plain)
 		RSX_LAUNCH_SEG(DIG_PLAIN);
 	else
@@ -1232,7 +1264,10 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, 1u);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
-	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, LeafShapes<KT>::shape_for_slots(cap2), (const u64 *)off1));
+	u32 leaf_shape = LeafShapes<KT>::shape_for_slots(cap2);
+	if (dense_slots<KT>(c))
+		leaf_shape = 16u;   // (the leaves that read 2-byte slots: the shape cut to 5120 keys)
+	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, leaf_shape, (const u64 *)off1));
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
 		blind_called_off(c, blind_kind<KT>(0));

@@ -592,7 +592,11 @@ template <typename KT, int NW_, int KPT_, int WPE_ = 1, bool RANK1_ = true, bool
 // half is put back when the keys leave (one copy per leaf): the leaf of 2^28 u64 keys with three low columns then costs what
 // a u32 leaf does instead of three times as much.  The instantiation with CT narrower than KT takes exactly the leaves that
 // allow it; `skip_narrowable` tells the KT-wide instantiation launched beside it to leave those alone.
-template <typename KT, typename C, typename CT = KT>
+// DENSE (with CT narrower than KT): the slots hold CT elements -- the low bytes of the DERIVED keys, written by a level-2 pass
+// with KTO = CT (rsx_scatter2.hpp) -- and nothing else of the keys exists there: the bytes above CT are the two MSB digits the
+// slot stands for and, in columns that were skipped, the bytes of the array's first key (SegCtl::key0; sorts without a
+// histogram only).  Half the bytes written by the pass and read here for 4-byte keys with two columns per leaf.
+template <typename KT, typename C, typename CT = KT, bool DENSE = false>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__restrict__ src, KT *__restrict__ aux, u64 n,
                                                                   const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
                                                                   const LeafSeg *__restrict__ segtab,
@@ -675,6 +679,20 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		const u32 ngall = (cnt + BLOCK * G - 1) / (BLOCK * G);
 		const u32 ng = wave_groups(cnt, ngall);
 		const u32 wo = opaque(wid * (ngall * 64 * G) + lane);
+		if constexpr (DENSE) {
+			const CT *q = (const CT *)slots + (u64)(slot - 1) * slack_cap;
+#pragma unroll
+			for (int g = 0; g < KPT / G; ++g) {
+				if (g < (int)ng) {
+#pragma unroll
+					for (int r = g * G; r < (g + 1) * G; ++r) {
+						const u32 i = wo + r * 64;
+						dst[r] = i < cnt ? q[i] : pad;
+					}
+				}
+			}
+			return;
+		}
 		const KT *p = slot ? slots + (u64)(slot - 1) * slack_cap : in + beg;
 		if constexpr (NARROW)
 			first_raw = p[0];
@@ -692,7 +710,18 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 			}
 		}
 	};
-	auto derive = [&](auto &dst, u32 cnt) {
+	auto derive = [&](auto &dst, u32 cnt, u32 slot) {
+		if constexpr (DENSE) {
+			// the slots hold derived keys already; what lies above the carried bytes follows from the slot
+			if (tid == 0) {
+				const u32 c1 = (colpack >> (4 * (ncols - 1))) & 15u, c2 = (colpack >> (4 * (ncols - 2))) & 15u;
+				const KT key0 = (KT)(((u64)ctl->key0_hi << 32) | ctl->key0_lo);
+				const KT digits = (KT)((KT)0xFFu << (8 * c1)) | (KT)((KT)0xFFu << (8 * c2));
+				const KT low = (KT)(((KT)1 << (8 * sizeof(CT))) - 1);
+				s_upper = (KT)((key0 & ~digits & ~low) | ((KT)((slot - 1) >> 8) << (8 * c1)) | ((KT)((slot - 1) & 255u) << (8 * c2)));
+			}
+			return;
+		}
 		// (straight-line over all rounds, also those of groups that were not requested: the compiler can then wait for the
 		// loads one by one instead of for all of them at the first group's door; what it derives from a register that was
 		// never loaded is never looked at)
@@ -726,7 +755,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		const u32 beg = nbeg, cnt = ncnt, nrem = nnc, slot = nslot;
 		// is this leaf this instantiation's?  (all its columns -- ascending -- inside the carried type, or not)
 		const bool narrowable = nrem != 0 && ((colpack >> (4 * (nrem - 1))) & 15u) < 4u && sizeof(KT) == 8;
-		if (cnt == 0 || (NARROW && !narrowable) || (!NARROW && (skip_narrowable & 1u) && narrowable)) {   // (cnt 0: an empty bucket's table entry)
+		if (cnt == 0 || (!DENSE && ((NARROW && !narrowable) || (!NARROW && (skip_narrowable & 1u) && narrowable)))) {   // (cnt 0: an empty bucket's table entry)
 			s += gridDim.x;
 			if (s >= nseg)
 				break;
@@ -745,7 +774,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		} else {
 			request(keep, beg, cnt, slot);
 		}
-		derive(keep, cnt);
+		derive(keep, cnt, slot);
 		s += gridDim.x;
 		const bool more = s < nseg;
 		if (more) {

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                                                 HybCaps{0, 0, 0, 0}})
 {
 	constexpr bool NARROW = !std::is_same<KTO, KT>::value;
-	static_assert(!SEG || (!NARROW && C::TPS == 1 && !HOT_), "segmented passes: plain tiles, keys of one type");
+	// (SEG with KTO narrower than KT: only the pass into slots whose leaves need no more than KTO's bytes of the derived key --
+	// SCATTER_SEG_SLACK, oshift 0; the in-place segmented passes exchange kin and kout and need one type)
+	static_assert(!SEG || (C::TPS == 1 && !HOT_), "segmented passes: plain tiles");
 	typedef StatusBits<ST> SB_;
 	constexpr int NWAVES = C::NWAVES, BLOCK = C::BLOCK, KPT = C::KPT, TPS = C::TPS, SB = C::SB, CHUNK = C::CHUNK;
 	// Device-scheduled pass: launched before the host has seen the plan (the first pass of every sort, so that the host's
@@ -189,10 +191,12 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			if (mode != SEG_MODE_LSD || pass_index >= dplan->ncols - 1)
 				return;
 			seg_slot = pass_index;
-			if (pass_index & 1) {
-				const KT *t = kin;
-				kin = (const KT *)kout;
-				kout = (KTO *)const_cast<KT *>(t);
+			if constexpr (!NARROW) {
+				if (pass_index & 1) {
+					const KT *t = kin;
+					kin = (const KT *)kout;
+					kout = (KTO *)const_cast<KT *>(t);
+				}
 			}
 		}
 		if (!(flags & SCATTER_BLIND_TOP)) {
