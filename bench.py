@@ -357,11 +357,15 @@ def main():
                 "histogram_GBps": (prof.hist_bytes / max(prof.hist_ms, 1e-9) / 1e6) if prof.hist_ms > 0 else None,
                 "leaf_ms_per_step": prof.leaf_ms / K,
                 "leaf_GBps": (prof.leaf_bytes / max(prof.leaf_ms, 1e-9) / 1e6) if prof.leaf_ms > 0 else None,
+                # the level-2 pass of a sort without a histogram writes two bytes per 4-byte key (another instantiation of the
+                # pass kernel, 6 algorithmic bytes per key; `roofline` above is the full-width one's)
+                "narrow_pass_ms_per_step": prof.narrow_ms / K,
+                "narrow_pass_GBps": (prof.narrow_bytes / max(prof.narrow_ms, 1e-9) / 1e6) if prof.narrow_ms > 0 else None,
                 # algorithmic bytes per key of the whole sort, summed over the kernels that ran: 4 (histogram) +
                 # 4 passes x 8 = 36 with one pass per kept column; two MSB passes + leaves: 4 + 2 x 8 + 8 = 28 (+ 4 when the
                 # second pass needs per-bucket counts first)
-                "sort_algorithmic_bytes_per_key": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes) / total_keys,
-                "sort_algorithmic_GBps": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes) / elapsed / 1e9,
+                "sort_algorithmic_bytes_per_key": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes + prof.narrow_bytes) / total_keys,
+                "sort_algorithmic_GBps": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes + prof.narrow_bytes) / elapsed / 1e9,
                 "lsd_only_ms_per_step": None if lsd_only is None else lsd_only * 1e3,
                 "lsd_only_Gkeys_per_s": None if lsd_only is None else n / lsd_only / 1e9,
             },

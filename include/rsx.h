@@ -311,9 +311,14 @@ typedef struct rsx_profile {
 	uint64_t scatter_launches;
 	uint64_t hist_bytes;
 	uint64_t scatter_bytes;
-	double   leaf_ms;        /* rsx_leaf_sort_kernel (sorts that take one MSB pass and leaves): n * 2 * key bytes per launch */
+	double   leaf_ms;        /* rsx_leaf_sort_kernel (sorts that take one MSB pass and leaves): n * 2 * key bytes per launch
+	                            (n * (2 + key bytes) where the leaves read two-byte slots) */
 	uint64_t leaf_launches;
 	uint64_t leaf_bytes;
+	double   narrow_ms;      /* scatter passes that write their keys narrowed into slots (a different instantiation of the
+	                            pass kernel, counted apart from scatter_*): n * (key bytes + 2) per launch */
+	uint64_t narrow_launches;
+	uint64_t narrow_bytes;
 } rsx_profile;
 int rsx_profile_begin(void);
 int rsx_profile_end(rsx_profile *out);

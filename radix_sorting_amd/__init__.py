@@ -33,7 +33,8 @@ class Profile(C.Structure):
     """rsx_profile: HIP-event kernel timings collected between profile_begin() and profile_end()."""
     _fields_ = [("hist_ms", C.c_double), ("scatter_ms", C.c_double), ("hist_launches", C.c_uint64),
                 ("scatter_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("scatter_bytes", C.c_uint64),
-                ("leaf_ms", C.c_double), ("leaf_launches", C.c_uint64), ("leaf_bytes", C.c_uint64)]
+                ("leaf_ms", C.c_double), ("leaf_launches", C.c_uint64), ("leaf_bytes", C.c_uint64),
+                ("narrow_ms", C.c_double), ("narrow_launches", C.c_uint64), ("narrow_bytes", C.c_uint64)]
 
 
 class Info(C.Structure):

@@ -966,7 +966,7 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	const unsigned grid_b = 256u;
 	const LeafSeg *segtab = level == HYB_TWO_LEVEL ? (const LeafSeg *)((char *)c.seg.p + c.seg_segtab_off) : nullptr;
 	const SegCtl *ctl = (const SegCtl *)c.seg.p;
-	ProfScope prof(2, (u64)n * 2 * sizeof(KT), c.stream);
+	ProfScope prof(2, (u64)n * ((shapes & 16u) ? 2 + sizeof(KT) : 2 * sizeof(KT)), c.stream);   // (bit 4: the leaves read two-byte slots)
 	const KT *slots = level == HYB_TWO_LEVEL ? (const KT *)c.slack.p : nullptr;   // (only leaves of a slack attempt name slots)
 	const u32 nopre = env().no_leaf_prefix ? 2u : 0u;   // RSX_NO_LEAF_PREFIX=1: 8-byte-key leaves go through all their columns
 	u32 skip_narrowable = nopre;
@@ -1037,7 +1037,8 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 		src = (KT *)c.slack1.p;
 	if (blind == 2)
 		aux = (const KT *)c.slack1.p;
-	ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
+	const bool dense = sizeof(KT) == 4 && blind == 2 && dense_slots<KT>(c);   // (keys written as two bytes: its own line in the profile)
+	ProfScope prof(dense ? 3 : 1, (u64)n * (dense ? sizeof(KT) + 2 : 2 * sizeof(KT)), c.stream);
 	const bool plain = ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0;
 	u32 flags = j == -2 ? (u32)SCATTER_SEG_SLACK : j < 0 ? (u32)SCATTER_SEG_LEAVES : 0u;
 	if (blind)
@@ -1051,7 +1052,7 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	                   (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,             \
 	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
 	if constexpr (sizeof(KT) == 4) {
-		if (blind == 2 && dense_slots<KT>(c)) {
+		if (dense) {
 			// 4-byte keys, every column kept: the leaves sort by the two low bytes and the slot says the rest -- the pass writes
 			// the low half of every DERIVED key (rsx_leaf_sort_kernel, DENSE)
 #define RSX_LAUNCH_SEG16(DIGV)                                                                                             \
@@ -2776,6 +2777,10 @@ int rsx_profile_end(rsx_profile *out)
 			out->hist_ms += ms;
 			out->hist_launches += 1;
 			out->hist_bytes += r.bytes;
+		} else if (r.kind == 3) {
+			out->narrow_ms += ms;
+			out->narrow_launches += 1;
+			out->narrow_bytes += r.bytes;
 		} else if (r.kind == 2) {
 			out->leaf_ms += ms;
 			out->leaf_launches += 1;

@@ -10,7 +10,7 @@ rows = json.load(open(table))
 sc = [r for r in rows if "rsx_scatter2_kernel<u32, NoVal" in r["kernel"] and r["fabric_bytes_per_launch"]]
 # the timed steps of bench.py make both their passes with the SEG instantiation (last template argument true: passes into
 # slots); the plain one in the same trace belongs to the RSX_NO_HYBRID comparison bench.py runs afterwards
-seg = [r for r in sc if r["kernel"].rstrip().endswith("true>")]
+seg = [r for r in sc if r["kernel"].rstrip().endswith("u32, true>")]   # (the full-width one: bench.py's `roofline` object)
 main = max(seg or sc, key=lambda r: r["calls"])
 out = {
     "round": rnd,

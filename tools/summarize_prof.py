@@ -52,11 +52,14 @@ def algorithmic_bytes(name):
     if "rsx_scatter2_kernel" in name and len(t) >= 3:
         kin = SIZES.get(t[0], 0)
         val = SIZES.get(t[1], 0)
-        kout = SIZES.get(t[-1], kin) if t[-1] in SIZES else kin
+        tail = [x for x in t[-2:] if x in SIZES]      # <..., KTO> or <..., KTO, SEG>: the type the keys are written in
+        kout = SIZES[tail[-1]] if tail else kin
         return N * (kin + kout + 2 * val)
     if ("rsx_hist_kernel" in name or "rsx_seg_hist1_kernel" in name or "rsx_seg_hist_kernel" in name) and t:
         return N * SIZES.get(t[0], 0)
     if "rsx_leaf_sort_kernel" in name and t:      # a leaf pass reads and writes every key once (rsx_hybrid.hpp)
+        if t[-1] == "true" and len(t) >= 3 and t[-2] in SIZES:      # <KT, shape, CT, DENSE>: the slots hold CT-wide values
+            return N * (SIZES[t[-2]] + SIZES.get(t[0], 0))
         return N * 2 * SIZES.get(t[0], 0)
     return None
 
