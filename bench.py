@@ -340,8 +340,8 @@ def main():
                            4: "two MSB scatter passes (the second into per-bucket slots, no second count), then the other kept "
                               "columns per bucket in LDS (README.md:647-650)",
                            5: "no histogram (a sample proves all columns kept and the input unsorted): two MSB scatter passes, both "
-                              "into per-bucket slots with the bucket sizes read off the look-back chains, then the other kept "
-                              "columns per bucket in LDS (README.md:647-650)"}[how],
+                              "into per-bucket slots with the bucket sizes read off the look-back chains (the second writes only "
+                              "the two bytes the leaves sort by), then the other kept columns per bucket in LDS (README.md:647-650)"}[how],
             },
             "roofline": {
                 "kernel": "rsx_scatter2_kernel<u32,NoVal,u32>",
