@@ -236,7 +236,7 @@ struct Ctx {
 	DevBuf slack1;      // sorts without a histogram (sort_keys_blind): the level-1 pass's 256 slots of slack1_cap keys
 	u32 slack1_cap = 0;
 	// ... sorts to go before the next attempt, doubled by every attempt that is called off; per kind of sort (4- / 8-byte keys,
-	// keys + payload): what one kind's inputs look like says nothing about another's
+	// rank sorts, keys + payload): what one kind's inputs look like says nothing about another's
 	u32 blind_skip[4] = {0, 0, 0, 0}, blind_backoff[4] = {0, 0, 0, 0};
 	u32 env_epoch = 0;                       // ... forgotten when rsx_reload_env() has run since
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
@@ -1191,13 +1191,17 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 // *done = 0: called off (the sample did not prove what it has to, or a slot overflowed) -- `src` and `aux` are untouched and
 // the caller runs the ordinary path.  A context that has been called off skips the next attempts of its kind (1, 3, 7 ... 31 sorts).
 template <typename KT> HybCaps hybrid_caps_pairs(size_t n, size_t val_bytes_);
-template <typename KT> constexpr int blind_kind(size_t payload_bytes) { return (payload_bytes ? 2 : 0) + (sizeof(KT) == 8 ? 1 : 0); }
+// kinds of sorts that learn separately: 0 / 1 keys only (4- / 8-byte keys), 2 rank sorts, 3 key + payload sorts
+template <typename KT> constexpr int blind_kind(size_t payload_bytes, bool rank = false)
+{
+	return payload_bytes ? (rank ? 2 : 3) : (sizeof(KT) == 8 ? 1 : 0);
+}
 inline void blind_called_off(Ctx &c, int kind)
 {
 	c.blind_backoff[kind] = std::min<u32>(2 * c.blind_backoff[kind] + 1, 31);
 	c.blind_skip[kind] = c.blind_backoff[kind];
 }
-template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes = 0)
+template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes = 0, bool rank = false)
 {
 	if constexpr (sizeof(KT) < 4)
 		return false;
@@ -1213,7 +1217,7 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		for (int k = 0; k < 4; ++k)
 			c.blind_skip[k] = c.blind_backoff[k] = 0;
 	}
-	const int kind = blind_kind<KT>(payload_bytes);
+	const int kind = blind_kind<KT>(payload_bytes, rank);
 	if (c.blind_skip[kind]) {
 		--c.blind_skip[kind];
 		return false;
@@ -1752,10 +1756,10 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
-		blind_called_off(c, blind_kind<KT>(sizeof(VT)));
+		blind_called_off(c, blind_kind<KT>(sizeof(VT), vin == nullptr));   // (no payloads given: a rank sort)
 		return RSX_OK;
 	}
-	c.blind_backoff[blind_kind<KT>(sizeof(VT))] = 0;
+	c.blind_backoff[blind_kind<KT>(sizeof(VT), vin == nullptr)] = 0;
 	info_from_plan(info, *c.host_plan);
 	if (info)
 		info->hybrid = 5u;
@@ -1914,7 +1918,7 @@ int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int ord
 		return RSX_OK;
 	}
 	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
-		if (want_half < 0 && !env().compact_bits && blind_wanted<KT>(c, n, sizeof(IT))) {
+		if (want_half < 0 && !env().compact_bits && blind_wanted<KT>(c, n, sizeof(IT), true)) {
 			int done = 0;
 			RSX_TRY((pairs_blind<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, info, &done)));
 			if (done) {   // four kept columns: the ranks are in the first half (radix_sort_rank.hpp:91)
