@@ -105,6 +105,7 @@ struct Env {
 	bool no_slack = false;           // RSX_NO_SLACK=1
 	bool no_self_plan = false;       // RSX_NO_SELF_PLAN=1
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
+	unsigned blind_min_log2 = 0;     // RSX_BLIND_MIN_LOG2: keys-only sorts may skip the histogram from 2^this keys on (0: the measured floors)
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
@@ -138,6 +139,9 @@ struct Env {
 		no_slack = is_one("RSX_NO_SLACK");
 		no_self_plan = is_one("RSX_NO_SELF_PLAN");
 		no_blind = is_one("RSX_NO_BLIND");
+		blind_min_log2 = 0;
+		if (const char *e = getenv("RSX_BLIND_MIN_LOG2"))
+			blind_min_log2 = (unsigned)std::max(22, std::min(30, atoi(e)));
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		leaf_grid = 65536;
@@ -1208,9 +1212,23 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() ||
 	    c.small.external || env().no_speculation)
 		return false;
-	const HybCaps caps = payload_bytes ? hybrid_caps_pairs<KT>(n, payload_bytes) : hybrid_caps<KT>(n);
-	if (caps.cap2 == 0 || n < ((size_t)1 << 22) || n >= ((size_t)1 << 30))
+	if (n < ((size_t)1 << 22) || n >= ((size_t)1 << 30))
 		return false;
+	if (payload_bytes) {
+		if (hybrid_caps_pairs<KT>(n, payload_bytes).cap2 == 0)   // (where the pairs' two-level route is: 2^27 .. 2^28 pairs)
+			return false;
+	} else {
+		// keys only: without the histogram two levels beat one pass per column earlier than with it -- 4-byte keys from 56 Mi
+		// keys on (0.521 against 0.545 ms; 48 Mi: 0.497 against 0.463), 8-byte keys from 48 Mi (1.51 against 1.62 ms; 96 Mi:
+		// 2.06 against 3.09) (tools/blind_threshold_probe.py, profiles/r03/blind_threshold_probe.txt).  RSX_BLIND_MIN_LOG2
+		// sets another floor; a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers this with it.
+		size_t floor_keys = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)7 << 23;
+		if (env().blind_min_log2)
+			floor_keys = (size_t)1 << env().blind_min_log2;
+		floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);
+		if (n < floor_keys)
+			return false;
+	}
 	const u32 epoch = g_env_epoch.load();
 	if (c.env_epoch != epoch) {
 		c.env_epoch = epoch;
@@ -1258,7 +1276,7 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	static_assert(sizeof(SegCtl) <= 256, "the control block is not part of what is zeroed");
 	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl,
 	                   c.plan(), c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
-	                   hybrid_caps<KT>(n).min_cols2);
+	                   4u);   // (two levels want four kept columns: two for the passes, two or more for the leaves)
 	RSX_TRY(launch_seg_pass<KT>(c, src, nullptr, n, ka, -2, 1));
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
