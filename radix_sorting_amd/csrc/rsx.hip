@@ -1215,7 +1215,10 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 	if (n < ((size_t)1 << 22) || n >= ((size_t)1 << 30))
 		return false;
 	if (payload_bytes) {
-		if (hybrid_caps_pairs<KT>(n, payload_bytes).cap2 == 0)   // (where the pairs' two-level route is: 2^27 .. 2^28 pairs)
+		// 4-byte keys with 4-byte payloads, 96 Mi .. 2^28 pairs (tools/rank_threshold_probe.py: 96 Mi f32 keys -> ranks 1.20
+		// against 1.32 ms, pairs 1.31 against 1.41; 80 Mi: level); a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers the floor
+		if (sizeof(KT) != 4 || payload_bytes != 4 || n > ((size_t)1 << 28) ||
+		    n < std::min((size_t)3 << 25, (size_t)1 << env().two_level_min_log2))
 			return false;
 	} else {
 		// keys only: without the histogram two levels beat one pass per column earlier than with it -- 4-byte keys from 56 Mi
