@@ -108,6 +108,7 @@ struct Env {
 	unsigned blind_min_log2 = 0;     // RSX_BLIND_MIN_LOG2: keys-only sorts may skip the histogram from 2^this keys on (0: the measured floors)
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
+	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: ... two-byte values also where that does not pay (small slots; tests)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
@@ -144,6 +145,7 @@ struct Env {
 			blind_min_log2 = (unsigned)std::max(22, std::min(30, atoi(e)));
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
+		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		leaf_grid = 65536;
 		if (const char *e = getenv("RSX_LEAF_GRID"))
 			leaf_grid = std::max(256, std::min(65536, atoi(e)));
@@ -907,9 +909,18 @@ template <typename KT> struct LeafShapes {
 	// workgroup's registers the compiler spills: 1.5 ms)
 	static constexpr bool HAS_FIT = sizeof(KT) == 4;
 	typedef LeafCfg<KT, 4, 20, 4, true, false> Fit;
-	// ... the shape (bit 3: Fit) for leaves that lie in slots of `cap` keys
+	// ... and two smaller cuts for smaller arrays (the slots of 56 Mi .. 100 Mi keys hold up to 2048 keys, those of up to
+	// 157 Mi up to 3072): eight / twelve rounds per lane.  tools/ubench/leaf_probe, 65536 leaves of 1024 keys: 0.229 against
+	// 0.346 ms in the 5120-key shape; of 2048 keys: 0.321 against 0.421
+	typedef LeafCfg<KT, 4, 8, 8, true, false> Fit2k;
+	typedef LeafCfg<KT, 4, 12, 6, true, false> Fit3k;
+	// ... the shape (bits 5, 6, 3: the three cuts) for leaves that lie in slots of `cap` keys
 	static u32 shape_for_slots(u32 cap)
 	{
+		if (HAS_FIT && cap <= (u32)Fit2k::CAP)
+			return 32u;
+		if (HAS_FIT && cap <= (u32)Fit3k::CAP)
+			return 64u;
 		if (HAS_FIT && cap <= (u32)Fit::CAP)
 			return 8u;
 		return shape_for(cap);
@@ -953,7 +964,12 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 // (where the slots fit the leaf shape that reads them: up to 5120 keys each, 2^28 keys in all)
 template <typename KT> bool dense_slots(const Ctx &c)
 {
-	return sizeof(KT) == 4 && !env().no_dense_slots && c.slack_cap != 0 && c.slack_cap <= (u32)LeafShapes<KT>::Fit::CAP;
+	// (slots of 3073 .. 5120 keys: with the smaller cuts the two-byte leaves are level or a little behind -- 64 Mi keys 0.565
+	// against 0.548 ms, 128 Mi 0.867 against 0.862 --, with the larger shapes clearly behind)
+	// RSX_DENSE_SLOTS=1 (tests): for every slot size up to 5120 keys
+	if (sizeof(KT) != 4 || env().no_dense_slots || c.slack_cap == 0 || c.slack_cap > (u32)LeafShapes<KT>::Fit::CAP)
+		return false;
+	return env().force_dense_slots || c.slack_cap > (u32)LeafShapes<KT>::Fit3k::CAP;
 }
 
 // The leaves of a level (rsx_leaf_sort_kernel).  `shapes`: bit 0 the shape for leaves of up to 8 Ki keys, bit 1 the one that
@@ -970,7 +986,8 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	const unsigned grid_b = 256u;
 	const LeafSeg *segtab = level == HYB_TWO_LEVEL ? (const LeafSeg *)((char *)c.seg.p + c.seg_segtab_off) : nullptr;
 	const SegCtl *ctl = (const SegCtl *)c.seg.p;
-	ProfScope prof(2, (u64)n * ((shapes & 16u) ? 2 + sizeof(KT) : 2 * sizeof(KT)), c.stream);   // (bit 4: the leaves read two-byte slots)
+	const bool dense = (shapes & 0x100u) != 0;   // (bit 8: the leaves read two-byte slots, dense_slots)
+	ProfScope prof(2, (u64)n * (dense ? 2 + sizeof(KT) : 2 * sizeof(KT)), c.stream);
 	const KT *slots = level == HYB_TWO_LEVEL ? (const KT *)c.slack.p : nullptr;   // (only leaves of a slack attempt name slots)
 	const u32 nopre = env().no_leaf_prefix ? 2u : 0u;   // RSX_NO_LEAF_PREFIX=1: 8-byte-key leaves go through all their columns
 	u32 skip_narrowable = nopre;
@@ -986,15 +1003,23 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 		}
 	}
 	if constexpr (LeafShapes<KT>::HAS_FIT) {
-		typedef typename LeafShapes<KT>::Fit F;
-		if (shapes & 16u)   // slots of 2-byte values (dense_slots)
-			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F, uint16_t, true>), dim3(grid_s), dim3(F::BLOCK), 0, c.stream, src, aux,
-			                   (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)F::CAP, slots,
-			                   c.slack_cap, nopre, off1);
-		if (shapes & 8u)
-			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F>), dim3(grid_s), dim3(F::BLOCK), 0, c.stream, src, aux, (u64)n,
-			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)F::CAP, slots,
-			                   c.slack_cap, nopre, off1);
+		// the shapes cut to the slots' size (exactly one of them is asked for; each takes the leaves up to its capacity)
+#define RSX_LAUNCH_FIT(BIT, SHAPE)                                                                                          \
+		if (shapes & (BIT)) {                                                                                               \
+			typedef typename LeafShapes<KT>::SHAPE F_;                                                                      \
+			if (dense)                                                                                                      \
+				hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F_, uint16_t, true>), dim3(grid_s), dim3(F_::BLOCK), 0, c.stream, \
+				                   src, aux, (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, \
+				                   (u32)F_::CAP, slots, c.slack_cap, nopre, off1);                                          \
+			else                                                                                                            \
+				hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F_>), dim3(grid_s), dim3(F_::BLOCK), 0, c.stream, src, aux,     \
+				                   (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u,       \
+				                   (u32)F_::CAP, slots, c.slack_cap, nopre, off1);                                          \
+		}
+		RSX_LAUNCH_FIT(32u, Fit2k)
+		RSX_LAUNCH_FIT(64u, Fit3k)
+		RSX_LAUNCH_FIT(8u, Fit)
+#undef RSX_LAUNCH_FIT
 	}
 	if (shapes & 1u)
 		hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(grid_s), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
@@ -1292,7 +1317,7 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	u32 leaf_shape = LeafShapes<KT>::shape_for_slots(cap2);
 	if (dense_slots<KT>(c))
-		leaf_shape = 16u;   // (the leaves that read 2-byte slots: the shape cut to 5120 keys)
+		leaf_shape |= 0x100u;   // (the leaves read 2-byte slots: the cut shapes have that variant)
 	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, leaf_shape, (const u64 *)off1));
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {

@@ -479,11 +479,13 @@ def test_blind_dense_slots_off_is_the_same_sort(blind_on):
     """4-byte keys without a histogram: the level-2 pass writes only the low half of the derived keys and the leaves put the
     rest back from the slot's digits; RSX_NO_DENSE_SLOTS=1 writes whole keys.  Both against the oracle, all key types of
     that width, both orders (the upper half of a float's or a signed key's derived form is not its raw upper half)."""
-    n = (1 << 22) + 1234
-    for dt in (ol.U32, ol.I32, ol.F32):
-        for order in (ol.ASC, ol.DESC):
-            a = ol.splitmix_fill(n, dt, 500 + dt + order, 0xFFFFFFFF)
-            check(a, dt, order, 5, (dt, order, "dense"))
-            blind_on.setenv("RSX_NO_DENSE_SLOTS", "1")
-            check(a, dt, order, 5, (dt, order, "whole keys"))
-            blind_on.delenv("RSX_NO_DENSE_SLOTS")
+    for n in ((1 << 22) + 1234, 6000001):         # (slots of 256 keys: the library writes whole keys there unless told otherwise)
+        for dt in (ol.U32, ol.I32, ol.F32):
+            for order in (ol.ASC, ol.DESC):
+                a = ol.splitmix_fill(n, dt, 500 + dt + order, 0xFFFFFFFF)
+                blind_on.setenv("RSX_DENSE_SLOTS", "1")
+                check(a, dt, order, 5, (dt, order, "two-byte slots"))
+                blind_on.delenv("RSX_DENSE_SLOTS")
+                blind_on.setenv("RSX_NO_DENSE_SLOTS", "1")
+                check(a, dt, order, 5, (dt, order, "whole keys"))
+                blind_on.delenv("RSX_NO_DENSE_SLOTS")

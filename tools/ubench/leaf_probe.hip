@@ -183,5 +183,9 @@ int main(int argc, char **argv)
 	SHAPE(6, 16, 4, true, false, 8192);
 	SHAPE(4, 20, 4, true, false, 4096);
 	SHAPE(4, 20, 4, true, false, 65536);
+	// small leaves (2^26 keys in 65536 leaves of 1024: leaf_probe 26 10 1)
+	SHAPE(4, 8, 4, true, false, 65536);
+	SHAPE(4, 8, 8, true, false, 65536);
+	SHAPE(4, 12, 6, true, false, 65536);
 	return 0;
 }
