@@ -11,6 +11,7 @@
 #include "rsx_scatter2.hpp"
 #include "rsx_small.hpp"
 #include "rsx_hybrid.hpp"
+#include "rsx_leaf16.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -108,7 +109,9 @@ struct Env {
 	unsigned blind_min_log2 = 0;     // RSX_BLIND_MIN_LOG2: keys-only sorts may skip the histogram from 2^this keys on (0: the measured floors)
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
-	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: ... two-byte values also where that does not pay (small slots; tests)
+	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: (kept for old scripts: two-byte slots are now written for every slot size rsx_leaf16_kernel takes)
+	bool no_leaf16 = false;          // RSX_NO_LEAF16=1: two-byte slots are sorted by rsx_leaf_sort_kernel (two LDS passes) as in round 3
+	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	void load()
@@ -146,6 +149,10 @@ struct Env {
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
+		no_leaf16 = is_one("RSX_NO_LEAF16");
+		leaf16_maxbin = 25;
+		if (const char *e = getenv("RSX_LEAF16_MAXBIN"))
+			leaf16_maxbin = (unsigned)std::max(0, std::min(25, atoi(e)));
 		leaf_grid = 65536;
 		if (const char *e = getenv("RSX_LEAF_GRID"))
 			leaf_grid = std::max(256, std::min(65536, atoi(e)));
@@ -229,7 +236,7 @@ struct Ctx {
 	DevBuf ckeys;       // rank sorts: the keys' varying bits packed together (RSX_COMPACT_BITS)
 	DevBuf joint;       // 2-byte keys: [65536 u32 counts][65537 u64 offsets] of the 16-bit digit (rsx_joint16_kernel)
 	DevBuf seg;         // two-level sorts (rsx_hybrid.hpp): [SegCtl][per-bucket digit counts][status regions][leaf segments][tiles]
-	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0, seg_btile_off = 0;
+	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0, seg_btile_off = 0, seg_redo_off = 0;
 	SelfPlanArgs pass_sp{nullptr, nullptr, nullptr, nullptr, HybCaps{0, 0, 0, 0}};   // a self-planned pass 0 (SCATTER_SELF_PLAN)
 	DevBuf gscan;       // [256] u64: the highest kept column's offsets from a self-planned pass 0 (for the leaves)
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
@@ -964,11 +971,14 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 // (where the slots fit the leaf shape that reads them: up to 5120 keys each, 2^28 keys in all)
 template <typename KT> bool dense_slots(const Ctx &c)
 {
-	// (slots of 3073 .. 5120 keys: with the smaller cuts the two-byte leaves are level or a little behind -- 64 Mi keys 0.565
-	// against 0.548 ms, 128 Mi 0.867 against 0.862 --, with the larger shapes clearly behind)
-	// RSX_DENSE_SLOTS=1 (tests): for every slot size up to 5120 keys
 	if (sizeof(KT) != 4 || env().no_dense_slots || c.slack_cap == 0 || c.slack_cap > (u32)LeafShapes<KT>::Fit::CAP)
 		return false;
+	// round 4: rsx_leaf16_kernel (rsx_leaf16.hpp) sorts two-byte slots of every size up to 5120 values faster than the
+	// leaves of whole keys are sorted (tools/ubench/leaf16_probe: 2^28 keys 0.39 against 0.67 ms, 2^27 0.25 against 0.46)
+	if (!env().no_leaf16)
+		return true;
+	// RSX_NO_LEAF16=1, round 3's leaves: slots of 3073 .. 5120 keys only (with the smaller cuts the two-byte leaves are level
+	// or a little behind -- 64 Mi keys 0.565 against 0.548 ms, 128 Mi 0.867 against 0.862); RSX_DENSE_SLOTS=1: every size
 	return env().force_dense_slots || c.slack_cap > (u32)LeafShapes<KT>::Fit3k::CAP;
 }
 
@@ -1000,6 +1010,30 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
 			                   c.slack_cap, nopre, off1);
 			skip_narrowable |= 1u;
+		}
+	}
+	if constexpr (sizeof(KT) == 4) {
+		if (dense && !env().no_leaf16) {
+			// two-byte slots: one placement by the top bits + two register passes (rsx_leaf16.hpp); what that kernel leaves
+			// alone (a list; or everything, if the sample saw the low sixteen bits cluster) goes through the two LDS passes
+			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
+			SegCtl *wctl = (SegCtl *)c.seg.p;
+			typedef Leaf16Cfg<256, 5120, 8, 12> L5k;
+			typedef Leaf16Cfg<256, 2560, 8, 11> L2k;
+			if (c.slack_cap <= (u32)L2k::CAP)
+				hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L2k>), dim3(grid_s), dim3(L2k::BLOCK), 0, c.stream, src, aux,
+				                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L2k::CAP, (const uint16_t *)slots, c.slack_cap,
+				                   redo, (u32)env().leaf16_maxbin);
+			else
+				hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L5k>), dim3(grid_s), dim3(L5k::BLOCK), 0, c.stream, src, aux,
+				                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L5k::CAP, (const uint16_t *)slots, c.slack_cap,
+				                   redo, (u32)env().leaf16_maxbin);
+			typedef typename LeafShapes<KT>::Fit F_;
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F_, uint16_t, true>), dim3(4096), dim3(F_::BLOCK), 0, c.stream, src, aux,
+			                   (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)F_::CAP, slots,
+			                   c.slack_cap, nopre, off1, (const u32 *)redo);
+			HIP_TRY(hipGetLastError());
+			return RSX_OK;
 		}
 	}
 	if constexpr (LeafShapes<KT>::HAS_FIT) {
@@ -1119,7 +1153,8 @@ template <typename KT> int seg_layout(Ctx &c, size_t n)
 	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
 	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
 	c.seg_btile_off = c.seg_tiles_off + rows * sizeof(SegTile);
-	return c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32));
+	c.seg_redo_off = c.seg_btile_off + 260 * sizeof(u32);   // the leaves rsx_leaf16_kernel leaves to rsx_leaf_sort_kernel
+	return c.seg.ensure(c.seg_redo_off + 65536 * sizeof(u32));
 }
 
 // The second level of a two-level sort.  Pass 1 (by the highest kept column, src -> aux) is on its way; `plan` says so.

@@ -47,7 +47,9 @@ struct SegCtl {
 	// ... the byte columns the sample found constant (0xFF per column, derived-key space) and the first key's derived key: the
 	// level-1 pass checks EVERY key against them (a column is skipped only if all keys share its byte, radix_sort.hpp:64-70)
 	u32 cmask_lo, cmask_hi, key0_lo, key0_hi;
-	u32 pad[5];
+	u32 nredo;      // leaves rsx_leaf16_kernel (rsx_leaf16.hpp) left to rsx_leaf_sort_kernel: entries of its `redo` list
+	u32 leaf16;     // rsx_blind_precheck_kernel: the sampled keys spread over the top twelve of their low sixteen bits (rsx_leaf16_kernel's bins)
+	u32 pad[3];
 };
 enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
 
@@ -474,6 +476,10 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
 	__shared__ u32 s_desc, s_distinct[W], s_max[W];
+	// 4-byte keys: the sample's counts over the top twelve of the low sixteen bits, rsx_leaf16_kernel's bins (rsx_leaf16.hpp)
+	constexpr bool L16 = sizeof(KT) == 4;
+	__shared__ u32 h12[L16 ? 4096 : 1];
+	__shared__ u32 s_max12;
 	const u32 tid = threadIdx.x;
 	if (blockIdx.x != 0) {
 		const u32x4 zero = {0, 0, 0, 0};
@@ -488,7 +494,12 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		s_max[tid] = 0;
 	}
 	if (tid == 0)
-		s_desc = 0;
+		s_desc = s_max12 = 0;
+	if constexpr (L16) {
+#pragma unroll
+		for (u32 i = 0; i < 4; ++i)
+			h12[tid + 1024 * i] = 0;
+	}
 	__syncthreads();
 	const u64 i0 = ((n - 16 * S) / 63) * (tid >> 4) + (tid & 15u) * S;   // (n >= 2^20: the places do not overlap)
 	KT k[S];
@@ -503,10 +514,25 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 #pragma unroll
 		for (u32 c = 0; c < W; ++c)
 			atomicAdd(&h[c][(u32)(k[e] >> (8 * c)) & 0xFFu], 1u);
+		if constexpr (L16)
+			atomicAdd(&h12[((u32)k[e] >> 4) & 0xFFFu], 1u);
 	}
 	if (__ballot(desc) && (tid & 63) == 0)
 		s_desc = 1;
 	__syncthreads();
+	if constexpr (L16) {
+		u32 m = 0;
+#pragma unroll
+		for (u32 i = 0; i < 4; ++i)
+			m = m > h12[tid + 1024 * i] ? m : h12[tid + 1024 * i];
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {
+			const u32 y = __shfl_xor(m, off);
+			m = y > m ? y : m;
+		}
+		if ((tid & 63) == 0)
+			atomicMax(&s_max12, m);
+	}
 	if (tid < 256) {
 #pragma unroll
 		for (u32 c = 0; c < W; ++c) {
@@ -541,8 +567,11 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 			// mean); the columns the leaves sort by: no digit with a tenth of the sample (Plan::hot: lanes queue at one counter)
 			go = go && s_max[cols[i]] <= (i + 2 >= nk ? 2 * NS / 256 : NS / 10);
 		}
-		ctl->ntiles = ctl->mode = ctl->maxleaf = ctl->done = ctl->nleaf = ctl->overflow = 0;   // (nobody else zeroes the control block)
+		ctl->ntiles = ctl->mode = ctl->maxleaf = ctl->done = ctl->nleaf = ctl->overflow = ctl->nredo = 0;   // (nobody else zeroes the control block)
 		ctl->blind = go ? BLIND_GO : BLIND_FAILED;
+		// NS samples over 4096 bins: two per bin on average, the fullest holds ten or eleven; a leaf of 4096 keys sees half of
+		// what the sample sees, and rsx_leaf16_kernel takes bins of up to 25 keys
+		ctl->leaf16 = L16 && s_max12 <= 24u ? 1u : 0u;
 		ctl->cmask_lo = (u32)cmask;
 		ctl->cmask_hi = (u32)(cmask >> 32);
 		ctl->key0_lo = (u32)(u64)k[0];               // (thread 0's first sample is the array's first key)
@@ -603,7 +632,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
                                                                   const SegCtl *__restrict__ ctl, KdfArgs<KT> ka, u32 level,
                                                                   u32 lo, u32 hi, const KT *__restrict__ slots = nullptr,
                                                                   u32 slack_cap = 0, u32 skip_narrowable = 0,
-                                                                  const u64 *__restrict__ off1_given = nullptr)
+                                                                  const u64 *__restrict__ off1_given = nullptr,
+                                                                  const u32 *__restrict__ redo = nullptr)
 {
 	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK;
 	constexpr bool NARROW = sizeof(CT) < sizeof(KT);
@@ -621,7 +651,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 		colpack |= (plan->cols[k] & 15u) << (4 * k);
 	const u32 mode = level == HYB_TWO_LEVEL ? ctl->mode : (u32)SEG_MODE_LEAVES;
 	const u32 maxleaf = level == HYB_TWO_LEVEL ? ctl->maxleaf : max1;
-	const u32 nseg = level == HYB_TWO_LEVEL ? ctl->nleaf : 256u;
+	// redo: the launch behind rsx_leaf16_kernel (rsx_leaf16.hpp) -- only the table entries its list names (SegCtl::nredo of
+	// them), or every entry if that kernel was told to stay away (SegCtl::leaf16 == 0)
+	const bool listed = redo != nullptr && ctl->leaf16 != 0;
+	const u32 nseg = level == HYB_TWO_LEVEL ? (listed ? ctl->nredo : ctl->nleaf) : 256u;
 	if (hyb != level || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi)
 		return;
 	// the level-1 buckets' starts: the highest kept column's scanned offsets (from a self-planned pass 0: its own copy)
@@ -648,7 +681,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 	auto bounds = [&](u32 s, u32 &beg, u32 &cnt, u32 &nc, u32 &slot) {
 		slot = 0;
 		if (level == HYB_TWO_LEVEL) {
-			const LeafSeg ls = segtab[s];
+			const LeafSeg ls = segtab[listed ? redo[s] : s];
 			beg = ls.beg;
 			cnt = ls.cnt;
 			nc = ls.ncols;

@@ -1,0 +1,369 @@
+// rsx_leaf16.hpp -- the leaves of a keys-only two-level sort whose slots hold TWO-BYTE values (rsx_hybrid.hpp, DENSE), gfx950.
+//
+// What such a leaf has to do: a slot holds up to `slack_cap` 16-bit values -- the low half of the derived keys of one
+// (digit, digit) bucket, in any order -- and the dense result wants them ascending, widened to the caller's element images
+// (the upper half follows from the slot, kdf_invert gives the caller's bits back).  The reference's two remaining passes
+// (radix_sort.hpp:82-90, columns 0 and 1) produce exactly that order; keys that compare equal are the same bits, so ANY
+// ascending order is the reference's output, and nothing here has to be stable.
+//
+// rsx_leaf_sort_kernel does it the reference's way, two stable 8-bit passes through the LDS: per key and column a returning
+// atomic, a read of the run start and a scattered store -- six data-dependent LDS operations per key, 59 % of the LDS cycles
+// lost to bank conflicts, 0.33-0.36 of the HBM peak (profiles/r03/bench/roofline_table.json).  This kernel does it in ONE
+// placement and two register passes:
+//
+//   1. place by the TOP TWELVE bits: one returning atomic on a cell per 12-bit bin shared by the whole workgroup (the order
+//      among the keys of a bin does not matter, so there is no row per wave), a scan of the 4096 cells, one read of the bin's
+//      start, one 2-byte store.  With ~4096 keys in 4096 bins a bin holds one key on average and every key then lies within
+//      (its bin's size - 1) places of where it belongs.
+//   2. finish the low four bits in registers: every lane sorts 16 consecutive staged values with a sorting network on packed
+//      16-bit halves (v_pk_min_u16 / v_pk_max_u16: an 8-input network on both halves at once, then a bitonic merge of the two
+//      halves: 98 instructions per 16 keys), then merges the upper half of its chunk with the lower half of the next lane's
+//      (a wave shift; 68 instructions): chunks at 16 i, then at 16 i + 8.  A bin of at most 9 keys is cut by at most one
+//      chunk boundary and lies inside the shifted chunk around that boundary, so after the two passes every bin is in order;
+//      every further pair of passes (through the LDS; rare) takes bins of 16 more keys.  The scan knows the largest bin:
+//      a leaf with a bin of more than MAXBIN2 keys does nothing here and is put on a list, which a launch of
+//      rsx_leaf_sort_kernel works off afterwards (evenly spread keys: never; the list is there for keys that cluster in
+//      their low sixteen bits although the sample let them pass).
+//
+// Three data-dependent LDS operations per key instead of six, and the rest is linear 16-byte traffic.
+#pragma once
+
+#include "rsx_hybrid.hpp"
+
+namespace rsx {
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b)
+{
+	return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+__device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b)
+{
+	return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+__device__ __forceinline__ u32 rot16(u32 x) { return __builtin_amdgcn_alignbit(x, x, 16); }
+// (lo(a), lo(b)) and (hi(a), hi(b)) as one register each
+__device__ __forceinline__ u32 lo_lo(u32 a, u32 b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ u32 hi_hi(u32 a, u32 b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// d[i] = (L_i, H_i) with L_0 <= ... <= L_7 in the low halves and H_0 <= ... <= H_7 in the high halves: afterwards the sixteen
+// values ascending in memory order, d[i] = value 2i (low half) and value 2i + 1 (high half).  (L_i, H_{7-i}) is a bitonic
+// sequence of 16; its merge needs one register rotated per pair of comparators down to distance 2 and a transposition for
+// distance 1 (tools/ubench/leaf16_net.py checks the arrangement over all 2^16 zero-one inputs).  60 instructions.
+__device__ __forceinline__ void merge16_packed(u32 (&d)[8])
+{
+	u32 q[2][4];   // q[0][i] = (X_i, X_{7-i}): the eight smaller values, bitonic; q[1][i] the eight larger ones
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const u32 s = rot16(d[7 - i]);
+		q[0][i] = pk_min_u16(d[i], s);
+		q[1][i] = pk_max_u16(d[i], s);
+	}
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		u32 quad[2][2];   // distance 4: quad[0] = the four smaller, as (p0, p3), (p1, p2); quad[1] the four larger
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const u32 s = rot16(q[h][3 - i]);
+			quad[0][i] = pk_min_u16(q[h][i], s);
+			quad[1][i] = pk_max_u16(q[h][i], s);
+		}
+#pragma unroll
+		for (int g = 0; g < 2; ++g) {
+			const u32 s = rot16(quad[g][1]);
+			const u32 mn = pk_min_u16(quad[g][0], s), mx = pk_max_u16(quad[g][0], s);   // distance 2: places (0, 1) and (2, 3)
+			const u32 t1 = lo_lo(mn, mx), t2 = hi_hi(mn, mx);                           // (0, 2) and (1, 3)
+			const u32 m2 = pk_min_u16(t1, t2), x2 = pk_max_u16(t1, t2);                 // distance 1
+			d[4 * h + 2 * g] = lo_lo(m2, x2);
+			d[4 * h + 2 * g + 1] = hi_hi(m2, x2);
+		}
+	}
+}
+
+// Sixteen 16-bit values in eight registers, memory order as above, in any order: ascending afterwards.  Batcher's
+// 19-comparator network on the registers sorts the low halves and the high halves (8 values each) at once, then the merge.
+__device__ __forceinline__ void sort16_packed(u32 (&d)[8])
+{
+#define RSX_CE(i, j)                           \
+	{                                          \
+		const u32 t_ = pk_min_u16(d[i], d[j]); \
+		d[j] = pk_max_u16(d[i], d[j]);         \
+		d[i] = t_;                             \
+	}
+	RSX_CE(0, 1) RSX_CE(2, 3) RSX_CE(4, 5) RSX_CE(6, 7)
+	RSX_CE(0, 2) RSX_CE(1, 3) RSX_CE(4, 6) RSX_CE(5, 7)
+	RSX_CE(1, 2) RSX_CE(5, 6)
+	RSX_CE(0, 4) RSX_CE(1, 5) RSX_CE(2, 6) RSX_CE(3, 7)
+	RSX_CE(2, 4) RSX_CE(3, 5)
+	RSX_CE(1, 2) RSX_CE(3, 4) RSX_CE(5, 6)
+#undef RSX_CE
+	merge16_packed(d);
+}
+
+// a[0..3] and b[0..3]: eight ascending values each, memory order -> d[0..7] as merge16_packed wants them
+__device__ __forceinline__ void planes_of_two_runs(u32 (&d)[8], const u32 (&a)[4], const u32 (&b)[4])
+{
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		d[2 * m] = lo_lo(a[m], b[m]);
+		d[2 * m + 1] = hi_hi(a[m], b[m]);
+	}
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (DPP: rows of 16 by shifts, then the rows' totals broadcast)
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x)
+{
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+	return x;
+}
+// lane l gets lane l + 1's value (lane 63: unspecified)
+__device__ __forceinline__ u32 from_next_lane(u32 x)
+{
+	return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+
+template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12, int SKIP_ = 0> struct Leaf16Cfg {
+	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64;
+	static constexpr int SKIP = SKIP_;   // probe only: 1 no register passes, 2 no count / scan / placement, 4 no write-out
+	static constexpr int NV = (CAP / 8 + BLOCK - 1) / BLOCK;     // 16-byte vectors of eight values per lane
+	static constexpr int NCH = (CAP / 16 + BLOCK - 1) / BLOCK;   // chunks of sixteen values per lane
+	static constexpr int NBITS = NBITS_;                         // the top NBITS of the sixteen bits name a value's bin:
+	static constexpr int NBIN = 1 << NBITS;                      // about as many bins as the leaf has keys
+	static constexpr int NCELLW = NBIN / 2;                      // two 16-bit cells to a word
+	static constexpr int PLANES = NCELLW / 4 / BLOCK;            // 16-byte vectors of cells per thread
+	static constexpr u32 MAXBIN = 9;     // the largest bin two passes over 16-value chunks put right
+	static constexpr u32 MAXBIN2 = 25;   // ... and four passes (ceil((m - 1) / 8) + 1 passes for a bin of m keys)
+	static_assert(NBITS >= 10 && NBITS <= 12, "");
+	static_assert(CAP % 16 == 0 && CAP <= 8192, "whole chunks; bin starts fit 16 bits");
+	static_assert(BLOCK == 256 || BLOCK == 512, "one or two vectors of cells per thread");
+};
+
+// segtab[s].slot names the slot (of slack_cap two-byte values) leaf s reads; the sorted keys go to out + segtab[s].beg.
+// Does nothing unless the device-side plan is a two-level one whose leaves lie in slots of (lo, hi] values.
+// redo / SegCtl::nredo: the leaves this kernel leaves alone (a bin of more than maxbin2 <= MAXBIN2 keys; 0: every leaf, tests).
+// SegCtl::leaf16 == 0 (the sample saw the keys cluster in their low sixteen bits): nothing at all.
+template <typename KT, typename C>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__restrict__ src, KT *__restrict__ aux,
+                                                                      const Plan *__restrict__ plan,
+                                                                      const LeafSeg *__restrict__ segtab, SegCtl *__restrict__ ctl,
+                                                                      KdfArgs<KT> ka, u32 lo, u32 hi,
+                                                                      const uint16_t *__restrict__ slots, u32 slack_cap,
+                                                                      u32 *__restrict__ redo, u32 maxbin2 = C::MAXBIN2)
+{
+	static_assert(sizeof(KT) == 4, "4-byte keys: two MSB digits in the slot, two bytes in the leaf");
+	constexpr int BLOCK = C::BLOCK, CAP = C::CAP, NV = C::NV, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
+	const u32 hyb = plan->hyb, ncols = plan->ncols;
+	const u32 c1 = plan->cols[3] & 15u, c2 = plan->cols[2] & 15u;
+	const u32 mode = ctl->mode, maxleaf = ctl->maxleaf, nseg = ctl->nleaf, on = ctl->leaf16;
+	if (hyb != HYB_TWO_LEVEL || ncols != 4 || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi || !on)
+		return;
+	KT *out = src;   // (four kept columns: the reference's passes end in src, radix_sort.hpp:92)
+	(void)aux;
+	// cells: 16 bits per bin, bin b in half (b & 1) of word b >> 1: a count, then the bin's start, then its cursor
+	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];           // + a word per lane for values that do not exist
+	__shared__ __attribute__((aligned(16))) uint16_t stage[CAP + 32 + 64];   // + padding behind the leaf + a place per lane
+	__shared__ u32 ws[NW], wmax[NW];
+	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const u32 swid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
+	const KT key0 = (KT)ctl->key0_lo;
+	const KT digits = (KT)((KT)0xFFu << (8 * c1)) | (KT)((KT)0xFFu << (8 * c2));
+	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+		const LeafSeg ls = segtab[s];
+		const u32 cnt = ls.cnt, slot = ls.slot;
+		if (cnt == 0)
+			continue;
+		// ---- the slot's values: 16 bytes per lane and step, all requested at once
+		const uint16_t *q = slots + (u64)(slot - 1) * slack_cap;
+		u32x4 kv[NV];
+		int nvalid[NV];
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			const u32 e0 = 8 * (tid + BLOCK * j);
+			const int left = (int)cnt - (int)e0;
+			nvalid[j] = left < 0 ? 0 : left > 8 ? 8 : left;
+			kv[j] = u32x4{0, 0, 0, 0};
+			if (left > 0)
+				kv[j] = *(const u32x4 *)(q + e0);
+		}
+		// vectors in which this WAVE has any value (the last round of a slot that is not full)
+		auto wave_has = [&](int j) { return 8 * (64 * swid + BLOCK * (u32)j) < cnt; };
+		{
+			const u32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j)
+				((u32x4 *)cell)[tid + BLOCK * j] = zero;
+		}
+		__syncthreads();
+		u32 mx = 0;
+		if constexpr (C::SKIP & 2) {
+#pragma unroll
+			for (int j = 0; j < NV; ++j)
+				if (wave_has(j))
+					*(u32x4 *)&stage[8 * (tid + BLOCK * j)] = kv[j];
+		} else {
+			// a value's cell: byte address of its word and the shift of its half; values that do not exist count in the lane's own word
+			auto cell_of = [&](u32 w, int k, bool valid, u32 &sh) -> u32 * {
+				// k even: the value is w[15:0], its bin w[15:4], word w[15:5], half w[4]; k odd: the same 16 bits higher
+				constexpr int D = 12 - C::NBITS;   // (twelve bits: word w[15:5], half w[4])
+				const u32 word = (k & 1) ? (w >> (21 + D)) : ((w >> (5 + D)) & (u32)(NCELLW - 1));
+				sh = (k & 1) ? ((w >> (16 + D)) & 16u) : ((w >> D) & 16u);
+				return &cell[valid ? word : NCELLW + lane];
+			};
+			// ---- count
+#pragma unroll
+			for (int j = 0; j < NV; ++j) {
+				if (wave_has(j)) {
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						u32 sh;
+						u32 *a = cell_of(kv[j][k >> 1], k, k < nvalid[j], sh);
+						__hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+				}
+			}
+			__syncthreads();
+			// ---- scan: thread t owns the 16-byte vectors t, t + BLOCK, ... of the cells (conflict-free); the order of the bins
+			// is vector-major, so one scan over the threads per vector is needed: 16-bit sums packed into one register
+			u32x4 c[PLANES];
+			u32 pk = 0, mxp = 0;
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j) {
+				c[j] = ((const u32x4 *)cell)[tid + BLOCK * j];
+				u32 run = 0;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const u32 x = c[j][i];
+					mxp = pk_max_u16(mxp, x);
+					const u32 lo16 = x & 0xFFFFu, hs = run + lo16;
+					c[j][i] = run | (hs << 16);   // the two bins' starts, relative to the vector's
+					run = hs + (x >> 16);
+				}
+				pk |= run << (16 * j);
+			}
+			mx = (mxp & 0xFFFFu) > (mxp >> 16) ? (mxp & 0xFFFFu) : (mxp >> 16);
+			const u32 incl = wave_incl_scan_dpp(pk);
+			// the workgroup's largest bin
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const u32 y = (u32)__shfl_xor((int)mx, o);
+				mx = mx > y ? mx : y;
+			}
+			if (lane == 63) {
+				ws[wid] = incl;
+				wmax[wid] = mx;
+			}
+			__syncthreads();
+			mx = wmax[0];
+#pragma unroll
+			for (int w = 1; w < NW; ++w)
+				mx = mx > wmax[w] ? mx : wmax[w];
+			if (mx > maxbin2) {
+				// a bin too large for the register passes: the leaf goes to rsx_leaf_sort_kernel (nothing was written)
+				if (tid == 0)
+					redo[atomicAdd(&ctl->nredo, 1u)] = s;
+				continue;
+			}
+			{
+				u32 base = 0, tot = 0;
+#pragma unroll
+				for (u32 w = 0; w < (u32)NW; ++w) {
+					const u32 a = ws[w];
+					base += w < wid ? a : 0u;
+					tot += a;
+				}
+				const u32 e = incl - pk + base;   // exclusive, per 16-bit field
+				u32 o[2];
+				o[0] = e & 0xFFFFu;
+				o[1] = (tot & 0xFFFFu) + (e >> 16);
+#pragma unroll
+				for (int j = 0; j < PLANES; ++j) {
+					const u32 bb = o[j] | (o[j] << 16);
+					u32x4 x;
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+						x[i] = c[j][i] + bb;
+					((u32x4 *)cell)[tid + BLOCK * j] = x;
+				}
+			}
+			__syncthreads();
+			// ---- place: the returning atomic on the bin's start is the key's place (any order inside a bin)
+#pragma unroll
+			for (int j = 0; j < NV; ++j) {
+				if (wave_has(j)) {
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						const u32 w = kv[j][k >> 1];
+						const bool valid = k < nvalid[j];
+						u32 sh;
+						u32 *a = cell_of(w, k, valid, sh);
+						const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						const u32 pos = (old >> sh) & 0xFFFFu;
+						stage[valid ? pos : CAP + 32 + lane] = (uint16_t)((k & 1) ? (w >> 16) : w);
+					}
+				}
+			}
+		}
+		if (tid < 32)
+			stage[cnt + tid] = (uint16_t)0xFFFFu;   // what the last chunks read behind the leaf's end sorts last
+		__syncthreads();
+		if constexpr (!(C::SKIP & 1)) {
+			// ---- the low four bits: chunks of 16 values at 16 i (sorted), then at 16 i + 8 (two sorted halves: merged), and
+			// twice more for bins of more than MAXBIN keys (evenly spread keys: one leaf in two thousand)
+			const u32 npass = mx > C::MAXBIN ? 4u : 2u;
+			for (u32 pass = 0; pass < npass; ++pass) {
+				const u32 off = 8 * (pass & 1);
+#pragma unroll
+				for (int r = 0; r < NCH; ++r) {
+					const u32 ch = tid + BLOCK * r;
+					if (16 * ch + off < cnt) {
+						u32x4 *p = (u32x4 *)&stage[16 * ch + off];
+						const u32x4 x0 = p[0], x1 = p[1];
+						u32 d[8];
+						if (pass == 0) {
+							d[0] = x0[0], d[1] = x0[1], d[2] = x0[2], d[3] = x0[3];
+							d[4] = x1[0], d[5] = x1[1], d[6] = x1[2], d[7] = x1[3];
+							sort16_packed(d);
+						} else {
+							const u32 a[4] = {x0[0], x0[1], x0[2], x0[3]}, b[4] = {x1[0], x1[1], x1[2], x1[3]};
+							planes_of_two_runs(d, a, b);   // (both halves were sorted by the pass before)
+							merge16_packed(d);
+						}
+						p[0] = u32x4{d[0], d[1], d[2], d[3]};
+						p[1] = u32x4{d[4], d[5], d[6], d[7]};
+					}
+				}
+				__syncthreads();
+			}
+		}
+		// ---- write out: four values (8 bytes of LDS) -> four keys (16 bytes) per lane and step
+		if constexpr (!(C::SKIP & 4)) {
+			const KT upper = (KT)((key0 & ~digits & ~(KT)0xFFFFu) | ((KT)((slot - 1) >> 8) << (8 * c1)) | ((KT)((slot - 1) & 255u) << (8 * c2)));
+			KT *o = out + ls.beg;
+			for (u32 i0 = 4 * tid; i0 < cnt; i0 += 4 * BLOCK) {
+				const uint2 x = *(const uint2 *)&stage[i0];
+				KT kk[4];
+				kk[0] = kdf_invert((KT)(upper | (x.x & 0xFFFFu)), ka);
+				kk[1] = kdf_invert((KT)(upper | (x.x >> 16)), ka);
+				kk[2] = kdf_invert((KT)(upper | (x.y & 0xFFFFu)), ka);
+				kk[3] = kdf_invert((KT)(upper | (x.y >> 16)), ka);
+				if (i0 + 4 <= cnt) {
+					store_chunk<KT, 4>(o + i0, kk);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 4; ++e)
+						if (i0 + e < cnt)
+							o[i0 + e] = kk[e];
+				}
+			}
+		}
+		// (the next leaf's first writes to `stage` lie behind three more barriers)
+	}
+}
+
+}  // namespace rsx

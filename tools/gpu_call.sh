@@ -1,11 +1,8 @@
 #!/bin/bash
-# scratch: the commands of the current gpurun call (here: what the driver runs at the end of a round)
-set -x
+# scratch: the commands of the current gpurun call
 cd /root/repo
-mkdir -p gpurun_out/final
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/final/pytest_gpu.txt 2>&1
-tail -3 gpurun_out/final/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.txt 2>&1
-tail -1 gpurun_out/final/smoke.txt
-timeout 600 python bench.py > gpurun_out/final/bench.txt 2>&1
-tail -1 gpurun_out/final/bench.txt | cut -c1-400
+mkdir -p gpurun_out/r4a
+timeout 900 python -m pytest tests/test_gpu_hybrid.py -x -q 2>&1 | tail -15 > gpurun_out/r4a/hybrid.txt
+cat gpurun_out/r4a/hybrid.txt
+timeout 300 python bench.py --no-cpu-baseline > gpurun_out/r4a/bench.txt 2>&1
+tail -1 gpurun_out/r4a/bench.txt | cut -c1-1500
