@@ -3,11 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one full sort (histogram + plan + every scatter pass) of one batch
-of synthetic keys that is already resident in HBM when the timed region starts.
+A "step" is one full sort of one batch of synthetic keys that is already resident
+in HBM when the timed region starts -- whatever route the library takes for it
+(`config.passes` names it from rsx_info.hybrid).  For the N = 1 workload that is,
+since round 3: a sample kernel that proves the input unsorted and every column kept,
+two MSB scatter passes into per-bucket slots (the second writes two bytes per key)
+and the leaves; the same run then times the reference's own loop --
+histogram + one pass per kept column, radix_sort.hpp:82-90 -- for comparison
+(`kernels.lsd_only_*`, never `value`).
 
   N = 1   BASELINE.json configs[1]: 2^28 uniform-random u32 keys (splitmix64,
-          seed 1 for the first batch), 4 x 8-bit LSD passes, keys only.
+          seed 1 for the first batch), 4 kept 8-bit columns, keys only.
   N > 1   configs[4]: each rank holds 2^29 u32 keys (N = 8 -> 2^32 keys in all),
           one MSD-digit split pass + RCCL all-to-all-v (in sub-ranges, overlapped
           with the local LSD sorts of the sub-ranges already received) per step
@@ -20,10 +26,14 @@ takes the reference's pre-sorted early exit and nothing is copied inside the
 timed region.
 
 The one JSON line printed by rank 0 carries, besides the contract's fields,
-  roofline      the scatter kernel (dominant: P of the 2P+1 array sweeps): algorithmic
-                bytes per launch = n * 2 * sizeof(key) over the kernel's
-                average duration measured with HIP events on the launch stream inside
-                the timed region (rsx_profile_begin/end), against the 8 TB/s HBM3E peak;
+  roofline      the kernel with the LARGEST time per step (the library times its kernels by
+                class with HIP events on the launch stream inside the timed region,
+                rsx_profile_begin/end): algorithmic bytes per launch (what that
+                launch must read and write) over its average duration, against the 8 TB/s
+                HBM3E peak; `per_kernel` lists every class that ran the same way, `whole_sort`
+                the sum of their algorithmic bytes over the step time; `traffic` = the
+                dominant kernel's HBM bytes per launch from the committed rocprofv3 --pmc
+                passes (profiles/pmc_kernels.json, which names the commit it was measured at);
   cpu_baseline  the real reference (oracle/_ref/libref*.so, kind "reference") or, when
                 that is absent, the C restatement (kind "port"), timed on ONE pinned host core
                 on the whole 2^28-key batch 0 (median of 5) and on 40 M keys (single shot),
@@ -55,16 +65,37 @@ def load_baseline_metric():
         return "Gkeys/s sorting 2^28 u32 (1 GPU) + HBM GB/s vs roofline; 1/2/4/8-GPU scaling"
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per scatter launch from the committed rocprofv3 --pmc passes, if any (profiles/pmc_scatter.json), and
-    the commit those counters were measured at (PMC counters need rocprofv3 around the process: not a per-run reading)."""
-    path = os.path.join(ROOT, "profiles", "pmc_scatter.json")
+def pmc_traffic_per_launch(kernel_marks):
+    """HBM bytes per launch of the kernel whose profiled name contains every string of `kernel_marks`, from the committed
+    rocprofv3 --pmc passes, if any (profiles/pmc_kernels.json), and the commit those counters were measured at (PMC counters
+    need rocprofv3 around the process: not a per-run reading)."""
+    path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return d["hbm_bytes_per_launch"], d.get("measured_at_commit")
+        for name, row in d["kernels"].items():
+            if all(m in name for m in kernel_marks):
+                return row["hbm_bytes_per_launch"], d.get("measured_at_commit")
     except Exception:
-        return None, None
+        pass
+    return None, None
+
+
+# The classes the library's profile separates (rsx_profile: ProfScope kinds 0 .. 3), per route of the N = 1 workload: the
+# kernel behind each and the marks its rocprofv3 name carries (profiles/pmc_kernels.json)
+def kernel_classes(how):
+    two_level = how in (2, 4, 5)
+    return {
+        "hist": ("rsx_hist_kernel<u32> (all columns' counts + the pre-sorted test, radix_sort.hpp:47-58)", ["rsx_hist_kernel<u32"]),
+        "scatter": (("rsx_scatter2_kernel<u32,NoVal,...,SEG> (level-1 pass: whole keys into 256 slots)", ["rsx_scatter2_kernel<u32, NoVal", "u32, true>"])
+                    if how == 5 else
+                    ("rsx_scatter2_kernel<u32,NoVal,u32> (one stable pass by an 8-bit column, radix_sort.hpp:82-90)", ["rsx_scatter2_kernel<u32, NoVal", "u32, false>"])),
+        "narrow": ("rsx_scatter2_kernel<u32,NoVal,...,KTO=u16,SEG> (level-2 pass: two bytes per key into 65536 slots)",
+                   ["rsx_scatter2_kernel<u32, NoVal", "u16, true>"]),
+        "leaf": (("rsx_leaf16_kernel<u32,Leaf16Cfg<256,5120,8,12>> (two-byte slots in, sorted keys out; + the list launch of rsx_leaf_sort_kernel)",
+                  ["rsx_leaf16_kernel<u32"]) if how == 5 else
+                 ("rsx_leaf_sort_kernel<u32> (%s)" % ("65536 buckets" if two_level else "256 buckets"), ["rsx_leaf_sort_kernel<u32"])),
+    }
 
 
 def cpu_model():
@@ -309,10 +340,27 @@ def main():
         rsa.reload_env()
     if rank == 0:
         total_keys = float(K) * n * world
-        launches = max(int(prof.scatter_launches), 1)
-        avg_ms = prof.scatter_ms / launches
-        bytes_per_launch = prof.scatter_bytes / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        classes = kernel_classes(how)
+        per_kernel = {}
+        for cls, (ms, launches, nbytes) in (("hist", (prof.hist_ms, prof.hist_launches, prof.hist_bytes)),
+                                            ("scatter", (prof.scatter_ms, prof.scatter_launches, prof.scatter_bytes)),
+                                            ("narrow", (prof.narrow_ms, prof.narrow_launches, prof.narrow_bytes)),
+                                            ("leaf", (prof.leaf_ms, prof.leaf_launches, prof.leaf_bytes))):
+            if not launches or ms <= 0:
+                continue
+            # (a class may be several launches per step -- four passes, or the leaves and their list launch: what is compared
+            # with the peak is the class's bytes over the class's time, i.e. the average over its launches)
+            gbps = nbytes / (ms * 1e-3) / 1e9
+            per_kernel[cls] = {"kernel": classes[cls][0], "ms_per_step": ms / K, "launches_per_step": launches / K,
+                               "bytes_per_launch": nbytes / launches, "avg_launch_ms": ms / launches,
+                               "achieved": gbps, "frac": gbps / HBM_PEAK_GBS}
+        if not per_kernel:   # (nothing was timed: cannot happen on a working library, but the line must still print)
+            per_kernel["scatter"] = {"kernel": classes["scatter"][0], "ms_per_step": 0.0, "launches_per_step": 0.0, "bytes_per_launch": 0.0,
+                                     "avg_launch_ms": 0.0, "achieved": 0.0, "frac": 0.0}
+        dominant = max(per_kernel, key=lambda c: per_kernel[c]["ms_per_step"])
+        dom = per_kernel[dominant]
+        traffic, traffic_commit = pmc_traffic_per_launch(classes[dominant][1])
+        all_bytes = prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes + prof.narrow_bytes
         out = {
             "metric": load_baseline_metric(),
             "value": total_keys / elapsed / 1e9,
@@ -344,12 +392,17 @@ def main():
                               "the two bytes the leaves sort by), then the other kept columns per bucket in LDS (README.md:647-650)"}[how],
             },
             "roofline": {
-                "kernel": "rsx_scatter2_kernel<u32,NoVal,u32>",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_per_launch()[0],
-                "traffic_measured_at_commit": pmc_traffic_per_launch()[1],
-                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(prof.scatter_launches),
+                "kernel": dom["kernel"], "kernel_class": dominant,
+                "dominant_by": "largest time per step among the kernel classes of the step (HIP events): %.3f of %.3f ms" % (dom["ms_per_step"], elapsed / K * 1e3),
+                "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["frac"],
+                "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
+                "bytes_per_launch": dom["bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
+                "launches": int(round(dom["launches_per_step"] * K)),
+                "per_kernel": per_kernel,
+                # every kernel's algorithmic bytes of a step over the whole step (launch gaps and the small kernels included)
+                "whole_sort": None if sharded else {"bytes_per_key": all_bytes / total_keys, "achieved": all_bytes / elapsed / 1e9,
+                                                    "frac": all_bytes / elapsed / 1e9 / HBM_PEAK_GBS},
             },
             "kernels": {
                 "scatter_ms_per_step": prof.scatter_ms / K,
@@ -364,8 +417,8 @@ def main():
                 # algorithmic bytes per key of the whole sort, summed over the kernels that ran: 4 (histogram) +
                 # 4 passes x 8 = 36 with one pass per kept column; two MSB passes + leaves: 4 + 2 x 8 + 8 = 28 (+ 4 when the
                 # second pass needs per-bucket counts first)
-                "sort_algorithmic_bytes_per_key": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes + prof.narrow_bytes) / total_keys,
-                "sort_algorithmic_GBps": None if sharded else (prof.hist_bytes + prof.scatter_bytes + prof.leaf_bytes + prof.narrow_bytes) / elapsed / 1e9,
+                "sort_algorithmic_bytes_per_key": None if sharded else all_bytes / total_keys,
+                "sort_algorithmic_GBps": None if sharded else all_bytes / elapsed / 1e9,
                 "lsd_only_ms_per_step": None if lsd_only is None else lsd_only * 1e3,
                 "lsd_only_Gkeys_per_s": None if lsd_only is None else n / lsd_only / 1e9,
             },

@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 N = 1 << 28
+# the routes (rsx_info.hybrid) BASELINE.json's configurations take at this size: 5 = no histogram, two MSB passes into slots and
+# leaves; 0 = histogram and one pass per kept column (the skewed inputs); DESIGN.md 4b / 4c
+ZIPF_ROUTE = 0
+RANK_ROUTE = {"random_bits": 5, "uniform_pm1": 0, "duplicate_heavy": 0}
 SIGN64 = -(1 << 63)
 SIGN32 = -(1 << 31)
 
@@ -22,6 +26,14 @@ SIGN32 = -(1 << 31)
 @pytest.fixture(scope="module", autouse=True)
 def _need_gpu():
     rsa.require_gpu()
+
+
+@pytest.fixture(autouse=True)
+def _fresh_routes():
+    """The library skips its next sorts without a histogram after an attempt that was called off (per context); a test that
+    asserts the route (rsx_info.hybrid) must not depend on what ran before it: rsx_reload_env() forgets."""
+    rsa.reload_env()
+    yield
 
 
 def _sorted_unsigned64(t):
@@ -42,6 +54,7 @@ def test_cfg3_u64_column_skipping(mask, cols, in_aux):
     res, info = rsa.radix_sort(src, aux, dtype=rsa.U64)
     torch.cuda.synchronize()
     assert info.ncols == cols and info.result_in_aux == in_aux          # SURVEY.md 8d cfg 3, appendix A item 5
+    assert info.hybrid == 5, info.hybrid                                # no histogram, two MSB passes into slots, leaves
     assert _sorted_unsigned64(res)
     assert _checksums(res) == before
     if cols == 5:   # one case bit for bit against the oracle (about half a minute of host time)
@@ -68,6 +81,7 @@ def test_cfg3_u64_zipf_like():
     res, info = rsa.radix_sort(keys, aux, dtype=rsa.U64)
     torch.cuda.synchronize()
     assert info.ncols == 5 and info.result_in_aux == 1
+    assert info.hybrid == ZIPF_ROUTE, info.hybrid                       # dominant top digits: no slot scheme takes them
     assert _sorted_unsigned64(res) and _checksums(res) == before
 
 
@@ -90,6 +104,7 @@ def test_cfg4_f32_keys_u32_ranks(variant):
     ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
     torch.cuda.synchronize()
     assert torch.equal(bits, keep)                                       # src is const (radix_sort_rank.hpp:97)
+    assert info.hybrid == RANK_ROUTE[variant], (variant, info.hybrid)
     assert info.result_in_aux == (info.ncols & 1)                        # radix_sort_rank.hpp:88,:91
     r64 = ranks.to(torch.int64)
     # a permutation: every index once
@@ -112,11 +127,13 @@ def test_cfg4_pairs_f32_u32_payload():
     """The same configuration through the key+payload entry point (keys and payloads both move)."""
     keys = torch.empty(N, dtype=torch.int32, device="cuda")
     rsa.fill_splitmix(keys, seed=12, mask=0xFFF000FF)
+    want_route = 0                                                       # (a column with two values: one pass per column)
     vals = torch.arange(N, dtype=torch.int32, device="cuda")
     ka, va = torch.empty_like(keys), torch.empty_like(vals)
     orig = keys.clone()
     kr, vr, info = rsa.radix_sort_pairs(keys, ka, vals, va, dtype=rsa.F32)
     torch.cuda.synchronize()
+    assert info.hybrid == want_route, info.hybrid
     assert torch.equal(orig[vr.to(torch.int64)], kr)                     # payload still belongs to its key
     kdf = torch.where(kr < 0, ~kr, kr ^ SIGN32) ^ SIGN32
     assert bool((kdf[1:] >= kdf[:-1]).all().item())

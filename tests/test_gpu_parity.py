@@ -823,9 +823,13 @@ def test_full_size_2p28_u32_properties():
     a = ol.splitmix_fill(n, ol.U32, 1)
     src = to_dev(a)
     aux = torch.empty_like(src)
+    rsa.reload_env()          # (no back-off left over from an earlier test's called-off attempt: the route is asserted)
     res, info = rsa.radix_sort(src, aux, dtype=ol.U32)
     torch.cuda.synchronize()
     assert info.kept_columns() == [0, 1, 2, 3] and info.result_in_aux == 0
+    # BASELINE.json's headline in its production geometry: no histogram, two MSB passes into slots (the second of two-byte
+    # values), rsx_leaf16_kernel on slots of ~4096 values: everything below checks THAT route
+    assert info.hybrid == 5, info.hybrid
     got = to_bits(res, ol.U32)
     assert np.all(got[:-1] <= got[1:])
     assert int(got.astype(np.uint64).sum()) == int(a.astype(np.uint64).sum())

@@ -1,0 +1,136 @@
+"""Every production route and leaf shape against the oracle AT THE SIZE THAT SELECTS IT, with the route asserted.
+
+The differential tests of tests/test_gpu_hybrid.py lower the library's thresholds (RSX_TWO_LEVEL_MIN_LOG2=22) so that every
+branch runs on arrays the oracle sorts in a second -- but a slot of 64 keys is not the geometry production runs in.  Here
+nothing is lowered: the arrays are as large as the sizes at which the library itself picks each leaf shape (slots of 1280,
+2048, 2560, 3840 and 5120 values; u64 leaves carried as u64 and as u32; pairs carried as 8-byte values), the result is
+compared bit for bit with the CPU restatement of rs_sort_main / rs_sort_rank (radix_sort.hpp:31-93,
+radix_sort_rank.hpp:22-92), and rsx_info.hybrid must name the route the size is meant to take (5: no histogram, two MSB
+passes into slots, leaves -- DESIGN.md 4c) -- a sort that was silently diverted would pass a result-only test.
+
+The oracle needs one to three seconds per case on one host core (rso_sort: 0.15 Gkeys/s).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+MI = 1 << 20
+_CARRIER = {4: np.int32, 8: np.int64}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    rsa.require_gpu()
+
+
+@pytest.fixture(autouse=True)
+def _fresh_routes():
+    rsa.reload_env()     # (no back-off from an earlier attempt that was called off: the route is asserted)
+    yield
+    torch.cuda.empty_cache()
+
+
+def _sort_and_compare(a, dt, order, want_route, what):
+    want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+    src = torch.from_numpy(np.ascontiguousarray(a).view(_CARRIER[a.itemsize]).copy()).cuda()
+    aux = torch.full_like(src, 0x5A5A5A5A)
+    res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)
+    torch.cuda.synchronize()
+    assert info.hybrid == want_route, (what, info.hybrid)
+    assert info.result_in_aux == want_aux, what
+    assert info.kept_columns() == list(winfo.cols[:winfo.ncols]), what
+    got = res.cpu().numpy().view(ol.NP_BITS[dt])
+    assert np.array_equal(got, want), what
+    return info
+
+
+# n, what selects: slots of cap = 1.25 n / 65536 rounded up to 256 values; rsx_leaf16_kernel's 2560-value shape (eleven bin
+# bits) up to 128 Mi keys, its 5120-value shape (twelve) above
+@pytest.mark.parametrize("n_mi", [64, 96, 128, 192])
+def test_u32_without_histogram_at_the_sizes_that_pick_each_leaf_shape(n_mi):
+    n = n_mi * MI + 12345 * (n_mi % 3)
+    a = ol.splitmix_fill(n, ol.U32, 4000 + n_mi, 0xFFFFFFFF)
+    _sort_and_compare(a, ol.U32, ol.ASC, 5, ("u32", n_mi))
+
+
+@pytest.mark.parametrize("switch", ["RSX_NO_LEAF16", "RSX_NO_DENSE_SLOTS"])
+@pytest.mark.parametrize("n_mi", [64, 96, 128, 192])
+def test_u32_round3_leaves_at_the_same_sizes(n_mi, switch, monkeypatch):
+    """The leaves of round 3 stay in the library (rsx_leaf_sort_kernel works off what rsx_leaf16_kernel leaves alone, and takes
+    everything when the sample finds the low sixteen bits clustered): its cut shapes (2048, 3072, 5120, 8 Ki keys) on two-byte
+    slots (RSX_NO_LEAF16=1: 3073 .. 5120-value slots only, as in round 3) and on whole keys (RSX_NO_DENSE_SLOTS=1)."""
+    monkeypatch.setenv(switch, "1")
+    n = n_mi * MI + 777
+    a = ol.splitmix_fill(n, ol.I32, 4100 + n_mi, 0xFFFFFFFF)
+    _sort_and_compare(a, ol.I32, ol.DESC, 5, ("i32 desc", n_mi, switch))
+
+
+def test_u32_every_leaf_through_the_list(monkeypatch):
+    """RSX_LEAF16_MAXBIN=0: rsx_leaf16_kernel puts every leaf on its list and the list launch sorts them all."""
+    monkeypatch.setenv("RSX_LEAF16_MAXBIN", "0")
+    n = 160 * MI + 5
+    a = ol.splitmix_fill(n, ol.F32, 4200, 0xFFFFFFFF)
+    _sort_and_compare(a, ol.F32, ol.ASC, 5, "f32, every leaf listed")
+
+
+def test_u32_low_bits_clustered_in_some_buckets_only():
+    """Keys whose low sixteen bits take few values, but only in some (digit, digit) buckets -- the sample (8192 keys of the
+    whole array) sees nothing of it: those leaves' bins hold 10 .. 25 keys (two more register passes) or more (the list)."""
+    n = 160 * MI
+    a = ol.splitmix_fill(n, ol.U32, 4300, 0xFFFFFFFF).view(np.uint32).copy()
+    top = a >> 16
+    some = (top % 97) == 5                     # one bucket in 97: low bits from 256 values -> bins of ~10 keys of 2560
+    a[some] &= np.uint32(0xFFFF0FF0)
+    few = (top % 389) == 7                     # one in 389: 16 values -> bins of 160 keys
+    a[few] &= np.uint32(0xFFFF000F)
+    _sort_and_compare(a, ol.U32, ol.ASC, 5, "locally clustered low bits")
+
+
+def test_u32_low_bits_clustered_everywhere_keeps_the_route_and_changes_the_leaves():
+    """The same clustering in every bucket: every column still has 16 or more values and no hot digit, so the sort still goes
+    without a histogram -- and the sample's count over rsx_leaf16_kernel's bins (SegCtl::leaf16) hands every leaf to
+    rsx_leaf_sort_kernel."""
+    n = 160 * MI + 3
+    a = ol.splitmix_fill(n, ol.U32, 4400, 0xFFFFFC0F)
+    _sort_and_compare(a, ol.U32, ol.ASC, 5, "low bits & 0xFC0F")
+
+
+@pytest.mark.parametrize("n_mi,mask", [(48, 0xFFFFFFFFFFFFFFFF), (96, 0xFFFFFFFFFFFFFFFF), (48, 0xFFFFFFFFFF), (96, 0xFFFFFFFFFF),
+                                       (96, 0xFFFFFFFF)])
+def test_u64_without_histogram(n_mi, mask):
+    """8-byte keys from 48 Mi keys on: uniform (six columns per leaf: the top three + odd-even transposition, carried as u64)
+    and with constant top bytes (leaves carried as u32; the constant columns checked on every key by the level-1 pass)."""
+    n = n_mi * MI + 4242
+    a = ol.splitmix_fill(n, ol.U64, 4500 + n_mi, mask)
+    _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64", n_mi, hex(mask)))
+
+
+@pytest.mark.parametrize("n_mi", [96, 128])
+def test_f32_ranks_and_pairs_without_histogram(n_mi):
+    """Rank sorts and key + payload sorts of 4-byte keys take the route from 96 Mi pairs on (rsx_leaf_pairs_kernel: the pair
+    carried as one 8-byte value)."""
+    n = n_mi * MI + 99
+    a = ol.splitmix_fill(n, ol.F32, 4600 + n_mi, 0xFFFFFFFF)
+    want, want_aux, _, _ = ol.oracle_rank(a, ol.F32)          # (the C restatement of rs_sort_rank with Listing 6's loop)
+    want = want.copy()
+    bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert info.hybrid == 5, info.hybrid
+    assert info.result_in_aux == want_aux == (info.ncols & 1)
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)
+    del ib, ranks
+    rsa.reload_env()
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    ka, va = torch.empty_like(bits), torch.empty_like(vals)
+    kr, vr, info = rsa.radix_sort_pairs(bits, ka, vals, va, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert info.hybrid == 5, info.hybrid
+    assert np.array_equal(vr.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(kr.cpu().numpy().view(np.uint32), a.view(np.uint32)[want])
