@@ -1020,14 +1020,28 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			SegCtl *wctl = (SegCtl *)c.seg.p;
 			typedef Leaf16Cfg<256, 5120, 8, 12> L5k;
 			typedef Leaf16Cfg<256, 2560, 8, 11> L2k;
+			typedef Leaf16WCfg<1024, 10, 4> W1k;   // small slots (arrays of up to ~50 Mi keys): a wave per leaf
+			typedef Leaf16WCfg<512, 9, 4> W512;
+			if (c.slack_cap <= (u32)W1k::CAP) {
+				// (no list, no second launch: the wave kernel goes on until its leaf is in order)
+				if (c.slack_cap <= (u32)W512::CAP)
+					hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W512>), dim3(grid_s / W512::NW), dim3(W512::BLOCK), 0, c.stream, src, aux,
+					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)W512::CAP, (const uint16_t *)slots, c.slack_cap);
+				else
+					hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W1k>), dim3(grid_s / W1k::NW), dim3(W1k::BLOCK), 0, c.stream, src, aux,
+					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)W1k::CAP, (const uint16_t *)slots, c.slack_cap);
+				HIP_TRY(hipGetLastError());
+				return RSX_OK;
+			}
+#define RSX_LAUNCH_L16(KERNEL, CFG, GRID)                                                                                     \
+			hipLaunchKernelGGL((KERNEL<KT, CFG>), dim3(GRID), dim3(CFG::BLOCK), 0, c.stream, src, aux, (const Plan *)c.plan(),  \
+			                   segtab, wctl, ka, 0u, (u32)CFG::CAP, (const uint16_t *)slots, c.slack_cap, redo,                \
+			                   (u32)env().leaf16_maxbin)
 			if (c.slack_cap <= (u32)L2k::CAP)
-				hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L2k>), dim3(grid_s), dim3(L2k::BLOCK), 0, c.stream, src, aux,
-				                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L2k::CAP, (const uint16_t *)slots, c.slack_cap,
-				                   redo, (u32)env().leaf16_maxbin);
+				RSX_LAUNCH_L16(rsx_leaf16_kernel, L2k, grid_s);
 			else
-				hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L5k>), dim3(grid_s), dim3(L5k::BLOCK), 0, c.stream, src, aux,
-				                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L5k::CAP, (const uint16_t *)slots, c.slack_cap,
-				                   redo, (u32)env().leaf16_maxbin);
+				RSX_LAUNCH_L16(rsx_leaf16_kernel, L5k, grid_s);
+#undef RSX_LAUNCH_L16
 			typedef typename LeafShapes<KT>::Fit F_;
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F_, uint16_t, true>), dim3(4096), dim3(F_::BLOCK), 0, c.stream, src, aux,
 			                   (u64)n, (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)F_::CAP, slots,
@@ -1281,11 +1295,14 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		    n < std::min((size_t)3 << 25, (size_t)1 << env().two_level_min_log2))
 			return false;
 	} else {
-		// keys only: without the histogram two levels beat one pass per column earlier than with it -- 4-byte keys from 56 Mi
-		// keys on (0.521 against 0.545 ms; 48 Mi: 0.497 against 0.463), 8-byte keys from 48 Mi (1.51 against 1.62 ms; 96 Mi:
-		// 2.06 against 3.09) (tools/blind_threshold_probe.py, profiles/r03/blind_threshold_probe.txt).  RSX_BLIND_MIN_LOG2
-		// sets another floor; a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers this with it.
-		size_t floor_keys = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)7 << 23;
+		// keys only: without the histogram two levels beat one pass per column earlier than with it.  8-byte keys from 48 Mi
+		// keys on (1.51 against 1.62 ms; 96 Mi: 2.06 against 3.09; tools/blind_threshold_probe.py,
+		// profiles/r03/blind_threshold_probe.txt).  4-byte keys, round 4 (their leaves read two-byte slots and are one wave's
+		// work each, rsx_leaf16.hpp): from 10^7 keys on -- 10^7 keys 140 against 157 us, 4 * 10^7 (the reference's own headline
+		// size, radix_bench.cpp:135-138) 299 against 401, 48 Mi 347 against 461; at 8 Mi one pass per column still wins, 126
+		// against 134 (tools/mid_route_probe.py, profiles/r04/mid_route_probe.txt).  RSX_BLIND_MIN_LOG2 sets another floor;
+		// a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers this with it.
+		size_t floor_keys = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)9 << 20;
 		if (env().blind_min_log2)
 			floor_keys = (size_t)1 << env().blind_min_log2;
 		floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);

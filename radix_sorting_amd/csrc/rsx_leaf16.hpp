@@ -366,4 +366,202 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 	}
 }
 
+// ---- small slots: a WAVE per leaf ---------------------------------------------------------------------------------------
+// Arrays of 8 Mi .. 50 Mi keys (the reference's own headline, 4 * 10^7 keys, radix_bench.cpp:135-138, among them) leave slots of
+// a few hundred values: a workgroup per leaf then spends its time in barriers and in being launched (65536 leaves of 610
+// values: 148 us, 1.6 TB/s).  Here a leaf is one wave's: the same algorithm, everything in the wave's own part of the LDS --
+// a wave's DS operations execute in order, so nothing waits for anybody -- the scan is one DPP scan, the second register pass
+// takes the next chunk's lower half from the next LANE, and a workgroup's waves work on leaves of their own.
+template <int CAP_, int NBITS_, int WAVES_> struct Leaf16WCfg {
+	static constexpr int CAP = CAP_, NBITS = NBITS_, NW = WAVES_, BLOCK = 64 * WAVES_;
+	static constexpr int NV = CAP / 512;                 // 16-byte vectors of eight values per lane
+	static constexpr int NBIN = 1 << NBITS, NCELLW = NBIN / 2;
+	static constexpr int PLANES = NCELLW / 4 / 64;       // 16-byte vectors of cells per lane
+	static constexpr u32 MAXBIN = 9;
+	static_assert(CAP == 512 || CAP == 1024, "a chunk of sixteen values per lane at most");
+	static_assert(PLANES == 1 || PLANES == 2, "");
+};
+
+template <typename KT, typename C>
+__global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict__ src, KT *__restrict__ aux,
+                                                                  const Plan *__restrict__ plan,
+                                                                  const LeafSeg *__restrict__ segtab, SegCtl *__restrict__ ctl,
+                                                                  KdfArgs<KT> ka, u32 lo, u32 hi,
+                                                                  const uint16_t *__restrict__ slots, u32 slack_cap)
+{
+	static_assert(sizeof(KT) == 4, "4-byte keys: two MSB digits in the slot, two bytes in the leaf");
+	constexpr int CAP = C::CAP, NV = C::NV, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
+	const u32 hyb = plan->hyb, ncols = plan->ncols;
+	const u32 c1 = plan->cols[3] & 15u, c2 = plan->cols[2] & 15u;
+	const u32 mode = ctl->mode, maxleaf = ctl->maxleaf, nseg = ctl->nleaf;
+	// (takes every leaf, whatever the sample made of the low sixteen bits: SegCtl::leaf16 is for the workgroup kernel)
+	if (hyb != HYB_TWO_LEVEL || ncols != 4 || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi)
+		return;
+	KT *out = src;   // (four kept columns: the reference's passes end in src, radix_sort.hpp:92)
+	(void)aux;
+	__shared__ __attribute__((aligned(16))) u32 cell_all[NW][NCELLW + 64];
+	__shared__ __attribute__((aligned(16))) uint16_t stage_all[NW][CAP + 32 + 64];
+	const u32 lane = threadIdx.x & 63;
+	const u32 swid = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	u32 *cell = cell_all[swid];
+	uint16_t *stage = stage_all[swid];
+	const KT key0 = (KT)ctl->key0_lo;
+	const KT digits = (KT)((KT)0xFFu << (8 * c1)) | (KT)((KT)0xFFu << (8 * c2));
+	for (u32 s = blockIdx.x * NW + swid; s < nseg; s += gridDim.x * NW) {
+		const LeafSeg ls = segtab[s];
+		const u32 cnt = ls.cnt, slot = ls.slot;
+		if (cnt == 0)
+			continue;
+		const uint16_t *q = slots + (u64)(slot - 1) * slack_cap;
+		u32x4 kv[NV];
+		int nvalid[NV];
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			const u32 e0 = 8 * (lane + 64 * j);
+			const int left = (int)cnt - (int)e0;
+			nvalid[j] = left < 0 ? 0 : left > 8 ? 8 : left;
+			kv[j] = u32x4{0, 0, 0, 0};
+			if (left > 0)
+				kv[j] = *(const u32x4 *)(q + e0);
+		}
+		auto wave_has = [&](int j) { return 8 * (64 * (u32)j) < cnt; };
+		{
+			const u32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j)
+				((u32x4 *)cell)[lane + 64 * j] = zero;
+		}
+		RSX_COMPILER_FENCE();
+		auto cell_of = [&](u32 w, int k, bool valid, u32 &sh) -> u32 * {
+			constexpr int D = 12 - C::NBITS;
+			const u32 word = (k & 1) ? (w >> (21 + D)) : ((w >> (5 + D)) & (u32)(NCELLW - 1));
+			sh = (k & 1) ? ((w >> (16 + D)) & 16u) : ((w >> D) & 16u);
+			return &cell[valid ? word : NCELLW + lane];
+		};
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			if (wave_has(j)) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					u32 sh;
+					u32 *a = cell_of(kv[j][k >> 1], k, k < nvalid[j], sh);
+					__hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+		}
+		RSX_COMPILER_FENCE();
+		u32x4 c[PLANES];
+		u32 pk = 0, mxp = 0;
+#pragma unroll
+		for (int j = 0; j < PLANES; ++j) {
+			c[j] = ((const u32x4 *)cell)[lane + 64 * j];
+			u32 run = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const u32 x = c[j][i];
+				mxp = pk_max_u16(mxp, x);
+				const u32 lo16 = x & 0xFFFFu, hs = run + lo16;
+				c[j][i] = run | (hs << 16);
+				run = hs + (x >> 16);
+			}
+			pk |= run << (16 * j);
+		}
+		u32 mx = (mxp & 0xFFFFu) > (mxp >> 16) ? (mxp & 0xFFFFu) : (mxp >> 16);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const u32 y = (u32)__shfl_xor((int)mx, o);
+			mx = mx > y ? mx : y;
+		}
+		mx = (u32)__builtin_amdgcn_readfirstlane((int)mx);
+		{
+			const u32 incl = wave_incl_scan_dpp(pk);
+			const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+			const u32 e = incl - pk;
+			const u32 o[2] = {e & 0xFFFFu, (tot & 0xFFFFu) + (e >> 16)};
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j) {
+				const u32 bb = o[j] | (o[j] << 16);
+				u32x4 x;
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					x[i] = c[j][i] + bb;
+				((u32x4 *)cell)[lane + 64 * j] = x;
+			}
+		}
+		RSX_COMPILER_FENCE();
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			if (wave_has(j)) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const u32 w = kv[j][k >> 1];
+					const bool valid = k < nvalid[j];
+					u32 sh;
+					u32 *a = cell_of(w, k, valid, sh);
+					const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					const u32 pos = (old >> sh) & 0xFFFFu;
+					stage[valid ? pos : CAP + 32 + lane] = (uint16_t)((k & 1) ? (w >> 16) : w);
+				}
+			}
+		}
+		if (lane < 32)
+			stage[cnt + lane] = (uint16_t)0xFFFFu;
+		RSX_COMPILER_FENCE();
+		// chunks of 16 values at 16 i (sorted), then at 16 i + 8 (the upper half merged with the next lane's lower half): a
+		// bin of m keys is in order after ceil((m - 1) / 8) + 1 such passes (odd-even transposition over the half chunks it
+		// touches) -- one round for bins of up to 9 keys, which is what evenly spread keys give; no leaf is handed on
+		const u32 nch = (cnt + 15) >> 4;
+		const u32 rounds = mx <= C::MAXBIN ? 1u : ((mx + 6) / 8 + 2) / 2;
+		for (u32 r = 0; r < rounds; ++r) {
+			u32 d[8];
+			{
+				const u32x4 *p = (const u32x4 *)&stage[16 * lane];
+				const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+				const u32x4 x0 = lane < nch ? p[0] : ones, x1 = lane < nch ? p[1] : ones;
+				d[0] = x0[0], d[1] = x0[1], d[2] = x0[2], d[3] = x0[3];
+				d[4] = x1[0], d[5] = x1[1], d[6] = x1[2], d[7] = x1[3];
+			}
+			sort16_packed(d);
+			if (lane == 0)
+				*(u32x4 *)&stage[0] = u32x4{d[0], d[1], d[2], d[3]};   // (the first eight values are in place)
+			u32 lowa[4], nxt[4];
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				lowa[m] = d[4 + m];
+				const u32 y = from_next_lane(d[m]);
+				nxt[m] = lane == 63 ? ~0u : y;
+			}
+			planes_of_two_runs(d, lowa, nxt);
+			merge16_packed(d);
+			if (lane < nch) {
+				u32x4 *p = (u32x4 *)&stage[16 * lane + 8];
+				p[0] = u32x4{d[0], d[1], d[2], d[3]};
+				p[1] = u32x4{d[4], d[5], d[6], d[7]};
+			}
+			RSX_COMPILER_FENCE();
+		}
+		{
+			const KT upper = (KT)((key0 & ~digits & ~(KT)0xFFFFu) | ((KT)((slot - 1) >> 8) << (8 * c1)) | ((KT)((slot - 1) & 255u) << (8 * c2)));
+			KT *o = out + ls.beg;
+			for (u32 i0 = 4 * lane; i0 < cnt; i0 += 4 * 64) {
+				const uint2 x = *(const uint2 *)&stage[i0];
+				KT kk[4];
+				kk[0] = kdf_invert((KT)(upper | (x.x & 0xFFFFu)), ka);
+				kk[1] = kdf_invert((KT)(upper | (x.x >> 16)), ka);
+				kk[2] = kdf_invert((KT)(upper | (x.y & 0xFFFFu)), ka);
+				kk[3] = kdf_invert((KT)(upper | (x.y >> 16)), ka);
+				if (i0 + 4 <= cnt) {
+					store_chunk<KT, 4>(o + i0, kk);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 4; ++e)
+						if (i0 + e < cnt)
+							o[i0 + e] = kk[e];
+				}
+			}
+		}
+		RSX_COMPILER_FENCE();
+	}
+}
+
 }  // namespace rsx

@@ -58,6 +58,27 @@ def test_u32_without_histogram_at_the_sizes_that_pick_each_leaf_shape(n_mi):
     _sort_and_compare(a, ol.U32, ol.ASC, 5, ("u32", n_mi))
 
 
+@pytest.mark.parametrize("n,seed", [(10000000, 10), (40000000, 40), (48 * MI + 1, 48)])
+def test_u32_mid_size_arrays_a_wave_per_leaf(n, seed):
+    """BASELINE.json configs[0]'s sizes (radix_bench.cpp:135-138: 10^7 and 4 * 10^7 keys; the key file's stand-in is splitmix64
+    seed 40) and the largest array whose slots one wave takes (1024 values): rsx_leaf16w_kernel."""
+    a = ol.splitmix_fill(n, ol.U32, seed, 0xFFFFFFFF)
+    _sort_and_compare(a, ol.U32, ol.ASC, 5, ("u32", n))
+    _sort_and_compare(a, ol.F32, ol.DESC, 5, ("f32 desc", n))
+
+
+def test_u32_mid_size_low_bits_clustered():
+    """... with keys whose low sixteen bits take 64 x 16 values everywhere, and only 16 values in some buckets: the wave kernel
+    has no list to hand a leaf to -- it goes on (more rounds of register passes) until the leaf is in order."""
+    n = 40000000
+    a = ol.splitmix_fill(n, ol.U32, 41, 0xFFFFFC0F).view(np.uint32).copy()
+    _sort_and_compare(a, ol.U32, ol.ASC, 5, "low bits & 0xFC0F")
+    b = ol.splitmix_fill(n, ol.U32, 42, 0xFFFFFFFF).view(np.uint32).copy()
+    few = ((b >> 16) % 389) == 7
+    b[few] &= np.uint32(0xFFFF000F)
+    _sort_and_compare(b, ol.U32, ol.ASC, 5, "16 values in some buckets")
+
+
 @pytest.mark.parametrize("switch", ["RSX_NO_LEAF16", "RSX_NO_DENSE_SLOTS"])
 @pytest.mark.parametrize("n_mi", [64, 96, 128, 192])
 def test_u32_round3_leaves_at_the_same_sizes(n_mi, switch, monkeypatch):

@@ -1,8 +1,9 @@
 #!/bin/bash
-# scratch: the commands of the current gpurun call
 cd /root/repo
-mkdir -p gpurun_out/r4b
-timeout 1500 python -m pytest tests/test_gpu_routes.py tests/test_gpu_fullsize.py "tests/test_gpu_parity.py::test_full_size_2p28_u32_properties" -x -q --durations=8 2>&1 | tail -25 > gpurun_out/r4b/routes.txt
-cat gpurun_out/r4b/routes.txt
-timeout 300 python bench.py > gpurun_out/r4b/bench.txt 2>&1
-tail -1 gpurun_out/r4b/bench.txt | cut -c1-3000
+mkdir -p gpurun_out/r4e
+timeout 1500 python -m pytest tests/test_gpu_routes.py -x -q -k "mid_size or every_leaf or clustered" 2>&1 | tail -5 > gpurun_out/r4e/routes.txt
+cat gpurun_out/r4e/routes.txt
+./tools/radix_bench --device 0 --verify > gpurun_out/r4e/radix_bench.txt 2>&1
+grep -E "radix_sort/" gpurun_out/r4e/radix_bench.txt | head -20
+python tools/size_sweep.py > gpurun_out/r4e/size_sweep.txt 2>&1
+tail -24 gpurun_out/r4e/size_sweep.txt

@@ -133,11 +133,36 @@ template <typename C, typename OldCfg> void bench_new(const char *name, unsigned
 	       nredo, n * 6.0 / (ms + ms_redo) / 1e6, (unsigned long long)chk[0]);
 }
 
+template <typename C, typename OldCfg> void bench_wave(const char *name, unsigned grid)
+{
+	KdfArgs<u32> ka{0, 0, 0};
+	float ms = 0, ms_redo = 0;
+	u32 nredo = 0;
+	for (int rep = 0; rep < 3; ++rep) {
+		CK(hipMemset(d_out, 0xEE, n * 4));
+		CK(hipMemset(&d_ctl->nredo, 0, 4));
+		ms = timed([&] {
+			hipLaunchKernelGGL((rsx_leaf16w_kernel<u32, C>), dim3(grid), dim3(C::BLOCK), 0, 0, d_out, (u32 *)nullptr,
+			                   (const Plan *)d_plan, (const LeafSeg *)d_seg, d_ctl, ka, 0u, (u32)C::CAP,
+			                   (const uint16_t *)d_slots, cap);
+		});
+		CK(hipMemcpy(&nredo, &d_ctl->nredo, 4, hipMemcpyDeviceToHost));
+	}
+	CK(hipMemset(d_chk, 0, 24));
+	hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, 0, (const u32 *)d_out, (const u32 *)d_ref, (u64)n, d_chk);
+	u64 chk[3];
+	CK(hipMemcpy(chk, d_chk, 24, hipMemcpyDeviceToHost));
+	printf("%-40s grid %6u: %.3f ms + %.3f ms for %u leaves left over = %.0f GB/s; differences %llu\n", name, grid, ms, ms_redo,
+	       nredo, n * 6.0 / (ms + ms_redo) / 1e6, (unsigned long long)chk[0]);
+}
+
 int main(int argc, char **argv)
 {
-	const int log2n = argc > 1 ? atoi(argv[1]) : 28;
+	// argv[1]: log2 of the number of keys, or the number itself (4 * 10^7: the reference's headline)
+	const long long a1 = argc > 1 ? atoll(argv[1]) : 28;
+	const size_t nkeys = a1 <= 40 ? (size_t)1 << a1 : (size_t)a1;
 	const u32 mode = argc > 2 ? (u32)atoi(argv[2]) : 0;
-	const u32 per = (u32)(((size_t)1 << log2n) >> 16);
+	const u32 per = (u32)(nkeys >> 16);
 	if (argc > 3)
 		nleaf = 1u << atoi(argv[3]);
 	cap = ((per + per / 4 + 255) / 256) * 256;
@@ -150,7 +175,8 @@ int main(int argc, char **argv)
 	std::vector<LeafSeg> seg(nleaf);
 	u32 acc = 0, mx = 0;
 	for (u32 i = 0; i < nleaf; ++i) {
-		u32 sz = per - 64 + (((i + 1) * 2654435761u) >> 25);
+		const u32 spread = per >= 1024 ? 64 : per / 16;
+		u32 sz = per - spread + (u32)((u64)(((i + 1) * 2654435761u) >> 16) * (2 * spread) >> 16);
 		if (i % 1000 == 7)
 			sz = cap;          // a full slot
 		if (i % 1000 == 8)
@@ -191,20 +217,32 @@ int main(int argc, char **argv)
 	CK(hipMemcpy(chk, d_chk, 24, hipMemcpyDeviceToHost));
 	printf("%-40s grid %6u: %.3f ms = %.0f GB/s; descents %llu, sum %s\n", "rsx_leaf_sort_kernel<u32, 4 x 20, u16, DENSE>", nleaf, ms,
 	       n * 6.0 / ms / 1e6, (unsigned long long)chk[0], chk[1] == want[1] ? "ok" : "DIFFERENT");
-#define NEW(BLK, CAPV, WPE, GRID) bench_new<Leaf16Cfg<BLK, CAPV, WPE>, Fit>("rsx_leaf16_kernel<" #BLK ", " #CAPV ", " #WPE ">", GRID)
-	NEW(256, 5120, 8, nleaf);
-	NEW(256, 5120, 7, nleaf);
-	NEW(256, 5120, 6, nleaf);
-	NEW(256, 5120, 5, nleaf);
-	NEW(512, 5120, 8, nleaf);
-	NEW(256, 5120, 8, 8192);
-	NEW(256, 5120, 8, 2048);
+#define NEW(BLK, CAPV, WPE, NB, GRID) bench_new<Leaf16Cfg<BLK, CAPV, WPE, NB>, Fit>("rsx_leaf16_kernel<" #BLK ", " #CAPV ", " #WPE ", " #NB ">", GRID)
+#define WAVE(CAPV, NB, NWV, GRID) bench_wave<Leaf16WCfg<CAPV, NB, NWV>, Fit>("rsx_leaf16w_kernel<" #CAPV ", " #NB ", " #NWV ">", GRID)
+	if (cap <= 1024) {
+		WAVE(1024, 10, 4, nleaf / 4);
+		WAVE(1024, 10, 8, nleaf / 8);
+		WAVE(1024, 10, 4, 4096);
+		WAVE(1024, 10, 4, 2048);
+		if (cap <= 512) {
+			WAVE(512, 9, 4, nleaf / 4);
+			WAVE(512, 9, 8, nleaf / 8);
+		}
+	}
+	if (cap <= 2560) {
+		NEW(256, 2560, 8, 11, nleaf);
+		NEW(256, 2560, 8, 11, 8192);
+	}
+	NEW(256, 5120, 8, 12, nleaf);
+	if (cap > 2560) {
+		NEW(256, 5120, 8, 12, 8192);
 #define SKIPV(SK) bench_new<Leaf16Cfg<256, 5120, 8, 12, SK>, Fit>("  probe: skip mask " #SK " (wrong output)", nleaf)
-	SKIPV(1);
-	SKIPV(2);
-	SKIPV(3);
-	SKIPV(4);
-	SKIPV(5);
-	SKIPV(7);
+		SKIPV(1);
+		SKIPV(2);
+		SKIPV(3);
+		SKIPV(4);
+		SKIPV(5);
+		SKIPV(7);
+	}
 	return 0;
 }
