@@ -179,6 +179,14 @@ int rsx_sort_rank_inplace_async(const void *d_src, void *d_index_buffer, size_t 
  * the count (RSX_EVERIFY if it is not zero) and resets it; the next blocking sort on the stream does the same. */
 int rsx_verify_poll(void *stream, uint64_t *mismatches);
 
+/* The route the LAST rsx_sort_inplace_async on (current device, stream) took -- the device decides it and the call never
+ * waits, so it can only be asked for afterwards: this waits for `stream` and reads the device's words back.  *route as
+ * rsx_info.hybrid: 5 = no histogram, two MSB passes into slots and leaves; 1 = one MSB pass and leaves; 0 = histogram and one
+ * pass per kept column (also: sorted input, and the one-launch sort of small arrays).  The loop all of them stand for is
+ * radix_sort.hpp:82-90.  Replaying a captured graph of such a sort re-decides the route on the device each time; what this
+ * reports is the last replay's. */
+int rsx_async_route(void *stream, uint32_t *route);
+
 /* rs_sort_main / rs_sort_rank with a caller-supplied Hist (radix_sort.hpp:28-33,
  * radix_sort_rank.hpp:22-23): arms the CALLING THREAD's next blocking sort call
  * (rsx_sort, rsx_sort_device, rsx_sort_rank*, rsx_sort_pairs_device,

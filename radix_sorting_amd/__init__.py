@@ -77,6 +77,7 @@ ABI = [
     ("rsx_msd_split_async", _I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP]),
     ("rsx_sort_rank_inplace_async", _I, [_VP, _VP, _SZ, _I, _SZ, _I, _VP]),
     ("rsx_verify_poll", _I, [_VP, C.POINTER(C.c_uint64)]),
+    ("rsx_async_route", _I, [_VP, C.POINTER(C.c_uint32)]),
     ("rsx_sort_multi", _I, [_VP, _VP, _SZ, _I, _I, _VP, _I, _PVP, _PINFO]),
     ("rsx_profile_begin", _I, []),
     ("rsx_profile_end", _I, [C.POINTER(Profile)]),
@@ -303,6 +304,13 @@ def verify_poll(stream=None):
     bad = C.c_uint64(0)
     check(lib().rsx_verify_poll(_stream_ptr(stream), C.byref(bad)))
     return int(bad.value)
+
+
+def async_route(stream=None):
+    """rsx_async_route: wait for the stream and return the route (as rsx_info.hybrid) the last radix_sort_inplace_async on it took."""
+    r = C.c_uint32(0)
+    check(lib().rsx_async_route(_stream_ptr(stream), C.byref(r)))
+    return int(r.value)
 
 
 def radix_sort_pairs(keys, keys_aux, vals, vals_aux, dtype=None, order=ASCENDING, stream=None):

@@ -239,6 +239,10 @@ struct Ctx {
 	size_t seg_hist_off = 0, seg_status_off = 0, seg_segtab_off = 0, seg_tiles_off = 0, seg_btile_off = 0, seg_redo_off = 0;
 	SelfPlanArgs pass_sp{nullptr, nullptr, nullptr, nullptr, HybCaps{0, 0, 0, 0}};   // a self-planned pass 0 (SCATTER_SELF_PLAN)
 	DevBuf gscan;       // [256] u64: the highest kept column's offsets from a self-planned pass 0 (for the leaves)
+	// rsx_sort_inplace_async after an attempt without the histogram: the control block whose `mode` tells the histogram-first
+	// kernels enqueued behind it that there is nothing left to do
+	const SegCtl *pass_gate = nullptr;
+	bool async_tried_blind = false;   // ... whether the last rsx_sort_inplace_async of this context enqueued such an attempt
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
 	DevBuf vsum;        // RSX_VERIFY=2: [descents, sum, mix] of the input and of the result
 	DevBuf vasync;      // RSX_VERIFY: mismatches found in device-scheduled passes, kept until rsx_verify_poll / the next blocking sort
@@ -580,6 +584,9 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 	// up to 128 workgroups add their counts to the histogram themselves (one launch and its gap less: 7 of the 62 us of
 	// a 10^5-key sort); beyond that the rows are summed by a kernel of their own
 	const bool direct = blocks <= 128;
+	const u32 *gate = c.pass_gate ? &c.pass_gate->mode : nullptr;
+	HistFuse nofuse{};
+	nofuse.gate = gate;
 	if (fuse) {
 		// the kernel also zeroes what the caller names (FUSED, rsx_hist.hpp)
 		if (ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0)
@@ -592,13 +599,13 @@ int launch_hist(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, u64 *d_hist, 
 	// keys that are their own KDF (unsigned, ascending) take the instantiation without the KDF arithmetic
 	if (ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0)
 		hipLaunchKernelGGL((rsx_hist_kernel<KT, C, HIST_PLAIN>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
-		                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr);
+		                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr, nofuse);
 	else
 		hipLaunchKernelGGL((rsx_hist_kernel<KT, C, HIST_GENERIC>), dim3((unsigned)blocks), dim3(C::BLOCK), 0, c.stream, d_src, (u64)n,
-		                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr);
+		                   (u32 *)c.hpart.p, d_unsorted, ka, colmask, direct ? d_hist : (u64 *)nullptr, nofuse);
 	if (!direct)
 		hipLaunchKernelGGL(rsx_hist_reduce_kernel, dim3((unsigned)sizeof(KT), HIST_REDUCE_SPLIT), dim3(256), 0, c.stream,
-		                   (const u32 *)c.hpart.p, d_hist, (u32)blocks, cols256);
+		                   (const u32 *)c.hpart.p, d_hist, (u32)blocks, cols256, gate);
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
@@ -646,14 +653,16 @@ int plan_phase(Ctx &c, const KT *d_src, size_t n, KdfArgs<KT> ka, Plan *out, siz
 		const u64 total16 = (256 + hist_bytes + status_total) / 16;
 		const unsigned blocks = (unsigned)std::min<u64>((total16 + 255) / 256, 2048);
 		hipLaunchKernelGGL(rsx_zero3_kernel, dim3(blocks), dim3(256), 0, c.stream, (u32x4 *)c.small_set(), (u64)(256 / 16),
-		                   (u32x4 *)c.ghist(), (u64)(hist_bytes / 16), (u32x4 *)c.status.p, (u64)(status_total / 16));
+		                   (u32x4 *)c.ghist(), (u64)(hist_bytes / 16), (u32x4 *)c.status.p, (u64)(status_total / 16),
+		                   c.pass_gate ? &c.pass_gate->mode : (const u32 *)nullptr);
 	} else {
 		HIP_TRY(hipMemsetAsync(c.ghist(), 0, hist_bytes, c.stream));
 		HIP_TRY(hipMemsetAsync(c.small_set(), 0, 256, c.stream));
 	}
 	RSX_TRY(launch_hist<KT>(c, d_src, n, ka, c.ghist(), c.unsorted()));
 	hipLaunchKernelGGL((rsx_plan_all_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, d_src, (u64)n, c.ghist(), ka, c.kept(),
-	                   c.hotd(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, caps);
+	                   c.hotd(), (const u32 *)c.unsorted(), c.plan(), c.dev_host_plan, caps,
+	                   c.pass_gate ? &c.pass_gate->mode : (const u32 *)nullptr);
 	HIP_TRY(hipGetLastError());
 	if (!out) {   // the caller enqueues more work and collects the plan with plan_wait()
 		if (c.small.external)
@@ -718,7 +727,7 @@ int launch_scatter2(Ctx &c, const KT *kin, KTO *kout, const VT *vin, VT *vout, s
 #define RSX_LAUNCH2(ST, DIGV, HOTV)                                                                                        \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, ST, C2, false, DIGV, HOTV, KTO>), grid, dim3(C2::BLOCK), 0, c.stream, kin, kout, \
 	                   vin, vout, (u64)n, shift, gbase, tps, (ST *)st, ticket, ka, flags, (u64 *)nullptr, dplan, pass_index,  \
-	                   oshift, (const u32 *)c.hotd(), SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr}, c.pass_alt, c.pass_sp)
+	                   oshift, (const u32 *)c.hotd(), SegArgs{nullptr, c.pass_gate, nullptr, 0, 0, nullptr}, c.pass_alt, c.pass_sp)
 	// quarter tiles are for arrays of a few million keys: never 2^30 of them, and hot digits cost little there -- those
 	// instantiations are left out of the build
 	constexpr bool SMALL_CFG = C2::KPT < Sc2Cfg<KT, VT>::KPT;
@@ -1323,11 +1332,29 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 	return true;
 }
 
+// The device's part: the sample, both passes, the tables and the leaves, enqueued; *enqueued = 0: no room for the slots (or no
+// leaf shape for them): nothing was enqueued.  Nothing waits for the host; SegCtl::mode == SEG_MODE_LEAVES (and the pinned
+// copy the slack plan writes) says afterwards whether the sort went through.
+// ... for a device-scheduled sort (rsx_sort_inplace_async): the same sizes, no back-off (nothing is ever read back)
+template <typename KT> bool async_blind_ok(Ctx &c, size_t n)
+{
+	if constexpr (sizeof(KT) < 4)
+		return false;
+	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() || c.small.external ||
+	    env().no_speculation)
+		return false;
+	size_t floor_keys = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)9 << 20;
+	if (env().blind_min_log2)
+		floor_keys = (size_t)1 << env().blind_min_log2;
+	floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);
+	return n >= std::max(floor_keys, (size_t)1 << 22) && n < ((size_t)1 << 30);
+}
+
 template <typename KT>
-int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **result, rsx_info *info, int *done)
+int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enqueued)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
-	*done = 0;
+	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
 	const u32 cap1 = ((mean1 + mean1 / 4 + 255) / 256) * 256;
 	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
@@ -1371,6 +1398,18 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	if (dense_slots<KT>(c))
 		leaf_shape |= 0x100u;   // (the leaves read 2-byte slots: the cut shapes have that variant)
 	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, leaf_shape, (const u64 *)off1));
+	*enqueued = 1;
+	return RSX_OK;
+}
+
+template <typename KT>
+int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **result, rsx_info *info, int *done)
+{
+	*done = 0;
+	int enqueued = 0;
+	RSX_TRY(blind_enqueue<KT>(c, src, aux, n, ka, &enqueued));
+	if (!enqueued)
+		return RSX_OK;
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
 		blind_called_off(c, blind_kind<KT>(0));
@@ -1644,9 +1683,40 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 		return RSX_OK;
 	}
 	const size_t status_total = status_bytes<KT, NoVal>(n) * sizeof(KT);
-	RSX_TRY(plan_phase<KT>(c, buf, n, ka, nullptr, status_total));
-	for (u32 i = 0; i < sizeof(KT); ++i)   // pass i = the i-th kept column, if there is one (radix_sort.hpp:83-90)
-		RSX_TRY((scatter_pass<KT, NoVal>(c, buf, scratch, nullptr, nullptr, n, 0, c.ghist(), ka, 0, c.plan(), (int)i, i)));
+	// The routes of the blocking sort (rsx_hybrid.hpp), chosen on the device with nobody to read a verdict back:
+	//  * arrays the sort without a histogram is for: the whole attempt is enqueued first -- sample, two MSB passes
+	//    into slots, leaves -- and what follows (histogram, plan, one pass per kept column) looks at the attempt's verdict,
+	//    SegCtl::mode, and does nothing if the keys are sorted by then; an attempt that is called off has only read `buf`.
+	//    (There is no back-off here: the host never learns how an attempt went.  It costs a sample kernel and a few empty
+	//    launches when it is called off, and the empty launches of the histogram-first kernels when it goes through.)
+	//  * mid-size arrays: one MSB pass and leaves where the device-side plan says so (Plan::hyb) -- pass 0 then goes by the
+	//    highest kept column, the leaf launches behind it do nothing otherwise, and the passes 1 .. do nothing if they do.
+	// A caller-owned workspace (rsx_sort_inplace_async_ws) has no room for slots: one level only.
+	HybCaps caps{0, 0, 0, 0};
+	int blind = 0;
+	if constexpr (sizeof(KT) >= 4) {
+		if (hybrid_enabled() && !verify_mode() && !env().no_speculation) {
+			caps = hybrid_caps<KT>(n);
+			caps.cap2 = caps.min_cols2 = 0;
+			if (async_blind_ok<KT>(c, n))
+				RSX_TRY(blind_enqueue<KT>(c, buf, scratch, n, ka, &blind));
+		}
+	}
+	c.pass_gate = blind ? (const SegCtl *)c.seg.p : nullptr;
+	c.async_tried_blind = blind != 0;
+	int rc = plan_phase<KT>(c, buf, n, ka, nullptr, status_total, caps);
+	for (u32 i = 0; i < sizeof(KT) && rc == RSX_OK; ++i)   // pass i = the i-th kept column, if there is one (radix_sort.hpp:83-90)
+		rc = scatter_pass<KT, NoVal>(c, buf, scratch, nullptr, nullptr, n, 0, c.ghist(), ka, 0, c.plan(), (int)i, i);
+	c.pass_gate = nullptr;
+	RSX_TRY(rc);
+	if constexpr (sizeof(KT) >= 4) {
+		if (caps.cap1 && n <= (size_t)256 * caps.cap1) {
+			// (every shape: which one the largest bucket needs is only known on the device, and each does nothing unless the
+			// plan's largest bucket is its size -- keys with 64 values in their top byte fill buckets four times the mean)
+			const u32 shapes = LeafShapes<KT>::HAS_MEDIUM ? 7u : 3u;
+			RSX_TRY(launch_leaves<KT>(c, buf, scratch, n, ka, HYB_ONE_LEVEL, shapes));
+		}
+	}
 	// an odd number of kept columns leaves the result in `scratch` (radix_sort.hpp:92): bring it home
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)buf, (const unsigned char *)scratch,
 	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
@@ -2585,6 +2655,30 @@ int rsx_verify_poll(void *stream, uint64_t *mismatches)
 		return fail(RSX_EVERIFY, "RSX_VERIFY: a device-scheduled sort on this stream had a pass whose checked tile differs from its "
 		                         "ballot-ranked re-computation in %llu places", (unsigned long long)bad);
 	}
+	return RSX_OK;
+}
+
+int rsx_async_route(void *stream, uint32_t *route)
+{
+	if (!route)
+		return fail(RSX_EINVAL, "rsx_async_route: bad argument");
+	*route = 0;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	Plan plan;
+	HIP_TRY(hipMemcpy(&plan, c->plan(), sizeof(plan), hipMemcpyDeviceToHost));
+	if (c->async_tried_blind && c->seg.p) {
+		SegCtl ctl;
+		HIP_TRY(hipMemcpy(&ctl, c->seg.p, sizeof(ctl), hipMemcpyDeviceToHost));
+		if (ctl.mode == SEG_MODE_LEAVES) {
+			*route = 5;
+			return RSX_OK;
+		}
+	}
+	if (!plan.sorted && plan.hyb == HYB_ONE_LEVEL)
+		*route = 1;
 	return RSX_OK;
 }
 

@@ -102,7 +102,11 @@ template <typename C> __device__ __forceinline__ void hist_collect(HistSmem<C> &
 struct HistFuse {
 	u32x4 *z0, *z1, *z2;
 	u64 n0, n1, n2;        // 16-byte units
+	// a device-scheduled sort (rsx_sort_inplace_async) that has first tried to do without this kernel: *gate == GATE_DONE
+	// (SegCtl::mode == SEG_MODE_LEAVES, rsx_hybrid.hpp) says that the keys are sorted already -- nothing is read or counted
+	const u32 *gate;
 };
+constexpr u32 GATE_DONE = 1;
 
 // colmask: the columns to count (the MSD split of the multi-GPU path wants one).
 // partial: [workgroup][WC * 256] u32 rows for rsx_hist_reduce_kernel; `direct` (few workgroups): the counts are added
@@ -121,6 +125,8 @@ __global__ __launch_bounds__(C::BLOCK, (C::OCC * C::BLOCK + 255) / 256) void rsx
 	const u32 tid = threadIdx.x;
 	const u32 lane = tid & 63;
 	const u32 nblk = gridDim.x, blk = blockIdx.x;
+	if (fuse.gate && *fuse.gate == GATE_DONE)
+		return;
 	if constexpr (FUSED) {
 		const u64 stride = (u64)nblk * C::BLOCK, t = (u64)blk * C::BLOCK + tid;
 		const u32x4 z = {0u, 0u, 0u, 0u};
@@ -359,8 +365,10 @@ __global__ __launch_bounds__(C::BLOCK, (C::OCC * C::BLOCK + 255) / 256) void rsx
 // per address instead of one per histogram workgroup); `ghist` is zeroed by the caller.
 constexpr u32 HIST_REDUCE_SPLIT = 32;
 __global__ __launch_bounds__(256) void rsx_hist_reduce_kernel(const u32 *__restrict__ partial, u64 *__restrict__ ghist,
-                                                              u32 blocks, u32 cols256)
+                                                              u32 blocks, u32 cols256, const u32 *gate = nullptr)
 {
+	if (gate && *gate == GATE_DONE)
+		return;
 	const u32 i = blockIdx.x * 256 + threadIdx.x;
 	const u32 *p = partial + i;
 	u64 s = 0;

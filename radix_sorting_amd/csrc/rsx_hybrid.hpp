@@ -28,6 +28,7 @@ namespace rsx {
 
 enum : u32 { HYB_NONE = 0, HYB_ONE_LEVEL = 1, HYB_TWO_LEVEL = 2 };
 enum : u32 { SEG_MODE_NONE = 0, SEG_MODE_LEAVES = 1, SEG_MODE_LSD = 2, SEG_MODE_RETRY = 3 };
+static_assert(GATE_DONE == SEG_MODE_LEAVES, "the gate of the histogram-first kernels is SegCtl::mode");
 
 // One tile of a segmented pass: [beg, beg + cnt) lies inside level-1 bucket `bucket`; `first` is the index of the bucket's
 // first tile (where the look-back chain of the bucket ends).

@@ -277,8 +277,11 @@ __device__ __forceinline__ void plan_finish(const u32 *kept, u32 wc, const u32 *
 template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_plan_all_kernel(const KT *__restrict__ src, u64 n, u64 *__restrict__ ghist, KdfArgs<KT> ka,
                                                             u32 *__restrict__ kept_out, u32 *__restrict__ hotd,
-                                                            const u32 *unsorted, Plan *plan, Plan *host_plan, HybCaps caps)
+                                                            const u32 *unsorted, Plan *plan, Plan *host_plan, HybCaps caps,
+                                                            const u32 *gate = nullptr)
 {
+	if (gate && *gate == GATE_DONE)   // (a device-scheduled sort that got by without the histogram: its plan stands)
+		return;
 	constexpr int WC = sizeof(KT);
 	__shared__ u64 tot[4][256];
 	__shared__ u64 lsum[4][64];
@@ -1407,8 +1410,12 @@ __global__ void rsx_convert_kernel(DT *dst, const ST_ *src, u64 n)
 
 // Zeroes up to three regions (16-byte granules) in one launch: the flags, the histogram and the status words of all the
 // passes of a sort.  (Each hipMemsetAsync is a launch of its own; at 10^5 keys six of them were a third of the sort.)
-__global__ __launch_bounds__(256) void rsx_zero3_kernel(u32x4 *a, u64 na, u32x4 *b, u64 nb, u32x4 *c, u64 nc)
+__global__ __launch_bounds__(256) void rsx_zero3_kernel(u32x4 *a, u64 na, u32x4 *b, u64 nb, u32x4 *c, u64 nc,
+                                                        const u32 *gate = nullptr)
 {
+	// (a device-scheduled sort that got by without the histogram: the flags hold ITS plan, which the copy home still reads)
+	if (gate && *gate == GATE_DONE)
+		return;
 	const u64 stride = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	const u32x4 z = {0u, 0u, 0u, 0u};
 	for (u64 i = t; i < na; i += stride)

@@ -204,6 +204,9 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			gbase += 256 * dplan->cols[dplan->ncols - 1];   // the level-1 column's offsets: bucket starts
 		}
 	} else if (dplan && !(flags & SCATTER_SELF_PLAN)) {
+		// (rsx_sort_inplace_async, after an attempt without the histogram that went through: the keys are sorted already)
+		if (seg.ctl && seg.ctl->mode == SEG_MODE_LEAVES)
+			return;
 		if (dplan->sorted || pass_index >= dplan->ncols)
 			return;
 		if ((flags & SCATTER_ONE_COL_FILLED) && dplan->ncols == 1)

@@ -1,0 +1,149 @@
+"""rsx_sort_inplace_async chooses its route on the device (round 4): one MSB pass + leaves for mid-size arrays, the sort
+without a histogram for large ones, histogram + one pass per kept column otherwise -- with nobody reading a verdict back.
+
+What is checked: the sorted keys against the CPU restatement of rs_sort_main (radix_sort.hpp:31-93), always in `buf`, and the
+route the device took (rsx_async_route, as rsx_info.hybrid) -- for plain calls and for a HIP graph captured ONCE and replayed on
+inputs that take different routes: the histogram-first kernels enqueued behind an attempt must do nothing when it went through
+and everything when it was called off.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+_CARRIER = {4: np.int32, 8: np.int64}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    rsa.require_gpu()
+
+
+@pytest.fixture(autouse=True)
+def _fresh(monkeypatch):
+    rsa.reload_env()
+    yield
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(_CARRIER[a.itemsize]).copy()).cuda()
+
+
+def run(a, dt, order=ol.ASC):
+    buf = to_dev(a)
+    scratch = torch.full_like(buf, 0x5B5B5B5B)
+    rsa.radix_sort_inplace_async(buf, scratch, dtype=dt, order=order)
+    route = rsa.async_route()
+    got = buf.cpu().numpy().view(ol.NP_BITS[dt])
+    want, _, winfo = ol.oracle_sort(a, dt, order)
+    assert np.array_equal(got, want), (len(a), dt, order, route)
+    return route, winfo
+
+
+@pytest.mark.parametrize("dt", [ol.U32, ol.F32, ol.I32, ol.U64], ids=["u32", "f32", "i32", "u64"])
+def test_one_level_on_the_device(dt):
+    """Mid-size arrays: the device-side plan picks one MSB pass + leaves (route 1) for keys that spread over their top column
+    and one pass per column (route 0) for keys that do not."""
+    full = (1 << (8 * ol.DTYPE_SIZE[dt])) - 1
+    for n in (70001, (1 << 20) + 3, 3000000):
+        for order in (ol.ASC, ol.DESC):
+            route, _ = run(ol.splitmix_fill(n, dt, 7000 + n % 89 + order, full), dt, order)
+            assert route == 1, (n, dt, order, route)
+    n = (1 << 20) + 17
+    # a constant top byte below which the keys spread: still one level (by the highest KEPT column), result in `buf` (odd count)
+    route, winfo = run(ol.splitmix_fill(n, dt, 7100, full >> 8), dt)
+    assert route == 1 and winfo.ncols == ol.DTYPE_SIZE[dt] - 1
+    # half the keys in one top digit: its bucket is larger than a leaf -> one pass per column
+    a = ol.splitmix_fill(n, dt, 7101, full)
+    half = a.copy()
+    half[::2] &= ol.NP_BITS[dt](full >> 8)
+    route, _ = run(half, dt)
+    assert route == 0, route
+    # few values in the top byte: buckets several times the mean, the leaves' larger shapes (chosen on the device)
+    for bits in ((7, 6) if ol.DTYPE_SIZE[dt] == 4 else (7,)):     # (the largest leaf holds 32 Ki 4-byte or 16 Ki 8-byte keys)
+        top_mask = full ^ (((0xFF << bits) & 0xFF) << (8 * ol.DTYPE_SIZE[dt] - 8))
+        route, _ = run(ol.splitmix_fill(n, dt, 7102 + bits, top_mask), dt)
+        assert route == 1, (bits, route)
+    # sorted input: nothing moves
+    srt = np.sort(ol.kdf_keys(a, dt))
+    if dt in (ol.U32, ol.U64):
+        route, winfo = run(srt, dt)
+        assert route == 0 and winfo.early_exit == 2
+
+
+def test_one_level_with_a_caller_owned_workspace():
+    n = (1 << 21) + 5
+    a = ol.splitmix_fill(n, ol.U32, 7200, 0xFFFFFFFF)
+    buf, scratch = to_dev(a), torch.empty(n, dtype=torch.int32, device="cuda")
+    ws = torch.empty(rsa.workspace_bytes(n, rsa.U32), dtype=torch.uint8, device="cuda")
+    rsa.radix_sort_inplace_async_ws(buf, scratch, ws, dtype=rsa.U32)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), ol.oracle_sort(a, ol.U32)[0])
+
+
+@pytest.mark.parametrize("dt,n", [(ol.U32, 10000000), (ol.F32, (1 << 24) + 99), (ol.U32, (1 << 27) + 12345), (ol.U64, (3 << 24) + 7)],
+                         ids=["u32-1e7", "f32-16Mi", "u32-128Mi", "u64-48Mi"])
+def test_without_histogram_on_the_device(dt, n):
+    """Large arrays: the attempt without a histogram is enqueued first; it goes through for keys that spread over all their
+    columns (route 5) and is called off -- the histogram-first kernels behind it then do the work -- for others."""
+    full = (1 << (8 * ol.DTYPE_SIZE[dt])) - 1
+    a = ol.splitmix_fill(n, dt, 7300, full)
+    for order in (ol.ASC, ol.DESC):
+        route, _ = run(a, dt, order)
+        assert route == 5, (dt, n, order, route)
+    # a constant low byte (4-byte keys need all four columns; 8-byte keys: an odd number of kept columns -> the copy home)
+    route, winfo = run(a & ol.NP_BITS[dt](full ^ 0xFF), dt)
+    assert route == (5 if ol.DTYPE_SIZE[dt] == 8 else 0), route
+    if dt != ol.F32:     # (a float's derived low byte is 0x00 or 0xFF by its sign: two values, a kept -- and hot -- column)
+        assert winfo.ncols == ol.DTYPE_SIZE[dt] - 1
+    # a dominant top digit: the sample calls the attempt off
+    half = a.copy()
+    half[::2] &= ol.NP_BITS[dt](full >> 8)
+    route, _ = run(half, dt)
+    assert route == 0, route
+    # a slot overflows although the sample saw nothing: one (digit, digit) pair with many times its share
+    b = a.copy()
+    top = ol.NP_BITS[dt](0x4321) << ol.NP_BITS[dt](8 * ol.DTYPE_SIZE[dt] - 16)
+    low = ol.NP_BITS[dt](full >> 16)
+    idx = np.arange(5000, 5000 + 9000 * 11, 11)
+    b[idx] = (b[idx] & low) | top
+    route, _ = run(b, dt)
+    assert route == 0, route
+
+
+@pytest.mark.parametrize("n", [1 << 23, 1 << 27])
+def test_routes_inside_one_captured_graph(n, monkeypatch):
+    """One capture, replayed on inputs that take different routes.  2^23 keys lie between the reach of one level and the
+    default floor of the sorts without a histogram: RSX_BLIND_MIN_LOG2=23 puts the floor there for this test."""
+    if n == 1 << 23:
+        monkeypatch.setenv("RSX_BLIND_MIN_LOG2", "23")
+    s = torch.cuda.Stream()
+    buf = torch.empty(n, dtype=torch.int32, device="cuda")
+    scratch = torch.empty_like(buf)
+    with torch.cuda.stream(s):
+        rsa.fill_splitmix(buf, seed=1, stream=s)
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=ol.U32, stream=s)     # sizes the workspace outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=ol.U32, stream=torch.cuda.current_stream())
+    base = ol.splitmix_fill(n, ol.U32, 7400, 0xFFFFFFFF).view(np.uint32)
+    cases = [("uniform", base, 5), ("column 1 constant", base & np.uint32(0xFFFF00FF), 0), ("uniform again", base[::-1].copy(), 5),
+             ("top digit dominant", np.where(np.arange(n) % 2 == 0, base & np.uint32(0x00FFFFFF), base).astype(np.uint32), 0),
+             ("sorted", np.sort(base[: n // 4]).repeat(4)[:n], 0), ("uniform, third time", base ^ np.uint32(0x5A5A5A5A), 5)]
+    for name, a, want_route in cases:
+        a = np.ascontiguousarray(a)
+        buf.copy_(to_dev(a))
+        scratch.fill_(0x6C6C6C6C)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()     # (the replay runs on the current stream; rsx_async_route waits for the capture stream's)
+        route = rsa.async_route(s)
+        assert route == want_route, (name, route)
+        want, _, _ = ol.oracle_sort(a, ol.U32)
+        assert np.array_equal(buf.cpu().numpy().view(np.uint32), want), name
+    rsa.release_stream(s)

@@ -1,9 +1,7 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/r4e
-timeout 1500 python -m pytest tests/test_gpu_routes.py -x -q -k "mid_size or every_leaf or clustered" 2>&1 | tail -5 > gpurun_out/r4e/routes.txt
-cat gpurun_out/r4e/routes.txt
-./tools/radix_bench --device 0 --verify > gpurun_out/r4e/radix_bench.txt 2>&1
-grep -E "radix_sort/" gpurun_out/r4e/radix_bench.txt | head -20
-python tools/size_sweep.py > gpurun_out/r4e/size_sweep.txt 2>&1
-tail -24 gpurun_out/r4e/size_sweep.txt
+mkdir -p gpurun_out/r4g
+timeout 1500 python -m pytest tests/test_gpu_async_routes.py -x -q 2>&1 | tail -15 > gpurun_out/r4g/async.txt
+cat gpurun_out/r4g/async.txt
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multi.py tests/test_gpu_soak.py -x -q -k "async or graph or multi or soak or verif" 2>&1 | tail -5 > gpurun_out/r4g/others.txt
+cat gpurun_out/r4g/others.txt
