@@ -1011,6 +1011,28 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	const u32 nopre = env().no_leaf_prefix ? 2u : 0u;   // RSX_NO_LEAF_PREFIX=1: 8-byte-key leaves go through all their columns
 	u32 skip_narrowable = nopre;
 	if constexpr (sizeof(KT) == 8) {
+		if ((shapes & 0x200u) && !env().no_leaf16) {
+			// a sort without a histogram, slots of up to 5120 keys: one placement by twelve bits + register passes on 4- or
+			// 8-byte values (rsx_leafk_kernel, rsx_leaf16.hpp: the instantiation whose carried type the leaves' columns need
+			// works, the other does nothing); what they leave alone goes through the LDS passes of round 3
+			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
+			SegCtl *wctl = (SegCtl *)c.seg.p;
+			typedef LeafKCfg<512, 5120, 8> K4;
+			typedef LeafKCfg<512, 5120, 6> K8;
+			hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4>), dim3(grid_s), dim3(K4::BLOCK), 0, c.stream, src, aux, (const Plan *)c.plan(),
+			                   segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo, (u32)env().leaf16_maxbin);
+			hipLaunchKernelGGL((rsx_leafk_kernel<KT, u64, K8>), dim3(grid_s), dim3(K8::BLOCK), 0, c.stream, src, aux, (const Plan *)c.plan(),
+			                   segtab, wctl, ka, 0u, (u32)K8::CAP, slots, c.slack_cap, redo, (u32)env().leaf16_maxbin);
+			typedef LeafCfg<u32, 4, 32, 3, true, false> N;
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, N, u32>), dim3(2048), dim3(N::BLOCK), 0, c.stream, src, aux, (u64)n,
+			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
+			                   c.slack_cap, nopre, off1, (const u32 *)redo);
+			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, S>), dim3(2048), dim3(S::BLOCK), 0, c.stream, src, aux, (u64)n,
+			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
+			                   c.slack_cap, nopre | 1u, off1, (const u32 *)redo);
+			HIP_TRY(hipGetLastError());
+			return RSX_OK;
+		}
 		// 8-byte keys: leaves whose columns all lie in the low four bytes are carried as 4-byte values (rsx_hybrid.hpp, CT)
 		if (shapes & 1u) {
 			typedef LeafCfg<u32, 4, 32, 3, true, false> N;   // (131 registers: three workgroups per CU)
@@ -1397,6 +1419,8 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	u32 leaf_shape = LeafShapes<KT>::shape_for_slots(cap2);
 	if (dense_slots<KT>(c))
 		leaf_shape |= 0x100u;   // (the leaves read 2-byte slots: the cut shapes have that variant)
+	if (sizeof(KT) == 8 && cap2 <= 5120u)
+		leaf_shape |= 0x200u;   // (8-byte keys in slots of up to 5120: rsx_leafk_kernel)
 	RSX_TRY(launch_leaves<KT>(c, src, aux, n, ka, HYB_TWO_LEVEL, leaf_shape, (const u64 *)off1));
 	*enqueued = 1;
 	return RSX_OK;

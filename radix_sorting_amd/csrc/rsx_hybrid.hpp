@@ -477,9 +477,9 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
 	__shared__ u32 s_desc, s_distinct[W], s_max[W];
-	// 4-byte keys: the sample's counts over the top twelve of the low sixteen bits, rsx_leaf16_kernel's bins (rsx_leaf16.hpp)
-	constexpr bool L16 = sizeof(KT) == 4;
-	__shared__ u32 h12[L16 ? 4096 : 1];
+	// the sample's counts over the bins of the keys-only leaves that place by twelve bits (rsx_leaf16.hpp: the leaf's highest
+	// column and the top nibble of the one below it -- for 4-byte keys with four kept columns the top twelve of the low sixteen bits)
+	__shared__ u32 h12[4096];
 	__shared__ u32 s_max12;
 	const u32 tid = threadIdx.x;
 	if (blockIdx.x != 0) {
@@ -496,11 +496,9 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 	}
 	if (tid == 0)
 		s_desc = s_max12 = 0;
-	if constexpr (L16) {
 #pragma unroll
-		for (u32 i = 0; i < 4; ++i)
-			h12[tid + 1024 * i] = 0;
-	}
+	for (u32 i = 0; i < 4; ++i)
+		h12[tid + 1024 * i] = 0;
 	__syncthreads();
 	const u64 i0 = ((n - 16 * S) / 63) * (tid >> 4) + (tid & 15u) * S;   // (n >= 2^20: the places do not overlap)
 	KT k[S];
@@ -515,25 +513,10 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 #pragma unroll
 		for (u32 c = 0; c < W; ++c)
 			atomicAdd(&h[c][(u32)(k[e] >> (8 * c)) & 0xFFu], 1u);
-		if constexpr (L16)
-			atomicAdd(&h12[((u32)k[e] >> 4) & 0xFFFu], 1u);
 	}
 	if (__ballot(desc) && (tid & 63) == 0)
 		s_desc = 1;
 	__syncthreads();
-	if constexpr (L16) {
-		u32 m = 0;
-#pragma unroll
-		for (u32 i = 0; i < 4; ++i)
-			m = m > h12[tid + 1024 * i] ? m : h12[tid + 1024 * i];
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) {
-			const u32 y = __shfl_xor(m, off);
-			m = y > m ? y : m;
-		}
-		if ((tid & 63) == 0)
-			atomicMax(&s_max12, m);
-	}
 	if (tid < 256) {
 #pragma unroll
 		for (u32 c = 0; c < W; ++c) {
@@ -552,6 +535,34 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		}
 	}
 	__syncthreads();
+	{
+		// every thread: the columns the sample proved kept, then its samples' bins (the leaves' two highest columns)
+		u32 nk = 0, ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for (u32 c = 0; c < W; ++c) {
+			if (s_distinct[c] >= 2)
+				ck[nk++] = c;
+		}
+		if (nk >= 4) {
+			const u32 sh_hi = 8 * ck[nk - 3], sh_nx = 8 * ck[nk - 4] + 4;
+#pragma unroll
+			for (u32 e = 0; e < S; ++e)
+				atomicAdd(&h12[(((u32)(k[e] >> sh_hi) & 0xFFu) << 4) | ((u32)(k[e] >> sh_nx) & 0xFu)], 1u);
+		}
+		__syncthreads();
+		u32 m = 0;
+#pragma unroll
+		for (u32 i = 0; i < 4; ++i)
+			m = m > h12[tid + 1024 * i] ? m : h12[tid + 1024 * i];
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {
+			const u32 y = __shfl_xor(m, off);
+			m = y > m ? y : m;
+		}
+		if ((tid & 63) == 0)
+			atomicMax(&s_max12, m);
+		__syncthreads();
+	}
 	if (tid == 0) {
 		bool go = s_desc != 0;
 		u32 nk = 0, cols[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		ctl->blind = go ? BLIND_GO : BLIND_FAILED;
 		// NS samples over 4096 bins: two per bin on average, the fullest holds ten or eleven; a leaf of 4096 keys sees half of
 		// what the sample sees, and rsx_leaf16_kernel takes bins of up to 25 keys
-		ctl->leaf16 = L16 && s_max12 <= 24u ? 1u : 0u;
+		ctl->leaf16 = s_max12 <= 24u ? 1u : 0u;
 		ctl->cmask_lo = (u32)cmask;
 		ctl->cmask_hi = (u32)(cmask >> 32);
 		ctl->key0_lo = (u32)(u64)k[0];               // (thread 0's first sample is the array's first key)

@@ -564,4 +564,239 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 	}
 }
 
+// ---- leaves of 8-byte keys (keys only): the same placement, the register passes on whole 4- or 8-byte values -----------------
+// BASELINE.json's cfg 3: 2^28 u64 keys keep eight, five or four columns; two MSB passes leave a leaf six, three or two of
+// them (48 / 24 / 16 bits), which rsx_leaf_sort_kernel goes through one LDS pass per column (six columns: the top three and
+// odd-even transposition sweeps) at 0.28 of the HBM peak.  Here: the slot's keys (whole element images: the level-2 pass of
+// 8-byte keys writes them unchanged) become derived keys cut to the carried type CT -- 4 bytes if the leaf's columns all lie
+// in the low word, else 8 --, are placed by twelve bits (the leaf's highest column and the top nibble of the next one) and
+// finished by Batcher's odd-even merge sort on sixteen values per lane: 63 comparators on aligned chunks, then the 25 of its
+// last merge step on chunks shifted by 8, min / max for 4-byte values, compare + select for 8-byte ones.
+template <int P, typename T, typename F> __device__ __forceinline__ void batcher_stage(T (&d)[16], F &&ce)
+{
+#pragma unroll
+	for (int k = P; k >= 1; k /= 2) {
+#pragma unroll
+		for (int j = k % P; j <= 15 - k; j += 2 * k) {
+#pragma unroll
+			for (int i = 0; i <= (k - 1 < 15 - j - k ? k - 1 : 15 - j - k); ++i) {
+				if ((i + j) / (2 * P) == (i + j + k) / (2 * P))
+					ce(d[i + j], d[i + j + k]);
+			}
+		}
+	}
+}
+template <typename T> __device__ __forceinline__ void ce_minmax(T &a, T &b)
+{
+	const T lo = a < b ? a : b, hi = a < b ? b : a;
+	a = lo;
+	b = hi;
+}
+// sixteen values in any order -> ascending; two ascending runs of eight -> ascending
+template <typename T> __device__ __forceinline__ void sort16_values(T (&d)[16])
+{
+	auto ce = [](T &a, T &b) { ce_minmax(a, b); };
+	batcher_stage<1>(d, ce);
+	batcher_stage<2>(d, ce);
+	batcher_stage<4>(d, ce);
+	batcher_stage<8>(d, ce);
+}
+template <typename T> __device__ __forceinline__ void merge16_values(T (&d)[16])
+{
+	auto ce = [](T &a, T &b) { ce_minmax(a, b); };
+	batcher_stage<8>(d, ce);
+}
+
+template <int BLOCK_, int CAP_, int WPE_> struct LeafKCfg {
+	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64;
+	static constexpr int NCH = (CAP / 16 + BLOCK - 1) / BLOCK;   // chunks of sixteen values per lane
+	static constexpr int NBIN = 4096, NCELLW = NBIN / 2;
+	static constexpr int PLANES = NCELLW / 4 / BLOCK;
+	static constexpr u32 MAXBIN = 9, MAXBIN2 = 25;
+	// The staged leaf is kept TRANSPOSED: value p lies in row p % 16, column p / 16 of a 16 x S matrix, so that the lanes of a
+	// wave -- one chunk of sixteen consecutive values each -- read and write consecutive words (one value per DS instruction,
+	// no bank conflicts).  With the values in staging order a lane's chunk is 64 or 128 contiguous bytes, sixteen lanes share
+	// four (two) bank groups, and the chunk traffic of 8-byte values cost more than the placement (first version: the u64
+	// leaves of cfg 3 1.95 ms against 1.87 with the LDS passes of round 3).
+	static constexpr int S = CAP / 16 + 3;   // columns: the chunks + what the shifted pass and the padding reach behind them (odd)
+	static_assert(CAP % 16 == 0 && CAP <= 8192, "whole chunks; bin starts fit 16 bits");
+	static_assert(BLOCK == 256 || BLOCK == 512, "one or two vectors of cells per thread");
+	static_assert(S % 2 == 1, "rows that start in different banks");
+};
+
+// KT: 8-byte keys; CT: u32 (every column of the leaf in the low word) or u64.  A launch takes the leaves that need its CT.
+// redo / SegCtl::nredo / SegCtl::leaf16: as rsx_leaf16_kernel.
+template <typename KT, typename CT, typename C>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restrict__ src, KT *__restrict__ aux,
+                                                                     const Plan *__restrict__ plan,
+                                                                     const LeafSeg *__restrict__ segtab, SegCtl *__restrict__ ctl,
+                                                                     KdfArgs<KT> ka, u32 lo, u32 hi, const KT *__restrict__ slots,
+                                                                     u32 slack_cap, u32 *__restrict__ redo, u32 maxbin2 = C::MAXBIN2)
+{
+	static_assert(sizeof(KT) == 8 && (sizeof(CT) == 4 || sizeof(CT) == 8), "8-byte keys carried as 4- or 8-byte values");
+	constexpr int BLOCK = C::BLOCK, CAP = C::CAP, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
+	constexpr int NK = (CAP + BLOCK - 1) / BLOCK;   // keys per thread
+	const u32 hyb = plan->hyb, ncols = plan->ncols;
+	const u32 mode = ctl->mode, maxleaf = ctl->maxleaf, nseg = ctl->nleaf, on = ctl->leaf16;
+	if (hyb != HYB_TWO_LEVEL || ncols < 4 || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi || !on)
+		return;
+	// the leaf's columns: all kept columns below the two the MSB passes went by; bins from the highest and the one below it
+	const u32 c_hi = plan->cols[ncols - 3] & 7u, c_nx = plan->cols[ncols >= 4 ? ncols - 4 : 0] & 7u;
+	const bool one_col = ncols - 2 < 2;   // (cannot happen with four kept columns; kept for the shifts below)
+	if ((sizeof(CT) == 4) != (c_hi <= 3u))
+		return;   // (the other instantiation's leaves)
+	const u32 sh_hi = 8 * c_hi, sh_nx = one_col ? 0u : 8 * c_nx + 4;
+	KT *out = (ncols & 1) ? aux : src;   // radix_sort.hpp:92
+	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
+	constexpr int S = C::S;
+	__shared__ __attribute__((aligned(16))) CT stage[16 * S + 64];   // + a place per lane for values that do not exist
+	auto at = [](u32 p) { return (p & 15u) * (u32)S + (p >> 4); };
+	__shared__ u32 ws[NW], wmax[NW];
+	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+		const LeafSeg ls = segtab[s];
+		const u32 cnt = ls.cnt, slot = ls.slot;
+		if (cnt == 0)
+			continue;
+		const KT *q = slot ? slots + (u64)(slot - 1) * slack_cap : (const KT *)src + ls.beg;
+		// the keys, one per lane and round (consecutive lanes read consecutive keys), cut to the carried type
+		CT kv[NK];
+		const KT first = kdf_apply(q[0], ka);
+#pragma unroll
+		for (int j = 0; j < NK; ++j) {
+			const u32 e = tid + BLOCK * j;
+			kv[j] = e < cnt ? (CT)kdf_apply(q[e], ka) : (CT)0;
+		}
+		{
+			const u32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j)
+				((u32x4 *)cell)[tid + BLOCK * j] = zero;
+		}
+		__syncthreads();
+		auto cell_of = [&](CT v, bool valid, u32 &sh) -> u32 * {
+			const u32 bin = (((u32)(v >> sh_hi) & 0xFFu) << 4) | ((u32)(v >> sh_nx) & 0xFu);
+			sh = (bin & 1u) << 4;
+			return &cell[valid ? bin >> 1 : NCELLW + lane];
+		};
+#pragma unroll
+		for (int j = 0; j < NK; ++j) {
+			if (BLOCK * j < (int)cnt) {
+				u32 sh;
+				u32 *a = cell_of(kv[j], tid + BLOCK * j < cnt, sh);
+				__hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+		__syncthreads();
+		u32x4 c[PLANES];
+		u32 pk = 0, mxp = 0;
+#pragma unroll
+		for (int j = 0; j < PLANES; ++j) {
+			c[j] = ((const u32x4 *)cell)[tid + BLOCK * j];
+			u32 run = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const u32 x = c[j][i];
+				mxp = pk_max_u16(mxp, x);
+				const u32 lo16 = x & 0xFFFFu, hs = run + lo16;
+				c[j][i] = run | (hs << 16);
+				run = hs + (x >> 16);
+			}
+			pk |= run << (16 * j);
+		}
+		u32 mx = (mxp & 0xFFFFu) > (mxp >> 16) ? (mxp & 0xFFFFu) : (mxp >> 16);
+		const u32 incl = wave_incl_scan_dpp(pk);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const u32 y = (u32)__shfl_xor((int)mx, o);
+			mx = mx > y ? mx : y;
+		}
+		if (lane == 63) {
+			ws[wid] = incl;
+			wmax[wid] = mx;
+		}
+		__syncthreads();
+		mx = wmax[0];
+#pragma unroll
+		for (int w = 1; w < NW; ++w)
+			mx = mx > wmax[w] ? mx : wmax[w];
+		if (mx > maxbin2) {
+			if (tid == 0)
+				redo[atomicAdd(&ctl->nredo, 1u)] = s;
+			continue;
+		}
+		{
+			u32 base = 0, tot = 0;
+#pragma unroll
+			for (u32 w = 0; w < (u32)NW; ++w) {
+				const u32 a = ws[w];
+				base += w < wid ? a : 0u;
+				tot += a;
+			}
+			const u32 e = incl - pk + base;
+			const u32 o[2] = {e & 0xFFFFu, (tot & 0xFFFFu) + (e >> 16)};
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j) {
+				const u32 bb = o[j] | (o[j] << 16);
+				u32x4 x;
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					x[i] = c[j][i] + bb;
+				((u32x4 *)cell)[tid + BLOCK * j] = x;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < NK; ++j) {
+			if (BLOCK * j < (int)cnt) {
+				const bool valid = tid + BLOCK * j < cnt;
+				u32 sh;
+				u32 *a = cell_of(kv[j], valid, sh);
+				const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				stage[valid ? at((old >> sh) & 0xFFFFu) : 16 * S + lane] = kv[j];
+			}
+		}
+		if (tid < 32)
+			stage[at(cnt + tid)] = (CT)~(CT)0;   // what the last chunks read behind the leaf's end sorts last
+		__syncthreads();
+		const u32 npass = mx > C::MAXBIN ? 4u : 2u;
+		for (u32 pass = 0; pass < npass; ++pass) {
+			const u32 off = 8 * (pass & 1);
+#pragma unroll
+			for (int r = 0; r < NCH; ++r) {
+				const u32 ch = tid + BLOCK * r;
+				if (16 * ch + off < cnt) {
+					// value i of the chunk at 16 ch + off: row (i + off) % 16, column ch or ch + 1
+					CT d[16];
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						d[i] = stage[(pass & 1) ? (i < 8 ? (i + 8) * S + ch : (i - 8) * S + ch + 1) : i * S + ch];
+					if (pass == 0)
+						sort16_values(d);
+					else
+						merge16_values(d);   // (both halves were sorted by the pass before)
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						stage[(pass & 1) ? (i < 8 ? (i + 8) * S + ch : (i - 8) * S + ch + 1) : i * S + ch] = d[i];
+				}
+			}
+			__syncthreads();
+		}
+		{
+			constexpr u32 CBITS = 8 * sizeof(CT);
+			const KT upper = sizeof(CT) == 8 ? (KT)0 : (KT)(first >> (CBITS & 63) << (CBITS & 63));
+			KT *o = out + ls.beg;
+			for (u32 i0 = 2 * tid; i0 < cnt; i0 += 2 * BLOCK) {
+				KT kk[2];
+				kk[0] = kdf_invert((KT)(upper | (KT)stage[at(i0)]), ka);
+				kk[1] = kdf_invert((KT)(upper | (KT)stage[at(i0 + 1)]), ka);
+				if (i0 + 2 <= cnt)
+					store_chunk<KT, 2>(o + i0, kk);
+				else
+					o[i0] = kk[0];
+			}
+		}
+	}
+}
+
 }  // namespace rsx

@@ -1,7 +1,11 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/r4g
-timeout 1500 python -m pytest tests/test_gpu_async_routes.py -x -q 2>&1 | tail -15 > gpurun_out/r4g/async.txt
-cat gpurun_out/r4g/async.txt
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multi.py tests/test_gpu_soak.py -x -q -k "async or graph or multi or soak or verif" 2>&1 | tail -5 > gpurun_out/r4g/others.txt
-cat gpurun_out/r4g/others.txt
+mkdir -p gpurun_out/r4j
+timeout 1500 python -m pytest tests/test_gpu_routes.py tests/test_gpu_hybrid.py -x -q -k "u64 or blind" 2>&1 | tail -5 > gpurun_out/r4j/routes.txt
+cat gpurun_out/r4j/routes.txt
+python tools/bench_configs.py --only "cfg3 u64 " --out gpurun_out/r4j/bench_configs.json > /dev/null 2>&1
+python3 -c "
+import json
+for r in json.load(open('gpurun_out/r4j/bench_configs.json')):
+    print(r['config'], 'ms', round(r['ms_per_sort'],3), 'leaf', round(r['leaf_ms'],3), 'scatter/launch', round(r['scatter_ms_per_launch'],3))
+"
