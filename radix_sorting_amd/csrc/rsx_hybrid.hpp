@@ -50,7 +50,12 @@ struct SegCtl {
 	u32 cmask_lo, cmask_hi, key0_lo, key0_hi;
 	u32 nredo;      // leaves rsx_leaf16_kernel (rsx_leaf16.hpp) left to rsx_leaf_sort_kernel: entries of its `redo` list
 	u32 leaf16;     // rsx_blind_precheck_kernel: the sampled keys spread over the top twelve of their low sixteen bits (rsx_leaf16_kernel's bins)
-	u32 pad[3];
+	// sorts without a histogram: the bit positions of the two MSB passes' 8-bit digits.  8 x the two highest kept columns, as the
+	// reference's bytes (radix_sort.hpp:40-45) -- or, for 4-byte keys whose top bits are the same in every key (shift1 + 8 < 32:
+	// values below 2^30, one rank's share of a distributed sort), the sixteen bits below the highest bit that varies: the
+	// order is the same (the bits above are constant, checked on every key through cmask) and the buckets are even again
+	u32 shift1, shift2;
+	u32 pad[1];
 };
 enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
 
@@ -472,7 +477,8 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka,
                                                                   SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
-                                                                  Plan *host_plan, u32x4 *__restrict__ z, u64 nz, u32 min_cols)
+                                                                  Plan *host_plan, u32x4 *__restrict__ z, u64 nz, u32 min_cols,
+                                                                  u32 allow_shift = 0)
 {
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
@@ -481,6 +487,8 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 	// column and the top nibble of the one below it -- for 4-byte keys with four kept columns the top twelve of the low sixteen bits)
 	__shared__ u32 h12[4096];
 	__shared__ u32 s_max12;
+	__shared__ u32 hs[2][256];         // the sample's counts over the two MSB digits at their bit positions (SegCtl::shift1 / shift2)
+	__shared__ u32 s_vary, s_maxs[2];  // the bits in which sampled keys differ from the first key
 	const u32 tid = threadIdx.x;
 	if (blockIdx.x != 0) {
 		const u32x4 zero = {0, 0, 0, 0};
@@ -495,10 +503,12 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		s_max[tid] = 0;
 	}
 	if (tid == 0)
-		s_desc = s_max12 = 0;
+		s_desc = s_max12 = s_vary = s_maxs[0] = s_maxs[1] = 0;
 #pragma unroll
 	for (u32 i = 0; i < 4; ++i)
 		h12[tid + 1024 * i] = 0;
+	if (tid < 512)
+		(&hs[0][0])[tid] = 0;
 	__syncthreads();
 	const u64 i0 = ((n - 16 * S) / 63) * (tid >> 4) + (tid & 15u) * S;   // (n >= 2^20: the places do not overlap)
 	KT k[S];
@@ -516,6 +526,19 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 	}
 	if (__ballot(desc) && (tid & 63) == 0)
 		s_desc = 1;
+	if constexpr (W == 4) {
+		// (all samples against the wave's first: what differs from the array's first key differs from that one or it does)
+		const u32 kw = (u32)__builtin_amdgcn_readfirstlane((int)(u32)k[0]);
+		u32 v = 0;
+#pragma unroll
+		for (u32 e = 0; e < S; ++e)
+			v |= (u32)k[e] ^ kw;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+			v |= (u32)__shfl_xor((int)v, off);
+		if ((tid & 63) == 0)
+			atomicOr(&s_vary, v | (kw ^ (u32)kdf_apply(src[0], ka)));
+	}
 	__syncthreads();
 	if (tid < 256) {
 #pragma unroll
@@ -535,32 +558,66 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		}
 	}
 	__syncthreads();
+	u32 shift1 = 0, shift2 = 0;
 	{
-		// every thread: the columns the sample proved kept, then its samples' bins (the leaves' two highest columns)
+		// every thread: the columns the sample proved kept, the MSB digits' bit positions, then its samples' digits and bins
 		u32 nk = 0, ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
 		for (u32 c = 0; c < W; ++c) {
 			if (s_distinct[c] >= 2)
 				ck[nk++] = c;
 		}
+		bool shifted = false;
+		if (nk >= 2) {
+			shift1 = 8 * ck[nk - 1];
+			shift2 = 8 * ck[nk - 2];
+		}
+		if constexpr (W == 4) {
+			// 4-byte keys, all four columns kept, the top bits constant in the sample: digits below the highest varying bit
+			// (at least eight bits stay for the leaves)
+			const u32 hb = s_vary ? 31u - (u32)__builtin_clz(s_vary) : 0u;
+			if (allow_shift && nk == 4 && hb < 31u && hb >= 23u) {
+				shift1 = hb - 7;
+				shift2 = hb - 15;
+				shifted = true;
+			}
+		}
 		if (nk >= 4) {
-			const u32 sh_hi = 8 * ck[nk - 3], sh_nx = 8 * ck[nk - 4] + 4;
 #pragma unroll
-			for (u32 e = 0; e < S; ++e)
-				atomicAdd(&h12[(((u32)(k[e] >> sh_hi) & 0xFFu) << 4) | ((u32)(k[e] >> sh_nx) & 0xFu)], 1u);
+			for (u32 e = 0; e < S; ++e) {
+				atomicAdd(&hs[0][(u32)(k[e] >> shift1) & 0xFFu], 1u);
+				atomicAdd(&hs[1][(u32)(k[e] >> shift2) & 0xFFu], 1u);
+			}
+			if (shifted) {
+				// the leaves' bins: the top twelve of the shift2 bits below the MSB digits
+				const u32 lowmask = (1u << shift2) - 1u, d = shift2 > 12u ? shift2 - 12u : 0u;
+#pragma unroll
+				for (u32 e = 0; e < S; ++e)
+					atomicAdd(&h12[((u32)k[e] & lowmask) >> d], 1u);
+			} else {
+				const u32 sh_hi = 8 * ck[nk - 3], sh_nx = 8 * ck[nk - 4] + 4;
+#pragma unroll
+				for (u32 e = 0; e < S; ++e)
+					atomicAdd(&h12[(((u32)(k[e] >> sh_hi) & 0xFFu) << 4) | ((u32)(k[e] >> sh_nx) & 0xFu)], 1u);
+			}
 		}
 		__syncthreads();
 		u32 m = 0;
 #pragma unroll
 		for (u32 i = 0; i < 4; ++i)
 			m = m > h12[tid + 1024 * i] ? m : h12[tid + 1024 * i];
+		u32 ms = tid < 512 ? (&hs[0][0])[tid] : 0u;   // (a wave lies inside one of the two digit tables)
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) {
-			const u32 y = __shfl_xor(m, off);
+			const u32 y = __shfl_xor(m, off), ys = __shfl_xor(ms, off);
 			m = y > m ? y : m;
+			ms = ys > ms ? ys : ms;
 		}
-		if ((tid & 63) == 0)
+		if ((tid & 63) == 0) {
 			atomicMax(&s_max12, m);
+			if (tid < 512)
+				atomicMax(&s_maxs[tid >> 8], ms);
+		}
 		__syncthreads();
 	}
 	if (tid == 0) {
@@ -573,17 +630,30 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 			else
 				cmask |= (u64)0xFFu << (8 * c);      // taken for constant; the level-1 pass will know
 		}
+		if (shift1 + 8 < 8 * W)                      // ... and so are the bits above the level-1 digit
+			cmask |= ~(((u64)1 << (shift1 + 8)) - 1) & (W == 8 ? ~(u64)0 : (((u64)1 << (8 * (W & 7))) - 1));
 		go = go && nk >= min_cols;
-		for (u32 i = 0; i < nk; ++i) {
-			// the two columns the MSB passes go by: no digit with twice its share of the sample (a slot holds 1.25 times the
-			// mean); the columns the leaves sort by: no digit with a tenth of the sample (Plan::hot: lanes queue at one counter)
-			go = go && s_max[cols[i]] <= (i + 2 >= nk ? 2 * NS / 256 : NS / 10);
+		for (u32 i = 0; i + 2 < nk; ++i) {
+			// the columns the leaves sort by: no digit with a tenth of the sample (Plan::hot: lanes queue at one counter)
+			go = go && s_max[cols[i]] <= NS / 10;
 		}
+		// the two digits the MSB passes go by (at their bit positions: the two highest kept columns, or below the highest
+		// varying bit): none with twice its share of the sample (a slot holds 1.25 times the mean)
+		go = go && s_maxs[0] <= 2 * NS / 256 && s_maxs[1] <= 2 * NS / 256;
+		// (digits that are not bytes: the leaves of round 3, which take over when the bins are uneven, sort by bytes)
+		// the leaves' bins (4096 of them, fewer when fewer than twelve bits are left below the MSB digits): NS samples give each
+		// NS / bins on average; a bin with three times that (and a margin for the small counts) means clustered low bits
+		const u32 nbins12 = (shift1 & 7u) && shift2 < 12u ? 1u << shift2 : 4096u;
+		const u32 max12_ok = 3 * (NS / nbins12) + 18u;
+		if (shift1 & 7u)
+			go = go && s_max12 <= max12_ok;
 		ctl->ntiles = ctl->mode = ctl->maxleaf = ctl->done = ctl->nleaf = ctl->overflow = ctl->nredo = 0;   // (nobody else zeroes the control block)
 		ctl->blind = go ? BLIND_GO : BLIND_FAILED;
 		// NS samples over 4096 bins: two per bin on average, the fullest holds ten or eleven; a leaf of 4096 keys sees half of
 		// what the sample sees, and rsx_leaf16_kernel takes bins of up to 25 keys
-		ctl->leaf16 = s_max12 <= 24u ? 1u : 0u;
+		ctl->leaf16 = s_max12 <= max12_ok ? 1u : 0u;
+		ctl->shift1 = shift1;
+		ctl->shift2 = shift2;
 		ctl->cmask_lo = (u32)cmask;
 		ctl->cmask_hi = (u32)(cmask >> 32);
 		ctl->key0_lo = (u32)(u64)k[0];               // (thread 0's first sample is the array's first key)

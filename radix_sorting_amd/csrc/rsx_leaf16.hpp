@@ -159,7 +159,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 	static_assert(sizeof(KT) == 4, "4-byte keys: two MSB digits in the slot, two bytes in the leaf");
 	constexpr int BLOCK = C::BLOCK, CAP = C::CAP, NV = C::NV, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
 	const u32 hyb = plan->hyb, ncols = plan->ncols;
-	const u32 c1 = plan->cols[3] & 15u, c2 = plan->cols[2] & 15u;
+	const u32 sh1 = ctl->shift1, sh2 = ctl->shift2;   // the MSB digits' bit positions (24 and 16 unless the keys' top bits are constant)
 	const u32 mode = ctl->mode, maxleaf = ctl->maxleaf, nseg = ctl->nleaf, on = ctl->leaf16;
 	if (hyb != HYB_TWO_LEVEL || ncols != 4 || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi || !on)
 		return;
@@ -172,7 +172,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const u32 swid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
 	const KT key0 = (KT)ctl->key0_lo;
-	const KT digits = (KT)((KT)0xFFu << (8 * c1)) | (KT)((KT)0xFFu << (8 * c2));
+	// the leaf's values: the sh2 bits below the MSB digits (sixteen of them unless ...); their bins: the top NBITS of those
+	const u32 lowmask = sh2 >= 32u ? ~0u : (1u << sh2) - 1u, D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
+	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));   // what every key has above the level-1 digit
 	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
 		const LeafSeg ls = segtab[s];
 		const u32 cnt = ls.cnt, slot = ls.slot;
@@ -209,11 +211,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 		} else {
 			// a value's cell: byte address of its word and the shift of its half; values that do not exist count in the lane's own word
 			auto cell_of = [&](u32 w, int k, bool valid, u32 &sh) -> u32 * {
-				// k even: the value is w[15:0], its bin w[15:4], word w[15:5], half w[4]; k odd: the same 16 bits higher
-				constexpr int D = 12 - C::NBITS;   // (twelve bits: word w[15:5], half w[4])
-				const u32 word = (k & 1) ? (w >> (21 + D)) : ((w >> (5 + D)) & (u32)(NCELLW - 1));
-				sh = (k & 1) ? ((w >> (16 + D)) & 16u) : ((w >> D) & 16u);
-				return &cell[valid ? word : NCELLW + lane];
+				// k even: the value is w[15:0], k odd: w[31:16]; its bin: nb bits from bit D of the value on (one bit-field extract)
+				const u32 bin = __builtin_amdgcn_ubfe(w, D + 16u * (u32)(k & 1), nb);
+				sh = (bin << 4) & 16u;
+				return &cell[valid ? bin >> 1 : NCELLW + lane];
 			};
 			// ---- count
 #pragma unroll
@@ -263,8 +264,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 #pragma unroll
 			for (int w = 1; w < NW; ++w)
 				mx = mx > wmax[w] ? mx : wmax[w];
-			if (mx > maxbin2) {
-				// a bin too large for the register passes: the leaf goes to rsx_leaf_sort_kernel (nothing was written)
+			if (mx > maxbin2 && !(sh1 & 7u)) {
+				// a bin too large for the register passes: the leaf goes to rsx_leaf_sort_kernel (nothing was written) -- which
+				// sorts by byte columns: with MSB digits at other bit positions this kernel goes on until the leaf is in order
 				if (tid == 0)
 					redo[atomicAdd(&ctl->nredo, 1u)] = s;
 				continue;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 		if constexpr (!(C::SKIP & 1)) {
 			// ---- the low four bits: chunks of 16 values at 16 i (sorted), then at 16 i + 8 (two sorted halves: merged), and
 			// twice more for bins of more than MAXBIN keys (evenly spread keys: one leaf in two thousand)
-			const u32 npass = mx > C::MAXBIN ? 4u : 2u;
+			const u32 npass = mx <= C::MAXBIN ? 2u : mx <= C::MAXBIN2 ? 4u : 2u * (((mx + 6) / 8 + 2) / 2);   // ceil((m - 1) / 8) + 1 passes for a bin of m
 			for (u32 pass = 0; pass < npass; ++pass) {
 				const u32 off = 8 * (pass & 1);
 #pragma unroll
@@ -343,15 +345,15 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 		}
 		// ---- write out: four values (8 bytes of LDS) -> four keys (16 bytes) per lane and step
 		if constexpr (!(C::SKIP & 4)) {
-			const KT upper = (KT)((key0 & ~digits & ~(KT)0xFFFFu) | ((KT)((slot - 1) >> 8) << (8 * c1)) | ((KT)((slot - 1) & 255u) << (8 * c2)));
+			const KT upper = (KT)(above | ((KT)((slot - 1) >> 8) << sh1) | ((KT)((slot - 1) & 255u) << sh2));
 			KT *o = out + ls.beg;
 			for (u32 i0 = 4 * tid; i0 < cnt; i0 += 4 * BLOCK) {
 				const uint2 x = *(const uint2 *)&stage[i0];
 				KT kk[4];
-				kk[0] = kdf_invert((KT)(upper | (x.x & 0xFFFFu)), ka);
-				kk[1] = kdf_invert((KT)(upper | (x.x >> 16)), ka);
-				kk[2] = kdf_invert((KT)(upper | (x.y & 0xFFFFu)), ka);
-				kk[3] = kdf_invert((KT)(upper | (x.y >> 16)), ka);
+				kk[0] = kdf_invert((KT)(upper | (x.x & lowmask)), ka);
+				kk[1] = kdf_invert((KT)(upper | ((x.x >> 16) & lowmask)), ka);
+				kk[2] = kdf_invert((KT)(upper | (x.y & lowmask)), ka);
+				kk[3] = kdf_invert((KT)(upper | ((x.y >> 16) & lowmask)), ka);
 				if (i0 + 4 <= cnt) {
 					store_chunk<KT, 4>(o + i0, kk);
 				} else {
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 	static_assert(sizeof(KT) == 4, "4-byte keys: two MSB digits in the slot, two bytes in the leaf");
 	constexpr int CAP = C::CAP, NV = C::NV, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
 	const u32 hyb = plan->hyb, ncols = plan->ncols;
-	const u32 c1 = plan->cols[3] & 15u, c2 = plan->cols[2] & 15u;
+	const u32 sh1 = ctl->shift1, sh2 = ctl->shift2;   // the MSB digits' bit positions (rsx_leaf16_kernel)
 	const u32 mode = ctl->mode, maxleaf = ctl->maxleaf, nseg = ctl->nleaf;
 	// (takes every leaf, whatever the sample made of the low sixteen bits: SegCtl::leaf16 is for the workgroup kernel)
 	if (hyb != HYB_TWO_LEVEL || ncols != 4 || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi)
@@ -406,7 +408,8 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 	u32 *cell = cell_all[swid];
 	uint16_t *stage = stage_all[swid];
 	const KT key0 = (KT)ctl->key0_lo;
-	const KT digits = (KT)((KT)0xFFu << (8 * c1)) | (KT)((KT)0xFFu << (8 * c2));
+	const u32 lowmask = sh2 >= 32u ? ~0u : (1u << sh2) - 1u, D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
+	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));
 	for (u32 s = blockIdx.x * NW + swid; s < nseg; s += gridDim.x * NW) {
 		const LeafSeg ls = segtab[s];
 		const u32 cnt = ls.cnt, slot = ls.slot;
@@ -433,10 +436,9 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 		}
 		RSX_COMPILER_FENCE();
 		auto cell_of = [&](u32 w, int k, bool valid, u32 &sh) -> u32 * {
-			constexpr int D = 12 - C::NBITS;
-			const u32 word = (k & 1) ? (w >> (21 + D)) : ((w >> (5 + D)) & (u32)(NCELLW - 1));
-			sh = (k & 1) ? ((w >> (16 + D)) & 16u) : ((w >> D) & 16u);
-			return &cell[valid ? word : NCELLW + lane];
+			const u32 bin = __builtin_amdgcn_ubfe(w, D + 16u * (u32)(k & 1), nb);
+			sh = (bin << 4) & 16u;
+			return &cell[valid ? bin >> 1 : NCELLW + lane];
 		};
 #pragma unroll
 		for (int j = 0; j < NV; ++j) {
@@ -541,15 +543,15 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 			RSX_COMPILER_FENCE();
 		}
 		{
-			const KT upper = (KT)((key0 & ~digits & ~(KT)0xFFFFu) | ((KT)((slot - 1) >> 8) << (8 * c1)) | ((KT)((slot - 1) & 255u) << (8 * c2)));
+			const KT upper = (KT)(above | ((KT)((slot - 1) >> 8) << sh1) | ((KT)((slot - 1) & 255u) << sh2));
 			KT *o = out + ls.beg;
 			for (u32 i0 = 4 * lane; i0 < cnt; i0 += 4 * 64) {
 				const uint2 x = *(const uint2 *)&stage[i0];
 				KT kk[4];
-				kk[0] = kdf_invert((KT)(upper | (x.x & 0xFFFFu)), ka);
-				kk[1] = kdf_invert((KT)(upper | (x.x >> 16)), ka);
-				kk[2] = kdf_invert((KT)(upper | (x.y & 0xFFFFu)), ka);
-				kk[3] = kdf_invert((KT)(upper | (x.y >> 16)), ka);
+				kk[0] = kdf_invert((KT)(upper | (x.x & lowmask)), ka);
+				kk[1] = kdf_invert((KT)(upper | ((x.x >> 16) & lowmask)), ka);
+				kk[2] = kdf_invert((KT)(upper | (x.y & lowmask)), ka);
+				kk[3] = kdf_invert((KT)(upper | ((x.y >> 16) & lowmask)), ka);
 				if (i0 + 4 <= cnt) {
 					store_chunk<KT, 4>(o + i0, kk);
 				} else {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		if (flags & SCATTER_BLIND_TOP) {
 			// the level-1 pass of such a sort: by the highest column the sample proved kept, no offsets
 			seg_slot = 0;
-			shift = 8 * dplan->cols[dplan->ncols - 1];
+			shift = seg.ctl->shift1;   // (8 x the highest kept column, or the bits below the highest varying one: rsx_blind_precheck_kernel)
 			bl_cmask = (KT)(((u64)seg.ctl->cmask_hi << 32) | seg.ctl->cmask_lo);
 			bl_key0 = (KT)(((u64)seg.ctl->key0_hi << 32) | seg.ctl->key0_lo);
 		} else if (dplan->hyb != HYB_TWO_LEVEL) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			}
 		}
 		if (!(flags & SCATTER_BLIND_TOP)) {
-			shift = 8 * dplan->cols[seg_slot];
+			shift = ((flags & SCATTER_BLIND) && (flags & SCATTER_SEG_SLACK)) ? seg.ctl->shift2 : 8 * dplan->cols[seg_slot];
 			gbase += 256 * dplan->cols[dplan->ncols - 1];   // the level-1 column's offsets: bucket starts
 		}
 	} else if (dplan && !(flags & SCATTER_SELF_PLAN)) {

@@ -489,3 +489,51 @@ def test_blind_dense_slots_off_is_the_same_sort(blind_on):
                 blind_on.setenv("RSX_NO_DENSE_SLOTS", "1")
                 check(a, dt, order, 5, (dt, order, "whole keys"))
                 blind_on.delenv("RSX_NO_DENSE_SLOTS")
+
+
+# ---- MSB digits below constant top bits (SegCtl::shift1 / shift2; 4-byte keys, two-byte slots) ---------------------------
+@pytest.mark.parametrize("dt", [ol.U32, ol.I32, ol.F32], ids=["u32", "i32", "f32"])
+def test_blind_digits_below_constant_top_bits(dt, blind_on):
+    """4-byte keys whose top bits are the same in every key -- values below 2^30 / 2^27 / 2^25, or one rank's share of a
+    distributed sort (top byte in [64, 128)): all four byte columns are kept (the reference's view, radix_sort.hpp:64-70), but
+    the top byte takes few values and two passes by whole bytes would fill a few slots only.  The sample sees the constant
+    bits, the passes go by the sixteen bits below the highest varying one, the level-1 pass checks the constant bits on every
+    key; result, kept columns and returned buffer as the oracle's."""
+    for n in ((1 << 22) + 321, 5555555):
+        for mask, base in ((0x3FFFFFFF, 0), (0x07FFFFFF, 0), (0x01FFFFFF, 0), (0x3FFFFFFF, 0x40000000), (0x00FFFFFF, 0xA5000000)):
+            for order in (ol.ASC, ol.DESC):
+                a = (ol.splitmix_fill(n, dt, 900 + n % 31 + order, mask).view(np.uint32) | np.uint32(base)).view(ol.NP_BITS[dt])
+                want_route = 5 if mask != 0x00FFFFFF else None      # (a constant top BYTE is a skipped column: three kept, another route)
+                info = check(np.ascontiguousarray(a), dt, order, want_route, (n, hex(mask), hex(base), dt, order))
+                if mask == 0x00FFFFFF:
+                    assert info.hybrid != 5 and info.ncols == 3
+
+
+def test_blind_constant_top_bits_disproved_by_one_key(blind_on):
+    """One key with a bit set above what the sample saw: the level-1 pass finds it, the attempt is called off, the ordinary sort
+    follows (and gives the oracle's result)."""
+    n = (1 << 22) + 77
+    for where in (1, n // 2, n - 1):
+        a = ol.splitmix_fill(n, ol.U32, 950, 0x07FFFFFF).view(np.uint32).copy()
+        a[where] |= np.uint32(0x20000000)
+        blind_on.setenv("RSX_NO_BLIND", "0")
+        info = check(a, ol.U32, ol.ASC, None, where)
+        assert info.hybrid != 5, (where, info.hybrid)
+
+
+def test_blind_unaligned_range_of_top_bytes_is_called_off(blind_on):
+    """Top bytes 63 .. 127: the bits that vary reach bit 30, the digits below them fill 130 of 256 slots twice over -- the sample
+    says no."""
+    n = (1 << 22) + 5
+    a = ol.splitmix_fill(n, ol.U32, 960, 0xFFFFFFFF).view(np.uint32)
+    top = np.uint32(63) + (a >> 24) % np.uint32(65)
+    a = (a & np.uint32(0x00FFFFFF)) | (top << 24)
+    info = check(np.ascontiguousarray(a), ol.U32, ol.ASC, None, "63..127")
+    assert info.hybrid != 5
+
+
+def test_blind_no_shift_switch(blind_on):
+    a = ol.splitmix_fill((1 << 22) + 9, ol.U32, 970, 0x07FFFFFF)
+    assert check(a, ol.U32, ol.ASC, None, "shifted").hybrid == 5
+    blind_on.setenv("RSX_NO_SHIFT", "1")
+    assert check(a, ol.U32, ol.ASC, None, "RSX_NO_SHIFT=1").hybrid != 5

@@ -79,6 +79,16 @@ def test_u32_mid_size_low_bits_clustered():
     _sort_and_compare(b, ol.U32, ol.ASC, 5, "16 values in some buckets")
 
 
+@pytest.mark.parametrize("n_mi,mask,base", [(128, 0x07FFFFFF, 0x18000000), (40, 0x3FFFFFFF, 0), (200, 0x1FFFFFFF, 0xE0000000)])
+def test_u32_constant_top_bits_at_production_sizes(n_mi, mask, base):
+    """One rank's sub-range of a distributed sort (2^27 keys whose top byte lies in [24, 32)), values below 2^30, keys with
+    their top three bits set: the MSB digits lie below the constant bits (SegCtl::shift1 / shift2), route 5, bit for bit."""
+    n = n_mi * MI + 31
+    a = ol.splitmix_fill(n, ol.U32, 4700 + n_mi, mask).view(np.uint32) | np.uint32(base)
+    _sort_and_compare(np.ascontiguousarray(a), ol.U32, ol.ASC, 5, ("u32", n_mi, hex(mask), hex(base)))
+    _sort_and_compare(np.ascontiguousarray(a), ol.U32, ol.DESC, 5, ("u32 desc", n_mi, hex(mask), hex(base)))
+
+
 @pytest.mark.parametrize("switch", ["RSX_NO_LEAF16", "RSX_NO_DENSE_SLOTS"])
 @pytest.mark.parametrize("n_mi", [64, 96, 128, 192])
 def test_u32_round3_leaves_at_the_same_sizes(n_mi, switch, monkeypatch):

@@ -202,6 +202,8 @@ int main(int argc, char **argv)
 	c.maxleaf = cap;
 	c.nleaf = nleaf;
 	c.leaf16 = 1;
+	c.shift1 = 24;
+	c.shift2 = 16;
 	CK(hipMemcpy(d_ctl, &c, sizeof c, hipMemcpyHostToDevice));
 	printf("n = %zu u32 keys in %u slots of %u two-byte values (%u +- 64 in each), mode %u\n", n, nleaf, cap, per, mode);
 	typedef LeafCfg<u32, 4, 20, 4, true, false> Fit;
