@@ -27,6 +27,15 @@
  *   - Order is a stable sort by kdf(key): output element images are bit-exact
  *     copies of the input's (NaN payloads, -0.0), radix_sort.hpp:85-87.
  *
+ * Scratch memory.  The reference allocates nothing (radix_sort.hpp:98-115: two caller buffers, counters on the stack).
+ *   This library keeps, per (device, stream) and until rsx_release / rsx_release_stream: status words of the look-back
+ *   chains (1 KiB per 32 Ki-key tile and pass), and -- for the sorts without a histogram, which large evenly spread arrays
+ *   take (rsx_info.hybrid == 5) -- two arrays of slots: 256 x 1.25 n / 256 keys for the first MSB pass and 65536 slots of
+ *   1.25 n / 65536 keys for the second (two bytes per key for 4-byte keys: 0.625 n keys' worth; key + payload sorts: the same
+ *   again for the payloads).  2^28 u32 keys: 1.25 + 0.63 GiB.  If an allocation fails the sort takes the histogram-first
+ *   route and the (device, stream) context does not ask again until rsx_reload_env() or rsx_release_stream();
+ *   RSX_NO_BLIND=1 never asks.
+ *
  * Environment switches (read ONCE, at the library's first call; rsx_reload_env() reads them again)
  *   RSX_VERIFY=1            after every scatter pass one tile is re-ranked without LDS
  *                           atomics and compared with the pass's output; a mismatch fails
@@ -118,7 +127,9 @@ void        rsx_release_stream(void *stream);
 
 /* The RSX_* switches of the environment (diagnostics and A/B switches; every one is named where it acts, in
  * DESIGN.md) are read once, at the library's first call.  A process that changes them afterwards -- tests do -- calls
- * this to have them read again; RSX_FORCE_TABLE_RANK is only honoured before the first sort on a device. */
+ * this to have them read again; RSX_FORCE_TABLE_RANK is only honoured before the first sort on a device.
+ * NOT thread-safe against running sorts: the switches live in one process-wide record that every entry point reads
+ * without a lock, so no other thread may be inside the library while this runs (as for rsx_release_stream). */
 void        rsx_reload_env(void);
 
 /* ---- radix_sort<T>(src, aux, n) -- radix_sort.hpp:98-115 ------------------ */
@@ -137,7 +148,12 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * contents afterwards are unspecified, untouched if the input was sorted).  Nothing
  * is returned but the status of the enqueue: the call can be captured into a HIP
  * graph (after one uncaptured call of the same size has sized the workspace) and
- * replayed on new contents of d_buf. */
+ * replayed on new contents of d_buf.
+ * Round 4: the ROUTE is chosen on the device as well (rsx_async_route reports it): one MSB pass and leaves for mid-size
+ * arrays; for large arrays (4-byte keys from 9 Mi keys, 8-byte keys from 48 Mi) the sort without a histogram is
+ * enqueued first and the histogram-first kernels behind it do nothing if it went through.  That attempt works in scratch
+ * slots in the (device, stream) workspace: 1.25 n + 0.625 n .. 1.25 n keys of device memory beside d_buf and d_scratch
+ * (see "Scratch memory" below); rsx_sort_inplace_async_ws, whose state lies in the caller's workspace, never makes it. */
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
                            void *stream);
 
@@ -288,7 +304,10 @@ int rsx_msd_split_device(const void *d_src, void *d_dst, size_t n, rsx_dtype dty
 
 /* The same pass for a caller that already has the shard's column counts -- d_hist: the 256 * key_bytes uint64 counts
  * rsx_histogram_device left in device memory (one read of the shard gives every column's, so the column to split by can be
- * chosen from them without a trial pass).  Counts nothing, waits for nothing: everything is only enqueued on `stream`. */
+ * chosen from them without a trial pass).  Counts nothing, waits for nothing: everything is only enqueued on `stream`.
+ * column | RSX_SPLIT_HOT: the caller, who has the counts, says that one digit of the column holds an eighth of the shard's
+ * keys or more -- the pass then ranks its dominant digits by ballots (what rsx_msd_split_device decides from its own counts). */
+#define RSX_SPLIT_HOT 0x100
 int rsx_msd_split_async(const void *d_src, void *d_dst, size_t n, rsx_dtype dtype, rsx_order order,
                         int column, const uint64_t *d_hist, void *stream);
 

@@ -257,6 +257,7 @@ struct Ctx {
 	// ... sorts to go before the next attempt, doubled by every attempt that is called off; per kind of sort (4- / 8-byte keys,
 	// rank sorts, keys + payload): what one kind's inputs look like says nothing about another's
 	u32 blind_skip[4] = {0, 0, 0, 0}, blind_backoff[4] = {0, 0, 0, 0};
+	bool blind_no_room = false;              // the slots could not be allocated once: not asked for again (until rsx_reload_env)
 	u32 env_epoch = 0;                       // ... forgotten when rsx_reload_env() has run since
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
 	hipEvent_t seg_ev = nullptr;
@@ -1312,6 +1313,17 @@ inline void blind_called_off(Ctx &c, int kind)
 	c.blind_backoff[kind] = std::min<u32>(2 * c.blind_backoff[kind] + 1, 31);
 	c.blind_skip[kind] = c.blind_backoff[kind];
 }
+// rsx_reload_env() makes every context forget what it has learnt about its inputs (and about its device's memory)
+inline void blind_refresh(Ctx &c)
+{
+	const u32 epoch = g_env_epoch.load();
+	if (c.env_epoch != epoch) {
+		c.env_epoch = epoch;
+		c.blind_no_room = false;
+		for (int k = 0; k < 4; ++k)
+			c.blind_skip[k] = c.blind_backoff[k] = 0;
+	}
+}
 template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes = 0, bool rank = false)
 {
 	if constexpr (sizeof(KT) < 4)
@@ -1342,12 +1354,7 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		if (n < floor_keys)
 			return false;
 	}
-	const u32 epoch = g_env_epoch.load();
-	if (c.env_epoch != epoch) {
-		c.env_epoch = epoch;
-		for (int k = 0; k < 4; ++k)
-			c.blind_skip[k] = c.blind_backoff[k] = 0;
-	}
+	blind_refresh(c);
 	const int kind = blind_kind<KT>(payload_bytes, rank);
 	if (c.blind_skip[kind]) {
 		--c.blind_skip[kind];
@@ -1371,6 +1378,7 @@ template <typename KT> bool async_blind_ok(Ctx &c, size_t n)
 	if (env().blind_min_log2)
 		floor_keys = (size_t)1 << env().blind_min_log2;
 	floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);
+	blind_refresh(c);
 	return n >= std::max(floor_keys, (size_t)1 << 22) && n < ((size_t)1 << 30);
 }
 
@@ -1384,9 +1392,17 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
 	if (cap2 > (u32)LeafShapes<KT>::Big::CAP)
 		return RSX_OK;
+	if (c.blind_no_room)
+		return RSX_OK;
 	if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK) {
-		(void)hipGetLastError();   // (no room for the slots: the ordinary path)
+		// no room for the slots: the ordinary path, now and for this context's later sorts (a multi-GiB hipMalloc that fails
+		// is not worth repeating per sort); what was allocated of the pair goes back
+		(void)hipGetLastError();
+		c.slack1.release();
+		c.slack.release();
+		c.slack1_cap = c.slack_cap = 0;
+		c.blind_no_room = true;
 		return RSX_OK;
 	}
 	RSX_TRY(seg_layout<KT>(c, n));
@@ -1888,11 +1904,19 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
 	if (cap2 > (u32)L::CAP)
 		return RSX_OK;
+	if (c.blind_no_room)
+		return RSX_OK;
 	if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack1_v.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(VT)) != RSX_OK ||
 	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack_v.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(VT)) != RSX_OK) {
-		(void)hipGetLastError();
+		(void)hipGetLastError();   // (no room: as blind_enqueue -- what was allocated goes back, nobody asks again)
+		c.slack1.release();
+		c.slack1_v.release();
+		c.slack.release();
+		c.slack_v.release();
+		c.slack1_cap = c.slack_cap = 0;
+		c.blind_no_room = true;
 		return RSX_OK;
 	}
 	RSX_TRY(seg_layout<KT>(c, n));   // (Sc2Cfg<KT, NoVal> and <KT, VT> have the same tile: 32 Ki elements)
@@ -2360,14 +2384,17 @@ int msd_split(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u3
 // The same pass for a caller that HAS the shard's column counts (rsx_histogram_device: one read gave every column): nothing
 // is counted again and nothing waits for the host.
 template <typename KT>
-int msd_split_known(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u32 col, const u64 *d_counts)
+int msd_split_known(Ctx &c, const KT *src, KT *dst, size_t n, int dtype, int order, u32 col, const u64 *d_counts, bool hot)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	HIP_TRY(hipMemcpyAsync(c.ghist(), d_counts, sizeof(KT) * 256 * sizeof(u64), hipMemcpyDeviceToDevice, c.stream));
 	hipLaunchKernelGGL((rsx_plan_kernel<KT>), dim3(sizeof(KT)), dim3(256), 0, c.stream, src, (u64)n, c.ghist(), ka, c.kept(),
 	                   c.hotd());   // (the exclusive scans, radix_sort.hpp:72-80)
 	HIP_TRY(hipGetLastError());
-	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka, 0u);
+	// (a dominant digit -- the caller has the counts on the host and says so: the ballot-ranked kernel, as msd_split's;
+	// its hot digits are rsx_plan_kernel's, on the device)
+	return scatter_pass<KT, NoVal>(c, src, dst, nullptr, nullptr, n, 8 * col, c.ghist() + 256 * col, ka,
+	                               hot ? hot_flags(1u << col, col) : 0u);
 }
 
 #include "rsx_multi_state.hpp"   // rsx_sort_multi: per-rank streams, buffers, phases, peer access
@@ -2953,6 +2980,9 @@ int rsx_msd_split_async(const void *d_src, void *d_dst, size_t n, rsx_dtype dtyp
                         const uint64_t *d_hist, void *stream)
 {
 	const size_t kb = dtype_size(dtype);
+	const bool hot = column >= 0 && (column & RSX_SPLIT_HOT) != 0;
+	if (column >= 0)
+		column &= ~RSX_SPLIT_HOT;
 	if (!kb || !d_hist || column >= (int)kb || (n && (!d_src || !d_dst)))
 		return fail(RSX_EINVAL, "rsx_msd_split_async: bad argument");
 	const u32 col = column < 0 ? (u32)kb - 1 : (u32)column;
@@ -2962,7 +2992,7 @@ int rsx_msd_split_async(const void *d_src, void *d_dst, size_t n, rsx_dtype dtyp
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	HIP_TRY(hipMemsetAsync(c->small_set(), 0, 256, c->stream));
-	RSX_DISPATCH_KT(dtype, return msd_split_known<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, (const u64 *)d_hist));
+	RSX_DISPATCH_KT(dtype, return msd_split_known<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, (const u64 *)d_hist, hot));
 	return RSX_OK;
 }
 

@@ -131,10 +131,11 @@ class HipEngine:
                                          h[self.kb * 256:].data_ptr(), _stream_ptr()))
         return h[:self.kb * 256]
 
-    def msd_split_known(self, shard, out, column, hist_all):
-        """msd_split for a caller that holds the shard's counts (histogram()): no second count, no host synchronisation."""
-        check(lib().rsx_msd_split_async(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order, column,
-                                        hist_all.data_ptr(), _stream_ptr()))
+    def msd_split_known(self, shard, out, column, hist_all, hot=False):
+        """msd_split for a caller that holds the shard's counts (histogram()): no second count, no host synchronisation.
+        hot: one digit of the column holds an eighth of the shard or more (RSX_SPLIT_HOT: the ballot-ranked pass)."""
+        check(lib().rsx_msd_split_async(shard.data_ptr(), out.data_ptr(), shard.numel(), self.dtype, self.order,
+                                        column | (0x100 if hot else 0), hist_all.data_ptr(), _stream_ptr()))
         self.split_passes += 1
 
     def local_sort(self, keys, aux):
@@ -222,6 +223,12 @@ def slice_bounds(n, slices):
     return b
 
 
+def _is_hot(counts):
+    """Plan::hot's rule (rsx_plan_kernel) on a column's 256 counts: one digit with an eighth of the keys or more."""
+    total = int(counts.sum())
+    return total > 0 and int(counts.max()) >= total // 8 + 1
+
+
 def split_plan(shard, part, engine, group, world, tmp=None, slices=1):
     """Steps 1-2 of the distributed sort: split the shard into BINS in key order and gather every rank's bin counts.
 
@@ -268,14 +275,15 @@ def split_plan(shard, part, engine, group, world, tmp=None, slices=1):
         # part by part; nothing is refined (a heavy bin's run must be contiguous in `part`), so this is the whole plan
         def split_one(i):
             if bounds[i + 1] > bounds[i]:
-                engine.msd_split_known(shard[bounds[i]:bounds[i + 1]], part[bounds[i]:bounds[i + 1]], column, halls[i])
+                engine.msd_split_known(shard[bounds[i]:bounds[i + 1]], part[bounds[i]:bounds[i + 1]], column, halls[i],
+                                       hot=_is_hot(every_s[rank, i, column, :]))
         split_one(0)
         pending = [lambda i=i: split_one(i) for i in range(1, slices)]
         return hists, column, heavy, 0, {"bounds": bounds, "hists": every_s[:, :, column, :], "pending": pending}
     hall = halls[0]
     for h in halls[1:]:
         hall = hall + h
-    engine.msd_split_known(shard, part, column, hall)
+    engine.msd_split_known(shard, part, column, hall, hot=_is_hot(hists[rank]))
     levels = 0
     # refinement, level by level: bins that are still too heavy are split by the next lower byte (their runs of `part`
     # are contiguous); one all-gather of the sub-counts per level

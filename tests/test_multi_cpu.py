@@ -48,8 +48,9 @@ class OracleEngine:
             h[256 * c:256 * c + 256] = np.bincount(d, minlength=256)
         return torch.from_numpy(h)
 
-    def msd_split_known(self, shard, out, column, hist_all):
+    def msd_split_known(self, shard, out, column, hist_all, hot=False):
         counts = self.msd_split(shard, out, column)
+        assert bool(hot) == (counts.sum() > 0 and int(counts.max()) >= int(counts.sum()) // 8 + 1)   # (the engine is told what the counts say)
         assert np.array_equal(counts.astype(np.int64), hist_all.numpy()[256 * column:256 * column + 256])
 
     def local_sort(self, keys, aux):

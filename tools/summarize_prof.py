@@ -61,7 +61,9 @@ def algorithmic_bytes(name):
         if t[-1] == "true" and len(t) >= 3 and t[-2] in SIZES:      # <KT, shape, CT, DENSE>: the slots hold CT-wide values
             return N * (SIZES[t[-2]] + SIZES.get(t[0], 0))
         return N * 2 * SIZES.get(t[0], 0)
-    if "rsx_leaf16_kernel" in name and t:         # two-byte slots in, whole keys out (rsx_leaf16.hpp)
+    if "rsx_leafk_kernel" in name and t:          # whole 8-byte keys in and out (rsx_leaf16.hpp)
+        return N * 2 * SIZES.get(t[0], 0)
+    if ("rsx_leaf16_kernel" in name or "rsx_leaf16w_kernel" in name) and t:         # two-byte slots in, whole keys out (rsx_leaf16.hpp)
         return N * (2 + SIZES.get(t[0], 0))
     if "rsx_leaf_pairs_kernel" in name and len(t) >= 2:
         # key + payload slots in; payloads out, and the keys too for pair sorts (a rank sort writes ranks only): the lower figure
@@ -124,6 +126,8 @@ def main(out):
         ab = algorithmic_bytes(name)
         if ab is None or avg_ns <= 0:
             continue
+        if avg_ns < 30000:      # (a launch that finds nothing to do -- the list launch behind rsx_leaf16_kernel, the instantiation
+            continue            #  for the other carried type -- moves no bytes: no roofline row)
         key = next((k for k in counters if re.sub(r"\(.*", "", k) == re.sub(r"\(.*", "", name)), None)
         fetch = counters.get(key, {}).get("FETCH_SIZE")
         write = counters.get(key, {}).get("WRITE_SIZE")
