@@ -51,6 +51,8 @@
  *   RSX_NO_BLIND=1          every sort starts with the histogram (rsx_info.hybrid never 5);
  *   RSX_NO_LEAF_PREFIX=1    leaves of 8-byte keys sort by every column they have left;
  *   RSX_NO_DENSE_SLOTS=1    the second pass of such a sort writes whole keys into its slots;
+ *   RSX_NO_LEAF16=1         its leaves are round 3's (two LDS passes per slot) instead of rsx_leaf16_kernel / rsx_leafk_kernel;
+ *   RSX_LEAF16_MAXBIN=k     (tests) the fullest bin a leaf may have before it goes to those; RSX_NO_SHIFT=1: MSB digits on bytes only;
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,

@@ -1,8 +1,15 @@
 #!/bin/bash
-# scratch: the commands of the current gpurun call (here: what the driver runs at the end of a round)
 cd /root/repo
-mkdir -p gpurun_out/full1
-timeout 2400 python -m pytest tests -x -q -m gpu --durations=12 > gpurun_out/full1/pytest_gpu.txt 2>&1
-tail -22 gpurun_out/full1/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/full1/smoke.txt 2>&1
-tail -1 gpurun_out/full1/smoke.txt
+mkdir -p gpurun_out/r4n
+python tools/bench_configs.py --out gpurun_out/r4n/bench_configs.json > gpurun_out/r4n/bench_configs.txt 2>&1
+python3 -c "
+import json
+for r in json.load(open('gpurun_out/r4n/bench_configs.json')):
+    print(r['config'], '| ms', round(r['ms_per_sort'],3), '| Gkeys/s', round(r['Gkeys_per_s'],1), '| route', r['route'], '| B/key', r['algorithmic_bytes_per_key'], '| frac', round(r['frac_of_8TBps'],3), '| leaf', round(r['leaf_ms'],3), 'scat', round(r['scatter_ms_per_launch'],3), 'hist', round(r['hist_ms'],3))
+"
+python tools/size_sweep.py > gpurun_out/r4n/size_sweep.txt 2>&1
+./tools/radix_bench --device 0 --verify > gpurun_out/r4n/radix_bench.txt 2>&1
+grep "radix_sort_device" gpurun_out/r4n/radix_bench.txt | grep -v verified
+python tools/mid_route_probe.py > gpurun_out/r4n/mid.txt 2>&1
+timeout 300 python bench.py > gpurun_out/r4n/bench.txt 2>&1
+tail -1 gpurun_out/r4n/bench.txt | cut -c1-200
