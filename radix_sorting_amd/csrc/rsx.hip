@@ -110,6 +110,7 @@ struct Env {
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
 	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: (kept for old scripts: two-byte slots are now written for every slot size rsx_leaf16_kernel takes)
+	bool no_unstable = false;        // RSX_NO_UNSTABLE=1: the MSB passes of a sort without a histogram rank per wave (stable), as every other pass
 	bool no_shift = false;           // RSX_NO_SHIFT=1: the MSB digits of a sort without a histogram are whole bytes (the two highest kept columns) always
 	bool no_leaf16 = false;          // RSX_NO_LEAF16=1: two-byte slots are sorted by rsx_leaf_sort_kernel (two LDS passes) as in round 3
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
@@ -152,6 +153,7 @@ struct Env {
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
 		no_shift = is_one("RSX_NO_SHIFT");
+		no_unstable = is_one("RSX_NO_UNSTABLE");
 		leaf16_maxbin = 25;
 		if (const char *e = getenv("RSX_LEAF16_MAXBIN"))
 			leaf16_maxbin = (unsigned)std::max(0, std::min(25, atoi(e)));
@@ -1154,6 +1156,10 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	u32 flags = j == -2 ? (u32)SCATTER_SEG_SLACK : j < 0 ? (u32)SCATTER_SEG_LEAVES : 0u;
 	if (blind)
 		flags |= SCATTER_BLIND | (blind == 1 ? (u32)SCATTER_BLIND_TOP : 0u);
+	// keys only, and what these two passes write is sorted by leaves that do not care in which order a bucket's keys arrive
+	// (any ascending order of equal bits is the reference's output): no row of cells per wave, no layout over the rows
+	if (blind && !env().no_unstable)
+		flags |= SCATTER_UNSTABLE;
 	const u32 pi = j < 0 ? 0u : (u32)j;
 	const unsigned grid = blind == 1 ? (unsigned)(rows - 256) : (unsigned)rows;
 	const u32 shift0 = 0u;   // (every segmented pass reads its column from the device-side plan)

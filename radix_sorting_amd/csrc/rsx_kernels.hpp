@@ -374,6 +374,9 @@ enum : u32 {
 	SCATTER_SELF_PLAN = 1u << 21,   // (bits 12-14 are the column, 16-19 the probe's run length) pass 0 derives the plan itself from the raw counts (SelfPlanArgs, rsx_scatter2.hpp)
 	SCATTER_BLIND = 1u << 22,       // segmented pass of a sort WITHOUT a histogram (rsx_hybrid.hpp, rsx_blind_*): runs only while SegCtl::blind says go
 	SCATTER_BLIND_TOP = 1u << 23,   // ... its first pass: by the highest column of the plan the sample made, plain tiles, ONE bucket whose 256 digits have a slot each
+	// keys-only MSB passes whose buckets go to leaves that sort them anyway (rsx_hybrid.hpp): the order of a bucket's keys does not
+	// matter, so the workgroup ranks in ONE row of cells shared by its waves -- no prefix over the waves' rows (the layout phase)
+	SCATTER_UNSTABLE = 1u << 24,
 	SCATTER_RANK_ASYNC = 1u << 20   // device-scheduled pass of rsx_sort_rank_inplace_async: buffers, index generation and the key-less last pass follow from the plan
 };
 

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 	const u32 swid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
 	const KT key0 = (KT)ctl->key0_lo;
 	// the leaf's values: the sh2 bits below the MSB digits (sixteen of them unless ...); their bins: the top NBITS of those
-	const u32 lowmask = sh2 >= 32u ? ~0u : (1u << sh2) - 1u, D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
+	const u32 D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
 	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));   // what every key has above the level-1 digit
 	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
 		const LeafSeg ls = segtab[s];
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 			// a value's cell: byte address of its word and the shift of its half; values that do not exist count in the lane's own word
 			auto cell_of = [&](u32 w, int k, bool valid, u32 &sh) -> u32 * {
 				// k even: the value is w[15:0], k odd: w[31:16]; its bin: nb bits from bit D of the value on (one bit-field extract)
-				const u32 bin = __builtin_amdgcn_ubfe(w, D + 16u * (u32)(k & 1), nb);
-				sh = (bin << 4) & 16u;
-				return &cell[valid ? bin >> 1 : NCELLW + lane];
+				const u32 o = D + 16u * (u32)(k & 1);   // (uniform)
+				sh = __builtin_amdgcn_ubfe(w, o, 1u) << 4;
+				return &cell[valid ? __builtin_amdgcn_ubfe(w, o + 1u, nb - 1u) : NCELLW + lane];
 			};
 			// ---- count
 #pragma unroll
@@ -350,10 +350,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 			for (u32 i0 = 4 * tid; i0 < cnt; i0 += 4 * BLOCK) {
 				const uint2 x = *(const uint2 *)&stage[i0];
 				KT kk[4];
-				kk[0] = kdf_invert((KT)(upper | (x.x & lowmask)), ka);
-				kk[1] = kdf_invert((KT)(upper | ((x.x >> 16) & lowmask)), ka);
-				kk[2] = kdf_invert((KT)(upper | (x.y & lowmask)), ka);
-				kk[3] = kdf_invert((KT)(upper | ((x.y >> 16) & lowmask)), ka);
+				kk[0] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.x, 0u, sh2)), ka);
+				kk[1] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.x, 16u, sh2)), ka);
+				kk[2] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.y, 0u, sh2)), ka);
+				kk[3] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.y, 16u, sh2)), ka);
 				if (i0 + 4 <= cnt) {
 					store_chunk<KT, 4>(o + i0, kk);
 				} else {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 	u32 *cell = cell_all[swid];
 	uint16_t *stage = stage_all[swid];
 	const KT key0 = (KT)ctl->key0_lo;
-	const u32 lowmask = sh2 >= 32u ? ~0u : (1u << sh2) - 1u, D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
+	const u32 D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
 	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));
 	for (u32 s = blockIdx.x * NW + swid; s < nseg; s += gridDim.x * NW) {
 		const LeafSeg ls = segtab[s];
@@ -436,9 +436,9 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 		}
 		RSX_COMPILER_FENCE();
 		auto cell_of = [&](u32 w, int k, bool valid, u32 &sh) -> u32 * {
-			const u32 bin = __builtin_amdgcn_ubfe(w, D + 16u * (u32)(k & 1), nb);
-			sh = (bin << 4) & 16u;
-			return &cell[valid ? bin >> 1 : NCELLW + lane];
+			const u32 o = D + 16u * (u32)(k & 1);
+			sh = __builtin_amdgcn_ubfe(w, o, 1u) << 4;
+			return &cell[valid ? __builtin_amdgcn_ubfe(w, o + 1u, nb - 1u) : NCELLW + lane];
 		};
 #pragma unroll
 		for (int j = 0; j < NV; ++j) {
@@ -548,10 +548,10 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 			for (u32 i0 = 4 * lane; i0 < cnt; i0 += 4 * 64) {
 				const uint2 x = *(const uint2 *)&stage[i0];
 				KT kk[4];
-				kk[0] = kdf_invert((KT)(upper | (x.x & lowmask)), ka);
-				kk[1] = kdf_invert((KT)(upper | ((x.x >> 16) & lowmask)), ka);
-				kk[2] = kdf_invert((KT)(upper | (x.y & lowmask)), ka);
-				kk[3] = kdf_invert((KT)(upper | ((x.y >> 16) & lowmask)), ka);
+				kk[0] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.x, 0u, sh2)), ka);
+				kk[1] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.x, 16u, sh2)), ka);
+				kk[2] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.y, 0u, sh2)), ka);
+				kk[3] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.y, 16u, sh2)), ka);
 				if (i0 + 4 <= cnt) {
 					store_chunk<KT, 4>(o + i0, kk);
 				} else {

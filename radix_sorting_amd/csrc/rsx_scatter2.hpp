@@ -435,6 +435,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		return x;
 	};
 
+	// SCATTER_UNSTABLE (keys-only passes into buckets that leaves sort): one row of cells for the whole workgroup
+	const bool unstable = RANK1 && !C::CELL16 && (flags & SCATTER_UNSTABLE) != 0;
 	// ---- phase A: count, per tile and wave.  Order inside a wave's slice does not matter here, so the
 	// slice is streamed with 16-byte loads (when the keys are 16-byte aligned), all of them in flight.
 	constexpr int VEC = 16 / sizeof(KT);
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		const u64 base = beg + (u64)t * C::TILE;
 		if (t < (int)tps && base < end) {
 			const u32 cnt = (end - base) < (u64)C::TILE ? (u32)(end - base) : (u32)C::TILE;
-			u32 *wc = sm.cell[t][wid];
+			u32 *wc = sm.cell[t][unstable ? 0u : wid];
 			if (vec_ok && cnt == (u32)C::TILE) {
 				typedef KT vec_t __attribute__((ext_vector_type(VEC)));
 				constexpr int NV = KPT / VEC;   // 16-byte loads per lane
@@ -638,9 +640,13 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 #pragma unroll
 		for (int t = 0; t < TPS; ++t) {
 			u32 c = 0;
+			if (unstable) {
+				c = sm.cell[t][0][tid & (CW - 1)];
+			} else {
 #pragma unroll
-			for (int k = 0; k < NWAVES; ++k)
-				c += C::CELL16 ? (u32)cell16[(t * NWAVES + k) * 256 + tid] : sm.cell[t][k][tid & (CW - 1)];
+				for (int k = 0; k < NWAVES; ++k)
+					c += C::CELL16 ? (u32)cell16[(t * NWAVES + k) * 256 + tid] : sm.cell[t][k][tid & (CW - 1)];
+			}
 			tc[t] = c;
 			st_cnt += c;
 		}
@@ -672,6 +678,10 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				tbase += sm.wsum[t][k];
 			tb[t] = tbase;
 			u32 acc = tbase;   // counts -> run starts, in place
+			if (unstable) {
+				sm.cell[t][0][tid & (CW - 1)] = tbase;
+				continue;
+			}
 #pragma unroll
 			for (int k = 0; k < NWAVES; ++k) {
 				u32 c;
@@ -751,7 +761,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	auto do_tile = [&](auto full_c, const int t, const u64 base, const u32 cnt) {
 		constexpr bool full = decltype(full_c)::value;   // a whole tile: no bounds checks
 		const u32 wo = full ? wofs : opaque(wofs);
-		u32 *wc = sm.cell[t][wid];
+		u32 *wc = sm.cell[t][unstable ? 0u : wid];
 		const ST *delta = sm.delta[t];
 		u32 hcur[NHOT] = {0, 0, 0, 0};   // HOT: the wave's cursors of the hot digits = their run starts after the layout
 		if constexpr (HOT && !RANK1) {
