@@ -1975,9 +1975,22 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	{
 		ProfScope prof(2, (u64)n * (sizeof(KT) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
-		hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
-		                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
-		                   (const SegCtl *)ctl, ka);
+		if (!env().no_leaf16) {
+			// the compounds (key half, position) through one placement and the register passes (rsx_leafp_kernel); what it
+			// leaves alone -- or everything, if the sample saw the keys' low bits cluster -- through the LDS passes of round 3
+			typedef LeafKCfg<512, 5120, 8> P5;
+			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
+			hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P5>), dim3(env().leaf_grid), dim3(P5::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab, ctl, ka,
+			                   redo, (u32)env().leaf16_maxbin);
+			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(4096), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+			                   (const SegCtl *)ctl, ka, (u32)HYB_TWO_LEVEL, (const u64 *)nullptr, (u64)0, (const u32 *)redo);
+		} else {
+			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+			                   (const SegCtl *)ctl, ka);
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventSynchronize(c.seg_ev));

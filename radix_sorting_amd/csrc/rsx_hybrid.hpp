@@ -1094,7 +1094,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
                                                                            const LeafSeg *__restrict__ segtab,
                                                                            const SegCtl *__restrict__ ctl, KdfArgs<KT> ka,
                                                                            u32 level = HYB_TWO_LEVEL,
-                                                                           const u64 *__restrict__ ghist = nullptr, u64 n = 0)
+                                                                           const u64 *__restrict__ ghist = nullptr, u64 n = 0,
+                                                                           const u32 *__restrict__ redo = nullptr)
 {
 	static_assert(sizeof(KT) == 4 && sizeof(VT) == 4, "pairs of 4-byte keys and 4-byte payloads");
 	constexpr int NW = C::NW, KPT = C::KPT, BLOCK = C::BLOCK, G = 4;
@@ -1106,7 +1107,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 	for (int k = 0; k < 8; ++k)
 		colpack |= (plan->cols[k] & 15u) << (4 * k);
 	const u32 ncols_all = plan->ncols;
-	const u32 nseg = level == HYB_TWO_LEVEL ? ctl->nleaf : 256u;
+	// redo: the launch behind rsx_leafp_kernel (rsx_leaf16.hpp) -- the leaves its list names, or all of them (SegCtl::leaf16 == 0)
+	const bool listed = redo != nullptr && ctl->leaf16 != 0;
+	const u32 nseg = level == HYB_TWO_LEVEL ? (listed ? ctl->nredo : ctl->nleaf) : 256u;
 	const u64 *off1 = ghist + 256 * ((colpack >> (4 * (ncols_all - 1))) & 15u);
 	__shared__ __attribute__((aligned(16))) u64 stage[C::CAP];
 	__shared__ u32 cell[NW][256];
@@ -1120,7 +1123,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
 		LeafSeg ls;
 		if (level == HYB_TWO_LEVEL) {
-			ls = segtab[s];
+			ls = segtab[listed ? redo[s] : s];
 		} else {
 			const u64 b = off1[s], e = s == 255 ? n : off1[s + 1];
 			ls.beg = (u32)b;

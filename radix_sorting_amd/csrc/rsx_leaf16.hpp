@@ -801,4 +801,212 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 	}
 }
 
+// ---- leaves of key + payload and rank sorts (4-byte keys, 4-byte payloads: BASELINE.json's cfg 4) --------------------------
+// These leaves must be STABLE (equal keys keep their payloads' order, radix_sort_rank.hpp:82-90).  A slot's pairs lie in the
+// order the two (stable) MSB passes brought them, so position i in the slot is the tie-break: the leaf sorts the 32-bit
+// compounds (low sixteen bits of the derived key << 16 | i), which are all different -- any sorting method sorts them the
+// stable way.  The payloads are staged where they lie (linear) and gathered through i at the end; the compounds go through
+// the placement by the key's top twelve bits and the register passes of rsx_leafk_kernel.  Four data-dependent LDS
+// operations per pair (count, cursor, staging store, payload gather) on 4-byte words instead of six on 8-byte ones
+// (rsx_leaf_pairs_kernel carries the pair as one 8-byte value through two LDS passes).
+template <typename KT, typename VT, typename C>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *__restrict__ kslots, const VT *__restrict__ vslots,
+                                                                     u32 slack_cap, KT *__restrict__ kout, VT *__restrict__ vout,
+                                                                     const Plan *__restrict__ plan,
+                                                                     const LeafSeg *__restrict__ segtab, SegCtl *__restrict__ ctl,
+                                                                     KdfArgs<KT> ka, u32 *__restrict__ redo, u32 maxbin2 = C::MAXBIN2)
+{
+	static_assert(sizeof(KT) == 4 && sizeof(VT) == 4, "pairs of 4-byte keys and 4-byte payloads");
+	constexpr int BLOCK = C::BLOCK, CAP = C::CAP, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES, S = C::S;
+	constexpr int NV = (CAP / 4 + BLOCK - 1) / BLOCK;   // 16-byte vectors of four keys (and of four payloads) per thread
+	const u32 hyb = plan->hyb, ncols = plan->ncols;
+	const u32 mode = ctl->mode, nseg = ctl->nleaf, on = ctl->leaf16, maxleaf = ctl->maxleaf;
+	if (hyb != HYB_TWO_LEVEL || ncols != 4 || mode != SEG_MODE_LEAVES || !on || maxleaf > (u32)CAP)
+		return;
+	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
+	__shared__ __attribute__((aligned(16))) u32 stage[16 * S + 64];   // the compounds, transposed (LeafKCfg::S)
+	__shared__ __attribute__((aligned(16))) VT pay[CAP];
+	__shared__ u32 ws[NW], wmax[NW];
+	auto at = [](u32 p) { return (p & 15u) * (u32)S + (p >> 4); };
+	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+		const LeafSeg ls = segtab[s];
+		const u32 cnt = ls.cnt, slot = ls.slot;
+		if (cnt == 0)
+			continue;
+		const KT *kp = kslots + (u64)(slot - 1) * slack_cap;
+		const VT *vp = vslots + (u64)(slot - 1) * slack_cap;
+		u32x4 kv[NV], vv[NV];
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			const u32 e0 = 4 * (tid + BLOCK * j);
+			kv[j] = u32x4{0, 0, 0, 0};
+			vv[j] = u32x4{0, 0, 0, 0};
+			if (e0 < cnt) {   // (a slot's capacity is a multiple of 256 pairs: the vector behind the last pair is the slot's own)
+				kv[j] = *(const u32x4 *)(kp + e0);
+				vv[j] = *(const u32x4 *)(vp + e0);
+			}
+		}
+		{
+			const u32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j)
+				((u32x4 *)cell)[tid + BLOCK * j] = zero;
+		}
+		// the compounds: low half of the derived key above, position in the slot below; the payloads staged where they lie
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			const u32 e0 = 4 * (tid + BLOCK * j);
+			if (e0 < cnt)
+				*(u32x4 *)&pay[e0] = vv[j];
+#pragma unroll
+			for (int e = 0; e < 4; ++e)
+				kv[j][e] = (kdf_apply((KT)kv[j][e], ka) << 16) | (e0 + e);
+		}
+		__syncthreads();
+		auto cell_of = [&](u32 c, bool valid, u32 &sh) -> u32 * {
+			sh = (c >> 16) & 16u;   // bin = c >> 20: word c >> 21, half bit 20
+			return &cell[valid ? c >> 21 : NCELLW + lane];
+		};
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			if (4 * BLOCK * j < (int)cnt) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					u32 sh;
+					u32 *a = cell_of(kv[j][e], 4 * (tid + BLOCK * j) + e < cnt, sh);
+					__hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+		}
+		__syncthreads();
+		u32x4 c[PLANES];
+		u32 pk = 0, mxp = 0;
+#pragma unroll
+		for (int j = 0; j < PLANES; ++j) {
+			c[j] = ((const u32x4 *)cell)[tid + BLOCK * j];
+			u32 run = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const u32 x = c[j][i];
+				mxp = pk_max_u16(mxp, x);
+				const u32 lo16 = x & 0xFFFFu, hs = run + lo16;
+				c[j][i] = run | (hs << 16);
+				run = hs + (x >> 16);
+			}
+			pk |= run << (16 * j);
+		}
+		u32 mx = (mxp & 0xFFFFu) > (mxp >> 16) ? (mxp & 0xFFFFu) : (mxp >> 16);
+		const u32 incl = wave_incl_scan_dpp(pk);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const u32 y = (u32)__shfl_xor((int)mx, o);
+			mx = mx > y ? mx : y;
+		}
+		if (lane == 63) {
+			ws[wid] = incl;
+			wmax[wid] = mx;
+		}
+		__syncthreads();
+		mx = wmax[0];
+#pragma unroll
+		for (int w = 1; w < NW; ++w)
+			mx = mx > wmax[w] ? mx : wmax[w];
+		if (mx > maxbin2) {   // (keys with many duplicates: the LDS passes of rsx_leaf_pairs_kernel)
+			if (tid == 0)
+				redo[atomicAdd(&ctl->nredo, 1u)] = s;
+			continue;
+		}
+		{
+			u32 base = 0, tot = 0;
+#pragma unroll
+			for (u32 w = 0; w < (u32)NW; ++w) {
+				const u32 a = ws[w];
+				base += w < wid ? a : 0u;
+				tot += a;
+			}
+			const u32 e = incl - pk + base;
+			const u32 o[2] = {e & 0xFFFFu, (tot & 0xFFFFu) + (e >> 16)};
+#pragma unroll
+			for (int j = 0; j < PLANES; ++j) {
+				const u32 bb = o[j] | (o[j] << 16);
+				u32x4 x;
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					x[i] = c[j][i] + bb;
+				((u32x4 *)cell)[tid + BLOCK * j] = x;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < NV; ++j) {
+			if (4 * BLOCK * j < (int)cnt) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					const bool valid = 4 * (tid + BLOCK * j) + e < cnt;
+					u32 sh;
+					u32 *a = cell_of(kv[j][e], valid, sh);
+					const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					stage[valid ? at((old >> sh) & 0xFFFFu) : 16 * S + lane] = kv[j][e];
+				}
+			}
+		}
+		if (tid < 32)
+			stage[at(cnt + tid)] = ~0u;
+		__syncthreads();
+		const u32 npass = mx > C::MAXBIN ? 4u : 2u;
+		for (u32 pass = 0; pass < npass; ++pass) {
+			const u32 off = 8 * (pass & 1);
+#pragma unroll
+			for (int r = 0; r < NCH; ++r) {
+				const u32 ch = tid + BLOCK * r;
+				if (16 * ch + off < cnt) {
+					u32 d[16];
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						d[i] = stage[(pass & 1) ? (i < 8 ? (i + 8) * S + ch : (i - 8) * S + ch + 1) : i * S + ch];
+					if (pass == 0)
+						sort16_values(d);
+					else
+						merge16_values(d);
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						stage[(pass & 1) ? (i < 8 ? (i + 8) * S + ch : (i - 8) * S + ch + 1) : i * S + ch] = d[i];
+				}
+			}
+			__syncthreads();
+		}
+		{
+			const KT upper = (KT)(((KT)((slot - 1) >> 8) << 24) | ((KT)((slot - 1) & 255u) << 16));
+			VT *vo = vout + ls.beg;
+			KT *ko = kout ? kout + ls.beg : nullptr;
+			for (u32 i0 = 4 * tid; i0 < cnt; i0 += 4 * BLOCK) {
+				VT pv[4];
+				KT kk[4];
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					const u32 x = stage[at(i0 + e)];
+					pv[e] = pay[(x & 0xFFFFu) < (u32)CAP ? (x & 0xFFFFu) : 0u];   // (behind the leaf's end: padding)
+					kk[e] = kdf_invert((KT)(upper | (x >> 16)), ka);
+				}
+				if (i0 + 4 <= cnt) {
+					store_chunk<VT, 4>(vo + i0, pv);
+					if (ko)
+						store_chunk<KT, 4>(ko + i0, kk);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						if (i0 + e < cnt) {
+							vo[i0 + e] = pv[e];
+							if (ko)
+								ko[i0 + e] = kk[e];
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();   // (the payloads are staged again before the next leaf's first barrier)
+	}
+}
+
 }  // namespace rsx

@@ -1,7 +1,14 @@
 #!/bin/bash
 cd /root/repo
-./tools/ubench/leaf16_probe.bin 28 0 | grep -v "skip mask"
-timeout 1500 python -m pytest tests/test_gpu_hybrid.py -x -q -k blind 2>&1 | tail -2
-for i in 1 2; do
-timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:round(v['ms_per_step'],4) for k,v in d['roofline']['per_kernel'].items()})"
-done
+timeout 1500 python -m pytest tests/test_gpu_hybrid.py -x -q -k "rank or pairs" 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_routes.py tests/test_gpu_fullsize.py -x -q -k "ranks or pairs or cfg4" 2>&1 | tail -3
+python tools/bench_configs.py --only "cfg4 f32 random" --out /tmp/bc.json 2>&1 | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        r=json.loads(l); print(r['config'], 'ms', round(r['ms_per_sort'],3), 'leaf', round(r['leaf_ms'],3), 'route', r['route'])"
+RSX_NO_LEAF16=1 python tools/bench_configs.py --only "cfg4 f32 random" --out /tmp/bc.json 2>&1 | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        r=json.loads(l); print('old:', r['config'], 'ms', round(r['ms_per_sort'],3), 'leaf', round(r['leaf_ms'],3), 'route', r['route'])"
