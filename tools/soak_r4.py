@@ -1,0 +1,62 @@
+"""Round-4 soak: keys-only sorts of random sizes (9 Mi .. 300 Mi keys, the range the sorts without a histogram cover with a wave /
+a workgroup per leaf) and random shapes of input -- uniform, constant top bits (digits below them), low bits clustered
+everywhere or in some buckets only, constant columns, a few strays -- under RSX_VERIFY=2: the library itself checks every
+result on the device (sorted, the input's key sum and key mix) whatever route the sort took.  Prints sorts per route.
+
+    RSX_VERIFY=2 python tools/soak_r4.py [seconds]
+"""
+import os
+import sys
+import time
+
+os.environ.setdefault("RSX_VERIFY", "2")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import radix_sorting_amd as rsa
+
+rsa.require_gpu()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(20261003)
+t_end = time.time() + budget
+routes, shapes = {}, {}
+nsorts = 0
+while time.time() < t_end:
+    n = int(rng.choice([rng.integers(9 << 20, 60 << 20), rng.integers(60 << 20, 160 << 20), rng.integers(160 << 20, 300 << 20)]))
+    dt, tdt = [(rsa.U32, torch.int32), (rsa.I32, torch.int32), (rsa.F32, torch.int32), (rsa.U64, torch.int64)][int(rng.integers(0, 4))]
+    if dt == rsa.U64 and n > (200 << 20):
+        n //= 2
+    order = int(rng.integers(0, 2))
+    src = torch.empty(n, dtype=tdt, device="cuda")
+    aux = torch.empty_like(src)
+    shape = int(rng.integers(0, 7))
+    bits = 8 * src.element_size()
+    full = (1 << bits) - 1
+    mask = full
+    if shape == 1:                       # constant top bits
+        mask = full >> int(rng.integers(1, 8))
+    elif shape == 2:                     # low bits from few values, everywhere
+        mask = full & ~int(rng.choice([0x0FF0, 0x03F0, 0xF0F0, 0x00FF]))
+    elif shape == 3:                     # a constant column somewhere
+        mask = full & ~(0xFF << (8 * int(rng.integers(0, bits // 8))))
+    rsa.fill_splitmix(src, seed=int(rng.integers(1, 1 << 40)), mask=mask)
+    if shape == 1 and rng.random() < 0.5:
+        src |= int(rng.integers(0, 1 << 7)) << (bits - 7) if dt != rsa.U64 else 0
+    if shape == 4:                       # low bits clustered in some (digit, digit) buckets only
+        top = (src >> (bits - 16)) & 0xFFFF
+        sel = (top % 97) == 5
+        src[sel] = src[sel] & ~0x0FF0
+        del top, sel
+    elif shape == 5:                     # a few strays above constant top bits
+        src &= full >> 3 if dt != rsa.U64 else full
+        idx = torch.from_numpy(rng.integers(0, n, size=3)).cuda()
+        src[idx] = src[idx] | (1 << (bits - 2))
+    rsa.reload_env()                      # (no back-off: every sort may try every route)
+    res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)     # RSX_VERIFY=2 raises on a wrong result
+    torch.cuda.synchronize()
+    routes[int(info.hybrid)] = routes.get(int(info.hybrid), 0) + 1
+    shapes[(shape, int(info.hybrid))] = shapes.get((shape, int(info.hybrid)), 0) + 1
+    nsorts += 1
+    del src, aux, res
+print("soak ok: %d sorts under RSX_VERIFY=%s; by route %s; by (input shape, route) %s" % (
+    nsorts, os.environ.get("RSX_VERIFY"), dict(sorted(routes.items())), dict(sorted(shapes.items()))))
