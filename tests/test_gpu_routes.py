@@ -165,3 +165,28 @@ def test_f32_ranks_and_pairs_without_histogram(n_mi):
     assert info.hybrid == 5, info.hybrid
     assert np.array_equal(vr.cpu().numpy().view(np.uint32), want)
     assert np.array_equal(kr.cpu().numpy().view(np.uint32), a.view(np.uint32)[want])
+
+
+@pytest.mark.parametrize("shape", ["every key twice", "low byte from 16 values", "every leaf through the list"])
+def test_f32_ranks_stable_through_the_compound_leaves(shape, monkeypatch):
+    """rsx_leafp_kernel sorts (key half, position in the slot) compounds: equal keys must keep their order
+    (radix_sort_rank.hpp:82-90).  Every key twice (ties everywhere, the bins even); a low byte with 16 values (ties and fat bins:
+    the sample hands every leaf to rsx_leaf_pairs_kernel); RSX_LEAF16_MAXBIN=0 (every leaf through the list launch)."""
+    n = 100 * MI + 6
+    if shape == "every key twice":
+        half = ol.splitmix_fill(n // 2, ol.F32, 4800, 0xFFFFFFFF)
+        a = np.concatenate([half, half])
+    elif shape == "low byte from 16 values":
+        a = ol.splitmix_fill(n, ol.F32, 4801, 0xFFFFFF0F)
+    else:
+        monkeypatch.setenv("RSX_LEAF16_MAXBIN", "0")
+        a = ol.splitmix_fill(n, ol.F32, 4802, 0xFFFFFFFF)
+    want, want_aux, _, _ = ol.oracle_rank(a, ol.F32)
+    want = want.copy()
+    bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert info.hybrid == 5, (shape, info.hybrid)
+    assert info.result_in_aux == want_aux
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), shape
