@@ -42,9 +42,11 @@
  *                           the call (RSX_EVERIFY) -- at once for the blocking sorts (which
  *                           then keep to one pass per kept column), at rsx_verify_poll() or
  *                           the next blocking sort for the *_inplace_async ones.
- *   RSX_VERIFY=2            every keys-only sort runs as usual (any route, see rsx_info.hybrid)
- *                           and its RESULT is checked on the device: sorted, and the input's
- *                           key sum and key mix (RSX_EVERIFY if not).
+ *   RSX_VERIFY=2            every blocking device sort runs as usual (any route, see rsx_info.hybrid)
+ *                           and its RESULT is checked on the device (RSX_EVERIFY if not): keys only --
+ *                           sorted, the input's key sum and key mix; key + payload -- no descent, the
+ *                           input's key sum and a mix of its PAIRS; ranks -- a permutation of 0 .. n-1
+ *                           through which the keys do not descend, equal keys in index order.
  *   RSX_FORCE_TABLE_RANK=1  use the table-ranked scatter kernel, which does not rely
  *                           on the lane order of returning LDS atomics (slower).
  *   RSX_NO_HYBRID=1         one scatter pass per kept column always (the reference's loop);

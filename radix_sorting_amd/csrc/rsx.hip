@@ -2008,7 +2008,43 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 
 // ---- key + payload -----------------------------------------------------------------
 template <typename KT, typename VT>
+int sort_pairs_device_impl(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info);
+
+// RSX_VERIFY=2 (as for keys-only sorts): the sort on its usual route, bracketed by checksums of the PAIRS: the result's keys
+// must not descend and its key sum and pair mix must be the input's.
+template <typename KT, typename VT>
 int sort_pairs_device(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
+{
+	if (!env().verify_whole)
+		return sort_pairs_device_impl<KT, VT>(c, k0, k1, v0, v1, n, dtype, order, info);
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	RSX_TRY(c.vsum.ensure(6 * sizeof(u64)));
+	u64 *vs = (u64 *)c.vsum.p;
+	HIP_TRY(hipMemsetAsync(vs, 0, 6 * sizeof(u64), c.stream));
+	hipLaunchKernelGGL((rsx_checksum_pairs_kernel<KT, VT>), dim3(2048), dim3(256), 0, c.stream, (const KT *)k0, (const VT *)v0, (u64)n, ka, vs);
+	HIP_TRY(hipGetLastError());
+	rsx_info local;
+	memset(&local, 0, sizeof(local));
+	rsx_info *inf = info ? info : &local;
+	RSX_TRY((sort_pairs_device_impl<KT, VT>(c, k0, k1, v0, v1, n, dtype, order, inf)));
+	const KT *kr = inf->result_in_aux ? k1 : k0;
+	const VT *vr = inf->result_in_aux ? v1 : v0;
+	hipLaunchKernelGGL((rsx_checksum_pairs_kernel<KT, VT>), dim3(2048), dim3(256), 0, c.stream, kr, vr, (u64)n, ka, vs + 3);
+	HIP_TRY(hipGetLastError());
+	u64 h[6];
+	HIP_TRY(hipMemcpyAsync(h, vs, sizeof h, hipMemcpyDeviceToHost, c.stream));
+	HIP_TRY(hipStreamSynchronize(c.stream));
+	if (env().verify_inject)
+		h[5] ^= 1;
+	if (h[3] != 0 || h[1] != h[4] || h[2] != h[5])
+		return fail(RSX_EVERIFY, "RSX_VERIFY=2: the result of a key + payload sort of %zu pairs (route %u) is %s: %llu descents, key sum %s, pair mix %s",
+		            n, inf->hybrid, h[3] ? "not sorted" : "not a permutation of the input's pairs", (unsigned long long)h[3],
+		            h[1] == h[4] ? "kept" : "changed", h[2] == h[5] ? "kept" : "changed");
+	return RSX_OK;
+}
+
+template <typename KT, typename VT>
+int sort_pairs_device_impl(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int dtype, int order, rsx_info *info)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	if (c.fast && n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES && !env().no_small_sort && !capture_armed()) {
@@ -2137,7 +2173,37 @@ bool bit_runs(u64 mask, BitRuns *out)
 // want_half: -1 = the half the number of kept columns dictates (radix_sort_rank.hpp:91); 0 / 1 = leave the ranks in that half
 // whatever the number of passes is (the first pass generates its indices, so it can write to either half).
 template <typename KT, typename IT>
+int sort_rank_device_impl(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info, int want_half);
+
+// RSX_VERIFY=2: the ranks must be a permutation of 0 .. n-1 (sum and mix) through which the keys do not descend, equal keys in
+// index order (radix_sort_rank.hpp:82-90: stable) -- checked on the device, whatever route the sort took.
+template <typename KT, typename IT>
 int sort_rank_device(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info, int want_half = -1)
+{
+	RSX_TRY((sort_rank_device_impl<KT, IT>(c, src, ib, n, dtype, order, result, info, want_half)));
+	if (!env().verify_whole || n < 2)
+		return RSX_OK;
+	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
+	RSX_TRY(c.vsum.ensure(6 * sizeof(u64)));
+	u64 *vs = (u64 *)c.vsum.p;
+	HIP_TRY(hipMemsetAsync(vs, 0, 6 * sizeof(u64), c.stream));
+	hipLaunchKernelGGL((rsx_check_ranks_kernel<KT, IT>), dim3(2048), dim3(256), 0, c.stream, (const KT *)nullptr, (const IT *)nullptr, (u64)n, ka, vs);
+	hipLaunchKernelGGL((rsx_check_ranks_kernel<KT, IT>), dim3(2048), dim3(256), 0, c.stream, src, (const IT *)*result, (u64)n, ka, vs + 3);
+	HIP_TRY(hipGetLastError());
+	u64 h[6];
+	HIP_TRY(hipMemcpyAsync(h, vs, sizeof h, hipMemcpyDeviceToHost, c.stream));
+	HIP_TRY(hipStreamSynchronize(c.stream));
+	if (env().verify_inject)
+		h[5] ^= 1;
+	if (h[3] != 0 || h[1] != h[4] || h[2] != h[5])
+		return fail(RSX_EVERIFY, "RSX_VERIFY=2: the ranks of a sort of %zu keys (route %u) are %s: %llu places out of order, rank sum %s, rank mix %s",
+		            n, info ? info->hybrid : 0u, h[3] ? "not the stable order" : "not a permutation of 0 .. n-1", (unsigned long long)h[3],
+		            h[1] == h[4] ? "right" : "wrong", h[2] == h[5] ? "right" : "wrong");
+	return RSX_OK;
+}
+
+template <typename KT, typename IT>
+int sort_rank_device_impl(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, int order, void **result, rsx_info *info, int want_half)
 {
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	if (c.fast && n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES && !env().no_small_sort && !capture_armed() &&

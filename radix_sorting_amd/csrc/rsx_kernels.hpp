@@ -1153,6 +1153,76 @@ __global__ __launch_bounds__(256) void rsx_checksum_kernel(const KT *__restrict_
 	}
 }
 
+// RSX_VERIFY=2 for key + payload sorts: out[0] += descents of the keys, out[1] += sum of the derived keys, out[2] ^= a mix of
+// every (key, payload) PAIR -- a result with no descent and the input's sum and pair mix is a sorted permutation of the
+// input's pairs (which of two equal keys' payloads comes first -- stability -- is not visible to it).
+template <typename KT, typename VT>
+__global__ __launch_bounds__(256) void rsx_checksum_pairs_kernel(const KT *__restrict__ k, const VT *__restrict__ v, u64 n, KdfArgs<KT> ka,
+                                                                 u64 *out)
+{
+	u64 bad = 0, sum = 0, mix = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+		const KT x = kdf_apply(k[i], ka);
+		if (i + 1 < n && x > kdf_apply(k[i + 1], ka))
+			++bad;
+		sum += (u64)x;
+		mix ^= (((u64)x + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull) ^ (((u64)v[i] + 0x632BE59BD9B4E019ull) * 0x94D049BB133111EBull + (u64)x);
+	}
+	__shared__ u64 s[3];
+	if (threadIdx.x < 3)
+		s[threadIdx.x] = 0;
+	__syncthreads();
+	atomicAdd((unsigned long long *)&s[0], (unsigned long long)bad);
+	atomicAdd((unsigned long long *)&s[1], (unsigned long long)sum);
+	atomicXor((unsigned long long *)&s[2], (unsigned long long)mix);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicAdd((unsigned long long *)&out[0], (unsigned long long)s[0]);
+		atomicAdd((unsigned long long *)&out[1], (unsigned long long)s[1]);
+		atomicXor((unsigned long long *)&out[2], (unsigned long long)s[2]);
+	}
+}
+
+// ... for rank sorts (radix_sort_rank.hpp:97-112): out[0] += places where keys[r[i]] > keys[r[i + 1]], or the keys are equal and
+// r[i] > r[i + 1] (not stable), or r[i] >= n; out[1] += sum of the ranks, out[2] ^= a mix of them.  keys == nullptr: only the
+// sum and the mix of 0 .. n-1 (what a permutation must give).
+template <typename KT, typename IT>
+__global__ __launch_bounds__(256) void rsx_check_ranks_kernel(const KT *__restrict__ keys, const IT *__restrict__ r, u64 n, KdfArgs<KT> ka,
+                                                              u64 *out)
+{
+	u64 bad = 0, sum = 0, mix = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+		const u64 a = keys ? (u64)r[i] : i;
+		if (keys) {
+			if (a >= n) {
+				++bad;
+			} else if (i + 1 < n) {
+				const u64 b = (u64)r[i + 1];
+				if (b < n) {
+					const KT ka_ = kdf_apply(keys[a], ka), kb_ = kdf_apply(keys[b], ka);
+					if (ka_ > kb_ || (ka_ == kb_ && a > b))
+						++bad;
+				}
+			}
+		}
+		sum += a;
+		mix ^= (a + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+	}
+	__shared__ u64 s[3];
+	if (threadIdx.x < 3)
+		s[threadIdx.x] = 0;
+	__syncthreads();
+	atomicAdd((unsigned long long *)&s[0], (unsigned long long)bad);
+	atomicAdd((unsigned long long *)&s[1], (unsigned long long)sum);
+	atomicXor((unsigned long long *)&s[2], (unsigned long long)mix);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicAdd((unsigned long long *)&out[0], (unsigned long long)s[0]);
+		atomicAdd((unsigned long long *)&out[1], (unsigned long long)s[1]);
+		atomicXor((unsigned long long *)&out[2], (unsigned long long)s[2]);
+	}
+}
+
 template <typename IT>
 __global__ void rsx_iota_kernel(IT *dst, u64 n)
 {

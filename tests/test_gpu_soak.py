@@ -169,3 +169,44 @@ def test_whole_result_verification_failure_is_reported():
     out = _run(["-c", WHOLE_VERIFY_SCRIPT], {"RSX_VERIFY": "2", "RSX_VERIFY_INJECT": "1"})
     assert out.returncode != 0
     assert "rsx error -5" in out.stderr and "RSX_VERIFY=2" in out.stderr, out.stderr
+
+
+PAIRS_VERIFY_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np, torch
+import oracle_lib as ol
+import radix_sorting_amd as rsa
+routes = set()
+for dt, n, mask in [(ol.F32, 70001, 0xFFFFFFFF), (ol.U32, 600000, 0xFFFFFFFF), (ol.I32, (1 << 22) + 99, 0xFFFFFFFF), (ol.U32, 3000001, 0x00FFFF0F),
+                    (ol.F32, 6000001, 0xFFFFFFFF)]:
+    a = ol.splitmix_fill(n, dt, 35 + dt, mask)
+    for order in (0, 1):
+        keys = torch.from_numpy(a.view(np.int32).copy()).cuda()
+        ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+        ranks, info = rsa.radix_sort_rank(keys, ib, dtype=dt, order=order)          # RSX_VERIFY=2 checks the ranks on the device
+        torch.cuda.synchronize()
+        routes.add(("rank", int(info.hybrid)))
+        assert np.array_equal(ranks.cpu().numpy().view(np.uint32), ol.oracle_rank(a, dt, 4, order)[0])
+        vals = torch.arange(n, dtype=torch.int32, device="cuda") * 3 + 1
+        ka, va = torch.empty_like(keys), torch.empty_like(vals)
+        kr, vr, info = rsa.radix_sort_pairs(keys, ka, vals, va, dtype=dt, order=order)   # ... and the pairs
+        torch.cuda.synchronize()
+        routes.add(("pairs", int(info.hybrid)))
+print("pairs verify ok, routes", sorted(routes))
+""" % (ROOT, ROOT)
+
+
+def test_whole_result_verification_of_rank_and_pair_sorts():
+    """RSX_VERIFY=2 for rank sorts (a permutation of 0 .. n-1 through which the keys do not descend, equal keys in index order)
+    and key + payload sorts (no descent, the input's key sum and pair mix), on the routes they take -- one pass per column, one
+    MSB pass + leaves, two MSB passes into slots + the compound leaves."""
+    out = _run(["-c", PAIRS_VERIFY_SCRIPT], {"RSX_VERIFY": "2", "RSX_TWO_LEVEL_MIN_LOG2": "22"})
+    assert out.returncode == 0 and "pairs verify ok" in out.stdout, out.stdout + out.stderr
+    assert "('rank', 5)" in out.stdout and "('pairs', 5)" in out.stdout and "('rank', 1)" in out.stdout, out.stdout
+
+
+def test_whole_result_verification_of_rank_sorts_reports_failure():
+    out = _run(["-c", PAIRS_VERIFY_SCRIPT], {"RSX_VERIFY": "2", "RSX_VERIFY_INJECT": "1"})
+    assert out.returncode != 0
+    assert "rsx error -5" in out.stderr and "RSX_VERIFY=2" in out.stderr and "ranks" in out.stderr, out.stderr
