@@ -9,6 +9,7 @@
 #include "rsx_scatter6_digit_waves.hpp"
 #include "rsx_scatter7_rerank_windows.hpp"
 #include "rsx_scatter8_pipelined.hpp"
+#include "rsx_scatter11_cursor.hpp"
 #include "rsx_scatter9_handoff.hpp"
 #include "rsx_scatter10_one_atomic.hpp"
 
@@ -596,6 +597,98 @@ void bench_read_ahead()
 	printf("  %s\n", a == b ? "output identical with and without the helper" : "OUTPUT DIFFERS with the helper");
 }
 
+// v11: the pipelined persistent pass with atomic cursors instead of the chain (rsx_scatter11_cursor.hpp); output partitioned by
+// digit but unstable across tiles: checked for digit order and for the keys' sum / xor
+__global__ void partition_check_kernel(const u32 *a, u64 n, u32 shift, u64 *out)
+{
+	u64 bad = 0, sum = 0, x = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+		if (i + 1 < n && ((a[i] >> shift) & 0xFFu) > ((a[i + 1] >> shift) & 0xFFu))
+			++bad;
+		sum += a[i];
+		x ^= (u64)a[i] * 0x9E3779B97F4A7C15ull;
+	}
+	atomicAdd((unsigned long long *)&out[0], bad);
+	atomicAdd((unsigned long long *)&out[1], sum);
+	atomicXor((unsigned long long *)&out[2], x);
+}
+static u32 *d_cursor;
+template <typename C, bool TL>
+float run11_once(u32 shift, bool dump, u32 grid)
+{
+	const u32 ntiles = (u32)(n / C::TILE);
+	if (!d_cursor)
+		CK(hipMalloc(&d_cursor, 1024));
+	CK(hipMemsetAsync(d_cursor, 0, 1024, 0));
+	CK(hipMemsetAsync(d_status, 0, 256, 0));
+	if (TL)
+		CK(hipMemsetAsync(d_tl, 0, (size_t)ntiles * 16 * 8, 0));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	KdfArgs<u32> ka{0, 0, 0};
+	CK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL((rsx_scatter11_kernel<u32, u32, C, TL, DIG_PLAIN>), dim3(grid), dim3(C::BLOCK), 0, 0, d_in, d_out, ntiles, shift,
+	                   d_hist + 256 * (shift / 8), d_cursor, (u32 *)d_status, ka, g_flags, d_tl);
+	CK(hipGetLastError());
+	CK(hipEventRecord(e1, 0));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	CK(hipEventDestroy(e0));
+	CK(hipEventDestroy(e1));
+	if (TL && dump) {
+		std::vector<u64> tl(ntiles * 16);
+		CK(hipMemcpy(tl.data(), d_tl, (size_t)ntiles * 16 * 8, hipMemcpyDeviceToHost));
+		double lay = 0, st = 0, bar = 0, wr = 0, life = 0;
+		u64 cnt = 0;
+		for (u64 t = 0; t < ntiles; ++t) {
+			const u64 *r = &tl[t * 16];
+			lay += (double)(r[1] - r[0]);
+			st += (double)(r[2] - r[1]);
+			bar += (double)(r[3] - r[1]);
+			wr += (double)(r[4] - r[3]);
+			life += (double)(r[4] - r[0]);
+			++cnt;
+		}
+		printf("  per tile: layout + cursor atomic %6.0f | prefetch issue + stage (wave 0) %6.0f, barrier at %6.0f | write-out + rank next %6.0f | period %7.0f\n",
+		       lay / cnt, st / cnt, bar / cnt, wr / cnt, life / cnt);
+	}
+	return ms;
+}
+
+template <typename C>
+void bench11(const char *name, u32 grid)
+{
+	run11_once<C, false>(0, false, grid);
+	float best = 1e9, sum = 0;
+	const int reps = 5;
+	for (int i = 0; i < reps; ++i) {
+		float ms = run11_once<C, false>(8 * (i % 4), false, grid);
+		best = std::min(best, ms);
+		sum += ms;
+	}
+	printf("%-26s grid %u tile %6d: avg %.3f ms best %.3f ms  -> %.0f GB/s (algorithmic 8 B/key)\n", name, grid, C::TILE, sum / reps, best,
+	       n * 8.0 / (best * 1e-3) / 1e9);
+	run11_once<C, true>(0, true, grid);
+	for (u32 shift = 0; shift < 32; shift += 8) {
+		run11_once<C, false>(shift, false, grid);
+		u64 *d_chk, chk[6];
+		CK(hipMalloc(&d_chk, 48));
+		CK(hipMemset(d_chk, 0, 48));
+		hipLaunchKernelGGL(partition_check_kernel, dim3(2048), dim3(256), 0, 0, (const u32 *)d_out, (u64)n, shift, d_chk);
+		hipLaunchKernelGGL(partition_check_kernel, dim3(2048), dim3(256), 0, 0, (const u32 *)d_in, (u64)n, shift, d_chk + 3);
+		CK(hipMemcpy(chk, d_chk, 48, hipMemcpyDeviceToHost));
+		printf("  column %u: digit-order violations %llu, keys %s\n", shift / 8, (unsigned long long)chk[0],
+		       chk[1] == chk[4] && chk[2] == chk[5] ? "preserved" : "CHANGED");
+		CK(hipFree(d_chk));
+	}
+	const u32 keepf = g_flags;
+	g_flags = SCATTER_DBG_NOSTORE;
+	printf("  without global stores: %.3f ms\n", run11_once<C, true>(0, false, grid));
+	g_flags = keepf;
+}
+
 template <typename C, bool TL>
 float run8_once(u32 shift, bool dump, u32 grid)
 {
@@ -934,6 +1027,13 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("n = 2^%d u32 keys\n", log2n);
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+	if (getenv("RSX_PROBE_V11")) {
+		bench11<Sc11Cfg<u32, 8>>("v11 pipelined, cursors", 256);
+		bench11<Sc11Cfg<u32, 8>>("v11 pipelined, cursors", 512);
+		bench8<Sc8Cfg<u32, 8>>("v8 pipelined LB 8", 256);
+		bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
+		return 0;
+	}
 	if (getenv("RSX_PROBE_LB")) {
 		bench2<Sc2Cfg<u32, NoVal, 16, 1, 4>>("v2 LB 4", 1);
 		bench2<Sc2Cfg<u32, NoVal, 16, 1, 12>>("v2 LB 12", 1);
