@@ -1029,7 +1029,9 @@ int main(int argc, char **argv)
 	bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
 	if (getenv("RSX_PROBE_V11")) {
 		bench11<Sc11Cfg<u32, 8>>("v11 pipelined, cursors", 256);
-		bench11<Sc11Cfg<u32, 8>>("v11 pipelined, cursors", 512);
+		g_flags = SCATTER_DBG_LINEAR;
+		bench2<Sc2Cfg<u32, NoVal>>("v2, staged tile written back to its own place", 1);
+		g_flags = 0;
 		bench8<Sc8Cfg<u32, 8>>("v8 pipelined LB 8", 256);
 		bench2<Sc2Cfg<u32, NoVal>>("v2 default", 1);
 		return 0;
