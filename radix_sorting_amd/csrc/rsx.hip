@@ -1340,10 +1340,13 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 	if (n < ((size_t)1 << 22) || n >= ((size_t)1 << 30))
 		return false;
 	if (payload_bytes) {
-		// 4-byte keys with 4-byte payloads, 96 Mi .. 2^28 pairs (tools/rank_threshold_probe.py: 96 Mi f32 keys -> ranks 1.20
-		// against 1.32 ms, pairs 1.31 against 1.41; 80 Mi: level); a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers the floor
+		// 4-byte keys with 4-byte payloads, 16 Mi .. 2^28 pairs.  Round 3: from 96 Mi (one leaf shape, 5120 pairs, whose fixed
+		// costs made 16 Mi pairs cost 0.63 ms); with the leaves' three shapes (pairs_blind) -- f32 keys -> ranks / pairs, ms,
+		// against one pass per column: 16 Mi 0.271 / 0.273 against 0.271 / 0.299, 32 Mi 0.41 / 0.44 against 0.47 / 0.52, 64 Mi
+		// 0.68 / 0.74 against 0.84 / 1.00, 2^27 1.21 / 1.33 (round 3's shape: 1.54 / 1.63)
+		// (tools/rank_threshold_probe.py, profiles/r04/rank_threshold_probe.txt); a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers the floor
 		if (sizeof(KT) != 4 || payload_bytes != 4 || n > ((size_t)1 << 28) ||
-		    n < std::min((size_t)3 << 25, (size_t)1 << env().two_level_min_log2))
+		    n < std::min((size_t)1 << 24, (size_t)1 << env().two_level_min_log2))
 			return false;
 	} else {
 		// keys only: without the histogram two levels beat one pass per column earlier than with it.  8-byte keys from 48 Mi
@@ -1978,11 +1981,24 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 		if (!env().no_leaf16) {
 			// the compounds (key half, position) through one placement and the register passes (rsx_leafp_kernel); what it
 			// leaves alone -- or everything, if the sample saw the keys' low bits cluster -- through the LDS passes of round 3
+			// Three shapes by the slots' capacity (the host knows it): a leaf's fixed costs -- cells zeroed and scanned, barriers
+			// of the whole workgroup -- follow the shape, not the pairs in it (16 Mi pairs through the 5120-pair shape: 0.48 ms
+			// for the leaves alone, as much as 128 Mi pairs take)
 			typedef LeafKCfg<512, 5120, 8> P5;
+			typedef LeafKCfg<256, 2560, 8, 11> P2;
+			typedef LeafKCfg<128, 1280, 6, 10> P1;
 			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
-			hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P5>), dim3(env().leaf_grid), dim3(P5::BLOCK), 0, c.stream, (const KT *)c.slack.p,
-			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab, ctl, ka,
-			                   redo, (u32)env().leaf16_maxbin);
+#define RSX_LEAFP(P) \
+	hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P>), dim3(env().leaf_grid), dim3(P::BLOCK), 0, c.stream, (const KT *)c.slack.p, \
+	                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab, ctl, ka, redo, \
+	                   (u32)env().leaf16_maxbin)
+			if (cap2 <= (u32)P1::CAP)
+				RSX_LEAFP(P1);
+			else if (cap2 <= (u32)P2::CAP)
+				RSX_LEAFP(P2);
+			else
+				RSX_LEAFP(P5);
+#undef RSX_LEAFP
 			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(4096), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
 			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
 			                   (const SegCtl *)ctl, ka, (u32)HYB_TWO_LEVEL, (const u64 *)nullptr, (u64)0, (const u32 *)redo);

@@ -609,10 +609,10 @@ template <typename T> __device__ __forceinline__ void merge16_values(T (&d)[16])
 	batcher_stage<8>(d, ce);
 }
 
-template <int BLOCK_, int CAP_, int WPE_> struct LeafKCfg {
-	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64;
+template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12> struct LeafKCfg {
+	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64, NBITS = NBITS_;
 	static constexpr int NCH = (CAP / 16 + BLOCK - 1) / BLOCK;   // chunks of sixteen values per lane
-	static constexpr int NBIN = 4096, NCELLW = NBIN / 2;
+	static constexpr int NBIN = 1 << NBITS, NCELLW = NBIN / 2;   // (fewer bins for smaller leaves: rsx_leafp_kernel)
 	static constexpr int PLANES = NCELLW / 4 / BLOCK;
 	static constexpr u32 MAXBIN = 9, MAXBIN2 = 25;
 	// The staged leaf is kept TRANSPOSED: value p lies in row p % 16, column p / 16 of a 16 x S matrix, so that the lanes of a
@@ -622,7 +622,8 @@ template <int BLOCK_, int CAP_, int WPE_> struct LeafKCfg {
 	// leaves of cfg 3 1.95 ms against 1.87 with the LDS passes of round 3).
 	static constexpr int S = CAP / 16 + 3;   // columns: the chunks + what the shifted pass and the padding reach behind them (odd)
 	static_assert(CAP % 16 == 0 && CAP <= 8192, "whole chunks; bin starts fit 16 bits");
-	static_assert(BLOCK == 256 || BLOCK == 512, "one or two vectors of cells per thread");
+	static_assert(PLANES == 1 || PLANES == 2, "one or two vectors of cells per thread");
+	static_assert(NCELLW == 4 * BLOCK * PLANES, "every cell in some thread's vectors");
 	static_assert(S % 2 == 1, "rows that start in different banks");
 };
 
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
                                                                      u32 slack_cap, u32 *__restrict__ redo, u32 maxbin2 = C::MAXBIN2)
 {
 	static_assert(sizeof(KT) == 8 && (sizeof(CT) == 4 || sizeof(CT) == 8), "8-byte keys carried as 4- or 8-byte values");
+	static_assert(C::NBITS == 12, "bins: a column and the top nibble of the next");
 	constexpr int BLOCK = C::BLOCK, CAP = C::CAP, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
 	constexpr int NK = (CAP + BLOCK - 1) / BLOCK;   // keys per thread
 	const u32 hyb = plan->hyb, ncols = plan->ncols;
@@ -865,8 +867,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 		}
 		__syncthreads();
 		auto cell_of = [&](u32 c, bool valid, u32 &sh) -> u32 * {
-			sh = (c >> 16) & 16u;   // bin = c >> 20: word c >> 21, half bit 20
-			return &cell[valid ? c >> 21 : NCELLW + lane];
+			constexpr int B = 32 - C::NBITS;   // bin = c >> B: word c >> (B + 1), half bit B
+			sh = (c >> (B - 4)) & 16u;
+			return &cell[valid ? c >> (B + 1) : NCELLW + lane];
 		};
 #pragma unroll
 		for (int j = 0; j < NV; ++j) {

@@ -141,10 +141,11 @@ def test_u64_without_histogram(n_mi, mask):
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64", n_mi, hex(mask)))
 
 
-@pytest.mark.parametrize("n_mi", [96, 128])
+@pytest.mark.parametrize("n_mi", [16, 40, 64, 96, 128])
 def test_f32_ranks_and_pairs_without_histogram(n_mi):
-    """Rank sorts and key + payload sorts of 4-byte keys take the route from 96 Mi pairs on (rsx_leaf_pairs_kernel: the pair
-    carried as one 8-byte value)."""
+    """Rank sorts and key + payload sorts of 4-byte keys take the route from 16 Mi pairs on; the leaves (rsx_leafp_kernel) come
+    in three shapes chosen by the slots' capacity: 1280 pairs and 1024 bins (16 .. 64 Mi pairs), 2560 and 2048 (.. 2^27), 5120
+    and 4096 (2^28: tests/test_gpu_fullsize.py)."""
     n = n_mi * MI + 99
     a = ol.splitmix_fill(n, ol.F32, 4600 + n_mi, 0xFFFFFFFF)
     want, want_aux, _, _ = ol.oracle_rank(a, ol.F32)          # (the C restatement of rs_sort_rank with Listing 6's loop)
@@ -167,16 +168,17 @@ def test_f32_ranks_and_pairs_without_histogram(n_mi):
     assert np.array_equal(kr.cpu().numpy().view(np.uint32), a.view(np.uint32)[want])
 
 
-@pytest.mark.parametrize("shape", ["every key twice", "low byte from 16 values", "every leaf through the list"])
+@pytest.mark.parametrize("shape", ["every key twice", "every key twice, small leaves", "low byte from 16 values",
+                                   "low byte from 16 values, small leaves", "every leaf through the list"])
 def test_f32_ranks_stable_through_the_compound_leaves(shape, monkeypatch):
     """rsx_leafp_kernel sorts (key half, position in the slot) compounds: equal keys must keep their order
     (radix_sort_rank.hpp:82-90).  Every key twice (ties everywhere, the bins even); a low byte with 16 values (ties and fat bins:
     the sample hands every leaf to rsx_leaf_pairs_kernel); RSX_LEAF16_MAXBIN=0 (every leaf through the list launch)."""
-    n = 100 * MI + 6
-    if shape == "every key twice":
+    n = (24 if shape.endswith("small leaves") else 100) * MI + 6
+    if shape.startswith("every key twice"):
         half = ol.splitmix_fill(n // 2, ol.F32, 4800, 0xFFFFFFFF)
         a = np.concatenate([half, half])
-    elif shape == "low byte from 16 values":
+    elif shape.startswith("low byte from 16 values"):
         a = ol.splitmix_fill(n, ol.F32, 4801, 0xFFFFFF0F)
     else:
         monkeypatch.setenv("RSX_LEAF16_MAXBIN", "0")

@@ -1,15 +1,15 @@
-"""Rank sorts (f32 keys -> u32 ranks) and key + payload sorts of 48 Mi .. 128 Mi elements: the library's default against the
-histogram-less two-level route forced from 2^25 (RSX_TWO_LEVEL_MIN_LOG2=25).  Best of 6 fresh sorts each."""
+"""Rank sorts (f32 keys -> u32 ranks) and key + payload sorts of 16 Mi .. 128 Mi elements: the library's default against the
+histogram-less two-level route forced from 2^24 (RSX_TWO_LEVEL_MIN_LOG2=24).  Best of 6 fresh sorts each."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import radix_sorting_amd as rsa
 rsa.require_gpu()
-for n in (3 << 24, 1 << 26, 5 << 24, 3 << 25, 1 << 27):
+for n in (1 << 24, 3 << 23, 1 << 25, 3 << 24, 1 << 26, 5 << 24, 3 << 25, 1 << 27):
     src = torch.empty(n, dtype=torch.int32, device="cuda")
     ib = torch.empty(2 * n, dtype=torch.int32, device="cuda")
     k1 = torch.empty_like(src); v0 = torch.empty_like(src); v1 = torch.empty_like(src)
-    for name, envs in (("default", {}), ("two levels from 2^25", {"RSX_TWO_LEVEL_MIN_LOG2": "25"})):
+    for name, envs in (("default", {}), ("two levels from 2^24", {"RSX_TWO_LEVEL_MIN_LOG2": "24"})):
         os.environ.pop("RSX_TWO_LEVEL_MIN_LOG2", None)
         os.environ.update(envs)
         rsa.reload_env()
