@@ -1022,12 +1022,27 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			// works, the other does nothing); what they leave alone goes through the LDS passes of round 3
 			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
 			SegCtl *wctl = (SegCtl *)c.seg.p;
+			// (three shapes by the slots' capacity, as the pairs' leaves: a leaf's fixed costs follow its shape)
+#define RSX_LEAFK(K4, K8)                                                                                                      \
+	do {                                                                                                                       \
+		hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4>), dim3(grid_s), dim3(K4::BLOCK), 0, c.stream, src, aux,               \
+		                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo,               \
+		                   (u32)env().leaf16_maxbin);                                                                          \
+		hipLaunchKernelGGL((rsx_leafk_kernel<KT, u64, K8>), dim3(grid_s), dim3(K8::BLOCK), 0, c.stream, src, aux,               \
+		                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K8::CAP, slots, c.slack_cap, redo,               \
+		                   (u32)env().leaf16_maxbin);                                                                          \
+	} while (0)
 			typedef LeafKCfg<512, 5120, 8> K4;
 			typedef LeafKCfg<512, 5120, 6> K8;
-			hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4>), dim3(grid_s), dim3(K4::BLOCK), 0, c.stream, src, aux, (const Plan *)c.plan(),
-			                   segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo, (u32)env().leaf16_maxbin);
-			hipLaunchKernelGGL((rsx_leafk_kernel<KT, u64, K8>), dim3(grid_s), dim3(K8::BLOCK), 0, c.stream, src, aux, (const Plan *)c.plan(),
-			                   segtab, wctl, ka, 0u, (u32)K8::CAP, slots, c.slack_cap, redo, (u32)env().leaf16_maxbin);
+			typedef LeafKCfg<256, 2560, 8, 11> K2;
+			typedef LeafKCfg<128, 1280, 6, 10> K1;
+			if (c.slack_cap <= (u32)K1::CAP)
+				RSX_LEAFK(K1, K1);
+			else if (c.slack_cap <= (u32)K2::CAP)
+				RSX_LEAFK(K2, K2);
+			else
+				RSX_LEAFK(K4, K8);
+#undef RSX_LEAFK
 			typedef LeafCfg<u32, 4, 32, 3, true, false> N;
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, N, u32>), dim3(2048), dim3(N::BLOCK), 0, c.stream, src, aux, (u64)n,
 			                   (const u64 *)c.ghist(), (const Plan *)c.plan(), segtab, ctl, ka, level, 0u, (u32)S::CAP, slots,
@@ -1349,14 +1364,12 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		    n < std::min((size_t)1 << 24, (size_t)1 << env().two_level_min_log2))
 			return false;
 	} else {
-		// keys only: without the histogram two levels beat one pass per column earlier than with it.  8-byte keys from 48 Mi
-		// keys on (1.51 against 1.62 ms; 96 Mi: 2.06 against 3.09; tools/blind_threshold_probe.py,
-		// profiles/r03/blind_threshold_probe.txt).  4-byte keys, round 4 (their leaves read two-byte slots and are one wave's
-		// work each, rsx_leaf16.hpp): from 10^7 keys on -- 10^7 keys 140 against 157 us, 4 * 10^7 (the reference's own headline
-		// size, radix_bench.cpp:135-138) 299 against 401, 48 Mi 347 against 461; at 8 Mi one pass per column still wins, 126
-		// against 134 (tools/mid_route_probe.py, profiles/r04/mid_route_probe.txt).  RSX_BLIND_MIN_LOG2 sets another floor;
-		// a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers this with it.
-		size_t floor_keys = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)9 << 20;
+		// keys only: without the histogram two levels beat one pass per column earlier than with it.  8-byte keys from 8 Mi
+		// keys on since their leaves come in three shapes (launch_leaves; one shape: from 48 Mi) -- uniform keys 8 Mi 0.287
+		// against 0.347 ms, 16 Mi 0.386 against 0.605, 32 Mi 0.58 against 1.18, 64 Mi 0.93 against 2.15; five kept columns: 8 Mi
+		// level, 16 Mi 0.337 against 0.404 (tools/u64_threshold_probe.py, profiles/r04/u64_threshold_probe.txt).
+		// 4-byte keys, round 4 (their leaves read two-byte slots and are one wave's
+		size_t floor_keys = sizeof(KT) == 8 ? (size_t)1 << 23 : (size_t)9 << 20;
 		if (env().blind_min_log2)
 			floor_keys = (size_t)1 << env().blind_min_log2;
 		floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);

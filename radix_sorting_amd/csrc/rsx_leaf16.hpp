@@ -637,7 +637,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
                                                                      u32 slack_cap, u32 *__restrict__ redo, u32 maxbin2 = C::MAXBIN2)
 {
 	static_assert(sizeof(KT) == 8 && (sizeof(CT) == 4 || sizeof(CT) == 8), "8-byte keys carried as 4- or 8-byte values");
-	static_assert(C::NBITS == 12, "bins: a column and the top nibble of the next");
+	static_assert(C::NBITS >= 9 && C::NBITS <= 12, "bins: a column and the top bits of the next");
+	constexpr u32 NB2 = C::NBITS - 8;
 	constexpr int BLOCK = C::BLOCK, CAP = C::CAP, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
 	constexpr int NK = (CAP + BLOCK - 1) / BLOCK;   // keys per thread
 	const u32 hyb = plan->hyb, ncols = plan->ncols;
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 	const bool one_col = ncols - 2 < 2;   // (cannot happen with four kept columns; kept for the shifts below)
 	if ((sizeof(CT) == 4) != (c_hi <= 3u))
 		return;   // (the other instantiation's leaves)
-	const u32 sh_hi = 8 * c_hi, sh_nx = one_col ? 0u : 8 * c_nx + 4;
+	const u32 sh_hi = 8 * c_hi, sh_nx = one_col ? 0u : 8 * c_nx + 8 - NB2;
 	KT *out = (ncols & 1) ? aux : src;   // radix_sort.hpp:92
 	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
 	constexpr int S = C::S;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 		}
 		__syncthreads();
 		auto cell_of = [&](CT v, bool valid, u32 &sh) -> u32 * {
-			const u32 bin = (((u32)(v >> sh_hi) & 0xFFu) << 4) | ((u32)(v >> sh_nx) & 0xFu);
+			const u32 bin = (((u32)(v >> sh_hi) & 0xFFu) << NB2) | ((u32)(v >> sh_nx) & ((1u << NB2) - 1u));
 			sh = (bin & 1u) << 4;
 			return &cell[valid ? bin >> 1 : NCELLW + lane];
 		};

@@ -131,14 +131,31 @@ def test_u32_low_bits_clustered_everywhere_keeps_the_route_and_changes_the_leave
     _sort_and_compare(a, ol.U32, ol.ASC, 5, "low bits & 0xFC0F")
 
 
-@pytest.mark.parametrize("n_mi,mask", [(48, 0xFFFFFFFFFFFFFFFF), (96, 0xFFFFFFFFFFFFFFFF), (48, 0xFFFFFFFFFF), (96, 0xFFFFFFFFFF),
-                                       (96, 0xFFFFFFFF)])
+@pytest.mark.parametrize("n_mi,mask", [(9, 0xFFFFFFFFFFFFFFFF), (20, 0xFFFFFFFFFFFFFFFF), (48, 0xFFFFFFFFFFFFFFFF),
+                                       (96, 0xFFFFFFFFFFFFFFFF), (12, 0xFFFFFFFFFF), (48, 0xFFFFFFFFFF), (96, 0xFFFFFFFFFF),
+                                       (24, 0xFFFFFFFF), (96, 0xFFFFFFFF)])
 def test_u64_without_histogram(n_mi, mask):
-    """8-byte keys from 48 Mi keys on: uniform (six columns per leaf: the top three + odd-even transposition, carried as u64)
+    """8-byte keys from 8 Mi keys on (leaves in three shapes by the slots' capacity: up to 1280 keys with 1024 bins -- arrays up
+    to 64 Mi --, 2560 with 2048, 5120 with 4096): uniform (six columns per leaf: the top three + odd-even transposition, carried as u64)
     and with constant top bytes (leaves carried as u32; the constant columns checked on every key by the level-1 pass)."""
     n = n_mi * MI + 4242
     a = ol.splitmix_fill(n, ol.U64, 4500 + n_mi, mask)
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64", n_mi, hex(mask)))
+
+
+@pytest.mark.parametrize("n_mi,maxbin", [(20, "0"), (80, "0"), (20, None)])
+def test_u64_small_leaves_lists_and_fat_bins(n_mi, maxbin, monkeypatch):
+    """The smaller shapes of rsx_leafk_kernel (1280 keys / 1024 bins, 2560 / 2048): every leaf through the list launch
+    (RSX_LEAF16_MAXBIN=0), and bins of 10 .. 25 keys (two more register passes) or more (the list) in some buckets only."""
+    n = n_mi * MI + 31
+    a = ol.splitmix_fill(n, ol.U64, 4700 + n_mi, 0xFFFFFFFFFFFFFFFF).view(np.uint64).copy()
+    if maxbin is not None:
+        monkeypatch.setenv("RSX_LEAF16_MAXBIN", maxbin)
+    else:
+        top = a >> np.uint64(48)
+        a[(top % np.uint64(53)) == 3] &= np.uint64(0xFFFF0FFFFFFFFFFF)     # 16 values in the leaf's top byte: ~20 keys in the fullest bins
+        a[(top % np.uint64(211)) == 9] &= np.uint64(0xFFFF000FFFFFFFFF)    # the bin bits from 16 values: bins of ~20 of 320 keys
+    _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64 small leaves", n_mi, maxbin))
 
 
 @pytest.mark.parametrize("n_mi", [16, 40, 64, 96, 128])
