@@ -30,9 +30,13 @@
  * Scratch memory.  The reference allocates nothing (radix_sort.hpp:98-115: two caller buffers, counters on the stack).
  *   This library keeps, per (device, stream) and until rsx_release / rsx_release_stream: status words of the look-back
  *   chains (1 KiB per 32 Ki-key tile and pass), and -- for the sorts without a histogram, which large evenly spread arrays
- *   take (rsx_info.hybrid == 5) -- two arrays of slots: 256 x 1.25 n / 256 keys for the first MSB pass and 65536 slots of
- *   1.25 n / 65536 keys for the second (two bytes per key for 4-byte keys: 0.625 n keys' worth; key + payload sorts: the same
- *   again for the payloads).  2^28 u32 keys: 1.25 + 0.63 GiB.  If an allocation fails the sort takes the histogram-first
+ *   take (rsx_info.hybrid == 5) -- slots: 256 x 1.25 n / 256 keys for the first MSB pass, of which the 204 that fit lie in the
+ *   caller's SECOND buffer (keys-only sorts: the sample has proven the input unsorted before anything is written, so that
+ *   buffer belongs to the sort as in the reference, radix_sort.hpp:82-92; the early exits leave it untouched as before) and
+ *   the other 52 -- 0.25 n keys -- in scratch memory, and 65536 slots of 1.25 n / 65536 keys for the second pass (two bytes per
+ *   key for 4-byte keys: 0.63 n keys' worth).  Measured (tools/footprint_probe.py): 2^28 u32 keys 1.06 GiB in all (round 3:
+ *   2.1), 2^27 u64 keys 1.58 (2.9).  Key + payload and rank sorts keep all their level-1 slots, keys and payloads, in scratch
+ *   memory.  If an allocation fails the sort takes the histogram-first
  *   route and the (device, stream) context does not ask again until rsx_reload_env() or rsx_release_stream();
  *   RSX_NO_BLIND=1 never asks.
  *

@@ -108,6 +108,7 @@ struct Env {
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
 	unsigned blind_min_log2 = 0;     // RSX_BLIND_MIN_LOG2: keys-only sorts may skip the histogram from 2^this keys on (0: the measured floors)
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
+	bool no_aux_slots = false;       // RSX_NO_AUX_SLOTS=1: the level-1 slots of a sort without a histogram all lie in scratch memory
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
 	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: (kept for old scripts: two-byte slots are now written for every slot size rsx_leaf16_kernel takes)
 	bool no_unstable = false;        // RSX_NO_UNSTABLE=1: the MSB passes of a sort without a histogram rank per wave (stable), as every other pass
@@ -149,6 +150,7 @@ struct Env {
 		if (const char *e = getenv("RSX_BLIND_MIN_LOG2"))
 			blind_min_log2 = (unsigned)std::max(22, std::min(30, atoi(e)));
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
+		no_aux_slots = is_one("RSX_NO_AUX_SLOTS");
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
@@ -193,8 +195,9 @@ struct DevBuf {
 			p = nullptr;
 			cap = 0;
 		}
-		// grow geometrically-ish so repeated slightly larger sorts do not thrash
-		size_t want = bytes + bytes / 8;
+		// grow geometrically-ish so repeated slightly larger sorts do not thrash (small buffers only: an eighth of a GiB-sized
+		// slot array is memory the caller may need)
+		size_t want = bytes + (bytes < ((size_t)64 << 20) ? bytes / 8 : 0);
 		hipError_t e = hipMalloc(&p, want);
 		if (e != hipSuccess) {
 			(void)hipGetLastError();
@@ -256,6 +259,7 @@ struct Ctx {
 	DevBuf slack1_v;    // ... and of as many payloads (pairs_blind)
 	DevBuf slack1;      // sorts without a histogram (sort_keys_blind): the level-1 pass's 256 slots of slack1_cap keys
 	u32 slack1_cap = 0;
+	u32 slack1_lo = 0;  // ... of which the first slack1_lo lie in the caller's second buffer (keys-only sorts; 0: all in slack1)
 	// ... sorts to go before the next attempt, doubled by every attempt that is called off; per kind of sort (4- / 8-byte keys,
 	// rank sorts, keys + payload): what one kind's inputs look like says nothing about another's
 	u32 blind_skip[4] = {0, 0, 0, 0}, blind_backoff[4] = {0, 0, 0, 0};
@@ -1152,19 +1156,34 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
 	const size_t st_bytes = 256 + rows * 256 * 4;
 	char *base = (char *)c.seg.p + c.seg_status_off + (size_t)(blind == 1 ? 1 : j < 0 ? 0 : j) * st_bytes;
-	SegArgs sa;
+	SegArgs sa{};
 	sa.ctl = (const SegCtl *)c.seg.p;
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
 	sa.tiles = (const SegTile *)((char *)c.seg.p + c.seg_tiles_off);
 	sa.slots = (u32)sizeof(KT) - 1;
 	sa.slack_cap = blind == 1 ? c.slack1_cap : j == -2 ? c.slack_cap : 0u;
 	sa.overflow = &((SegCtl *)c.seg.p)->overflow;
+	KT *const second = blind == 1 ? src : blind == 2 ? const_cast<KT *>(aux) : nullptr;
 	if (j == -2)
 		src = (KT *)c.slack.p;
-	if (blind == 1)
-		src = (KT *)c.slack1.p;
-	if (blind == 2)
-		aux = (const KT *)c.slack1.p;
+	// blind: `src` (level-1 pass) / `aux` (level-2 pass) name the caller's second buffer when the first slack1_lo level-1 slots
+	// lie there (blind_enqueue); the others lie in c.slack1
+	if (blind == 1 || blind == 2) {
+		KT *first = (KT *)c.slack1.p;
+		if (second && c.slack1_lo) {
+			sa.lo_slots = c.slack1_lo;
+			KT *const hi = (KT *)c.slack1.p - (size_t)c.slack1_lo * c.slack1_cap;
+			if (blind == 1)
+				sa.kout_hi = hi;
+			else
+				sa.kin_hi = hi;
+			first = second;
+		}
+		if (blind == 1)
+			src = first;
+		else
+			aux = first;
+	}
 	const bool dense = sizeof(KT) == 4 && blind == 2 && dense_slots<KT>(c);   // (keys written as two bytes: its own line in the profile)
 	ProfScope prof(dense ? 3 : 1, (u64)n * (dense ? sizeof(KT) + 2 : 2 * sizeof(KT)), c.stream);
 	const bool plain = ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0;
@@ -1416,8 +1435,17 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 		return RSX_OK;
 	if (c.blind_no_room)
 		return RSX_OK;
-	if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
-	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK) {
+	// Where the level-1 slots lie.  The attempt only writes after its sample has PROVEN the input unsorted and four columns kept
+	// -- from then on the caller's second buffer belongs to the sort whatever route finishes it (radix_sort.hpp:60-62 keeps it
+	// untouched only on the early exits) -- so the slots that fit there (n / cap1 of them: 204 of 256) lie there and the library
+	// allocates the rest only: 0.25 n keys instead of 1.25 n (2^28 u32 keys: 0.25 GiB + 0.63 GiB of two-byte level-2 slots
+	// instead of 1.25 + 1.25).  Needs a slot that holds a tile (a lost attempt's runs go over the slot's own beginning there,
+	// rsx_scatter2.hpp); RSX_NO_AUX_SLOTS=1: all slots in scratch memory.
+	const u32 lo = (aux && !env().no_aux_slots && cap1 >= (u32)C2::TILE) ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
+	c.slack_cap = cap2;   // (dense_slots asks for it)
+	const size_t slot2_bytes = dense_slots<KT>(c) ? 2 : sizeof(KT);
+	if (c.slack1.ensure(((size_t)(256 - lo) * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
+	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * slot2_bytes) != RSX_OK) {
 		// no room for the slots: the ordinary path, now and for this context's later sorts (a multi-GiB hipMalloc that fails
 		// is not worth repeating per sort); what was allocated of the pair goes back
 		(void)hipGetLastError();
@@ -1427,6 +1455,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 		c.blind_no_room = true;
 		return RSX_OK;
 	}
+	c.slack1_lo = lo;
 	RSX_TRY(seg_layout<KT>(c, n));
 	RSX_TRY(c.gscan.ensure(256 * sizeof(u64)));
 	const u64 ntiles0 = (n + C2::TILE - 1) / C2::TILE;
@@ -1448,11 +1477,11 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	                   4u,   // (two levels want four kept columns: two for the passes, two or more for the leaves)
 	                   // 4-byte keys whose leaves read two-byte slots (rsx_leaf16.hpp): the MSB digits may lie below constant top bits
 	                   (u32)(sizeof(KT) == 4 && dense_slots<KT>(c) && !env().no_leaf16 && !env().no_shift ? 1 : 0));
-	RSX_TRY(launch_seg_pass<KT>(c, src, nullptr, n, ka, -2, 1));
+	RSX_TRY(launch_seg_pass<KT>(c, src, lo ? aux : nullptr, n, ka, -2, 1));
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0);
-	RSX_TRY(launch_seg_pass<KT>(c, nullptr, nullptr, n, ka, -2, 2));
+	RSX_TRY(launch_seg_pass<KT>(c, lo ? aux : nullptr, nullptr, n, ka, -2, 2));
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
 	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, 1u);
@@ -1869,7 +1898,7 @@ int pairs_two_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   (u32)C2::TILE, tiles, ctl, btile);
 	char *base = (char *)c.seg.p + c.seg_status_off;
-	SegArgs sa;
+	SegArgs sa{};
 	sa.ctl = ctl;
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
 	sa.tiles = tiles;
@@ -1958,7 +1987,7 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, kin, (u64)n, ka, ctl, c.plan(),
 	                   c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
 	                   (u32)sizeof(KT));   // (every column kept: the callers' parity rule below counts on it)
-	SegArgs sa;
+	SegArgs sa{};
 	sa.ctl = ctl;
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);
 	sa.tiles = tiles;

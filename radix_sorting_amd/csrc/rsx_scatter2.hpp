@@ -127,6 +127,13 @@ struct SegArgs {
 	// of the bucket with the digit).  A slot that would overflow sets *overflow; the caller then discards the attempt.
 	u32 slack_cap;
 	u32 *overflow;
+	// The level-1 slots of a keys-only sort without a histogram lie in TWO arrays (rsx.hip, blind_enqueue): slots 0 .. lo_slots-1
+	// in the caller's second buffer (`kout` of the level-1 pass, `kin` of the level-2 pass: proven unsorted, the input leaves that
+	// buffer to the sort), the others in the library's scratch array -- *_hi points lo_slots slots BEFORE that array, so that one
+	// offset serves both.  Null: one array.
+	void *kout_hi;
+	const void *kin_hi;
+	u32 lo_slots;
 };
 
 // SCATTER_SELF_PLAN (pass 0 of a blocking keys-only sort of a mid-size array): no plan kernel has run.  `gbase` is the
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags, u64 *tl,
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
                                                                  u32 oshift = 0, const u32 *__restrict__ hotd = nullptr,
-                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr},
+                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0},
                                                                  const void *__restrict__ kalt = nullptr,
                                                                  SelfPlanArgs sp = SelfPlanArgs{nullptr, nullptr, nullptr, nullptr,
                                                                                                 HybCaps{0, 0, 0, 0}})
@@ -420,6 +427,16 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			seg_first = st.first;
 			seg_bucket = st.bucket;
 		}
+	}
+	if constexpr (SEG) {
+		// SegArgs::kin_hi: the tile lies in the other array -- the same element index from there, as a shift of the tile's bounds.
+		// (Where this stands matters to the compiler: the same lines next to the tile-table read above, or an assignment to
+		// `kin` there, gave a build whose level-2 pass faulted even with kin_hi null.)
+		u64 shift_elems = 0;
+		if (seg.kin_hi && seg_bucket >= seg.lo_slots)
+			shift_elems = (u64)(((const char *)seg.kin_hi - (const char *)kin) / (long long)sizeof(KT));
+		beg += shift_elems;
+		end += shift_elems;
 	}
 	const u32 wofs = wid * (64 * KPT) + lane;   // wave w owns [w*64*KPT, +64*KPT) of a tile; round r: element 64 r + lane
 	// Element `base + wofs + 64 r` of an array: a uniform (scalar) address for (base, r) plus ONE 32-bit lane offset,
@@ -739,6 +756,10 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					// a heavy bucket's runs must not walk over the end of the scratch array
 					atomicOr(seg.overflow, 1u);
 					running = (u64)((flags & SCATTER_BLIND_TOP) ? 256u : 65536u) * seg.slack_cap;
+					// (slots in the caller's buffer, which has no room behind them: over the slot's own beginning -- a level-1
+					// slot holds more than a tile there, blind_enqueue)
+					if (seg.kout_hi && tid < seg.lo_slots)
+						running = (u64)tid * seg.slack_cap;
 				}
 			} else {
 				running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;
@@ -892,6 +913,14 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		// consecutive addresses: a lane takes CHUNK consecutive elements and, when they share a digit
 		// (first == last), stores them with one wide store; chunks straddling a run boundary go element-wise.
 		u32 pk[HAS_VAL ? KPT / CHUNK : 1];
+		// (SegArgs::kout_hi: the level-1 slots from lo_slots on lie in another array, hi_bytes from where `kout` would put them)
+		const long long hi_bytes = (SEG && seg.kout_hi) ? (long long)((const char *)seg.kout_hi - (const char *)kout) : 0ll;
+		auto kdst = [&](KTO *q, const u32 dg) -> KTO * {
+			if constexpr (SEG)
+				return (KTO *)((char *)q + (dg >= seg.lo_slots ? hi_bytes : 0ll));
+			else
+				return q;
+		};
 #pragma unroll
 		for (int j = 0; j < KPT / CHUNK; ++j) {
 			if (j % 4 == 0)
@@ -924,20 +953,20 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					for (int e = 0; e < CHUNK; ++e)
 						ov[e] = (KTO)(kdf_apply(kv[e], ka) >> oshift);
 					if (sizeof(KTO) * CHUNK >= 4 && whole && d[0] == d[CHUNK - 1]) {
-						store_chunk<KTO, CHUNK>(kout + (ST)(delta[d[0]] + i0), ov);
+						store_chunk<KTO, CHUNK>(kdst(kout + (ST)(delta[d[0]] + i0), d[0]), ov);
 					} else {
 #pragma unroll
 						for (int e = 0; e < CHUNK; ++e)
 							if (full || i0 + e < cnt)
-								kout[(ST)(delta[d[e]] + i0 + e)] = ov[e];
+								*kdst(kout + (ST)(delta[d[e]] + i0 + e), d[e]) = ov[e];
 					}
 				} else if (sizeof(KT) >= 4 && whole && d[0] == d[CHUNK - 1]) {
-					store_chunk<KT, CHUNK>(kout + (ST)(delta[d[0]] + i0), kv);
+					store_chunk<KT, CHUNK>(kdst(kout + (ST)(delta[d[0]] + i0), d[0]), kv);
 				} else {
 #pragma unroll
 					for (int e = 0; e < CHUNK; ++e)
 						if (full || i0 + e < cnt)
-							kout[(ST)(delta[d[e]] + i0 + e)] = kv[e];
+							*kdst(kout + (ST)(delta[d[e]] + i0 + e), d[e]) = kv[e];
 				}
 			}
 		}

@@ -67,6 +67,29 @@ def test_u32_mid_size_arrays_a_wave_per_leaf(n, seed):
     _sort_and_compare(a, ol.F32, ol.DESC, 5, ("f32 desc", n))
 
 
+@pytest.mark.parametrize("dt,n_mi", [(ol.U32, 64), (ol.U64, 20)], ids=["u32", "u64"])
+def test_level1_slots_all_in_scratch_memory(dt, n_mi, monkeypatch):
+    """By default the level-1 slots that fit (n / cap1 of the 256) lie in the caller's second buffer -- every other test of this
+    file runs that way --; RSX_NO_AUX_SLOTS=1 keeps them all in the library's scratch array."""
+    monkeypatch.setenv("RSX_NO_AUX_SLOTS", "1")
+    n = n_mi * MI + 17
+    a = ol.splitmix_fill(n, dt, 4150 + n_mi, (1 << (8 * ol.DTYPE_SIZE[dt])) - 1)
+    _sort_and_compare(a, dt, ol.ASC, 5, ("all slots in scratch", n_mi))
+
+
+@pytest.mark.parametrize("digit", [0x05, 0xF3])
+def test_level1_slot_overflows_after_the_second_buffer_was_written(digit):
+    """One top digit with 1.4 times its share: too little for the sample (8192 keys) to notice, too much for the digit's level-1
+    slot (1.25 times the mean).  The attempt is called off AFTER its level-1 pass has written -- with the slots in the caller's
+    second buffer (digit 0x05) the lost run goes over the slot's own beginning, in the scratch array (0xF3) behind the last slot --
+    and the histogram-first sort then uses that buffer as the reference does (radix_sort.hpp:82-92)."""
+    n = 16 * MI + 3
+    a = ol.splitmix_fill(n, ol.U32, 4160 + digit, 0xFFFFFFFF).view(np.uint32).copy()
+    idx = np.arange(1000, 1000 + 26000 * 7, 7)
+    a[idx] = (a[idx] & np.uint32(0x00FFFFFF)) | np.uint32(digit << 24)
+    _sort_and_compare(a, ol.U32, ol.ASC, 0, ("level-1 overflow", hex(digit)))
+
+
 def test_u32_mid_size_low_bits_clustered():
     """... with keys whose low sixteen bits take 64 x 16 values everywhere, and only 16 values in some buckets: the wave kernel
     has no list to hand a leaf to -- it goes on (more rounds of register passes) until the leaf is in order."""
