@@ -1415,12 +1415,23 @@ template <typename KT> bool async_blind_ok(Ctx &c, size_t n)
 	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() || c.small.external ||
 	    env().no_speculation)
 		return false;
-	size_t floor_keys = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)9 << 20;
+	size_t floor_keys = sizeof(KT) == 8 ? (size_t)1 << 23 : (size_t)9 << 20;   // (blind_wanted's floors)
 	if (env().blind_min_log2)
 		floor_keys = (size_t)1 << env().blind_min_log2;
 	floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);
 	blind_refresh(c);
 	return n >= std::max(floor_keys, (size_t)1 << 22) && n < ((size_t)1 << 30);
+}
+// ... for key + payload and rank sorts (4-byte keys, 4-byte payloads: blind_wanted's window, without its back-off)
+template <typename KT> bool async_pairs_blind_ok(Ctx &c, size_t n, size_t payload_bytes)
+{
+	if (sizeof(KT) != 4 || payload_bytes != 4)
+		return false;
+	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() || c.small.external ||
+	    env().no_speculation)
+		return false;
+	blind_refresh(c);
+	return n >= std::min((size_t)1 << 24, (size_t)1 << env().two_level_min_log2) && n >= ((size_t)1 << 22) && n <= ((size_t)1 << 28);
 }
 
 template <typename KT>
@@ -1821,6 +1832,9 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 
 // ---- key + payload, no host synchronisation: as sort_keys_inplace_async, the result always in (k, v) -----------------------
 template <typename KT, typename VT>
+int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, int *enqueued);
+
+template <typename KT, typename VT>
 int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int dtype, int order)
 {
 	if (!c.fast)
@@ -1833,9 +1847,21 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 		return RSX_OK;
 	}
 	const size_t status_total = status_bytes<KT, VT>(n) * sizeof(KT);
-	RSX_TRY(plan_phase<KT>(c, k, n, ka, nullptr, status_total));
-	for (u32 i = 0; i < sizeof(KT); ++i)
-		RSX_TRY((scatter_pass<KT, VT>(c, k, ks, v, vs, n, 0, c.ghist(), ka, 0, c.plan(), (int)i, i)));
+	// as sort_keys_inplace_async: the attempt without a histogram first (4-byte keys and payloads, 16 Mi .. 2^28 pairs: two MSB
+	// passes into slots and the pairs' leaves, which write (k, v) -- an attempt that is called off has only read them), the
+	// histogram-first kernels behind it gated on its verdict
+	int blind = 0;
+	if constexpr (sizeof(KT) == 4 && sizeof(VT) == 4) {
+		if (async_pairs_blind_ok<KT>(c, n, sizeof(VT)))
+			RSX_TRY((pairs_blind_enqueue<KT, VT>(c, k, v, k, v, n, ka, &blind)));
+	}
+	c.pass_gate = blind ? (const SegCtl *)c.seg.p : nullptr;
+	c.async_tried_blind = blind != 0;
+	int rc = plan_phase<KT>(c, k, n, ka, nullptr, status_total);
+	for (u32 i = 0; i < sizeof(KT) && rc == RSX_OK; ++i)
+		rc = scatter_pass<KT, VT>(c, k, ks, v, vs, n, 0, c.ghist(), ka, 0, c.plan(), (int)i, i);
+	c.pass_gate = nullptr;
+	RSX_TRY(rc);
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)k, (const unsigned char *)ks,
 	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)v, (const unsigned char *)vs,
@@ -1945,11 +1971,11 @@ int pairs_one_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 // the pairs' leaves): both MSB passes into slots -- the first reads the caller's (kin, vin), or makes the indices (vin ==
 // nullptr) --, the leaves write to (kfinal, vfinal).  *done = 0: called off, nothing the caller owns has been written.
 template <typename KT, typename VT>
-int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, rsx_info *info, int *done)
+int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, int *enqueued)
 {
 	typedef Sc2Cfg<KT, VT> C2;
 	typedef LeafCfg<u32, 4, 20, 3> L;
-	*done = 0;
+	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
 	const u32 cap1 = ((mean1 + mean1 / 4 + 255) / 256) * 256;
 	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
@@ -2051,6 +2077,20 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 		}
 	}
 	HIP_TRY(hipGetLastError());
+	*enqueued = 1;
+	return RSX_OK;
+}
+
+// ... and the blocking sorts' use of it: the host waits for the verdict (the event lies behind the slack plan kernel, in front of
+// the leaves) and remembers an attempt that was called off (blind_called_off: back-off)
+template <typename KT, typename VT>
+int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, rsx_info *info, int *done)
+{
+	*done = 0;
+	int enqueued = 0;
+	RSX_TRY((pairs_blind_enqueue<KT, VT>(c, kin, vin, kfinal, vfinal, n, ka, &enqueued)));
+	if (!enqueued)
+		return RSX_OK;
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
 		blind_called_off(c, blind_kind<KT>(sizeof(VT), vin == nullptr));   // (no payloads given: a rank sort)
@@ -2474,12 +2514,21 @@ int sort_rank_inplace_async(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, 
 	RSX_TRY(c.keys[0].ensure(n * sizeof(KT)));
 	RSX_TRY(c.keys[1].ensure(n * sizeof(KT)));
 	const size_t status_total = status_bytes<KT, IT>(n) * sizeof(KT);
-	RSX_TRY(plan_phase<KT>(c, src, n, ka, nullptr, status_total));
+	// the attempt without a histogram first (4-byte keys, 4-byte indices, 16 Mi .. 2^28 keys: its leaves write the ranks to the
+	// first half), the histogram-first kernels behind it gated on its verdict -- as sort_keys_inplace_async
+	int blind = 0;
+	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
+		if (async_pairs_blind_ok<KT>(c, n, sizeof(IT)))
+			RSX_TRY((pairs_blind_enqueue<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, &blind)));
+	}
+	c.pass_gate = blind ? (const SegCtl *)c.seg.p : nullptr;
+	c.async_tried_blind = blind != 0;
+	int rc = plan_phase<KT>(c, src, n, ka, nullptr, status_total);
 	c.pass_alt = c.keys[1].p;
-	int rc = RSX_OK;
 	for (u32 i = 0; i < sizeof(KT) && rc == RSX_OK; ++i)   // pass i = the i-th kept column, if there is one
 		rc = scatter_pass<KT, IT>(c, src, (KT *)c.keys[0].p, ib, ib + n, n, 0, c.ghist(), ka, SCATTER_RANK_ASYNC, c.plan(), (int)i, i);
 	c.pass_alt = nullptr;
+	c.pass_gate = nullptr;
 	RSX_TRY(rc);
 	// sorted keys: no pass ran, the ranks are 0 .. n-1 (radix_sort_rank.hpp:52,:55-57)
 	hipLaunchKernelGGL((rsx_iota_if_sorted_kernel<IT>), dim3(1024), dim3(256), 0, c.stream, ib, (u64)n, (const Plan *)c.plan());

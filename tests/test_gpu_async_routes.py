@@ -147,3 +147,67 @@ def test_routes_inside_one_captured_graph(n, monkeypatch):
         want, _, _ = ol.oracle_sort(a, ol.U32)
         assert np.array_equal(buf.cpu().numpy().view(np.uint32), want), name
     rsa.release_stream(s)
+
+
+@pytest.mark.parametrize("n", [(1 << 24) + 5, (1 << 26) + 77])
+def test_ranks_and_pairs_without_histogram_on_the_device(n):
+    """rsx_sort_rank_inplace_async and rsx_sort_pairs_inplace_async (4-byte keys, 4-byte indices / payloads, 16 Mi .. 2^28): the
+    attempt without a histogram is enqueued first, its leaves write the ranks to the first half of the index buffer / the pairs
+    to (keys, vals); equal keys keep their order (radix_sort_rank.hpp:82-90).  Called off (a dominant top digit; a constant
+    column): the gated histogram-first kernels do the work."""
+    base = ol.splitmix_fill(n, ol.F32, 7500, 0xFFFFFFFF)
+    twice = np.concatenate([base[: n // 2], base[: n - n // 2]])          # every key (at least) twice: ties everywhere
+    half = twice.copy()
+    half[::2] &= np.uint32(0x00FFFFFF)                                      # a dominant top digit
+    const_col = twice & np.uint32(0xFFFF00FF)                               # column 1 constant: three kept columns
+    cases = (("uniform, ties", twice, 5), ("dominant top digit", half, 0), ("constant column", const_col, 0))
+    for name, a, want_route in (cases if n < (1 << 25) else cases[:2]):
+        a = np.ascontiguousarray(a)
+        want, _, _, _ = ol.oracle_rank(a, ol.F32)
+        want = want.copy()
+        bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
+        ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+        ranks = rsa.radix_sort_rank_inplace_async(bits, ib, dtype=rsa.F32)
+        route = rsa.async_route()
+        assert route == want_route, (name, "ranks", route)
+        assert np.array_equal(bits.cpu().numpy().view(np.uint32), a.view(np.uint32)), name      # the keys are only read
+        assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), (name, "ranks")
+        del ib, ranks
+        vals = torch.arange(n, dtype=torch.int32, device="cuda")
+        ks, vs = torch.empty_like(bits), torch.empty_like(vals)
+        rsa.radix_sort_pairs_inplace_async(bits, ks, vals, vs, dtype=rsa.F32)
+        route = rsa.async_route()
+        assert route == want_route, (name, "pairs", route)
+        assert np.array_equal(vals.cpu().numpy().view(np.uint32), want), (name, "pairs")
+        assert np.array_equal(bits.cpu().numpy().view(np.uint32), a.view(np.uint32)[want]), (name, "pairs' keys")
+        del vals, ks, vs, bits
+
+
+def test_rank_routes_inside_one_captured_graph():
+    """One capture of rsx_sort_rank_inplace_async, replayed on inputs that take different routes."""
+    n = 1 << 25
+    s = torch.cuda.Stream()
+    bits = torch.empty(n, dtype=torch.int32, device="cuda")
+    ib = torch.empty(2 * n, dtype=torch.int32, device="cuda")
+    with torch.cuda.stream(s):
+        rsa.fill_splitmix(bits, seed=1, stream=s)
+        rsa.radix_sort_rank_inplace_async(bits, ib, dtype=ol.U32, stream=s)     # sizes the workspace outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        rsa.radix_sort_rank_inplace_async(bits, ib, dtype=ol.U32, stream=torch.cuda.current_stream())
+    base = ol.splitmix_fill(n, ol.U32, 7600, 0xFFFFFFFF).view(np.uint32)
+    cases = [("uniform", base, 5), ("top digit dominant", np.where(np.arange(n) % 2 == 0, base & np.uint32(0x00FFFFFF), base).astype(np.uint32), 0),
+             ("uniform again", base[::-1].copy(), 5), ("sorted", np.sort(base), 0), ("uniform, ties", np.concatenate([base[: n // 2]] * 2), 5)]
+    for name, a, want_route in cases:
+        a = np.ascontiguousarray(a)
+        bits.copy_(to_dev(a))
+        ib.fill_(-1)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        route = rsa.async_route(s)
+        assert route == want_route, (name, route)
+        want, _, _, _ = ol.oracle_rank(a, ol.U32)
+        assert np.array_equal(ib[:n].cpu().numpy().view(np.uint32), want), name
+    rsa.release_stream(s)

@@ -181,7 +181,7 @@ def test_u64_small_leaves_lists_and_fat_bins(n_mi, maxbin, monkeypatch):
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64 small leaves", n_mi, maxbin))
 
 
-@pytest.mark.parametrize("n_mi", [16, 40, 64, 96, 128])
+@pytest.mark.parametrize("n_mi", [16, 64, 128])
 def test_f32_ranks_and_pairs_without_histogram(n_mi):
     """Rank sorts and key + payload sorts of 4-byte keys take the route from 16 Mi pairs on; the leaves (rsx_leafp_kernel) come
     in three shapes chosen by the slots' capacity: 1280 pairs and 1024 bins (16 .. 64 Mi pairs), 2560 and 2048 (.. 2^27), 5120
