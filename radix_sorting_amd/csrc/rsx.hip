@@ -108,6 +108,7 @@ struct Env {
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
 	unsigned blind_min_log2 = 0;     // RSX_BLIND_MIN_LOG2: keys-only sorts may skip the histogram from 2^this keys on (0: the measured floors)
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
+	bool no_narrow_slots = false;    // RSX_NO_NARROW_SLOTS=1: the level-2 slots of 8-byte keys always hold whole keys (SegCtl::narrow)
 	bool no_aux_slots = false;       // RSX_NO_AUX_SLOTS=1: the level-1 slots of a sort without a histogram all lie in scratch memory
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
 	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: (kept for old scripts: two-byte slots are now written for every slot size rsx_leaf16_kernel takes)
@@ -150,6 +151,7 @@ struct Env {
 		if (const char *e = getenv("RSX_BLIND_MIN_LOG2"))
 			blind_min_log2 = (unsigned)std::max(22, std::min(30, atoi(e)));
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
+		no_narrow_slots = is_one("RSX_NO_NARROW_SLOTS");
 		no_aux_slots = is_one("RSX_NO_AUX_SLOTS");
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
@@ -984,6 +986,15 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 	return caps;
 }
 
+// 8-byte keys: may the sample choose four-byte level-2 slots (SegCtl::narrow)?  Where rsx_leafk_kernel sorts the slots, from
+// slots of 512 keys (arrays of ~13 Mi keys) on: the second form of the level-2 pass and of the leaves are two more launches, which
+// 8 Mi keys notice (0.267 against 0.252 ms; 16 Mi: 0.328 against 0.337, 64 Mi 0.77 against 0.87, 192 Mi 2.06 against 2.29:
+// tools/u64_threshold_probe.py, keys & 0xFFFFFFFFFF).
+template <typename KT> bool narrow_slots_ok(u32 cap2)
+{
+	return sizeof(KT) == 8 && cap2 >= 512u && cap2 <= 5120u && !env().no_leaf16 && !env().no_narrow_slots;
+}
+
 // Sorts without a histogram of 4-byte keys (all four columns kept): the level-2 pass writes only the low two bytes of the
 // derived keys into its slots and the leaves put the rest back from the slot's digits (RSX_NO_DENSE_SLOTS=1: whole keys).
 // (where the slots fit the leaf shape that reads them: up to 5120 keys each, 2^28 keys in all)
@@ -1035,6 +1046,10 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 		hipLaunchKernelGGL((rsx_leafk_kernel<KT, u64, K8>), dim3(grid_s), dim3(K8::BLOCK), 0, c.stream, src, aux,               \
 		                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K8::CAP, slots, c.slack_cap, redo,               \
 		                   (u32)env().leaf16_maxbin);                                                                          \
+		if (narrow_slots_ok<KT>(c.slack_cap))   /* four-byte slots (SegCtl::narrow) */                                          \
+			hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4, true>), dim3(grid_s), dim3(K4::BLOCK), 0, c.stream, src, aux,     \
+			                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo,           \
+			                   (u32)env().leaf16_maxbin);                                                                      \
 	} while (0)
 			typedef LeafKCfg<512, 5120, 8> K4;
 			typedef LeafKCfg<512, 5120, 6> K8;
@@ -1225,6 +1240,22 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	else
 		RSX_LAUNCH_SEG(DIG_GENERIC);
 #undef RSX_LAUNCH_SEG
+	if constexpr (sizeof(KT) == 8) {
+		if (blind == 2 && narrow_slots_ok<KT>(c.slack_cap)) {
+			// ... and the form that writes the low word of every derived key (SegCtl::narrow decides on the device which of the
+			// two works; it uses its own status words: the same region, which the form that left has not touched)
+#define RSX_LAUNCH_SEG32(DIGV)                                                                                             \
+	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, u32, true>), dim3(grid),                \
+	                   dim3(C2::BLOCK), 0, c.stream, aux, (u32 *)src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n,     \
+	                   shift0, (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,     \
+	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
+			if (plain)
+				RSX_LAUNCH_SEG32(DIG_PLAIN);
+			else
+				RSX_LAUNCH_SEG32(DIG_GENERIC);
+#undef RSX_LAUNCH_SEG32
+		}
+	}
 	HIP_TRY(hipGetLastError());
 	return RSX_OK;
 }
@@ -1487,7 +1518,9 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	                   c.plan(), c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
 	                   4u,   // (two levels want four kept columns: two for the passes, two or more for the leaves)
 	                   // 4-byte keys whose leaves read two-byte slots (rsx_leaf16.hpp): the MSB digits may lie below constant top bits
-	                   (u32)(sizeof(KT) == 4 && dense_slots<KT>(c) && !env().no_leaf16 && !env().no_shift ? 1 : 0));
+	                   (u32)(sizeof(KT) == 4 && dense_slots<KT>(c) && !env().no_leaf16 && !env().no_shift ? 1 : 0),
+	                   // 8-byte keys in slots rsx_leafk_kernel takes: four-byte slots where the leaves' columns lie in the low word
+	                   (u32)(narrow_slots_ok<KT>(cap2) ? 1 : 0));
 	RSX_TRY(launch_seg_pass<KT>(c, src, lo ? aux : nullptr, n, ka, -2, 1));
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1,

@@ -55,7 +55,10 @@ struct SegCtl {
 	// values below 2^30, one rank's share of a distributed sort), the sixteen bits below the highest bit that varies: the
 	// order is the same (the bits above are constant, checked on every key through cmask) and the buckets are even again
 	u32 shift1, shift2;
-	u32 pad[1];
+	// 8-byte keys whose leaves sort columns of the low word only (keys below 2^40, say): the level-2 pass writes the low word
+	// of every DERIVED key into its slots (four bytes per key instead of eight) and rsx_leafk_kernel's SLOT32 form reads them;
+	// the upper word comes back from key0, the constant columns and the slot's two digits
+	u32 narrow;
 };
 enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
 
@@ -478,7 +481,7 @@ template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka,
                                                                   SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
                                                                   Plan *host_plan, u32x4 *__restrict__ z, u64 nz, u32 min_cols,
-                                                                  u32 allow_shift = 0)
+                                                                  u32 allow_shift = 0, u32 allow_narrow = 0)
 {
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
@@ -652,6 +655,8 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		// NS samples over 4096 bins: two per bin on average, the fullest holds ten or eleven; a leaf of 4096 keys sees half of
 		// what the sample sees, and rsx_leaf16_kernel takes bins of up to 25 keys
 		ctl->leaf16 = s_max12 <= max12_ok ? 1u : 0u;
+		// (8-byte keys, the leaves' columns all in the low word, their bins even: the leaves that read four-byte slots)
+		ctl->narrow = (W == 8 && allow_narrow && go && nk >= 4 && cols[nk - 3] <= 3u && s_max12 <= max12_ok) ? 1u : 0u;
 		ctl->shift1 = shift1;
 		ctl->shift2 = shift2;
 		ctl->cmask_lo = (u32)cmask;

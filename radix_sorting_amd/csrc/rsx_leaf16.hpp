@@ -609,6 +609,34 @@ template <typename T> __device__ __forceinline__ void merge16_values(T (&d)[16])
 	batcher_stage<8>(d, ce);
 }
 
+// Batcher's odd-even merge sort over `cnt` values held in the LDS, by a whole workgroup (at: index -> LDS word): every comparator
+// puts the smaller value at the lower index, so the places behind `cnt` up to the next power of two can be left out (they would
+// hold +infinity and never move).  (log2 N)(log2 N + 1) / 2 rounds of at most N / 2 comparators: 91 rounds for 5120 values --
+// the bounded way out for a leaf whose bins are too uneven for the placement + register passes (they would need one pass per
+// eight values of the fullest bin).
+template <int BLOCK, typename T, typename AT> __device__ __forceinline__ void batcher_sort_lds(T *stage, const u32 cnt, AT &&at)
+{
+	u32 N = 16;
+	while (N < cnt)
+		N <<= 1;
+	for (u32 p = 1; p < N; p <<= 1) {
+		for (u32 k = p; k >= 1; k >>= 1) {
+			const u32 j0 = k % p;   // (k == p: 0)
+			for (u32 idx = threadIdx.x; idx < N / 2; idx += BLOCK) {
+				const u32 a = j0 + (idx / k) * 2 * k + idx % k, b = a + k;
+				if (b < cnt && a / (2 * p) == b / (2 * p)) {
+					const T x = stage[at(a)], y = stage[at(b)];
+					if (y < x) {
+						stage[at(a)] = y;
+						stage[at(b)] = x;
+					}
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+
 template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12> struct LeafKCfg {
 	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64, NBITS = NBITS_;
 	static constexpr int NCH = (CAP / 16 + BLOCK - 1) / BLOCK;   // chunks of sixteen values per lane
@@ -629,7 +657,10 @@ template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12> struct LeafKCfg {
 
 // KT: 8-byte keys; CT: u32 (every column of the leaf in the low word) or u64.  A launch takes the leaves that need its CT.
 // redo / SegCtl::nredo / SegCtl::leaf16: as rsx_leaf16_kernel.
-template <typename KT, typename CT, typename C>
+// SLOT32: the slots hold the low word of the DERIVED keys (SegCtl::narrow: the level-2 pass wrote four bytes per key); the
+// upper word is the same for a whole slot -- key0's, with the slot's two digits where the MSB passes' columns lie above bit 32.
+// That form has no list: a leaf with bins too full for the register passes is sorted by batcher_sort_lds.
+template <typename KT, typename CT, typename C, bool SLOT32 = false>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restrict__ src, KT *__restrict__ aux,
                                                                      const Plan *__restrict__ plan,
                                                                      const LeafSeg *__restrict__ segtab, SegCtl *__restrict__ ctl,
@@ -645,6 +676,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 	const u32 mode = ctl->mode, maxleaf = ctl->maxleaf, nseg = ctl->nleaf, on = ctl->leaf16;
 	if (hyb != HYB_TWO_LEVEL || ncols < 4 || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi || !on)
 		return;
+	static_assert(!SLOT32 || sizeof(CT) == 4, "four-byte slots, four-byte values");
+	if ((ctl->narrow != 0u) != SLOT32)
+		return;   // (the other form's sort)
 	// the leaf's columns: all kept columns below the two the MSB passes went by; bins from the highest and the one below it
 	const u32 c_hi = plan->cols[ncols - 3] & 7u, c_nx = plan->cols[ncols >= 4 ? ncols - 4 : 0] & 7u;
 	const bool one_col = ncols - 2 < 2;   // (cannot happen with four kept columns; kept for the shifts below)
@@ -666,11 +700,27 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 		const KT *q = slot ? slots + (u64)(slot - 1) * slack_cap : (const KT *)src + ls.beg;
 		// the keys, one per lane and round (consecutive lanes read consecutive keys), cut to the carried type
 		CT kv[NK];
-		const KT first = kdf_apply(q[0], ka);
+		KT first;
+		if constexpr (SLOT32) {
+			const u32 *q32 = (const u32 *)slots + (u64)(slot - 1) * slack_cap;
+			// the slot's upper word: the first key's, with the slot's digits at the MSB passes' bit positions
+			const u32 sh1 = ctl->shift1, sh2 = ctl->shift2;
+			KT up = (KT)(((u64)ctl->key0_hi << 32) | ctl->key0_lo);
+			up = (up & ~((KT)0xFFu << sh1)) | ((KT)((slot - 1) >> 8) << sh1);
+			up = (up & ~((KT)0xFFu << sh2)) | ((KT)((slot - 1) & 255u) << sh2);
+			first = up;
 #pragma unroll
-		for (int j = 0; j < NK; ++j) {
-			const u32 e = tid + BLOCK * j;
-			kv[j] = e < cnt ? (CT)kdf_apply(q[e], ka) : (CT)0;
+			for (int j = 0; j < NK; ++j) {
+				const u32 e = tid + BLOCK * j;
+				kv[j] = e < cnt ? (CT)q32[e] : (CT)0;
+			}
+		} else {
+			first = kdf_apply(q[0], ka);
+#pragma unroll
+			for (int j = 0; j < NK; ++j) {
+				const u32 e = tid + BLOCK * j;
+				kv[j] = e < cnt ? (CT)kdf_apply(q[e], ka) : (CT)0;
+			}
 		}
 		{
 			const u32x4 zero = {0, 0, 0, 0};
@@ -725,7 +775,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 #pragma unroll
 		for (int w = 1; w < NW; ++w)
 			mx = mx > wmax[w] ? mx : wmax[w];
-		if (mx > maxbin2) {
+		if (!SLOT32 && mx > maxbin2) {
 			if (tid == 0)
 				redo[atomicAdd(&ctl->nredo, 1u)] = s;
 			continue;
@@ -764,7 +814,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 		if (tid < 32)
 			stage[at(cnt + tid)] = (CT)~(CT)0;   // what the last chunks read behind the leaf's end sorts last
 		__syncthreads();
-		const u32 npass = mx > C::MAXBIN ? 4u : 2u;
+		if (SLOT32 && mx > maxbin2)
+			batcher_sort_lds<BLOCK>(stage, cnt, at);   // (bins too full for the register passes: the network over the whole leaf)
+		const u32 npass = (SLOT32 && mx > maxbin2) ? 0u : mx > C::MAXBIN ? 4u : 2u;
 		for (u32 pass = 0; pass < npass; ++pass) {
 			const u32 off = 8 * (pass & 1);
 #pragma unroll

@@ -206,6 +206,13 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				}
 			}
 		}
+		if constexpr (sizeof(KT) == 8) {
+			// 8-byte keys, the level-2 pass of a sort without a histogram: the sample decided whether the slots hold whole keys or
+			// the low word of the derived keys (SegCtl::narrow); both forms are enqueued, the other one leaves
+			if ((flags & SCATTER_BLIND) && (flags & SCATTER_SEG_SLACK) && !(flags & SCATTER_BLIND_TOP) &&
+			    (seg.ctl->narrow != 0u) != NARROW)
+				return;
+		}
 		if (!(flags & SCATTER_BLIND_TOP)) {
 			shift = ((flags & SCATTER_BLIND) && (flags & SCATTER_SEG_SLACK)) ? seg.ctl->shift2 : 8 * dplan->cols[seg_slot];
 			gbase += 256 * dplan->cols[dplan->ncols - 1];   // the level-1 column's offsets: bucket starts

@@ -181,6 +181,36 @@ def test_u64_small_leaves_lists_and_fat_bins(n_mi, maxbin, monkeypatch):
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64 small leaves", n_mi, maxbin))
 
 
+@pytest.mark.parametrize("case", ["u64 asc", "i64 desc", "f64 asc", "f64 negative desc", "whole-key slots", "every leaf by the network",
+                                  "fat bins in some buckets"])
+def test_u64_four_byte_slots(case, monkeypatch):
+    """8-byte keys whose leaves sort columns of the low word only (here: 40 varying bits below constant ones): the level-2 pass
+    writes the low word of every derived key (SegCtl::narrow) and rsx_leafk_kernel's SLOT32 form puts the upper word back from
+    the first key and the slot's digits -- for every KDF (the derived upper word is constant whatever the type's flips do).
+    RSX_NO_NARROW_SLOTS=1: whole keys as before.  That form has no list: leaves with bins too full for the register passes go
+    through Batcher's network over the whole leaf (RSX_LEAF16_MAXBIN=0: every leaf; clustering in some buckets: those)."""
+    n = 20 * MI + 123
+    r = ol.splitmix_fill(n, ol.U64, 4900, 0xFFFFFFFFFF).view(np.uint64).copy()
+    dt, order = ol.U64, ol.ASC
+    if case == "i64 desc":
+        dt, order = ol.I64, ol.DESC
+    elif case == "f64 asc":
+        dt = ol.F64
+        r |= np.uint64(0x3FF0000000000000)          # doubles in [1, 1 + 2^-12)
+    elif case == "f64 negative desc":
+        dt, order = ol.F64, ol.DESC
+        r |= np.uint64(0xBFF0000000000000)
+    elif case == "whole-key slots":
+        monkeypatch.setenv("RSX_NO_NARROW_SLOTS", "1")
+    elif case == "every leaf by the network":
+        monkeypatch.setenv("RSX_LEAF16_MAXBIN", "0")
+    elif case == "fat bins in some buckets":
+        top = (r >> np.uint64(24)) & np.uint64(0xFFFF)
+        r[(top % np.uint64(53)) == 3] &= np.uint64(0xFFFFFFFFFF0F0FFF)     # the leaf's keys in 16 bins of ~20: two more register passes
+        r[(top % np.uint64(211)) == 9] &= np.uint64(0xFFFFFFFFFF000FFF)    # ... in ONE bin: the network
+    _sort_and_compare(r, dt, order, 5, ("u64 four-byte slots", case))
+
+
 @pytest.mark.parametrize("n_mi", [16, 64, 128])
 def test_f32_ranks_and_pairs_without_histogram(n_mi):
     """Rank sorts and key + payload sorts of 4-byte keys take the route from 16 Mi pairs on; the leaves (rsx_leafp_kernel) come
