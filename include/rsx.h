@@ -58,6 +58,7 @@
  *   RSX_NO_LEAF_PREFIX=1    leaves of 8-byte keys sort by every column they have left;
  *   RSX_NO_DENSE_SLOTS=1    the second pass of such a sort writes whole keys into its slots;
  *   RSX_NO_LEAF16=1         its leaves are round 3's (two LDS passes per slot) instead of rsx_leaf16_kernel / rsx_leafk_kernel;
+ *   RSX_NO_AUX_SLOTS=1      level-1 slots all in scratch memory; RSX_NO_NARROW_SLOTS=1: 8-byte keys always in whole-key slots;
  *   RSX_LEAF16_MAXBIN=k     (tests) the fullest bin a leaf may have before it goes to those; RSX_NO_SHIFT=1: MSB digits on bytes only;
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
@@ -159,9 +160,11 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * replayed on new contents of d_buf.
  * Round 4: the ROUTE is chosen on the device as well (rsx_async_route reports it): one MSB pass and leaves for mid-size
  * arrays; for large arrays (4-byte keys from 9 Mi keys, 8-byte keys from 8 Mi) the sort without a histogram is
- * enqueued first and the histogram-first kernels behind it do nothing if it went through.  That attempt works in scratch
- * slots in the (device, stream) workspace: 1.25 n + 0.625 n .. 1.25 n keys of device memory beside d_buf and d_scratch
- * (see "Scratch memory" below); rsx_sort_inplace_async_ws, whose state lies in the caller's workspace, never makes it. */
+ * enqueued first and the histogram-first kernels behind it do nothing if it went through.  That attempt works in d_scratch
+ * (once its sample has proven the input unsorted) and in slots in the (device, stream) workspace: 0.25 n + 0.625 n .. 1.25 n
+ * keys of device memory (see "Scratch memory" above); rsx_sort_inplace_async_ws, whose state lies in the caller's
+ * workspace, never makes it.  rsx_sort_pairs_inplace_async and rsx_sort_rank_inplace_async (4-byte keys with 4-byte
+ * payloads / indices, 16 Mi .. 2^28 pairs) make the same attempt; rsx_async_route reports the last call's route for them too. */
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
                            void *stream);
 
