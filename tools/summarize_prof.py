@@ -61,11 +61,13 @@ def algorithmic_bytes(name):
         if t[-1] == "true" and len(t) >= 3 and t[-2] in SIZES:      # <KT, shape, CT, DENSE>: the slots hold CT-wide values
             return N * (SIZES[t[-2]] + SIZES.get(t[0], 0))
         return N * 2 * SIZES.get(t[0], 0)
-    if "rsx_leafk_kernel" in name and t:          # whole 8-byte keys in and out (rsx_leaf16.hpp)
+    if "rsx_leafk_kernel" in name and t:          # whole 8-byte keys in and out (rsx_leaf16.hpp); SLOT32: four-byte slots in
+        if t[-1] == "true":
+            return N * (4 + SIZES.get(t[0], 0))
         return N * 2 * SIZES.get(t[0], 0)
     if ("rsx_leaf16_kernel" in name or "rsx_leaf16w_kernel" in name) and t:         # two-byte slots in, whole keys out (rsx_leaf16.hpp)
         return N * (2 + SIZES.get(t[0], 0))
-    if "rsx_leaf_pairs_kernel" in name and len(t) >= 2:
+    if ("rsx_leaf_pairs_kernel" in name or "rsx_leafp_kernel" in name) and len(t) >= 2:
         # key + payload slots in; payloads out, and the keys too for pair sorts (a rank sort writes ranks only): the lower figure
         return N * (2 * SIZES.get(t[1], 0) + SIZES.get(t[0], 0))
     return None
