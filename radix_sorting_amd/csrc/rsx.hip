@@ -108,6 +108,7 @@ struct Env {
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
 	unsigned blind_min_log2 = 0;     // RSX_BLIND_MIN_LOG2: keys-only sorts may skip the histogram from 2^this keys on (0: the measured floors)
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
+	bool no_leaf16q = false;         // RSX_NO_LEAF16Q=1: slots of up to 256 values take a wave per leaf (rsx_leaf16w_kernel) instead of a row of sixteen lanes
 	bool no_narrow_slots = false;    // RSX_NO_NARROW_SLOTS=1: the level-2 slots of 8-byte keys always hold whole keys (SegCtl::narrow)
 	bool no_aux_slots = false;       // RSX_NO_AUX_SLOTS=1: the level-1 slots of a sort without a histogram all lie in scratch memory
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
@@ -151,6 +152,7 @@ struct Env {
 		if (const char *e = getenv("RSX_BLIND_MIN_LOG2"))
 			blind_min_log2 = (unsigned)std::max(22, std::min(30, atoi(e)));
 		no_leaf_prefix = is_one("RSX_NO_LEAF_PREFIX");
+		no_leaf16q = is_one("RSX_NO_LEAF16Q");
 		no_narrow_slots = is_one("RSX_NO_NARROW_SLOTS");
 		no_aux_slots = is_one("RSX_NO_AUX_SLOTS");
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
@@ -1094,7 +1096,11 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			typedef Leaf16WCfg<512, 9, 4> W512;
 			if (c.slack_cap <= (u32)W1k::CAP) {
 				// (no list, no second launch: the wave kernel goes on until its leaf is in order)
-				if (c.slack_cap <= (u32)W512::CAP)
+				typedef Leaf16QCfg<4> Q256;            // slots of up to 256 values (arrays of up to ~13 Mi keys): four leaves per wave
+				if (c.slack_cap <= (u32)Q256::CAP && !env().no_leaf16q)
+					hipLaunchKernelGGL((rsx_leaf16q_kernel<KT, Q256>), dim3(grid_s / Q256::ROWS), dim3(Q256::BLOCK), 0, c.stream, src, aux,
+					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)Q256::CAP, (const uint16_t *)slots, c.slack_cap);
+				else if (c.slack_cap <= (u32)W512::CAP)
 					hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W512>), dim3(grid_s / W512::NW), dim3(W512::BLOCK), 0, c.stream, src, aux,
 					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)W512::CAP, (const uint16_t *)slots, c.slack_cap);
 				else

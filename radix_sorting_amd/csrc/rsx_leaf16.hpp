@@ -566,6 +566,193 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 	}
 }
 
+// ---- a ROW of sixteen lanes per leaf: slots of up to 256 values (arrays of 9 .. 13 Mi keys; radix_bench's 10^7) ---------------
+// rsx_leaf16w_kernel gives a leaf of ~150 values a whole wave, of which nineteen lanes load and ten sort.  Here a wave takes
+// four leaves, one per DPP row: sixteen values per lane (two 16-byte loads), 128 bins (four words of cells per lane), the scan
+// and the maximum over the row (row_shr steps, no row_bcast), the exchange with the next lane masked at the row's end.  Rows do
+// not wait for each other except in the number of rounds (the wave's maximum: a finished row's rounds change nothing).
+template <int WAVES_> struct Leaf16QCfg {
+	static constexpr int CAP = 256, NBITS = 7, NW = WAVES_, BLOCK = 64 * WAVES_, ROWS = 4 * WAVES_;
+	static constexpr int NCELLW = (1 << NBITS) / 2;      // 64 words of two cells: four per lane
+	static constexpr int CELL_ROW = NCELLW + 16;         // + a word per lane for values that do not exist
+	static constexpr int STAGE_ROW = CAP + 32 + 16;      // + what the last chunk reads behind the leaf + the same
+	static constexpr u32 MAXBIN = 9;
+};
+
+__device__ __forceinline__ u32 row_incl_scan_dpp(u32 x)
+{
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+	return x;
+}
+
+template <typename KT, typename C>
+__global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16q_kernel(KT *__restrict__ src, KT *__restrict__ aux,
+                                                                  const Plan *__restrict__ plan,
+                                                                  const LeafSeg *__restrict__ segtab, SegCtl *__restrict__ ctl,
+                                                                  KdfArgs<KT> ka, u32 lo, u32 hi,
+                                                                  const uint16_t *__restrict__ slots, u32 slack_cap)
+{
+	static_assert(sizeof(KT) == 4, "4-byte keys: two MSB digits in the slot, two bytes in the leaf");
+	constexpr int CAP = C::CAP, NCELLW = C::NCELLW, NW = C::NW;
+	const u32 hyb = plan->hyb, ncols = plan->ncols;
+	const u32 sh1 = ctl->shift1, sh2 = ctl->shift2;
+	const u32 mode = ctl->mode, maxleaf = ctl->maxleaf, nseg = ctl->nleaf;
+	if (hyb != HYB_TWO_LEVEL || ncols != 4 || mode != SEG_MODE_LEAVES || maxleaf <= lo || maxleaf > hi)
+		return;
+	KT *out = src;   // (four kept columns: radix_sort.hpp:92)
+	(void)aux;
+	__shared__ __attribute__((aligned(16))) u32 cell_all[C::ROWS][C::CELL_ROW];
+	__shared__ __attribute__((aligned(16))) uint16_t stage_all[C::ROWS][C::STAGE_ROW];
+	const u32 lane = threadIdx.x & 63, l16 = lane & 15u, row = lane >> 4, wid = threadIdx.x >> 6;
+	u32 *cell = cell_all[4 * wid + row];
+	uint16_t *stage = stage_all[4 * wid + row];
+	const KT key0 = (KT)ctl->key0_lo;
+	const u32 D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
+	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));
+	for (u32 s0 = (blockIdx.x * NW + wid) * 4; s0 < nseg; s0 += gridDim.x * NW * 4) {
+		const u32 s = s0 + row;
+		u32 cnt = 0, slot = 1, beg = 0;
+		if (s < nseg) {
+			const LeafSeg ls = segtab[s];
+			cnt = ls.cnt;
+			slot = cnt ? ls.slot : 1u;
+			beg = ls.beg;
+		}
+		const uint16_t *q = slots + (u64)(slot - 1) * slack_cap;
+		u32x4 kv[2];
+		int nvalid[2];
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const u32 e0 = 8 * (l16 + 16 * j);
+			const int left = (int)cnt - (int)e0;
+			nvalid[j] = left < 0 ? 0 : left > 8 ? 8 : left;
+			kv[j] = u32x4{0, 0, 0, 0};
+			if (left > 0)
+				kv[j] = *(const u32x4 *)(q + e0);
+		}
+		((u32x4 *)cell)[l16] = u32x4{0, 0, 0, 0};
+		RSX_COMPILER_FENCE();
+		auto cell_of = [&](u32 w, int k, bool valid, u32 &sh) -> u32 * {
+			const u32 o = D + 16u * (u32)(k & 1);
+			sh = __builtin_amdgcn_ubfe(w, o, 1u) << 4;
+			return &cell[valid ? __builtin_amdgcn_ubfe(w, o + 1u, nb - 1u) : NCELLW + l16];
+		};
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				u32 sh;
+				u32 *a = cell_of(kv[j][k >> 1], k, k < nvalid[j], sh);
+				__hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+		RSX_COMPILER_FENCE();
+		u32x4 c = ((const u32x4 *)cell)[l16];
+		u32 run = 0, mxp = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const u32 x = c[i];
+			mxp = pk_max_u16(mxp, x);
+			const u32 lo16 = x & 0xFFFFu, hs = run + lo16;
+			c[i] = run | (hs << 16);
+			run = hs + (x >> 16);
+		}
+		u32 mx = (mxp & 0xFFFFu) > (mxp >> 16) ? (mxp & 0xFFFFu) : (mxp >> 16);
+#pragma unroll
+		for (int o = 8; o > 0; o >>= 1) {   // (the row's fullest bin)
+			const u32 y = (u32)__shfl_xor((int)mx, o);
+			mx = mx > y ? mx : y;
+		}
+		{
+			const u32 e = row_incl_scan_dpp(run) - run, bb = e | (e << 16);
+			u32x4 x;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				x[i] = c[i] + bb;
+			((u32x4 *)cell)[l16] = x;
+		}
+		RSX_COMPILER_FENCE();
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const u32 w = kv[j][k >> 1];
+				const bool valid = k < nvalid[j];
+				u32 sh;
+				u32 *a = cell_of(w, k, valid, sh);
+				const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const u32 pos = (old >> sh) & 0xFFFFu;
+				stage[valid ? pos : CAP + 32 + l16] = (uint16_t)((k & 1) ? (w >> 16) : w);
+			}
+		}
+		stage[cnt + l16] = (uint16_t)0xFFFFu;
+		stage[cnt + 16 + l16] = (uint16_t)0xFFFFu;
+		RSX_COMPILER_FENCE();
+		// (the rounds of rsx_leaf16w_kernel; as many as the wave's neediest row wants)
+		const u32 nch = (cnt + 15) >> 4;
+		u32 rounds = mx <= C::MAXBIN ? 1u : ((mx + 6) / 8 + 2) / 2;
+		{
+			u32 y = (u32)__shfl_xor((int)rounds, 16);
+			rounds = rounds > y ? rounds : y;
+			y = (u32)__shfl_xor((int)rounds, 32);
+			rounds = rounds > y ? rounds : y;
+			rounds = (u32)__builtin_amdgcn_readfirstlane((int)rounds);
+		}
+		for (u32 r = 0; r < rounds; ++r) {
+			u32 d[8];
+			{
+				const u32x4 *p = (const u32x4 *)&stage[16 * l16];
+				const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+				const u32x4 x0 = l16 < nch ? p[0] : ones, x1 = l16 < nch ? p[1] : ones;
+				d[0] = x0[0], d[1] = x0[1], d[2] = x0[2], d[3] = x0[3];
+				d[4] = x1[0], d[5] = x1[1], d[6] = x1[2], d[7] = x1[3];
+			}
+			sort16_packed(d);
+			if (l16 == 0)
+				*(u32x4 *)&stage[0] = u32x4{d[0], d[1], d[2], d[3]};   // (the first eight values are in place)
+			u32 lowa[4], nxt[4];
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				lowa[m] = d[4 + m];
+				const u32 y = from_next_lane(d[m]);
+				nxt[m] = l16 == 15 ? ~0u : y;   // (the next lane is another leaf's)
+			}
+			planes_of_two_runs(d, lowa, nxt);
+			merge16_packed(d);
+			if (l16 < nch) {
+				u32x4 *p = (u32x4 *)&stage[16 * l16 + 8];
+				p[0] = u32x4{d[0], d[1], d[2], d[3]};
+				p[1] = u32x4{d[4], d[5], d[6], d[7]};
+			}
+			RSX_COMPILER_FENCE();
+		}
+		{
+			const KT upper = (KT)(above | ((KT)((slot - 1) >> 8) << sh1) | ((KT)((slot - 1) & 255u) << sh2));
+			KT *o = out + beg;
+			for (u32 i0 = 4 * l16; i0 < cnt; i0 += 4 * 16) {
+				const uint2 x = *(const uint2 *)&stage[i0];
+				KT kk[4];
+				kk[0] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.x, 0u, sh2)), ka);
+				kk[1] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.x, 16u, sh2)), ka);
+				kk[2] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.y, 0u, sh2)), ka);
+				kk[3] = kdf_invert((KT)(upper | __builtin_amdgcn_ubfe(x.y, 16u, sh2)), ka);
+				if (i0 + 4 <= cnt) {
+					store_chunk<KT, 4>(o + i0, kk);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 4; ++e)
+						if (i0 + e < cnt)
+							o[i0 + e] = kk[e];
+				}
+			}
+		}
+		RSX_COMPILER_FENCE();
+	}
+}
+
 // ---- leaves of 8-byte keys (keys only): the same placement, the register passes on whole 4- or 8-byte values -----------------
 // BASELINE.json's cfg 3: 2^28 u64 keys keep eight, five or four columns; two MSB passes leave a leaf six, three or two of
 // them (48 / 24 / 16 bits), which rsx_leaf_sort_kernel goes through one LDS pass per column (six columns: the top three and

@@ -90,6 +90,27 @@ def test_level1_slot_overflows_after_the_second_buffer_was_written(digit):
     _sort_and_compare(a, ol.U32, ol.ASC, 0, ("level-1 overflow", hex(digit)))
 
 
+@pytest.mark.parametrize("case", ["clustered low bits", "a wave per leaf", "ragged leaves"])
+def test_u32_1e7_a_row_of_sixteen_lanes_per_leaf(case, monkeypatch):
+    """10^7 keys (radix_bench.cpp:135-138's smaller size): slots of up to 256 values, four leaves per wave (rsx_leaf16q_kernel).
+    Low sixteen bits from 64 x 16 values everywhere and 16 values in some buckets (more rounds, as many as the wave's neediest
+    row wants); RSX_NO_LEAF16Q=1 (rsx_leaf16w_kernel as before); leaves of different sizes next to each other in a wave."""
+    n = 10000000
+    a = ol.splitmix_fill(n, ol.U32, 43, 0xFFFFFFFF).view(np.uint32).copy()
+    if case == "clustered low bits":
+        a &= np.uint32(0xFFFFFC0F)
+        a[((a >> np.uint32(16)) % np.uint32(97)) == 5] &= np.uint32(0xFFFF000F)
+    elif case == "a wave per leaf":
+        monkeypatch.setenv("RSX_NO_LEAF16Q", "1")
+    else:
+        # a fifth of every fourth (digit, digit) bucket moved into its neighbour (a slot holds 1.25 x the mean): leaves of 0.8 and
+        # 1.2 x the mean side by side in a wave
+        d2 = (a >> np.uint32(16)) & np.uint32(3)
+        a[(d2 == 1) & ((a & np.uint32(0xF)) < np.uint32(3))] ^= np.uint32(0x00010000)
+    _sort_and_compare(a, ol.U32, ol.ASC, 5, ("1e7", case))
+    _sort_and_compare(a, ol.I32, ol.DESC, 5, ("1e7 i32 desc", case))
+
+
 def test_u32_mid_size_low_bits_clustered():
     """... with keys whose low sixteen bits take 64 x 16 values everywhere, and only 16 values in some buckets: the wave kernel
     has no list to hand a leaf to -- it goes on (more rounds of register passes) until the leaf is in order."""
