@@ -1193,12 +1193,19 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 		KT *first = (KT *)c.slack1.p;
 		if (second && c.slack1_lo) {
 			sa.lo_slots = c.slack1_lo;
-			KT *const hi = (KT *)c.slack1.p - (size_t)c.slack1_lo * c.slack1_cap;
-			if (blind == 1)
-				sa.kout_hi = hi;
-			else
-				sa.kin_hi = hi;
-			first = second;
+			// (virtual slot 0 of the scratch part: slack1_lo slots before the array)
+			const uintptr_t lo_a = (uintptr_t)second, hi_a = (uintptr_t)c.slack1.p - (size_t)c.slack1_lo * c.slack1_cap * sizeof(KT);
+			if (blind == 1) {
+				// one base for the level-1 pass's stores, the parts' offsets in its run offsets (blind_enqueue has checked
+				// that both lie within 2^32 elements of the lower one)
+				const uintptr_t base_a = std::min(lo_a, hi_a);
+				sa.out_off_lo = (u32)((lo_a - base_a) / sizeof(KT));
+				sa.out_off_hi = (u32)((hi_a - base_a) / sizeof(KT));
+				first = (KT *)base_a;
+			} else {
+				sa.kin_hi = (const void *)hi_a;
+				first = second;
+			}
 		}
 		if (blind == 1)
 			src = first;
@@ -1489,7 +1496,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	// allocates the rest only: 0.25 n keys instead of 1.25 n (2^28 u32 keys: 0.25 GiB + 0.63 GiB of two-byte level-2 slots
 	// instead of 1.25 + 1.25).  Needs a slot that holds a tile (a lost attempt's runs go over the slot's own beginning there,
 	// rsx_scatter2.hpp); RSX_NO_AUX_SLOTS=1: all slots in scratch memory.
-	const u32 lo = (aux && !env().no_aux_slots && cap1 >= (u32)C2::TILE) ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
+	u32 lo = (aux && !env().no_aux_slots && cap1 >= (u32)C2::TILE) ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
 	c.slack_cap = cap2;   // (dense_slots asks for it)
 	const size_t slot2_bytes = dense_slots<KT>(c) ? 2 : sizeof(KT);
 	if (c.slack1.ensure(((size_t)(256 - lo) * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
@@ -1502,6 +1509,23 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 		c.slack1_cap = c.slack_cap = 0;
 		c.blind_no_room = true;
 		return RSX_OK;
+	}
+	if (lo) {
+		// the level-1 pass reaches both parts with 32-bit element offsets from the lower one (rsx_scatter2.hpp, SegArgs): they
+		// must lie within 2^32 elements of each other, the dump area behind the last slot included -- else everything in scratch
+		const uintptr_t lo_a = (uintptr_t)aux, hi_a = (uintptr_t)c.slack1.p - (size_t)lo * cap1 * sizeof(KT);
+		const uintptr_t span = (std::max(lo_a, hi_a) - std::min(lo_a, hi_a)) / sizeof(KT) + (size_t)257 * cap1 + C2::TILE;
+		if (span >= ((uintptr_t)1 << 32)) {
+			lo = 0;
+			if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK) {
+				(void)hipGetLastError();
+				c.slack1.release();
+				c.slack.release();
+				c.slack1_cap = c.slack_cap = 0;
+				c.blind_no_room = true;
+				return RSX_OK;
+			}
+		}
 	}
 	c.slack1_lo = lo;
 	RSX_TRY(seg_layout<KT>(c, n));

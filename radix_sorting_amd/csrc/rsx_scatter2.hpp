@@ -128,10 +128,12 @@ struct SegArgs {
 	u32 slack_cap;
 	u32 *overflow;
 	// The level-1 slots of a keys-only sort without a histogram lie in TWO arrays (rsx.hip, blind_enqueue): slots 0 .. lo_slots-1
-	// in the caller's second buffer (`kout` of the level-1 pass, `kin` of the level-2 pass: proven unsorted, the input leaves that
-	// buffer to the sort), the others in the library's scratch array -- *_hi points lo_slots slots BEFORE that array, so that one
-	// offset serves both.  Null: one array.
-	void *kout_hi;
+	// in the caller's second buffer (proven unsorted, the input leaves that buffer to the sort), the others in the library's
+	// scratch array.  The level-1 pass is given ONE base (`kout`: the lower of the two arrays) and the element offsets of slot 0
+	// of either part from it (out_off_lo for digits below lo_slots, out_off_hi -- of a virtual slot 0, lo_slots slots before the
+	// scratch array -- for the others): they go into the digits' run offsets, so no store knows about it.  (Both within 2^32
+	// elements of the base: the host checks.)  The level-2 pass reads buckets lo_slots .. from kin_hi (same element index).
+	u32 out_off_lo, out_off_hi;
 	const void *kin_hi;
 	u32 lo_slots;
 };
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
                                                                  u32 *ticket, KdfArgs<KT> ka, u32 flags, u64 *tl,
                                                                  const Plan *__restrict__ dplan = nullptr, u32 pass_index = 0,
                                                                  u32 oshift = 0, const u32 *__restrict__ hotd = nullptr,
-                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0},
+                                                                 SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0},
                                                                  const void *__restrict__ kalt = nullptr,
                                                                  SelfPlanArgs sp = SelfPlanArgs{nullptr, nullptr, nullptr, nullptr,
                                                                                                 HybCaps{0, 0, 0, 0}})
@@ -765,9 +767,11 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					running = (u64)((flags & SCATTER_BLIND_TOP) ? 256u : 65536u) * seg.slack_cap;
 					// (slots in the caller's buffer, which has no room behind them: over the slot's own beginning -- a level-1
 					// slot holds more than a tile there, blind_enqueue)
-					if (seg.kout_hi && tid < seg.lo_slots)
+					if ((flags & SCATTER_BLIND_TOP) && tid < seg.lo_slots)
 						running = (u64)tid * seg.slack_cap;
 				}
+				if (flags & SCATTER_BLIND_TOP)   // (SegArgs::out_off_*: which array the digit's slot lies in)
+					running += tid < seg.lo_slots ? seg.out_off_lo : seg.out_off_hi;
 			} else {
 				running = gbase[seg_bucket] + seg.hist[((u64)seg_bucket * seg.slots + seg_slot) * 256 + tid] + excl;
 			}
@@ -920,14 +924,6 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		// consecutive addresses: a lane takes CHUNK consecutive elements and, when they share a digit
 		// (first == last), stores them with one wide store; chunks straddling a run boundary go element-wise.
 		u32 pk[HAS_VAL ? KPT / CHUNK : 1];
-		// (SegArgs::kout_hi: the level-1 slots from lo_slots on lie in another array, hi_bytes from where `kout` would put them)
-		const long long hi_bytes = (SEG && seg.kout_hi) ? (long long)((const char *)seg.kout_hi - (const char *)kout) : 0ll;
-		auto kdst = [&](KTO *q, const u32 dg) -> KTO * {
-			if constexpr (SEG)
-				return (KTO *)((char *)q + (dg >= seg.lo_slots ? hi_bytes : 0ll));
-			else
-				return q;
-		};
 #pragma unroll
 		for (int j = 0; j < KPT / CHUNK; ++j) {
 			if (j % 4 == 0)
@@ -960,20 +956,20 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					for (int e = 0; e < CHUNK; ++e)
 						ov[e] = (KTO)(kdf_apply(kv[e], ka) >> oshift);
 					if (sizeof(KTO) * CHUNK >= 4 && whole && d[0] == d[CHUNK - 1]) {
-						store_chunk<KTO, CHUNK>(kdst(kout + (ST)(delta[d[0]] + i0), d[0]), ov);
+						store_chunk<KTO, CHUNK>(kout + (ST)(delta[d[0]] + i0), ov);
 					} else {
 #pragma unroll
 						for (int e = 0; e < CHUNK; ++e)
 							if (full || i0 + e < cnt)
-								*kdst(kout + (ST)(delta[d[e]] + i0 + e), d[e]) = ov[e];
+								kout[(ST)(delta[d[e]] + i0 + e)] = ov[e];
 					}
 				} else if (sizeof(KT) >= 4 && whole && d[0] == d[CHUNK - 1]) {
-					store_chunk<KT, CHUNK>(kdst(kout + (ST)(delta[d[0]] + i0), d[0]), kv);
+					store_chunk<KT, CHUNK>(kout + (ST)(delta[d[0]] + i0), kv);
 				} else {
 #pragma unroll
 					for (int e = 0; e < CHUNK; ++e)
 						if (full || i0 + e < cnt)
-							*kdst(kout + (ST)(delta[d[e]] + i0 + e), d[e]) = kv[e];
+							kout[(ST)(delta[d[e]] + i0 + e)] = kv[e];
 				}
 			}
 		}

@@ -37,6 +37,11 @@ def timed(name, make, run, bytes_per_key):
     # route that makes fewer trips moves fewer bytes, so that figure over the time is only an "as if by LSD passes" rate
     # and may exceed the peak (round 3's table printed it as if it were traffic).
     route_bytes = (p.hist_bytes + p.scatter_bytes + p.leaf_bytes + p.narrow_bytes) / (K * N)
+    # 8-byte keys on the route without a histogram whose leaves sort the low word only (kept columns 0 .. 4 or fewer): the
+    # DEVICE chooses four-byte level-2 slots (SegCtl::narrow) after the host has booked whole keys for the
+    # level-2 pass's writes and the leaves' reads -- 4 bytes per key less in each
+    if int(info.hybrid) == 5 and name.startswith("cfg3") and info.ncols <= 5 and not os.environ.get("RSX_NO_NARROW_SLOTS"):
+        route_bytes -= 8.0
     row = {"config": name, "ms_per_sort": dt * 1e3, "Gkeys_per_s": N / dt / 1e9, "kept_columns": info.ncols, "route": int(info.hybrid),
            "algorithmic_bytes_per_key": route_bytes, "algorithmic_GBps": N * route_bytes / dt / 1e9,
            "frac_of_8TBps": N * route_bytes / dt / 1e9 / 8000.0,
