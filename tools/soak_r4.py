@@ -1,4 +1,4 @@
-"""Round-4 soak: keys-only sorts of random sizes (9 Mi .. 300 Mi keys, the range the sorts without a histogram cover with a wave /
+"""Round-4 soak: keys-only sorts (and, for 4-byte keys, rank and key + payload sorts: shapes 1x / 2x in the report) of random sizes (9 Mi .. 300 Mi keys, the range the sorts without a histogram cover with a wave /
 a workgroup per leaf) and random shapes of input -- uniform, constant top bits (digits below them), low bits clustered
 everywhere or in some buckets only, constant columns, a few strays -- under RSX_VERIFY=2: the library itself checks every
 result on the device (sorted, the input's key sum and key mix) whatever route the sort took.  Prints sorts per route.
@@ -29,7 +29,7 @@ while time.time() < t_end:
     order = int(rng.integers(0, 2))
     src = torch.empty(n, dtype=tdt, device="cuda")
     aux = torch.empty_like(src)
-    shape = int(rng.integers(0, 7))
+    shape = int(rng.integers(0, 8))
     bits = 8 * src.element_size()
     full = (1 << bits) - 1
     mask = full
@@ -39,6 +39,8 @@ while time.time() < t_end:
         mask = full & ~int(rng.choice([0x0FF0, 0x03F0, 0xF0F0, 0x00FF]))
     elif shape == 3:                     # a constant column somewhere
         mask = full & ~(0xFF << (8 * int(rng.integers(0, bits // 8))))
+    elif shape == 7 and dt == rsa.U64:   # 8-byte keys below 2^40 / 2^32 / 2^44: four-byte level-2 slots where the leaves fit the low word
+        mask = int(rng.choice([0xFFFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFFFFF]))
     rsa.fill_splitmix(src, seed=int(rng.integers(1, 1 << 40)), mask=mask)
     if shape == 1 and rng.random() < 0.5:
         src |= int(rng.integers(0, 1 << 7)) << (bits - 7) if dt != rsa.U64 else 0
@@ -52,8 +54,20 @@ while time.time() < t_end:
         idx = torch.from_numpy(rng.integers(0, n, size=3)).cuda()
         src[idx] = src[idx] | (1 << (bits - 2))
     rsa.reload_env()                      # (no back-off: every sort may try every route)
-    res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)     # RSX_VERIFY=2 raises on a wrong result
+    kind = int(rng.integers(0, 4)) if (dt != rsa.U64 and n <= (200 << 20)) else 0
+    if kind == 1:                        # stable ranks (RSX_VERIFY=2: a permutation through which the keys do not descend, ties in index order)
+        ib = torch.empty(2 * n, dtype=torch.int32, device="cuda")
+        res, info = rsa.radix_sort_rank(src, ib, dtype=dt, order=order)
+        del ib
+    elif kind == 2:                      # key + payload (no descent, the input's key sum and pair mix)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda")
+        vaux = torch.empty_like(vals)
+        res, _, info = rsa.radix_sort_pairs(src, aux, vals, vaux, dtype=dt, order=order)
+        del vals, vaux
+    else:
+        res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)     # RSX_VERIFY=2 raises on a wrong result
     torch.cuda.synchronize()
+    shape = shape + 10 * kind
     routes[int(info.hybrid)] = routes.get(int(info.hybrid), 0) + 1
     shapes[(shape, int(info.hybrid))] = shapes.get((shape, int(info.hybrid)), 0) + 1
     nsorts += 1
