@@ -1432,7 +1432,7 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		// against 0.347 ms, 16 Mi 0.386 against 0.605, 32 Mi 0.58 against 1.18, 64 Mi 0.93 against 2.15; five kept columns: 8 Mi
 		// level, 16 Mi 0.337 against 0.404 (tools/u64_threshold_probe.py, profiles/r04/u64_threshold_probe.txt).
 		// 4-byte keys, round 4 (their leaves read two-byte slots and are one wave's
-		size_t floor_keys = sizeof(KT) == 8 ? (size_t)1 << 23 : (size_t)9 << 20;
+		size_t floor_keys = sizeof(KT) == 8 ? (size_t)1 << 23 : (size_t)15 << 19;
 		if (env().blind_min_log2)
 			floor_keys = (size_t)1 << env().blind_min_log2;
 		floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);
@@ -1459,7 +1459,9 @@ template <typename KT> bool async_blind_ok(Ctx &c, size_t n)
 	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() || c.small.external ||
 	    env().no_speculation)
 		return false;
-	size_t floor_keys = sizeof(KT) == 8 ? (size_t)1 << 23 : (size_t)9 << 20;   // (blind_wanted's floors)
+	// (blind_wanted's floors, except that 4-byte keys start at 9 Mi here: at 8 Mi the empty launches of the gated histogram-first
+	// kernels behind the attempt make it 153 us against 138 for one pass per column; the blocking sort: 127 against 135-139)
+	size_t floor_keys = sizeof(KT) == 8 ? (size_t)1 << 23 : (size_t)9 << 20;
 	if (env().blind_min_log2)
 		floor_keys = (size_t)1 << env().blind_min_log2;
 	floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo
-RSX_VERIFY=2 timeout 900 python tools/soak_r4.py 600 2>&1 | grep -v amdgpu.ids | tail -5 | tee gpurun_out/soak_r4_final.txt
+timeout 1500 python -m pytest tests/test_gpu_hybrid.py tests/test_gpu_parity.py tests/test_gpu_async_routes.py tests/test_gpu_cpp.py -q -k "not rank and not pairs and not report_script" 2>&1 | tail -12
