@@ -128,8 +128,9 @@ def main(out):
         ab = algorithmic_bytes(name)
         if ab is None or avg_ns <= 0:
             continue
-        if avg_ns < 30000:      # (a launch that finds nothing to do -- the list launch behind rsx_leaf16_kernel, the instantiation
-            continue            #  for the other carried type -- moves no bytes: no roofline row)
+        if avg_ns < 30000 or ab / avg_ns > 8000.0:   # (a launch that finds nothing to do -- the list launch behind
+            continue            #  rsx_leaf16_kernel, the instantiation for the other carried type or slot width: 65536 workgroups
+                                #  that return take ~30 us -- moves no bytes: no roofline row, and nothing above the peak)
         key = next((k for k in counters if re.sub(r"\(.*", "", k) == re.sub(r"\(.*", "", name)), None)
         fetch = counters.get(key, {}).get("FETCH_SIZE")
         write = counters.get(key, {}).get("WRITE_SIZE")
