@@ -159,7 +159,7 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * graph (after one uncaptured call of the same size has sized the workspace) and
  * replayed on new contents of d_buf.
  * Round 4: the ROUTE is chosen on the device as well (rsx_async_route reports it): one MSB pass and leaves for mid-size
- * arrays; for large arrays (4-byte keys from 9 Mi keys, 8-byte keys from 8 Mi) the sort without a histogram is
+ * arrays; for large arrays (4-byte keys from 9 Mi keys, 8-byte keys from 4.5 Mi -- 8 Mi here --) the sort without a histogram is
  * enqueued first and the histogram-first kernels behind it do nothing if it went through.  That attempt works in d_scratch
  * (once its sample has proven the input unsorted) and in slots in the (device, stream) workspace: 0.25 n + 0.625 n .. 1.25 n
  * keys of device memory (see "Scratch memory" above); rsx_sort_inplace_async_ws, whose state lies in the caller's

@@ -1057,7 +1057,10 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			typedef LeafKCfg<512, 5120, 6> K8;
 			typedef LeafKCfg<256, 2560, 8, 11> K2;
 			typedef LeafKCfg<128, 1280, 6, 10> K1;
-			if (c.slack_cap <= (u32)K1::CAP)
+			typedef LeafKCfg<64, 256, 8, 9> K0;    // slots of up to 256 keys (arrays of up to ~13 Mi keys): a wave per leaf
+			if (c.slack_cap <= (u32)K0::CAP && !env().no_leaf16q)
+				RSX_LEAFK(K0, K0);
+			else if (c.slack_cap <= (u32)K1::CAP)
 				RSX_LEAFK(K1, K1);
 			else if (c.slack_cap <= (u32)K2::CAP)
 				RSX_LEAFK(K2, K2);
@@ -1423,16 +1426,21 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		// against one pass per column: 16 Mi 0.271 / 0.273 against 0.271 / 0.299, 32 Mi 0.41 / 0.44 against 0.47 / 0.52, 64 Mi
 		// 0.68 / 0.74 against 0.84 / 1.00, 2^27 1.21 / 1.33 (round 3's shape: 1.54 / 1.63)
 		// (tools/rank_threshold_probe.py, profiles/r04/rank_threshold_probe.txt); a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers the floor
+		// With a wave per leaf for slots of up to 256 pairs (LeafKCfg<64, 256, 8, 9>): from 8 Mi pairs -- 8 Mi 0.169 / 0.170 against
+		// 0.176 / 0.177 ms, 10 Mi 0.180 / 0.186 against 0.229 / 0.233, 12 Mi 0.194 / 0.201 against 0.240 / 0.248.
 		if (sizeof(KT) != 4 || payload_bytes != 4 || n > ((size_t)1 << 28) ||
-		    n < std::min((size_t)1 << 24, (size_t)1 << env().two_level_min_log2))
+		    n < std::min((size_t)1 << 23, (size_t)1 << env().two_level_min_log2))
 			return false;
 	} else {
-		// keys only: without the histogram two levels beat one pass per column earlier than with it.  8-byte keys from 8 Mi
+		// keys only: without the histogram two levels beat one pass per column earlier than with it.  8-byte keys from 4.5 Mi
+		// keys on (a wave per leaf for slots of up to 256 keys, LeafKCfg<64, 256, 8, 9>: 5 Mi 204 against 278 us, 7 Mi 219 against
+		// 322, 8 Mi 234 where 128 threads per leaf took 284; five kept columns: 4 Mi 172 against 167, 5 Mi 184 against 207;
+		// one level reaches 3-4 Mi keys: tools/u64_small_probe.py), before that from 8 Mi
 		// keys on since their leaves come in three shapes (launch_leaves; one shape: from 48 Mi) -- uniform keys 8 Mi 0.287
 		// against 0.347 ms, 16 Mi 0.386 against 0.605, 32 Mi 0.58 against 1.18, 64 Mi 0.93 against 2.15; five kept columns: 8 Mi
 		// level, 16 Mi 0.337 against 0.404 (tools/u64_threshold_probe.py, profiles/r04/u64_threshold_probe.txt).
 		// 4-byte keys, round 4 (their leaves read two-byte slots and are one wave's
-		size_t floor_keys = sizeof(KT) == 8 ? (size_t)1 << 23 : (size_t)15 << 19;
+		size_t floor_keys = sizeof(KT) == 8 ? (size_t)9 << 19 : (size_t)15 << 19;
 		if (env().blind_min_log2)
 			floor_keys = (size_t)1 << env().blind_min_log2;
 		floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);
@@ -2125,7 +2133,10 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P>), dim3(env().leaf_grid), dim3(P::BLOCK), 0, c.stream, (const KT *)c.slack.p, \
 	                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab, ctl, ka, redo, \
 	                   (u32)env().leaf16_maxbin)
-			if (cap2 <= (u32)P1::CAP)
+			typedef LeafKCfg<64, 256, 8, 9> P0;    // slots of up to 256 pairs: a wave per leaf
+			if (cap2 <= (u32)P0::CAP && !env().no_leaf16q)
+				RSX_LEAFP(P0);
+			else if (cap2 <= (u32)P1::CAP)
 				RSX_LEAFP(P1);
 			else if (cap2 <= (u32)P2::CAP)
 				RSX_LEAFP(P2);

@@ -175,19 +175,19 @@ def test_u32_low_bits_clustered_everywhere_keeps_the_route_and_changes_the_leave
     _sort_and_compare(a, ol.U32, ol.ASC, 5, "low bits & 0xFC0F")
 
 
-@pytest.mark.parametrize("n_mi,mask", [(9, 0xFFFFFFFFFFFFFFFF), (20, 0xFFFFFFFFFFFFFFFF), (48, 0xFFFFFFFFFFFFFFFF),
+@pytest.mark.parametrize("n_mi,mask", [(5, 0xFFFFFFFFFFFFFFFF), (6, 0xFFFFFFFFFF), (9, 0xFFFFFFFFFFFFFFFF), (20, 0xFFFFFFFFFFFFFFFF), (48, 0xFFFFFFFFFFFFFFFF),
                                        (96, 0xFFFFFFFFFFFFFFFF), (12, 0xFFFFFFFFFF), (48, 0xFFFFFFFFFF), (96, 0xFFFFFFFFFF),
                                        (24, 0xFFFFFFFF), (96, 0xFFFFFFFF)])
 def test_u64_without_histogram(n_mi, mask):
-    """8-byte keys from 8 Mi keys on (leaves in three shapes by the slots' capacity: up to 1280 keys with 1024 bins -- arrays up
-    to 64 Mi --, 2560 with 2048, 5120 with 4096): uniform (six columns per leaf: the top three + odd-even transposition, carried as u64)
+    """8-byte keys from 4.5 Mi keys on (leaves in four shapes by the slots' capacity: a wave per leaf for up to 256 keys -- arrays
+    up to 13 Mi --, up to 1280 keys with 1024 bins -- up to 64 Mi --, 2560 with 2048, 5120 with 4096): uniform (six columns per leaf: the top three + odd-even transposition, carried as u64)
     and with constant top bytes (leaves carried as u32; the constant columns checked on every key by the level-1 pass)."""
     n = n_mi * MI + 4242
     a = ol.splitmix_fill(n, ol.U64, 4500 + n_mi, mask)
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64", n_mi, hex(mask)))
 
 
-@pytest.mark.parametrize("n_mi,maxbin", [(20, "0"), (80, "0"), (20, None)])
+@pytest.mark.parametrize("n_mi,maxbin", [(7, "0"), (20, "0"), (80, "0"), (7, None), (20, None)])
 def test_u64_small_leaves_lists_and_fat_bins(n_mi, maxbin, monkeypatch):
     """The smaller shapes of rsx_leafk_kernel (1280 keys / 1024 bins, 2560 / 2048): every leaf through the list launch
     (RSX_LEAF16_MAXBIN=0), and bins of 10 .. 25 keys (two more register passes) or more (the list) in some buckets only."""
@@ -232,11 +232,11 @@ def test_u64_four_byte_slots(case, monkeypatch):
     _sort_and_compare(r, dt, order, 5, ("u64 four-byte slots", case))
 
 
-@pytest.mark.parametrize("n_mi", [16, 64, 128])
+@pytest.mark.parametrize("n_mi", [9, 16, 64, 128])
 def test_f32_ranks_and_pairs_without_histogram(n_mi):
-    """Rank sorts and key + payload sorts of 4-byte keys take the route from 16 Mi pairs on; the leaves (rsx_leafp_kernel) come
-    in three shapes chosen by the slots' capacity: 1280 pairs and 1024 bins (16 .. 64 Mi pairs), 2560 and 2048 (.. 2^27), 5120
-    and 4096 (2^28: tests/test_gpu_fullsize.py)."""
+    """Rank sorts and key + payload sorts of 4-byte keys take the route from 8 Mi pairs on; the leaves (rsx_leafp_kernel) come
+    in four shapes chosen by the slots' capacity: a wave per leaf for up to 256 pairs (.. 13 Mi pairs), 1280 pairs and 1024 bins
+    (.. 64 Mi), 2560 and 2048 (.. 2^27), 5120 and 4096 (2^28: tests/test_gpu_fullsize.py)."""
     n = n_mi * MI + 99
     a = ol.splitmix_fill(n, ol.F32, 4600 + n_mi, 0xFFFFFFFF)
     want, want_aux, _, _ = ol.oracle_rank(a, ol.F32)          # (the C restatement of rs_sort_rank with Listing 6's loop)
@@ -259,13 +259,14 @@ def test_f32_ranks_and_pairs_without_histogram(n_mi):
     assert np.array_equal(kr.cpu().numpy().view(np.uint32), a.view(np.uint32)[want])
 
 
-@pytest.mark.parametrize("shape", ["every key twice", "every key twice, small leaves", "low byte from 16 values",
-                                   "low byte from 16 values, small leaves", "every leaf through the list"])
+@pytest.mark.parametrize("shape", ["every key twice", "every key twice, small leaves", "every key twice, a wave per leaf",
+                                   "low byte from 16 values", "low byte from 16 values, small leaves",
+                                   "low byte from 16 values, a wave per leaf", "every leaf through the list"])
 def test_f32_ranks_stable_through_the_compound_leaves(shape, monkeypatch):
     """rsx_leafp_kernel sorts (key half, position in the slot) compounds: equal keys must keep their order
     (radix_sort_rank.hpp:82-90).  Every key twice (ties everywhere, the bins even); a low byte with 16 values (ties and fat bins:
     the sample hands every leaf to rsx_leaf_pairs_kernel); RSX_LEAF16_MAXBIN=0 (every leaf through the list launch)."""
-    n = (24 if shape.endswith("small leaves") else 100) * MI + 6
+    n = (24 if shape.endswith("small leaves") else 10 if shape.endswith("a wave per leaf") else 100) * MI + 6
     if shape.startswith("every key twice"):
         half = ol.splitmix_fill(n // 2, ol.F32, 4800, 0xFFFFFFFF)
         a = np.concatenate([half, half])
