@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo
-timeout 2400 python -m pytest tests/test_gpu_routes.py tests/test_gpu_hybrid.py tests/test_gpu_async_routes.py -x -q -k "u64 or rank or pairs" 2>&1 | tail -5
+RSX_VERIFY=2 timeout 600 python tools/soak_r4.py 360 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/soak_r4_final2.txt

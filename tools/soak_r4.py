@@ -1,4 +1,4 @@
-"""Round-4 soak: keys-only sorts (and, for 4-byte keys, rank and key + payload sorts: shapes 1x / 2x in the report) of random sizes (9 Mi .. 300 Mi keys, the range the sorts without a histogram cover with a wave /
+"""Round-4 soak: keys-only sorts (and, for 4-byte keys, rank and key + payload sorts: shapes 1x / 2x in the report) of random sizes (4.5 Mi .. 300 Mi keys, the range the sorts without a histogram cover with a wave /
 a workgroup per leaf) and random shapes of input -- uniform, constant top bits (digits below them), low bits clustered
 everywhere or in some buckets only, constant columns, a few strays -- under RSX_VERIFY=2: the library itself checks every
 result on the device (sorted, the input's key sum and key mix) whatever route the sort took.  Prints sorts per route.
@@ -22,7 +22,7 @@ t_end = time.time() + budget
 routes, shapes = {}, {}
 nsorts = 0
 while time.time() < t_end:
-    n = int(rng.choice([rng.integers(9 << 20, 60 << 20), rng.integers(60 << 20, 160 << 20), rng.integers(160 << 20, 300 << 20)]))
+    n = int(rng.choice([rng.integers(9 << 19, 16 << 20), rng.integers(9 << 20, 60 << 20), rng.integers(60 << 20, 160 << 20), rng.integers(160 << 20, 300 << 20)]))
     dt, tdt = [(rsa.U32, torch.int32), (rsa.I32, torch.int32), (rsa.F32, torch.int32), (rsa.U64, torch.int64)][int(rng.integers(0, 4))]
     if dt == rsa.U64 and n > (200 << 20):
         n //= 2
