@@ -149,7 +149,7 @@ def test_routes_inside_one_captured_graph(n, monkeypatch):
     rsa.release_stream(s)
 
 
-@pytest.mark.parametrize("n", [(1 << 24) + 5, (1 << 26) + 77])
+@pytest.mark.parametrize("n", [(1 << 24) + 5, (1 << 25) + 77])
 def test_ranks_and_pairs_without_histogram_on_the_device(n):
     """rsx_sort_rank_inplace_async and rsx_sort_pairs_inplace_async (4-byte keys, 4-byte indices / payloads, 16 Mi .. 2^28): the
     attempt without a histogram is enqueued first, its leaves write the ranks to the first half of the index buffer / the pairs
@@ -198,7 +198,7 @@ def test_rank_routes_inside_one_captured_graph():
         rsa.radix_sort_rank_inplace_async(bits, ib, dtype=ol.U32, stream=torch.cuda.current_stream())
     base = ol.splitmix_fill(n, ol.U32, 7600, 0xFFFFFFFF).view(np.uint32)
     cases = [("uniform", base, 5), ("top digit dominant", np.where(np.arange(n) % 2 == 0, base & np.uint32(0x00FFFFFF), base).astype(np.uint32), 0),
-             ("uniform again", base[::-1].copy(), 5), ("sorted", np.sort(base), 0), ("uniform, ties", np.concatenate([base[: n // 2]] * 2), 5)]
+             ("sorted", np.sort(base), 0), ("uniform, ties", np.concatenate([base[: n // 2]] * 2), 5)]
     for name, a, want_route in cases:
         a = np.ascontiguousarray(a)
         bits.copy_(to_dev(a))

@@ -232,7 +232,7 @@ def test_u64_four_byte_slots(case, monkeypatch):
     _sort_and_compare(r, dt, order, 5, ("u64 four-byte slots", case))
 
 
-@pytest.mark.parametrize("n_mi", [9, 16, 64, 128])
+@pytest.mark.parametrize("n_mi", [9, 16, 64, 96])
 def test_f32_ranks_and_pairs_without_histogram(n_mi):
     """Rank sorts and key + payload sorts of 4-byte keys take the route from 8 Mi pairs on; the leaves (rsx_leafp_kernel) come
     in four shapes chosen by the slots' capacity: a wave per leaf for up to 256 pairs (.. 13 Mi pairs), 1280 pairs and 1024 bins
@@ -266,7 +266,7 @@ def test_f32_ranks_stable_through_the_compound_leaves(shape, monkeypatch):
     """rsx_leafp_kernel sorts (key half, position in the slot) compounds: equal keys must keep their order
     (radix_sort_rank.hpp:82-90).  Every key twice (ties everywhere, the bins even); a low byte with 16 values (ties and fat bins:
     the sample hands every leaf to rsx_leaf_pairs_kernel); RSX_LEAF16_MAXBIN=0 (every leaf through the list launch)."""
-    n = (24 if shape.endswith("small leaves") else 10 if shape.endswith("a wave per leaf") else 100) * MI + 6
+    n = (24 if shape.endswith("small leaves") else 10 if shape.endswith("a wave per leaf") else 72) * MI + 6
     if shape.startswith("every key twice"):
         half = ol.splitmix_fill(n // 2, ol.F32, 4800, 0xFFFFFFFF)
         a = np.concatenate([half, half])
