@@ -988,6 +988,19 @@ template <typename KT> HybCaps hybrid_caps(size_t n)
 	return caps;
 }
 
+// The capacity of a slot for buckets of `mean` keys: 1.25 times the mean, and at least seven standard deviations of an evenly
+// spread array's bucket sizes above it, rounded up to 256 keys.  (The second term is what small slots need: with 1.25 x alone a
+// mean of 200 keys gets 256-key slots, 3.6 sigma -- evenly spread arrays of 11.5 .. 13 Mi keys overflowed one of their 65536
+// slots in one sort out of seven to nine out of ten and were sorted by one pass per column after a lost attempt.)
+static inline u32 slot_cap_for(u32 mean)
+{
+	u32 r = 0;
+	while ((u64)(r + 1) * (r + 1) <= mean)
+		++r;
+	const u32 need = std::max(mean + mean / 4, mean + 7 * (r + 1) + 8);
+	return ((need + 255) / 256) * 256;
+}
+
 // 8-byte keys: may the sample choose four-byte level-2 slots (SegCtl::narrow)?  Where rsx_leafk_kernel sorts the slots, from
 // slots of 512 keys (arrays of ~13 Mi keys) on: the second form of the level-2 pass and of the leaves are two more launches, which
 // 8 Mi keys notice (0.267 against 0.252 ms; 16 Mi: 0.328 against 0.337, 64 Mi 0.77 against 0.87, 192 Mi 2.06 against 2.29:
@@ -1322,7 +1335,7 @@ int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, cons
 	c.slack_cap = 0;
 	if (!env().no_slack && n >= ((size_t)1 << 26)) {
 		const u32 mean = (u32)(n >> 16);
-		const u32 cap = ((mean + mean / 4 + 255) / 256) * 256;
+		const u32 cap = slot_cap_for(mean);
 		if (cap <= (u32)LeafShapes<KT>::Big::CAP && c.slack.ensure(((size_t)65536 * cap + C2::TILE) * sizeof(KT)) == RSX_OK) {
 			c.slack_cap = cap;
 			RSX_TRY(launch_seg_pass<KT>(c, aux, src, n, ka, -2));
@@ -1494,8 +1507,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	typedef Sc2Cfg<KT, NoVal> C2;
 	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
-	const u32 cap1 = ((mean1 + mean1 / 4 + 255) / 256) * 256;
-	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
+	const u32 cap1 = slot_cap_for(mean1), cap2 = slot_cap_for(mean2);
 	if (cap2 > (u32)LeafShapes<KT>::Big::CAP)
 		return RSX_OK;
 	if (c.blind_no_room)
@@ -1979,7 +1991,7 @@ int pairs_two_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 	c.seg_btile_off = c.seg_tiles_off + rows * sizeof(SegTile);
 	RSX_TRY(c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32)));
 	const u32 mean = (u32)(n >> 16);
-	const u32 cap = ((mean + mean / 4 + 255) / 256) * 256;
+	const u32 cap = slot_cap_for(mean);
 	if (cap > (u32)L::CAP)
 		return RSX_OK;
 	if (c.slack.ensure(((size_t)65536 * cap + C2::TILE) * sizeof(KT)) != RSX_OK ||
@@ -2050,8 +2062,7 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	typedef LeafCfg<u32, 4, 20, 3> L;
 	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
-	const u32 cap1 = ((mean1 + mean1 / 4 + 255) / 256) * 256;
-	const u32 cap2 = ((mean2 + mean2 / 4 + 255) / 256) * 256;
+	const u32 cap1 = slot_cap_for(mean1), cap2 = slot_cap_for(mean2);
 	if (cap2 > (u32)L::CAP)
 		return RSX_OK;
 	if (c.blind_no_room)

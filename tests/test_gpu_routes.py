@@ -49,7 +49,7 @@ def _sort_and_compare(a, dt, order, want_route, what):
     return info
 
 
-# n, what selects: slots of cap = 1.25 n / 65536 rounded up to 256 values; rsx_leaf16_kernel's 2560-value shape (eleven bin
+# n, what selects: slots of cap = 1.25 n / 65536 (small buckets: mean + 7 sigma) rounded up to 256 values; rsx_leaf16_kernel's 2560-value shape (eleven bin
 # bits) up to 128 Mi keys, its 5120-value shape (twelve) above
 @pytest.mark.parametrize("n_mi", [64, 96, 128, 192])
 def test_u32_without_histogram_at_the_sizes_that_pick_each_leaf_shape(n_mi):
@@ -109,6 +109,22 @@ def test_u32_1e7_a_row_of_sixteen_lanes_per_leaf(case, monkeypatch):
         a[(d2 == 1) & ((a & np.uint32(0xF)) < np.uint32(3))] ^= np.uint32(0x00010000)
     _sort_and_compare(a, ol.U32, ol.ASC, 5, ("1e7", case))
     _sort_and_compare(a, ol.I32, ol.DESC, 5, ("1e7 i32 desc", case))
+
+
+@pytest.mark.parametrize("n", [13000000, 13369344, 26738688])
+def test_slots_hold_an_even_array_whatever_its_size(n):
+    """A slot's capacity is 1.25 times the mean bucket AND at least seven standard deviations above it (rsx.hip, slot_cap_for).
+    With 1.25 x alone these sizes -- mean buckets of 198, 204 and 408 keys in slots of 256 / 512 -- lost nearly every attempt
+    (13 Mi keys: 147 of 150) to one overflowing slot of the 65536 and fell back to one pass per column."""
+    src = torch.empty(n, dtype=torch.int32, device="cuda")
+    aux = torch.empty_like(src)
+    for seed in range(12):
+        rsa.fill_splitmix(src, 8800 + seed)
+        rsa.reload_env()
+        res, info = rsa.radix_sort(src, aux, rsa.U32)
+        assert info.hybrid == 5, (n, seed, info.hybrid)
+    got = res.cpu().numpy().view(np.uint32)
+    assert np.all(got[1:] >= got[:-1])
 
 
 def test_u32_mid_size_low_bits_clustered():
