@@ -1071,8 +1071,11 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			typedef LeafKCfg<256, 2560, 8, 11> K2;
 			typedef LeafKCfg<128, 1280, 6, 10> K1;
 			typedef LeafKCfg<64, 256, 8, 9> K0;    // slots of up to 256 keys (arrays of up to ~13 Mi keys): a wave per leaf
+			typedef LeafKCfg<64, 512, 8, 10> K0b;  // ... and of 512 (arrays of 11.5 .. 27 Mi keys)
 			if (c.slack_cap <= (u32)K0::CAP && !env().no_leaf16q)
 				RSX_LEAFK(K0, K0);
+			else if (c.slack_cap <= (u32)K0b::CAP && !env().no_leaf16q)
+				RSX_LEAFK(K0b, K0b);
 			else if (c.slack_cap <= (u32)K1::CAP)
 				RSX_LEAFK(K1, K1);
 			else if (c.slack_cap <= (u32)K2::CAP)
@@ -1439,10 +1442,10 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		// against one pass per column: 16 Mi 0.271 / 0.273 against 0.271 / 0.299, 32 Mi 0.41 / 0.44 against 0.47 / 0.52, 64 Mi
 		// 0.68 / 0.74 against 0.84 / 1.00, 2^27 1.21 / 1.33 (round 3's shape: 1.54 / 1.63)
 		// (tools/rank_threshold_probe.py, profiles/r04/rank_threshold_probe.txt); a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers the floor
-		// With a wave per leaf for slots of up to 256 pairs (LeafKCfg<64, 256, 8, 9>): from 8 Mi pairs -- 8 Mi 0.169 / 0.170 against
+		// With a wave per leaf for slots of up to 256 / 512 pairs (LeafKCfg<64, 256, 8, 9>, <64, 512, 8, 10>): from 4 Mi pairs -- 8 Mi 0.169 / 0.170 against
 		// 0.176 / 0.177 ms, 10 Mi 0.180 / 0.186 against 0.229 / 0.233, 12 Mi 0.194 / 0.201 against 0.240 / 0.248.
 		if (sizeof(KT) != 4 || payload_bytes != 4 || n > ((size_t)1 << 28) ||
-		    n < std::min((size_t)1 << 23, (size_t)1 << env().two_level_min_log2))
+		    n < std::min((size_t)1 << 22, (size_t)1 << env().two_level_min_log2))   // (4 Mi: 140 against 151 us, 6 Mi 148 against 161)
 			return false;
 	} else {
 		// keys only: without the histogram two levels beat one pass per column earlier than with it.  8-byte keys from 4.5 Mi
@@ -2145,8 +2148,11 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab, ctl, ka, redo, \
 	                   (u32)env().leaf16_maxbin)
 			typedef LeafKCfg<64, 256, 8, 9> P0;    // slots of up to 256 pairs: a wave per leaf
+			typedef LeafKCfg<64, 512, 8, 10> P0b;  // ... and of 512 (arrays of 11.5 .. 27 Mi pairs)
 			if (cap2 <= (u32)P0::CAP && !env().no_leaf16q)
 				RSX_LEAFP(P0);
+			else if (cap2 <= (u32)P0b::CAP && !env().no_leaf16q)
+				RSX_LEAFP(P0b);
 			else if (cap2 <= (u32)P1::CAP)
 				RSX_LEAFP(P1);
 			else if (cap2 <= (u32)P2::CAP)

@@ -248,10 +248,10 @@ def test_u64_four_byte_slots(case, monkeypatch):
     _sort_and_compare(r, dt, order, 5, ("u64 four-byte slots", case))
 
 
-@pytest.mark.parametrize("n_mi", [9, 16, 64, 96])
+@pytest.mark.parametrize("n_mi", [5, 9, 16, 64, 96])
 def test_f32_ranks_and_pairs_without_histogram(n_mi):
-    """Rank sorts and key + payload sorts of 4-byte keys take the route from 8 Mi pairs on; the leaves (rsx_leafp_kernel) come
-    in four shapes chosen by the slots' capacity: a wave per leaf for up to 256 pairs (.. 13 Mi pairs), 1280 pairs and 1024 bins
+    """Rank sorts and key + payload sorts of 4-byte keys take the route from 4 Mi pairs on; the leaves (rsx_leafp_kernel) come
+    in five shapes chosen by the slots' capacity: a wave per leaf for up to 256 / 512 pairs (.. 27 Mi pairs), 1280 pairs and 1024 bins
     (.. 64 Mi), 2560 and 2048 (.. 2^27), 5120 and 4096 (2^28: tests/test_gpu_fullsize.py)."""
     n = n_mi * MI + 99
     a = ol.splitmix_fill(n, ol.F32, 4600 + n_mi, 0xFFFFFFFF)
@@ -282,7 +282,7 @@ def test_f32_ranks_stable_through_the_compound_leaves(shape, monkeypatch):
     """rsx_leafp_kernel sorts (key half, position in the slot) compounds: equal keys must keep their order
     (radix_sort_rank.hpp:82-90).  Every key twice (ties everywhere, the bins even); a low byte with 16 values (ties and fat bins:
     the sample hands every leaf to rsx_leaf_pairs_kernel); RSX_LEAF16_MAXBIN=0 (every leaf through the list launch)."""
-    n = (24 if shape.endswith("small leaves") else 10 if shape.endswith("a wave per leaf") else 72) * MI + 6
+    n = (40 if shape.endswith("small leaves") else 10 if shape.endswith("a wave per leaf") else 72) * MI + 6
     if shape.startswith("every key twice"):
         half = ol.splitmix_fill(n // 2, ol.F32, 4800, 0xFFFFFFFF)
         a = np.concatenate([half, half])

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd /root/repo
-RSX_VERIFY=2 timeout 1300 python tools/soak_r4.py 1080 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-700 | tee gpurun_out/soak_r4_final3.txt
+timeout 1500 python -m pytest tests/test_gpu_routes.py -x -q -k "u64 or ranks" 2>&1 | tail -4
+timeout 300 python tools/rank_mid_probe.py 2>&1 | grep -v amdgpu.ids | tail -6
