@@ -1,4 +1,3 @@
 #!/bin/bash
 cd /root/repo
-timeout 1500 python -m pytest tests/test_gpu_routes.py -x -q -k "u64 or ranks" 2>&1 | tail -4
-timeout 300 python tools/rank_mid_probe.py 2>&1 | grep -v amdgpu.ids | tail -6
+timeout 400 python bench.py --force-exchange --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config'].get('workload','')[:120])"
