@@ -1,3 +1,4 @@
 #!/bin/bash
 cd /root/repo
-timeout 400 python bench.py --force-exchange --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config'].get('workload','')[:120])"
+timeout 400 python tools/mid_route_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/mid_route_probe_final.txt | tail -12
+timeout 200 python tools/u64_small_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/u64_small_probe_final.txt | tail -12
