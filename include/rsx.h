@@ -60,6 +60,8 @@
  *   RSX_NO_LEAF16=1         its leaves are round 3's (two LDS passes per slot) instead of rsx_leaf16_kernel / rsx_leafk_kernel;
  *   RSX_NO_AUX_SLOTS=1      level-1 slots all in scratch memory; RSX_NO_NARROW_SLOTS=1: 8-byte keys always in whole-key slots;
  *   RSX_LEAF16_MAXBIN=k     (tests) the fullest bin a leaf may have before it goes to those; RSX_NO_SHIFT=1: MSB digits on bytes only;
+ *   RSX_NO_LEAF16Q=1        slots of up to 256 values take a wave per leaf instead of a row of sixteen lanes;
+ *   RSX_NO_UNSTABLE=1       the MSB passes of a sort without a histogram rank per wave (stable) as every other pass does;
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,
@@ -159,7 +161,8 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * graph (after one uncaptured call of the same size has sized the workspace) and
  * replayed on new contents of d_buf.
  * Round 4: the ROUTE is chosen on the device as well (rsx_async_route reports it): one MSB pass and leaves for mid-size
- * arrays; for large arrays (4-byte keys from 9 Mi keys, 8-byte keys from 4.5 Mi -- 8 Mi here --) the sort without a histogram is
+ * arrays; for large arrays (4-byte keys from 9 Mi keys, 8-byte keys from 8 Mi keys through this entry point; the blocking
+ * rsx_sort_device starts at 7.5 Mi / 4.5 Mi) the sort without a histogram is
  * enqueued first and the histogram-first kernels behind it do nothing if it went through.  That attempt works in d_scratch
  * (once its sample has proven the input unsorted) and in slots in the (device, stream) workspace: 0.25 n + 0.625 n .. 1.25 n
  * keys of device memory (see "Scratch memory" above); rsx_sort_inplace_async_ws, whose state lies in the caller's
@@ -211,7 +214,8 @@ int rsx_verify_poll(void *stream, uint64_t *mismatches);
  * rsx_info.hybrid: 5 = no histogram, two MSB passes into slots and leaves; 1 = one MSB pass and leaves; 0 = histogram and one
  * pass per kept column (also: sorted input, and the one-launch sort of small arrays).  The loop all of them stand for is
  * radix_sort.hpp:82-90.  Replaying a captured graph of such a sort re-decides the route on the device each time; what this
- * reports is the last replay's. */
+ * reports is the last replay's.  The words it reads are the context's: a BLOCKING sort on the same stream between the
+ * device-scheduled sort and this call overwrites them (ask before that sort, or use another stream for it). */
 int rsx_async_route(void *stream, uint32_t *route);
 
 /* rs_sort_main / rs_sort_rank with a caller-supplied Hist (radix_sort.hpp:28-33,
@@ -357,6 +361,13 @@ typedef struct rsx_profile {
 	                            pass kernel, counted apart from scatter_*): n * (key bytes + 2) per launch */
 	uint64_t narrow_launches;
 	uint64_t narrow_bytes;
+	double   called_off_ms;  /* launches that did nothing, or whose output was discarded: the kernels of a sort without a
+	                            histogram that its sample or an overflowing slot called off, leaves enqueued for a route the
+	                            plan did not choose.  Their time is here, their bytes are in none of the byte counts; the
+	                            narrowed level-2 pass and leaves of 8-byte keys are booked with the four-byte slots the device
+	                            chose (blocking sorts: the host knows the verdict; the *_inplace_async sorts never learn it
+	                            and book what they enqueued). */
+	uint64_t called_off_launches;
 } rsx_profile;
 int rsx_profile_begin(void);
 int rsx_profile_end(rsx_profile *out);

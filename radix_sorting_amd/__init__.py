@@ -34,7 +34,8 @@ class Profile(C.Structure):
     _fields_ = [("hist_ms", C.c_double), ("scatter_ms", C.c_double), ("hist_launches", C.c_uint64),
                 ("scatter_launches", C.c_uint64), ("hist_bytes", C.c_uint64), ("scatter_bytes", C.c_uint64),
                 ("leaf_ms", C.c_double), ("leaf_launches", C.c_uint64), ("leaf_bytes", C.c_uint64),
-                ("narrow_ms", C.c_double), ("narrow_launches", C.c_uint64), ("narrow_bytes", C.c_uint64)]
+                ("narrow_ms", C.c_double), ("narrow_launches", C.c_uint64), ("narrow_bytes", C.c_uint64),
+                ("called_off_ms", C.c_double), ("called_off_launches", C.c_uint64)]
 
 
 class Info(C.Structure):

@@ -182,11 +182,36 @@ inline const Env &env()
 	return g_env;
 }
 
+// ---- the *_inplace_async entry points (enqueue only; the stream may be capturing a graph) mark their extent ----------------
+// What the mark changes: a scratch buffer that would have to grow under a capture is an error instead of a hipFree / hipMalloc
+// (DevBuf::ensure), and no slot array is ever released from inside such a call (blind_enqueue, pairs_blind_enqueue): a graph
+// captured earlier on this context may still name it.
+thread_local bool g_in_async = false;
+thread_local hipStream_t g_async_stream = nullptr;
+struct AsyncScope {
+	bool prev;
+	hipStream_t prev_stream;
+	explicit AsyncScope(hipStream_t s) : prev(g_in_async), prev_stream(g_async_stream)
+	{
+		g_in_async = true;
+		g_async_stream = s;
+	}
+	~AsyncScope()
+	{
+		g_in_async = prev;
+		g_async_stream = prev_stream;
+	}
+	AsyncScope(const AsyncScope &) = delete;
+	AsyncScope &operator=(const AsyncScope &) = delete;
+};
+
 // ---- a growable device allocation -------------------------------------------
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
 	bool external = false;   // a slice of a caller-owned workspace (rsx_sort_inplace_async_ws): never grown, never freed
+	// Inside a *_inplace_async entry point (AsyncScope) the stream may be capturing: a buffer never grows under a capture -- the
+	// graph would keep the old address, and hipFree / hipMalloc are not capturable.
 	int ensure(size_t bytes)
 	{
 		if (bytes <= cap)
@@ -194,25 +219,49 @@ struct DevBuf {
 		if (external)
 			return fail(RSX_EINVAL, "the caller's workspace is too small: %zu bytes needed where %zu were set aside "
 			                        "(size it with rsx_workspace_bytes)", bytes, cap);
-		if (p) {
+		if (g_in_async) {
+			hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+			if (hipStreamIsCapturing(g_async_stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+				return fail(RSX_EINVAL, "a scratch buffer would have to grow (%zu -> %zu bytes) while the stream is capturing: run the "
+				                        "sort once outside the capture, or use the *_ws entry points with a workspace of your own",
+				            cap, bytes);
+			(void)hipGetLastError();
+		}
+		// Sizes are rounded up to an eighth of the power of two below them (buffers of 2 MiB and more; smaller ones get an eighth
+		// on top): a sort of slightly more keys than the last one -- the sub-ranges of a distributed sort, a growing table --
+		// finds room instead of paying hipFree + hipMalloc, and hipFree synchronises the device.  At most 12.5 % above the
+		// request (round 4 gave GiB-sized slot arrays no headroom at all and re-allocated on every record size).
+		size_t want = bytes + bytes / 8;
+		if (bytes >= ((size_t)2 << 20)) {
+			size_t p2 = (size_t)1 << 21;
+			while ((p2 << 1) <= bytes)
+				p2 <<= 1;
+			const size_t step = p2 / 8;
+			want = (bytes + step - 1) / step * step;
+		}
+		// The new allocation is made BEFORE the old one goes: if it fails the old buffer (which a graph captured earlier may
+		// still name) stays where it is; only then the old one is given up to make room.
+		void *np = nullptr;
+		hipError_t e = hipMalloc(&np, want);
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			want = bytes;
+			e = hipMalloc(&np, want);
+		}
+		if (e != hipSuccess && p && !g_in_async) {
+			(void)hipGetLastError();
 			(void)hipFree(p);
 			p = nullptr;
 			cap = 0;
-		}
-		// grow geometrically-ish so repeated slightly larger sorts do not thrash (small buffers only: an eighth of a GiB-sized
-		// slot array is memory the caller may need)
-		size_t want = bytes + (bytes < ((size_t)64 << 20) ? bytes / 8 : 0);
-		hipError_t e = hipMalloc(&p, want);
-		if (e != hipSuccess) {
-			(void)hipGetLastError();
-			e = hipMalloc(&p, bytes);
-			want = bytes;
+			e = hipMalloc(&np, want);
 		}
 		if (e != hipSuccess) {
 			(void)hipGetLastError();
-			p = nullptr;
 			return fail(RSX_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
 		}
+		if (p)
+			(void)hipFree(p);
+		p = np;
 		cap = want;
 		return RSX_OK;
 	}
@@ -254,6 +303,7 @@ struct Ctx {
 	// kernels enqueued behind it that there is nothing left to do
 	const SegCtl *pass_gate = nullptr;
 	bool async_tried_blind = false;   // ... whether the last rsx_sort_inplace_async of this context enqueued such an attempt
+	bool async_small = false;         // ... or was the one-launch sort of a small array (rsx_async_route: 0, whatever the device's words say)
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
 	DevBuf vsum;        // RSX_VERIFY=2: [descents, sum, mix] of the input and of the result
 	DevBuf vasync;      // RSX_VERIFY: mismatches found in device-scheduled passes, kept until rsx_verify_poll / the next blocking sort
@@ -404,13 +454,51 @@ struct HostRegScope {
 
 // ---- optional HIP-event bracketing of the kernels (rsx_profile_begin/end) ------
 struct ProfRec {
-	int kind;   // 0 histogram, 1 scatter, 2 leaves (rsx_hybrid.hpp)
+	int kind;   // 0 histogram, 1 scatter, 2 leaves (rsx_hybrid.hpp), 3 passes that write narrowed keys into slots
 	hipEvent_t start, stop;
 	u64 bytes;
+	hipStream_t stream;
+	bool called_off;   // launches of an attempt the device called off (or of a route the plan did not choose): they returned at
+	                   // once or their output was discarded -- their time is booked apart, their bytes are not booked at all
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
+
+// What a sort books is what the DEVICE chose.  Kernels are enqueued before the host knows the route (a sort without a histogram
+// may be called off by its sample; leaves are launched in every shape the plan may ask for); once the host has the verdict it
+// takes the records of the launches that did nothing out of the byte count (prof_called_off) or corrects their bytes
+// (prof_rebook: 8-byte keys whose level-2 slots the sample narrowed to four bytes).  prof_mark() = where this call's records start.
+size_t prof_mark()
+{
+	if (!g_prof_on)
+		return 0;
+	std::lock_guard<std::mutex> lock(g_prof_mu);
+	return g_prof.size();
+}
+void prof_called_off(size_t mark, hipStream_t s, int kind = -1)
+{
+	if (!g_prof_on)
+		return;
+	std::lock_guard<std::mutex> lock(g_prof_mu);
+	for (size_t i = mark; i < g_prof.size(); ++i)
+		if (g_prof[i].stream == s && (kind < 0 || g_prof[i].kind == kind))
+			g_prof[i].called_off = true;
+}
+// (the LAST record of `kind` since the mark: a sort's level-1 and level-2 passes are both kind 1, in that order)
+void prof_rebook(size_t mark, hipStream_t s, int kind, u64 bytes, int new_kind = -1)
+{
+	if (!g_prof_on)
+		return;
+	std::lock_guard<std::mutex> lock(g_prof_mu);
+	for (size_t i = g_prof.size(); i > mark; --i)
+		if (g_prof[i - 1].stream == s && g_prof[i - 1].kind == kind && !g_prof[i - 1].called_off) {
+			g_prof[i - 1].bytes = bytes;
+			if (new_kind >= 0)
+				g_prof[i - 1].kind = new_kind;
+			break;
+		}
+}
 
 struct ProfScope {
 	bool on;
@@ -422,6 +510,8 @@ struct ProfScope {
 			return;
 		rec.kind = kind;
 		rec.bytes = bytes;
+		rec.stream = s;
+		rec.called_off = false;
 		if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) {
 			on = false;
 			return;
@@ -1455,7 +1545,8 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		// keys on since their leaves come in three shapes (launch_leaves; one shape: from 48 Mi) -- uniform keys 8 Mi 0.287
 		// against 0.347 ms, 16 Mi 0.386 against 0.605, 32 Mi 0.58 against 1.18, 64 Mi 0.93 against 2.15; five kept columns: 8 Mi
 		// level, 16 Mi 0.337 against 0.404 (tools/u64_threshold_probe.py, profiles/r04/u64_threshold_probe.txt).
-		// 4-byte keys, round 4 (their leaves read two-byte slots and are one wave's
+		// 4-byte keys, round 4 (their leaves read two-byte slots and are one wave's -- or a row of sixteen lanes' -- work up to
+		// 1024 values, rsx_leaf16w_kernel / rsx_leaf16q_kernel): from 7.5 Mi keys (8 Mi 128 against 137 us, tools/size_sweep.py)
 		size_t floor_keys = sizeof(KT) == 8 ? (size_t)9 << 19 : (size_t)15 << 19;
 		if (env().blind_min_log2)
 			floor_keys = (size_t)1 << env().blind_min_log2;
@@ -1527,12 +1618,15 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	if (c.slack1.ensure(((size_t)(256 - lo) * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * slot2_bytes) != RSX_OK) {
 		// no room for the slots: the ordinary path, now and for this context's later sorts (a multi-GiB hipMalloc that fails
-		// is not worth repeating per sort); what was allocated of the pair goes back
+		// is not worth repeating per sort); what was allocated of the pair goes back -- unless this is a device-scheduled sort
+		// (AsyncScope): a graph captured earlier may name the old arrays, so nothing is released and nothing is remembered
 		(void)hipGetLastError();
-		c.slack1.release();
-		c.slack.release();
 		c.slack1_cap = c.slack_cap = 0;
-		c.blind_no_room = true;
+		if (!g_in_async) {
+			c.slack1.release();
+			c.slack.release();
+			c.blind_no_room = true;
+		}
 		return RSX_OK;
 	}
 	if (lo) {
@@ -1544,10 +1638,12 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 			lo = 0;
 			if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK) {
 				(void)hipGetLastError();
-				c.slack1.release();
-				c.slack.release();
 				c.slack1_cap = c.slack_cap = 0;
-				c.blind_no_room = true;
+				if (!g_in_async) {
+					c.slack1.release();
+					c.slack.release();
+					c.blind_no_room = true;
+				}
 				return RSX_OK;
 			}
 		}
@@ -1601,6 +1697,7 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 {
 	*done = 0;
 	int enqueued = 0;
+	const size_t pmark = prof_mark();
 	RSX_TRY(blind_enqueue<KT>(c, src, aux, n, ka, &enqueued));
 	if (!enqueued)
 		return RSX_OK;
@@ -1608,9 +1705,15 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
 		blind_called_off(c, blind_kind<KT>(0));
 		c.slack_cap = 0;
+		prof_called_off(pmark, c.stream);
 		return RSX_OK;
 	}
 	c.blind_backoff[blind_kind<KT>(0)] = 0;
+	if (sizeof(KT) == 8 && c.host_segctl->narrow) {
+		// the sample chose four-byte level-2 slots (SegCtl::narrow): the level-2 pass wrote 4 bytes per key, the leaves read 4
+		prof_rebook(pmark, c.stream, 2, (u64)n * (4 + sizeof(KT)));
+		prof_rebook(pmark, c.stream, 1, (u64)n * (sizeof(KT) + 4), 3);   // (the whole-key form of the level-2 pass returned at once)
+	}
 	const Plan plan = *c.host_plan;
 	info_from_plan(info, plan);
 	KT *final = (plan.ncols & 1) ? aux : src;   // radix_sort.hpp:92
@@ -1770,6 +1873,7 @@ int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int ord
 	};
 	u32 spec_leaves = 0;
 	bool self_planned = false;
+	const size_t pmark = prof_mark();
 	if (spec) {
 		// (the device may choose one MSB pass and leaves, rsx_hybrid.hpp: pass 0 then goes by the highest kept column)
 		const HybCaps caps = capture_armed() ? HybCaps{0, 0, 0, 0} : hybrid_caps<KT>(n);
@@ -1806,6 +1910,11 @@ int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int ord
 	}
 	info_from_plan(info, plan);
 	RSX_TRY(capture_hist(c, n, sizeof(KT)));
+	// (the profile books what the device chose: leaves enqueued for a plan that did not come, a pass 0 that found the input sorted)
+	if (spec_leaves && (plan.sorted || plan.hyb != HYB_ONE_LEVEL))
+		prof_called_off(pmark, c.stream, 2);
+	if (spec && plan.sorted)
+		prof_called_off(pmark, c.stream, 1);
 	if (plan.sorted) {                       // radix_sort.hpp:60-62
 		if (info) {
 			info->early_exit = 2;
@@ -1870,10 +1979,13 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 {
 	if (!c.fast)
 		return fail(RSX_EHIP, "rsx_sort_inplace_async needs the fast scatter kernel (the device self-check failed on this device)");
+	c.async_tried_blind = false;   // (rsx_async_route reports THIS call: set again below if an attempt is enqueued)
+	c.async_small = false;
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	if (n * sizeof(KT) <= SMALL_SORT_BYTES) {
 		hipLaunchKernelGGL((rsx_small_sort_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, buf, scratch, (u32)n, ka, c.dev_host_plan, true);
 		HIP_TRY(hipGetLastError());
+		c.async_small = true;
 		return RSX_OK;
 	}
 	const size_t status_total = status_bytes<KT, NoVal>(n) * sizeof(KT);
@@ -1927,11 +2039,14 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 {
 	if (!c.fast)
 		return fail(RSX_EHIP, "rsx_sort_pairs_inplace_async needs the fast scatter kernel (the device self-check failed on this device)");
+	c.async_tried_blind = false;   // (rsx_async_route reports THIS call: set again below if an attempt is enqueued)
+	c.async_small = false;
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	if (n * 2 * (sizeof(KT) + sizeof(VT)) <= SMALL_PAIR_BYTES) {
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, VT, false>), dim3(1), dim3(1024), 0, c.stream, (const KT *)k, ks, v, vs, (u32)n,
 		                   ka, c.dev_host_plan, true);
 		HIP_TRY(hipGetLastError());
+		c.async_small = true;
 		return RSX_OK;
 	}
 	const size_t status_total = status_bytes<KT, VT>(n) * sizeof(KT);
@@ -2075,12 +2190,14 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack_v.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(VT)) != RSX_OK) {
 		(void)hipGetLastError();   // (no room: as blind_enqueue -- what was allocated goes back, nobody asks again)
-		c.slack1.release();
-		c.slack1_v.release();
-		c.slack.release();
-		c.slack_v.release();
 		c.slack1_cap = c.slack_cap = 0;
-		c.blind_no_room = true;
+		if (!g_in_async) {
+			c.slack1.release();
+			c.slack1_v.release();
+			c.slack.release();
+			c.slack_v.release();
+			c.blind_no_room = true;
+		}
 		return RSX_OK;
 	}
 	RSX_TRY(seg_layout<KT>(c, n));   // (Sc2Cfg<KT, NoVal> and <KT, VT> have the same tile: 32 Ki elements)
@@ -2181,12 +2298,14 @@ int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, si
 {
 	*done = 0;
 	int enqueued = 0;
+	const size_t pmark = prof_mark();
 	RSX_TRY((pairs_blind_enqueue<KT, VT>(c, kin, vin, kfinal, vfinal, n, ka, &enqueued)));
 	if (!enqueued)
 		return RSX_OK;
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
 	if (c.host_segctl->mode != SEG_MODE_LEAVES) {
 		blind_called_off(c, blind_kind<KT>(sizeof(VT), vin == nullptr));   // (no payloads given: a rank sort)
+		prof_called_off(pmark, c.stream);
 		return RSX_OK;
 	}
 	c.blind_backoff[blind_kind<KT>(sizeof(VT), vin == nullptr)] = 0;
@@ -2597,11 +2716,14 @@ int sort_rank_inplace_async(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, 
 {
 	if (!c.fast)
 		return fail(RSX_EHIP, "rsx_sort_rank_inplace_async needs the fast scatter kernel (the device self-check failed on this device)");
+	c.async_tried_blind = false;   // (rsx_async_route reports THIS call: set again below if an attempt is enqueued)
+	c.async_small = false;
 	const KdfArgs<KT> ka = make_kdf<KT>(dtype, order);
 	if (n * 2 * (sizeof(KT) + sizeof(IT)) <= SMALL_PAIR_BYTES) {
 		hipLaunchKernelGGL((rsx_small_pairs_kernel<KT, IT, true>), dim3(1), dim3(1024), 0, c.stream, src, (KT *)nullptr, ib, ib + n,
 		                   (u32)n, ka, c.dev_host_plan, true);
 		HIP_TRY(hipGetLastError());
+		c.async_small = true;
 		return RSX_OK;
 	}
 	RSX_TRY(c.keys[0].ensure(n * sizeof(KT)));
@@ -2814,6 +2936,7 @@ int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dty
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	AsyncScope async_scope((hipStream_t)stream);
 	RSX_DISPATCH_KT(dtype, return sort_keys_inplace_async<KT>(*c, (KT *)d_buf, (KT *)d_scratch, n, dtype, order));
 	return RSX_OK;
 }
@@ -2898,6 +3021,7 @@ int rsx_sort_pairs_inplace_async(void *d_keys, void *d_keys_scratch, void *d_val
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	AsyncScope async_scope((hipStream_t)stream);
 	if (payload_bytes == 4) {
 		RSX_DISPATCH_KT(dtype, return (sort_pairs_inplace_async<KT, u32>(*c, (KT *)d_keys, (KT *)d_keys_scratch, (u32 *)d_vals,
 		                                                                 (u32 *)d_vals_scratch, n, dtype, order)));
@@ -2964,6 +3088,7 @@ int rsx_sort_rank_inplace_async(const void *d_src, void *d_index_buffer, size_t 
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	AsyncScope async_scope((hipStream_t)stream);
 	if (n == 1) {
 		HIP_TRY(hipMemsetAsync(d_index_buffer, 0, idx_bytes, c->stream));
 		return RSX_OK;
@@ -3007,6 +3132,8 @@ int rsx_async_route(void *stream, uint32_t *route)
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (c->async_small)
+		return RSX_OK;   // (the one-launch sort writes no device-side plan: what lies there is an earlier sort's)
 	Plan plan;
 	HIP_TRY(hipMemcpy(&plan, c->plan(), sizeof(plan), hipMemcpyDeviceToHost));
 	if (c->async_tried_blind && c->seg.p) {
@@ -3276,6 +3403,7 @@ int rsx_msd_split_async(const void *d_src, void *d_dst, size_t n, rsx_dtype dtyp
 	Ctx *c;
 	RSX_TRY(get_ctx(stream, &c));
 	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	AsyncScope async_scope((hipStream_t)stream);
 	HIP_TRY(hipMemsetAsync(c->small_set(), 0, 256, c->stream));
 	RSX_DISPATCH_KT(dtype, return msd_split_known<KT>(*c, (const KT *)d_src, (KT *)d_dst, n, dtype, order, col, (const u64 *)d_hist, hot));
 	return RSX_OK;
@@ -3312,7 +3440,10 @@ int rsx_profile_end(rsx_profile *out)
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(r.stop));
 		HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
-		if (r.kind == 0) {
+		if (r.called_off) {
+			out->called_off_ms += ms;
+			out->called_off_launches += 1;
+		} else if (r.kind == 0) {
 			out->hist_ms += ms;
 			out->hist_launches += 1;
 			out->hist_bytes += r.bytes;

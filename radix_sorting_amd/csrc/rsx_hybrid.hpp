@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 			host_ctl->maxleaf = slack_cap;
 			host_ctl->nleaf = 65536;
 			host_ctl->overflow = ctl->overflow;
+			host_ctl->narrow = ctl->narrow;
 			host_ctl->mode = mode;
 		}
 	}

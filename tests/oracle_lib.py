@@ -200,3 +200,68 @@ def kdf_keys(bits, dtype, order=ASC):
 
 def stable_argsort_by_kdf(bits, dtype, order=ASC):
     return np.argsort(kdf_keys(bits, dtype, order), kind="stable")
+
+
+def oracle_rank_by_records(bits, dtype, order=ASC):
+    """The stable ranks of rs_sort_rank (radix_sort_rank.hpp:22-92, Listing-6 semantics) for 4-byte keys, computed the way
+    SURVEY.md 8d pins cfg 4: the C restatement of radix_sort on {key, u32 index} RECORDS (rso_sort_records: sequential moves,
+    no gather through the index -- ten times faster than rso_sort_rank at 10^8 keys, which is what lets the GPU suite compare
+    whole rank arrays at production sizes).  Same kept columns, so the same half of the index buffer (radix_sort_rank.hpp:91
+    = radix_sort.hpp:92); tests/test_oracle.py pins it against rso_sort_rank and the real reference.
+    Returns (ranks uint32[n], result_in_second_half, info)."""
+    assert DTYPE_SIZE[dtype] == 4
+    src = np.ascontiguousarray(bits, dtype=NP_BITS[dtype])
+    n = src.size
+    recs = np.empty((n, 2), dtype=np.uint32)
+    recs[:, 0] = src.view(np.uint32)
+    recs[:, 1] = np.arange(n, dtype=np.uint32)
+    aux = np.empty_like(recs)
+    info = Info()
+    r = oracle().rso_sort_records(ptr(recs), ptr(aux), n, 8, 0, dtype, order, C.byref(info))
+    assert r in (0, 1)
+    out = aux if r else recs
+    return np.ascontiguousarray(out[:, 1]), r, info
+
+
+def ranks_by_compound_sort(bits, dtype, order=ASC):
+    """Stable ranks of 4-byte keys as np.sort of the 64-bit compounds (KDF key << 32 | index): the order rs_sort_rank's stable
+    passes produce (radix_sort_rank.hpp:82-90) written down directly -- every compound is
+    different, so any correct sort gives it.  NOT the restatement: it stands in for rso_sort_rank where that needs most of a
+    minute per case (10^8 keys and more; the C loop gathers src[idx[j]] in every pass), and tests/test_oracle.py pins the two
+    against each other (and both against the reference's record sort) at the sizes the C loop finishes in seconds.
+    Returns (ranks uint32[n], result_in_second_half) -- the half by the parity of the kept columns (radix_sort_rank.hpp:91)."""
+    assert DTYPE_SIZE[dtype] == 4
+    u = np.ascontiguousarray(bits).view(np.uint32)
+    n = u.size
+    if dtype == F32:
+        m = (u >> np.uint32(31)) * np.uint32(0x7FFFFFFF)
+        m |= np.uint32(0x80000000)
+        k = u ^ m
+    elif dtype == I32:
+        k = u ^ np.uint32(0x80000000)
+    else:
+        k = u.copy()
+    if order == DESC:
+        np.invert(k, out=k)
+    kept = 0
+    if n:
+        diff = np.bitwise_or.reduce(k ^ k[0])
+        kept = sum(1 for j in range(4) if (int(diff) >> (8 * j)) & 0xFF)
+    presorted = n < 2 or bool(np.all(k[1:] >= k[:-1]))
+    c = k.astype(np.uint64)
+    c <<= np.uint64(32)
+    c |= np.arange(n, dtype=np.uint64)
+    c.sort()
+    c &= np.uint64(0xFFFFFFFF)
+    return c.astype(np.uint32), (0 if presorted else kept & 1)
+
+
+def want_ranks(bits, dtype, order=ASC, big=1 << 24):
+    """(ranks, result_in_second_half) of a rank sort of 4-byte keys for the GPU suite: the C restatement (rso_sort_rank) up to
+    `big` keys, ranks_by_compound_sort above (pinned against it in tests/test_oracle.py) -- the C loop's gathers cost a minute
+    per 10^8 keys, and the suite has ten minutes."""
+    n = np.asarray(bits).size
+    if n <= big:
+        r, in_aux, _, _ = oracle_rank(bits, dtype, 4, order)
+        return r.copy(), in_aux
+    return ranks_by_compound_sort(bits, dtype, order)

@@ -114,7 +114,7 @@ def test_radix_cli_device_flag(tmp_path):
 def test_report_script(tmp_path):
     """tools/report.sh, the counterpart of the reference's bench.sh:6-18: uname, git revision, lscpu, the GPU, four `radix`
     runs on the whole key file and `radix_bench --device --verify`, written to bench-<date>.txt."""
-    out = subprocess.run(["sh", os.path.join(ROOT, "tools", "report.sh"), "0"], capture_output=True, text=True, timeout=1800, cwd=tmp_path)
+    out = subprocess.run(["sh", os.path.join(ROOT, "tools", "report.sh"), "0", "--min-time", "0.05"], capture_output=True, text=True, timeout=1800, cwd=tmp_path)
     assert out.returncode == 0, out.stdout + out.stderr
     name = out.stdout.strip().splitlines()[-1]
     text = open(os.path.join(str(tmp_path), name)).read()

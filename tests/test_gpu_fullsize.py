@@ -57,7 +57,9 @@ def test_cfg3_u64_column_skipping(mask, cols, in_aux):
     assert info.hybrid == 5, info.hybrid                                # no histogram, two MSB passes into slots, leaves
     assert _sorted_unsigned64(res)
     assert _checksums(res) == before
-    if cols == 5:   # one case bit for bit against the oracle (about half a minute of host time)
+    if cols in (5, 8):
+        # bit for bit against the oracle: P = 5 (four-byte level-2 slots, rsx_leafk_kernel's SLOT32 form) and P = 8 (whole-key slots,
+        # the 5120-key leaves carried as u64: the shape only arrays above 2^27 keys select) -- seconds of host time on the GPU box
         a = ol.splitmix_fill(N, ol.U64, 3, mask)
         want, want_aux, _ = ol.oracle_sort(a, ol.U64)
         assert want_aux == in_aux
@@ -106,6 +108,13 @@ def test_cfg4_f32_keys_u32_ranks(variant):
     assert torch.equal(bits, keep)                                       # src is const (radix_sort_rank.hpp:97)
     assert info.hybrid == RANK_ROUTE[variant], (variant, info.hybrid)
     assert info.result_in_aux == (info.ncols & 1)                        # radix_sort_rank.hpp:88,:91
+    if variant == "random_bits":
+        # the whole rank array against the host's (oracle_lib.ranks_by_compound_sort, pinned against the C restatement of
+        # rs_sort_rank in tests/test_oracle.py): the 5120-pair compound leaves at the only size that selects them
+        want, want_aux = ol.ranks_by_compound_sort(ol.splitmix_fill(N, ol.F32, 6, 0xFFFFFFFF), ol.F32)
+        assert want_aux == info.result_in_aux
+        assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)
+        del want
     r64 = ranks.to(torch.int64)
     # a permutation: every index once
     seen = torch.zeros(N, dtype=torch.int8, device="cuda")
@@ -121,6 +130,21 @@ def test_cfg4_f32_keys_u32_ranks(variant):
     assert bool((r64[1:][same] > r64[:-1][same]).all().item())
     if variant == "duplicate_heavy":
         assert int(same.sum().item()) > N // 2
+
+
+def test_cfg4_pairs_random_bits_against_the_host():
+    """Key + payload sort of 2^28 random bit patterns (route 5: rsx_leafp_kernel's 5120-pair shape writes keys AND payloads):
+    payloads = indices must come out as the host's stable ranks, the keys as the input gathered through them."""
+    a = ol.splitmix_fill(N, ol.F32, 6, 0xFFFFFFFF)
+    want, _ = ol.ranks_by_compound_sort(a, ol.F32)
+    keys = torch.from_numpy(a.view(np.int32)).cuda()
+    vals = torch.arange(N, dtype=torch.int32, device="cuda")
+    ka, va = torch.empty_like(keys), torch.empty_like(vals)
+    kr, vr, info = rsa.radix_sort_pairs(keys, ka, vals, va, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert info.hybrid == 5, info.hybrid
+    assert np.array_equal(vr.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(kr.cpu().numpy().view(np.uint32), a.view(np.uint32)[want])
 
 
 def test_cfg4_pairs_f32_u32_payload():

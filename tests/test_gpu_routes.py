@@ -150,7 +150,7 @@ def test_u32_constant_top_bits_at_production_sizes(n_mi, mask, base):
 
 
 @pytest.mark.parametrize("switch", ["RSX_NO_LEAF16", "RSX_NO_DENSE_SLOTS"])
-@pytest.mark.parametrize("n_mi", [64, 96, 128, 192])
+@pytest.mark.parametrize("n_mi", [96, 192])     # (fallback kernels since round 4: two of their four cut shapes are enough here)
 def test_u32_round3_leaves_at_the_same_sizes(n_mi, switch, monkeypatch):
     """The leaves of round 3 stay in the library (rsx_leaf_sort_kernel works off what rsx_leaf16_kernel leaves alone, and takes
     everything when the sample finds the low sixteen bits clustered): its cut shapes (2048, 3072, 5120, 8 Ki keys) on two-byte
@@ -192,7 +192,7 @@ def test_u32_low_bits_clustered_everywhere_keeps_the_route_and_changes_the_leave
 
 
 @pytest.mark.parametrize("n_mi,mask", [(5, 0xFFFFFFFFFFFFFFFF), (6, 0xFFFFFFFFFF), (9, 0xFFFFFFFFFFFFFFFF), (20, 0xFFFFFFFFFFFFFFFF), (48, 0xFFFFFFFFFFFFFFFF),
-                                       (96, 0xFFFFFFFFFFFFFFFF), (12, 0xFFFFFFFFFF), (48, 0xFFFFFFFFFF), (96, 0xFFFFFFFFFF),
+                                       (96, 0xFFFFFFFFFFFFFFFF), (160, 0xFFFFFFFFFFFFFFFF), (12, 0xFFFFFFFFFF), (48, 0xFFFFFFFFFF), (96, 0xFFFFFFFFFF),
                                        (24, 0xFFFFFFFF), (96, 0xFFFFFFFF)])
 def test_u64_without_histogram(n_mi, mask):
     """8-byte keys from 4.5 Mi keys on (leaves in four shapes by the slots' capacity: a wave per leaf for up to 256 keys -- arrays
@@ -248,15 +248,16 @@ def test_u64_four_byte_slots(case, monkeypatch):
     _sort_and_compare(r, dt, order, 5, ("u64 four-byte slots", case))
 
 
-@pytest.mark.parametrize("n_mi", [5, 9, 16, 64, 96])
+@pytest.mark.parametrize("n_mi", [5, 9, 16, 64, 160])
 def test_f32_ranks_and_pairs_without_histogram(n_mi):
     """Rank sorts and key + payload sorts of 4-byte keys take the route from 4 Mi pairs on; the leaves (rsx_leafp_kernel) come
     in five shapes chosen by the slots' capacity: a wave per leaf for up to 256 / 512 pairs (.. 27 Mi pairs), 1280 pairs and 1024 bins
-    (.. 64 Mi), 2560 and 2048 (.. 2^27), 5120 and 4096 (2^28: tests/test_gpu_fullsize.py)."""
+    (.. 64 Mi), 2560 and 2048 (.. 2^27), 5120 and 4096 (160 Mi here; 2^28: tests/test_gpu_fullsize.py)."""
     n = n_mi * MI + 99
     a = ol.splitmix_fill(n, ol.F32, 4600 + n_mi, 0xFFFFFFFF)
-    want, want_aux, _, _ = ol.oracle_rank(a, ol.F32)          # (the C restatement of rs_sort_rank with Listing 6's loop)
-    want = want.copy()
+    # up to 16 Mi keys the C restatement of rs_sort_rank with Listing 6's loop; above, the same ranks as sorted (key, index)
+    # compounds (oracle_lib.want_ranks: pinned against each other in tests/test_oracle.py)
+    want, want_aux = ol.want_ranks(a, ol.F32)
     bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
     ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
     ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
@@ -291,8 +292,7 @@ def test_f32_ranks_stable_through_the_compound_leaves(shape, monkeypatch):
     else:
         monkeypatch.setenv("RSX_LEAF16_MAXBIN", "0")
         a = ol.splitmix_fill(n, ol.F32, 4802, 0xFFFFFFFF)
-    want, want_aux, _, _ = ol.oracle_rank(a, ol.F32)
-    want = want.copy()
+    want, want_aux = ol.want_ranks(a, ol.F32, big=1 << 23)
     bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
     ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
     ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
