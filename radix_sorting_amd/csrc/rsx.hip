@@ -12,6 +12,7 @@
 #include "rsx_small.hpp"
 #include "rsx_hybrid.hpp"
 #include "rsx_leaf16.hpp"
+#include "rsx_pass16.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -115,6 +116,9 @@ struct Env {
 	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: (kept for old scripts: two-byte slots are now written for every slot size rsx_leaf16_kernel takes)
 	bool no_unstable = false;        // RSX_NO_UNSTABLE=1: the MSB passes of a sort without a histogram rank per wave (stable), as every other pass
 	bool no_shift = false;           // RSX_NO_SHIFT=1: the MSB digits of a sort without a histogram are whole bytes (the two highest kept columns) always
+	bool no_pass16 = false;          // RSX_NO_PASS16=1: the level-2 pass into two-byte slots is rsx_scatter2_kernel<..., KTO = u16, SEG> as in round 4 (rsx_pass16.hpp)
+	unsigned pass16_wgs = 2;         // RSX_PASS16_WGS=1: ... one workgroup per CU (probe)
+	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
 	bool no_leaf16 = false;          // RSX_NO_LEAF16=1: two-byte slots are sorted by rsx_leaf_sort_kernel (two LDS passes) as in round 3
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
@@ -158,6 +162,13 @@ struct Env {
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
+		no_pass16 = is_one("RSX_NO_PASS16");
+		pass16_wgs = 2;
+		if (const char *e = getenv("RSX_PASS16_WGS"))
+			pass16_wgs = atoi(e) == 1 ? 1u : 2u;
+		pass16_dbg = 0;
+		if (const char *e = getenv("RSX_PASS16_DBG"))
+			pass16_dbg = (unsigned)atoi(e);
 		no_shift = is_one("RSX_NO_SHIFT");
 		no_unstable = is_one("RSX_NO_UNSTABLE");
 		leaf16_maxbin = 25;
@@ -1157,7 +1168,7 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			                   (u32)env().leaf16_maxbin);                                                                      \
 	} while (0)
 			typedef LeafKCfg<512, 5120, 8> K4;
-			typedef LeafKCfg<512, 5120, 6> K8;
+			typedef LeafKCfg<512, 5120, 8> K8;   // (8-byte values staged in 6 bytes: four workgroups per CU)
 			typedef LeafKCfg<256, 2560, 8, 11> K2;
 			typedef LeafKCfg<128, 1280, 6, 10> K1;
 			typedef LeafKCfg<64, 256, 8, 9> K0;    // slots of up to 256 keys (arrays of up to ~13 Mi keys): a wave per leaf
@@ -1340,6 +1351,29 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	                   (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,             \
 	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
 	if constexpr (sizeof(KT) == 4) {
+		if (dense && !env().no_pass16 && !env().no_unstable && !env().no_leaf16) {
+			// round 5: the pass as a kernel of its own (rsx_pass16.hpp): values staged in two bytes, two workgroups per CU, cursors
+			// instead of the chain, 16-byte stores.  (Its slots hold a bucket's values in arbitrary order: for leaves that sort.)
+			const u32 *btile = (const u32 *)((char *)c.seg.p + c.seg_btile_off);
+#define RSX_LAUNCH_P16(DIGV, CFG)                                                                                          \
+	hipLaunchKernelGGL((rsx_pass16_kernel<KT, DIGV, CFG>), dim3(grid), dim3(CFG::BLOCK), 0, c.stream, (const KT *)aux,      \
+	                   (const KT *)sa.kin_hi, sa.lo_slots, (unsigned short *)src, sa.tiles, btile, sa.ctl,                  \
+	                   (const Plan *)c.plan(), (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka, (u32)env().pass16_dbg)
+			if (env().pass16_wgs == 1) {
+				if (plain)
+					RSX_LAUNCH_P16(DIG_PLAIN, Pass16Cfg<1>);
+				else
+					RSX_LAUNCH_P16(DIG_GENERIC, Pass16Cfg<1>);
+			} else {
+				if (plain)
+					RSX_LAUNCH_P16(DIG_PLAIN, Pass16Cfg<2>);
+				else
+					RSX_LAUNCH_P16(DIG_GENERIC, Pass16Cfg<2>);
+			}
+#undef RSX_LAUNCH_P16
+			HIP_TRY(hipGetLastError());
+			return RSX_OK;
+		}
 		if (dense) {
 			// 4-byte keys, every column kept: the leaves sort by the two low bytes and the slot says the rest -- the pass writes
 			// the low half of every DERIVED key (rsx_leaf_sort_kernel, DENSE)

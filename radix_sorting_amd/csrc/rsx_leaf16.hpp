@@ -128,6 +128,14 @@ __device__ __forceinline__ u32 from_next_lane(u32 x)
 	return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 }
 
+// Every kernel of this file is launched with ONE leaf per workgroup (per wave, per row of sixteen lanes): the grid covers the leaf
+// table (65536 entries, one per level-2 slot).  The loops over the table stay, for a smaller grid, but end after their first
+// trip: written as open loops, everything a leaf computes from thread indices and kernel arguments is loop-invariant, the
+// compiler hoists it in front of a loop that runs once and then spills it -- rsx_leafk_kernel<u64, u64> carried 20 bytes of
+// scratch and two spilled SGPRs per lane that way, 80 registers instead of 50 (round 5: tools/ubench/leafk_probe, 1.47 ->
+// 1.29 ms for the leaves of 2^28 u64 keys from this alone).  false: the open loops (a grid smaller than the table works again).
+constexpr bool LEAF_ONE_PER_GROUP = true;
+
 template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12, int SKIP_ = 0> struct Leaf16Cfg {
 	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64;
 	static constexpr int SKIP = SKIP_;   // probe only: 1 no register passes, 2 no count / scan / placement, 4 no write-out
@@ -176,10 +184,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 	const u32 D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
 	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));   // what every key has above the level-1 digit
 	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+		[&]() {   // (one leaf; see LEAF_ONE_PER_GROUP)
 		const LeafSeg ls = segtab[s];
 		const u32 cnt = ls.cnt, slot = ls.slot;
 		if (cnt == 0)
-			continue;
+			return;   // (next leaf)
 		// ---- the slot's values: 16 bytes per lane and step, all requested at once
 		const uint16_t *q = slots + (u64)(slot - 1) * slack_cap;
 		u32x4 kv[NV];
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 				// sorts by byte columns: with MSB digits at other bit positions this kernel goes on until the leaf is in order
 				if (tid == 0)
 					redo[atomicAdd(&ctl->nredo, 1u)] = s;
-				continue;
+				return;   // (next leaf)
 			}
 			{
 				u32 base = 0, tot = 0;
@@ -365,6 +374,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 			}
 		}
 		// (the next leaf's first writes to `stage` lie behind three more barriers)
+		}();
+		if constexpr (LEAF_ONE_PER_GROUP)
+			break;
 	}
 }
 
@@ -411,10 +423,11 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 	const u32 D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
 	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));
 	for (u32 s = blockIdx.x * NW + swid; s < nseg; s += gridDim.x * NW) {
+		[&]() {   // (one leaf; see LEAF_ONE_PER_GROUP)
 		const LeafSeg ls = segtab[s];
 		const u32 cnt = ls.cnt, slot = ls.slot;
 		if (cnt == 0)
-			continue;
+			return;   // (next leaf)
 		const uint16_t *q = slots + (u64)(slot - 1) * slack_cap;
 		u32x4 kv[NV];
 		int nvalid[NV];
@@ -563,6 +576,9 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 			}
 		}
 		RSX_COMPILER_FENCE();
+		}();
+		if constexpr (LEAF_ONE_PER_GROUP)
+			break;
 	}
 }
 
@@ -613,6 +629,7 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16q_kernel(KT *__restrict
 	const u32 D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
 	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));
 	for (u32 s0 = (blockIdx.x * NW + wid) * 4; s0 < nseg; s0 += gridDim.x * NW * 4) {
+		[&]() {   // (one leaf; see LEAF_ONE_PER_GROUP)
 		const u32 s = s0 + row;
 		u32 cnt = 0, slot = 1, beg = 0;
 		if (s < nseg) {
@@ -750,6 +767,9 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16q_kernel(KT *__restrict
 			}
 		}
 		RSX_COMPILER_FENCE();
+		}();
+		if constexpr (LEAF_ONE_PER_GROUP)
+			break;
 	}
 }
 
@@ -875,15 +895,44 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 	KT *out = (ncols & 1) ? aux : src;   // radix_sort.hpp:92
 	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
 	constexpr int S = C::S;
-	__shared__ __attribute__((aligned(16))) CT stage[16 * S + 64];   // + a place per lane for values that do not exist
+	// P6 (values carried as u64): what a leaf sorts by lies below bit 48 -- its columns are kept columns BELOW the two the MSB passes
+	// went by, so the highest of them is column 5 at most -- and the staged leaf holds exactly those 48 bits, as a 32-bit plane
+	// (bits 16 .. 47) and a 16-bit plane (bits 0 .. 15): 6 bytes per key instead of 8, 40 KB of LDS per 5120-key leaf instead of
+	// 50, FOUR workgroups per CU instead of three (tools/ubench/leafk_probe: the leaves of 2^28 u64 keys 1.29 -> 1.13 ms; the
+	// phases of a leaf hardly overlap inside one workgroup, so what counts is how many are resident).  In registers a value is
+	// the 48 bits in a u64: the networks compare it as before.
+	constexpr bool P6 = sizeof(CT) == 8;
+	constexpr int S2 = (S + 3) & ~1;   // (the 16-bit plane's row pitch)
+	__shared__ __attribute__((aligned(16))) CT stage[P6 ? 1 : 16 * S + 64];   // + a place per lane for values that do not exist
+	__shared__ __attribute__((aligned(16))) u32 st_hi[P6 ? 16 * S + 64 : 1];
+	__shared__ __attribute__((aligned(16))) unsigned short st_lo[P6 ? 16 * S2 + 64 : 1];
 	auto at = [](u32 p) { return (p & 15u) * (u32)S + (p >> 4); };
+	// element (row r, column c) of the transposed leaf
+	auto put = [&](u32 r, u32 c, CT v) {
+		if constexpr (P6) {
+			st_hi[r * S + c] = (u32)((u64)v >> 16);
+			st_lo[r * S2 + c] = (unsigned short)v;
+		} else {
+			stage[r * S + c] = v;
+		}
+	};
+	auto get = [&](u32 r, u32 c) -> CT {
+		if constexpr (P6)
+			return (CT)(((u64)st_hi[r * S + c] << 16) | st_lo[r * S2 + c]);
+		else
+			return stage[r * S + c];
+	};
+	auto put_at = [&](u32 p, CT v) { put(p & 15u, p >> 4, v); };
+	auto get_at = [&](u32 p) -> CT { return get(p & 15u, p >> 4); };
+	constexpr KT LOW48 = (KT)0xFFFFFFFFFFFFull;
 	__shared__ u32 ws[NW], wmax[NW];
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+		[&]() {   // (one leaf; see LEAF_ONE_PER_GROUP)
 		const LeafSeg ls = segtab[s];
 		const u32 cnt = ls.cnt, slot = ls.slot;
 		if (cnt == 0)
-			continue;
+			return;   // (next leaf)
 		const KT *q = slot ? slots + (u64)(slot - 1) * slack_cap : (const KT *)src + ls.beg;
 		// the keys, one per lane and round (consecutive lanes read consecutive keys), cut to the carried type
 		CT kv[NK];
@@ -906,7 +955,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 #pragma unroll
 			for (int j = 0; j < NK; ++j) {
 				const u32 e = tid + BLOCK * j;
-				kv[j] = e < cnt ? (CT)kdf_apply(q[e], ka) : (CT)0;
+				kv[j] = e < cnt ? (CT)(P6 ? (kdf_apply(q[e], ka) & LOW48) : kdf_apply(q[e], ka)) : (CT)0;
 			}
 		}
 		{
@@ -965,7 +1014,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 		if (!SLOT32 && mx > maxbin2) {
 			if (tid == 0)
 				redo[atomicAdd(&ctl->nredo, 1u)] = s;
-			continue;
+			return;   // (next leaf)
 		}
 		{
 			u32 base = 0, tot = 0;
@@ -995,14 +1044,22 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 				u32 sh;
 				u32 *a = cell_of(kv[j], valid, sh);
 				const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				stage[valid ? at((old >> sh) & 0xFFFFu) : 16 * S + lane] = kv[j];
+				const u32 pos = (old >> sh) & 0xFFFFu;
+				if constexpr (P6) {
+					st_hi[valid ? at(pos) : 16 * S + lane] = (u32)((u64)kv[j] >> 16);
+					st_lo[valid ? (pos & 15u) * (u32)S2 + (pos >> 4) : 16 * S2 + lane] = (unsigned short)kv[j];
+				} else {
+					stage[valid ? at(pos) : 16 * S + lane] = kv[j];
+				}
 			}
 		}
 		if (tid < 32)
-			stage[at(cnt + tid)] = (CT)~(CT)0;   // what the last chunks read behind the leaf's end sorts last
+			put_at(cnt + tid, P6 ? (CT)LOW48 : (CT)~(CT)0);   // what the last chunks read behind the leaf's end sorts last
 		__syncthreads();
-		if (SLOT32 && mx > maxbin2)
-			batcher_sort_lds<BLOCK>(stage, cnt, at);   // (bins too full for the register passes: the network over the whole leaf)
+		if constexpr (SLOT32) {
+			if (mx > maxbin2)
+				batcher_sort_lds<BLOCK>(stage, cnt, at);   // (bins too full for the register passes: the network over the whole leaf)
+		}
 		const u32 npass = (SLOT32 && mx > maxbin2) ? 0u : mx > C::MAXBIN ? 4u : 2u;
 		for (u32 pass = 0; pass < npass; ++pass) {
 			const u32 off = 8 * (pass & 1);
@@ -1014,32 +1071,44 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 					CT d[16];
 #pragma unroll
 					for (int i = 0; i < 16; ++i)
-						d[i] = stage[(pass & 1) ? (i < 8 ? (i + 8) * S + ch : (i - 8) * S + ch + 1) : i * S + ch];
+						d[i] = (pass & 1) ? (i < 8 ? get(i + 8, ch) : get(i - 8, ch + 1)) : get(i, ch);
 					if (pass == 0)
 						sort16_values(d);
 					else
 						merge16_values(d);   // (both halves were sorted by the pass before)
 #pragma unroll
-					for (int i = 0; i < 16; ++i)
-						stage[(pass & 1) ? (i < 8 ? (i + 8) * S + ch : (i - 8) * S + ch + 1) : i * S + ch] = d[i];
+					for (int i = 0; i < 16; ++i) {
+						if (pass & 1) {
+							if (i < 8)
+								put(i + 8, ch, d[i]);
+							else
+								put(i - 8, ch + 1, d[i]);
+						} else {
+							put(i, ch, d[i]);
+						}
+					}
 				}
 			}
 			__syncthreads();
 		}
 		{
 			constexpr u32 CBITS = 8 * sizeof(CT);
-			const KT upper = sizeof(CT) == 8 ? (KT)0 : (KT)(first >> (CBITS & 63) << (CBITS & 63));
+			// what every key of the leaf has above the carried bits (the MSB passes' digits, columns that were skipped)
+			const KT upper = P6 ? (KT)(first & ~LOW48) : (KT)(first >> (CBITS & 63) << (CBITS & 63));
 			KT *o = out + ls.beg;
 			for (u32 i0 = 2 * tid; i0 < cnt; i0 += 2 * BLOCK) {
 				KT kk[2];
-				kk[0] = kdf_invert((KT)(upper | (KT)stage[at(i0)]), ka);
-				kk[1] = kdf_invert((KT)(upper | (KT)stage[at(i0 + 1)]), ka);
+				kk[0] = kdf_invert((KT)(upper | (KT)get_at(i0)), ka);
+				kk[1] = kdf_invert((KT)(upper | (KT)get_at(i0 + 1)), ka);
 				if (i0 + 2 <= cnt)
 					store_chunk<KT, 2>(o + i0, kk);
 				else
 					o[i0] = kk[0];
 			}
 		}
+		}();
+		if constexpr (LEAF_ONE_PER_GROUP)
+			break;
 	}
 }
 
@@ -1072,10 +1141,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 	auto at = [](u32 p) { return (p & 15u) * (u32)S + (p >> 4); };
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
+		[&]() {   // (one leaf; see LEAF_ONE_PER_GROUP)
 		const LeafSeg ls = segtab[s];
 		const u32 cnt = ls.cnt, slot = ls.slot;
 		if (cnt == 0)
-			continue;
+			return;   // (next leaf)
 		const KT *kp = kslots + (u64)(slot - 1) * slack_cap;
 		const VT *vp = vslots + (u64)(slot - 1) * slack_cap;
 		u32x4 kv[NV], vv[NV];
@@ -1158,7 +1228,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 		if (mx > maxbin2) {   // (keys with many duplicates: the LDS passes of rsx_leaf_pairs_kernel)
 			if (tid == 0)
 				redo[atomicAdd(&ctl->nredo, 1u)] = s;
-			continue;
+			return;   // (next leaf)
 		}
 		{
 			u32 base = 0, tot = 0;
@@ -1249,6 +1319,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 			}
 		}
 		__syncthreads();   // (the payloads are staged again before the next leaf's first barrier)
+		}();
+		if constexpr (LEAF_ONE_PER_GROUP)
+			break;
 	}
 }
 

@@ -36,8 +36,8 @@ def main():
                     tot.append(a.elapsed_time(b))
             p = rsa.profile_end()
             k = len(tot)
-            print("%s=%s round %d: route %d, %.3f ms per sort; passes %.3f, leaves %.3f, histogram %.3f" %
-                  (var, v, rnd, info.hybrid, sum(tot) / k, (p.scatter_ms + p.narrow_ms) / k, p.leaf_ms / k, p.hist_ms / k), flush=True)
+            print("%s=%s round %d: route %d, %.3f ms per sort; level-1 / whole-key passes %.3f, narrowing pass %.3f, leaves %.3f, histogram %.3f" %
+                  (var, v, rnd, info.hybrid, sum(tot) / k, p.scatter_ms / k, p.narrow_ms / k, p.leaf_ms / k, p.hist_ms / k), flush=True)
 
 
 if __name__ == "__main__":

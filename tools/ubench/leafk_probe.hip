@@ -212,13 +212,15 @@ int main(int argc, char **argv)
 	c.shift2 = 48;
 	CK(hipMemcpy(d_ctl, &c, sizeof c, hipMemcpyHostToDevice));
 	printf("n = %zu u64 keys in %u slots of %u keys (%u +- 64 in each), mode %u\n", n, nleaf, cap, per, mode);
-	typedef LeafKCfg<512, 5120, 6, 12> K8;
-	bench("rsx_leafk_kernel<u64, u64, <512, 5120, 6, 12>> (shipped)", nleaf, true, [&](u64 *o, unsigned g) { launch_old<K8>(o, g); });
+	typedef LeafKCfg<512, 5120, 8, 12> K8;
+	bench("rsx_leafk_kernel<u64, u64, <512, 5120, 8, 12>> (csrc)", nleaf, true, [&](u64 *o, unsigned g) { launch_old<K8>(o, g); });
 #define NEW(GRID, ...) bench("leafk2 <" #__VA_ARGS__ ">", GRID, false, [&](u64 *o, unsigned g) { launch_new<LeafK2Cfg<__VA_ARGS__>>(o, g); })
 	NEW(nleaf, 512, 5120, 6, 12, false);
 	NEW(nleaf, 512, 5120, 6, 12, true);
 	NEW(nleaf, 512, 5120, 6, 12, false, 0, true);
 	NEW(nleaf, 512, 5120, 8, 12, false, 0, true);
+	NEW(nleaf, 512, 5120, 8, 12, false, 0, true, true);
+	NEW(nleaf, 512, 5120, 8, 12, false, 7, true, true);
 	NEW(nleaf, 512, 5120, 8, 12, false, 7, true);
 	NEW(nleaf, 512, 5120, 6, 12, false, 1);
 	NEW(nleaf, 512, 5120, 6, 12, false, 2);

@@ -15,10 +15,11 @@
 
 namespace rsx {
 
-template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12, bool LOOP_ = false, int SKIP_ = 0, bool P6_ = false> struct LeafK2Cfg {
+template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12, bool LOOP_ = false, int SKIP_ = 0, bool P6_ = false, bool VLOAD_ = false> struct LeafK2Cfg {
 	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64, NBITS = NBITS_;
 	static constexpr bool LOOP = LOOP_;
 	static constexpr int SKIP = SKIP_;
+	static constexpr bool VLOAD = VLOAD_;   // the slot's keys with 16-byte loads, two keys per lane (any order will do)
 	static constexpr bool P6 = P6_;   // values staged as a 32-bit plane (bits 16 .. 47) and a 16-bit plane (bits 0 .. 15)
 	static constexpr int NCH = (CAP / 16 + BLOCK - 1) / BLOCK;
 	static constexpr int NBIN = 1 << NBITS, NCELLW = NBIN / 2, NVEC = NCELLW / 4;
@@ -86,10 +87,27 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk2_kernel(KT *__rest
 			const KT *q = slot ? slots + (u64)(slot - 1) * slack_cap : (const KT *)src + ls.beg;
 			CT kv[NK];
 			const KT first = kdf_apply(q[0], ka);
+			// element index of register j (VLOAD: lane t holds elements 2 t, 2 t + 1 of every 2 * BLOCK: a slot starts on a 16-byte
+			// boundary and its capacity is even, so the second element of a vector is the slot's own even behind the last key)
+			auto elem_of = [&](int j) { return C::VLOAD ? 2u * tid + 2u * BLOCK * (u32)(j >> 1) + (u32)(j & 1) : tid + BLOCK * (u32)j; };
+			if constexpr (C::VLOAD) {
+				static_assert(NK % 2 == 0, "whole vectors");
+				typedef KT kvec_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-			for (int j = 0; j < NK; ++j) {
-				const u32 e = tid + BLOCK * j;
-				kv[j] = e < cnt ? (CT)(P6 ? (kdf_apply(q[e], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(q[e], ka)) : (CT)0;
+				for (int j = 0; j < NK; j += 2) {
+					const u32 e = elem_of(j);
+					kvec_t x = {0, 0};
+					if (e < cnt)
+						x = *(const kvec_t *)(q + e);
+					kv[j] = (CT)(P6 ? (kdf_apply(x[0], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(x[0], ka));
+					kv[j + 1] = (CT)(P6 ? (kdf_apply(x[1], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(x[1], ka));
+				}
+			} else {
+#pragma unroll
+				for (int j = 0; j < NK; ++j) {
+					const u32 e = tid + BLOCK * j;
+					kv[j] = e < cnt ? (CT)(P6 ? (kdf_apply(q[e], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(q[e], ka)) : (CT)0;
+				}
 			}
 			{
 				const u32x4 zero = {0, 0, 0, 0};
@@ -109,14 +127,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk2_kernel(KT *__rest
 			if constexpr (C::SKIP & 2) {
 #pragma unroll
 				for (int j = 0; j < NK; ++j)
-					if (tid + BLOCK * j < cnt)
-						put_at(tid + BLOCK * j, kv[j]);
+					if (elem_of(j) < cnt)
+						put_at(elem_of(j), kv[j]);
 			} else {
 #pragma unroll
 				for (int j = 0; j < NK; ++j) {
-					if (BLOCK * j < (int)cnt) {
+					if ((C::VLOAD ? 2 * BLOCK * (j >> 1) : BLOCK * j) < (int)cnt) {
 						u32 sh;
-						u32 *a = cell_of(kv[j], tid + BLOCK * j < cnt, sh);
+						u32 *a = cell_of(kv[j], elem_of(j) < cnt, sh);
 						__hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
@@ -183,8 +201,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk2_kernel(KT *__rest
 					__syncthreads();
 #pragma unroll
 					for (int j = 0; j < NK; ++j) {
-						if (BLOCK * j < (int)cnt) {
-							const bool valid = tid + BLOCK * j < cnt;
+						if ((C::VLOAD ? 2 * BLOCK * (j >> 1) : BLOCK * j) < (int)cnt) {
+							const bool valid = elem_of(j) < cnt;
 							u32 sh;
 							u32 *a = cell_of(kv[j], valid, sh);
 							const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
