@@ -118,6 +118,7 @@ struct Env {
 	bool no_shift = false;           // RSX_NO_SHIFT=1: the MSB digits of a sort without a histogram are whole bytes (the two highest kept columns) always
 	bool no_pass16 = false;          // RSX_NO_PASS16=1: the level-2 pass into two-byte slots is rsx_scatter2_kernel<..., KTO = u16, SEG> as in round 4 (rsx_pass16.hpp)
 	unsigned pass16_wgs = 2;         // RSX_PASS16_WGS=1: ... one workgroup per CU (probe)
+	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
 	bool no_leaf16 = false;          // RSX_NO_LEAF16=1: two-byte slots are sorted by rsx_leaf_sort_kernel (two LDS passes) as in round 3
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
@@ -163,6 +164,7 @@ struct Env {
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
 		no_pass16 = is_one("RSX_NO_PASS16");
+		no_pass16a = is_one("RSX_NO_PASS16A");
 		pass16_wgs = 2;
 		if (const char *e = getenv("RSX_PASS16_WGS"))
 			pass16_wgs = atoi(e) == 1 ? 1u : 2u;
@@ -1285,6 +1287,16 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	return RSX_OK;
 }
 
+// The level-2 pass of a keys-only sort of 4-byte keys without a histogram writes whole 64-byte atoms (rsx_pass16a_kernel,
+// rsx_pass16.hpp) where the leaves are rsx_leaf16_kernel's (slots of more than 1024 values: arrays from about 52 Mi keys),
+// which read a slot from both ends; its tiles are Pass16aCfg::TILE keys.
+template <typename KT> bool pass16a_wanted(const Ctx &c)
+{
+	if constexpr (sizeof(KT) == 4)
+		return dense_slots<KT>(c) && !env().no_pass16 && !env().no_pass16a && !env().no_unstable && !env().no_leaf16 && c.slack_cap > 1024u;
+	return false;
+}
+
 // a pass inside the level-1 buckets (SEG instantiation of the pass kernel): j < 0 the one by the level-2 column (runs in
 // SEG_MODE_LEAVES), j >= 0 LSB-first pass j (runs in SEG_MODE_LSD).  aux -> src, src -> aux for odd j.
 // j == -2: the slack attempt (aux -> the slots of c.slack, no counts needed).
@@ -1351,6 +1363,20 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	                   (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,             \
 	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
 	if constexpr (sizeof(KT) == 4) {
+		if (dense && pass16a_wanted<KT>(c)) {
+			// ... and with whole 64-byte atoms: a workgroup takes a range of tiles and carries what does not fill an atom
+			const unsigned pgrid = 512;
+			if (plain)
+				hipLaunchKernelGGL((rsx_pass16a_kernel<KT, DIG_PLAIN>), dim3(pgrid), dim3(Pass16aCfg::BLOCK), 0, c.stream, (const KT *)aux,
+				                   (const KT *)sa.kin_hi, sa.lo_slots, (unsigned short *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
+				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
+			else
+				hipLaunchKernelGGL((rsx_pass16a_kernel<KT, DIG_GENERIC>), dim3(pgrid), dim3(Pass16aCfg::BLOCK), 0, c.stream, (const KT *)aux,
+				                   (const KT *)sa.kin_hi, sa.lo_slots, (unsigned short *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
+				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
+			HIP_TRY(hipGetLastError());
+			return RSX_OK;
+		}
 		if (dense && !env().no_pass16 && !env().no_unstable && !env().no_leaf16) {
 			// round 5: the pass as a kernel of its own (rsx_pass16.hpp): values staged in two bytes, two workgroups per CU, cursors
 			// instead of the chain, 16-byte stores.  (Its slots hold a bucket's values in arbitrary order: for leaves that sort.)
@@ -1427,7 +1453,8 @@ template <typename KT> int seg_layout(Ctx &c, size_t n)
 	c.seg_status_off = c.seg_hist_off + hist_bytes;
 	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
 	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
-	c.seg_btile_off = c.seg_tiles_off + rows * sizeof(SegTile);
+	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 257 : rows;   // (rsx_pass16a_kernel's tiles are smaller)
+	c.seg_btile_off = c.seg_tiles_off + tile_rows * sizeof(SegTile);
 	c.seg_redo_off = c.seg_btile_off + 260 * sizeof(u32);   // the leaves rsx_leaf16_kernel leaves to rsx_leaf_sort_kernel
 	return c.seg.ensure(c.seg_redo_off + 65536 * sizeof(u32));
 }
@@ -1707,13 +1734,14 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	                   // 8-byte keys in slots rsx_leafk_kernel takes: four-byte slots where the leaves' columns lie in the low word
 	                   (u32)(narrow_slots_ok<KT>(cap2) ? 1 : 0));
 	RSX_TRY(launch_seg_pass<KT>(c, src, lo ? aux : nullptr, n, ka, -2, 1));
+	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
-	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
+	                   atoms ? (u32)Pass16aCfg::TILE : (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0);
 	RSX_TRY(launch_seg_pass<KT>(c, lo ? aux : nullptr, nullptr, n, ka, -2, 2));
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
-	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, 1u);
+	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, atoms ? 2u : 1u);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	u32 leaf_shape = LeafShapes<KT>::shape_for_slots(cap2);

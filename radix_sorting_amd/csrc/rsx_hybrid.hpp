@@ -434,9 +434,16 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 	const u32 t0 = btile[b], t1 = btile[b + 1];
 	const u32 ncols = plan->ncols;
 	const u64 bbeg = off1[b];
-	u32 c = 0;
-	if (t1 > t0)
+	u32 c = 0, back = 0;
+	if (blind == 2) {
+		// rsx_pass16a_kernel (rsx_pass16.hpp): no chain -- the slot's two cursors, its front's and its back's, at the beginning of
+		// the status region
+		c = (u32)__hip_atomic_load(status + ((u64)b * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		back = (u32)__hip_atomic_load(status + ((u64)65536 + b * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		c += back;
+	} else if (t1 > t0) {
 		c = (u32)(__hip_atomic_load(status + ((u64)(t1 - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SB_::VALMASK);
+	}
 	if (b == 0 && d == 0) {
 		const u32 mode = ctl->overflow == 0 ? SEG_MODE_LEAVES : SEG_MODE_RETRY;
 		ctl->mode = mode;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 	LeafSeg ls;
 	ls.beg = (u32)(bbeg + o);
 	ls.cnt = c <= slack_cap ? c : 0u;   // (an overflowed slot: the attempt is discarded anyway)
-	ls.ncols = ncols - 2;
+	ls.ncols = (ncols - 2) | (back << 16);   // (the upper half: how many of the values lie at the slot's end, rsx_leaf16_kernel)
 	ls.slot = b * 256 + d + 1;
 	segtab[b * 256 + d] = ls;   // (the buckets' order in the table makes no difference to the leaves: tools/blind_ab.py)
 }
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 			const LeafSeg ls = segtab[listed ? redo[s] : s];
 			beg = ls.beg;
 			cnt = ls.cnt;
-			nc = ls.ncols;
+			nc = ls.ncols & 0xFFFFu;   // (the upper half: how many of the slot's values lie at its end, rsx_leaf16_kernel)
 			slot = ls.slot;
 		} else {
 			const u64 b = off1[s], e = s == 255 ? n : off1[s + 1];

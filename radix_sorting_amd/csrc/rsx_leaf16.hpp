@@ -136,6 +136,9 @@ __device__ __forceinline__ u32 from_next_lane(u32 x)
 // 1.29 ms for the leaves of 2^28 u64 keys from this alone).  false: the open loops (a grid smaller than the table works again).
 constexpr bool LEAF_ONE_PER_GROUP = true;
 
+// the last places of a two-byte slot that rsx_pass16a_kernel (rsx_pass16.hpp) fills from both ends
+constexpr u32 LEAF16_BACK = 128;
+
 template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12, int SKIP_ = 0> struct Leaf16Cfg {
 	static constexpr int BLOCK = BLOCK_, CAP = CAP_, WPE = WPE_, NW = BLOCK_ / 64;
 	static constexpr int SKIP = SKIP_;   // probe only: 1 no register passes, 2 no count / scan / placement, 4 no write-out
@@ -189,21 +192,33 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 		const u32 cnt = ls.cnt, slot = ls.slot;
 		if (cnt == 0)
 			return;   // (next leaf)
+		// A slot filled by rsx_pass16a_kernel (rsx_pass16.hpp) holds its values at BOTH ends: `front` values from its beginning on
+		// (whole 64-byte atoms) and `back` (LeafSeg::ncols >> 16, at most LEAF16_BACK) in its last LEAF16_BACK places -- what
+		// that pass still carried when a workgroup's range of tiles ended.  back == 0: a slot as every other pass fills it.
+		const u32 back = ls.ncols >> 16, front = cnt - back;
 		// ---- the slot's values: 16 bytes per lane and step, all requested at once
 		const uint16_t *q = slots + (u64)(slot - 1) * slack_cap;
-		u32x4 kv[NV];
-		int nvalid[NV];
+		constexpr int NVX = NV + 1;   // (vector NV: the back's values, in the first lanes of wave 0)
+		u32x4 kv[NVX];
+		int nvalid[NVX];
 #pragma unroll
 		for (int j = 0; j < NV; ++j) {
 			const u32 e0 = 8 * (tid + BLOCK * j);
-			const int left = (int)cnt - (int)e0;
+			const int left = (int)front - (int)e0;
 			nvalid[j] = left < 0 ? 0 : left > 8 ? 8 : left;
 			kv[j] = u32x4{0, 0, 0, 0};
 			if (left > 0)
 				kv[j] = *(const u32x4 *)(q + e0);
 		}
-		// vectors in which this WAVE has any value (the last round of a slot that is not full)
-		auto wave_has = [&](int j) { return 8 * (64 * swid + BLOCK * (u32)j) < cnt; };
+		{
+			const int left = (int)back - (int)(8 * tid);
+			nvalid[NV] = left < 0 ? 0 : left > 8 ? 8 : left;
+			kv[NV] = u32x4{0, 0, 0, 0};
+			if (left > 0)
+				kv[NV] = *(const u32x4 *)(q + (slack_cap - LEAF16_BACK) + 8 * tid);
+		}
+		// vectors in which this WAVE has any value (the last round of a slot that is not full; the back: wave 0)
+		auto wave_has = [&](int j) { return j == NV ? (swid == 0 && back != 0) : 8 * (64 * swid + BLOCK * (u32)j) < front; };
 		{
 			const u32x4 zero = {0, 0, 0, 0};
 #pragma unroll
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 			};
 			// ---- count
 #pragma unroll
-			for (int j = 0; j < NV; ++j) {
+			for (int j = 0; j < NVX; ++j) {
 				if (wave_has(j)) {
 #pragma unroll
 					for (int k = 0; k < 8; ++k) {
@@ -278,6 +293,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 				// sorts by byte columns: with MSB digits at other bit positions this kernel goes on until the leaf is in order
 				if (tid == 0)
 					redo[atomicAdd(&ctl->nredo, 1u)] = s;
+				// (rsx_leaf_sort_kernel reads dense slots: the back's values move up behind the front's -- they are all in registers)
+				if (back) {
+					uint16_t *qw = const_cast<uint16_t *>(q) + front + 8 * tid;
+#pragma unroll
+					for (int k2 = 0; k2 < 8; ++k2)
+						if (k2 < nvalid[NV])
+							qw[k2] = (uint16_t)(kv[NV][k2 >> 1] >> (16 * (k2 & 1)));
+				}
 				return;   // (next leaf)
 			}
 			{
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 			__syncthreads();
 			// ---- place: the returning atomic on the bin's start is the key's place (any order inside a bin)
 #pragma unroll
-			for (int j = 0; j < NV; ++j) {
+			for (int j = 0; j < NVX; ++j) {
 				if (wave_has(j)) {
 #pragma unroll
 					for (int k = 0; k < 8; ++k) {

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WGS * 4) void rsx_pass16_kernel(const 
 // to 31 values wait in the LDS for the next tile.  A tile's values of digit d first complete the carried atom, then go out
 // as whole atoms, and the last < 32 are carried on.  A digit's place in its slot is a multiple of 32 values, taken from the
 // slot's cursor by one returning global atomic per tile and digit as above -- so EVERY store of the pass is a whole, aligned
-// 64-byte atom.  What is still carried when the range ends (or the bucket changes) goes to the last 256 values of the slot
+// 64-byte atom.  What is still carried when the range ends (or the bucket changes) goes to the last 128 values of the slot
 // (its own cursor): the leaves read a slot's front and its back (rsx_leaf16_kernel; LeafSeg::ncols >> 16 = the back's count).
 // The staged runs are laid out so that the part that goes out as atoms starts on a 16-byte boundary of the LDS: every lane of
 // the write-out moves one aligned quarter atom, there is no value-by-value path.
@@ -251,14 +251,15 @@ __global__ __launch_bounds__(C::BLOCK, C::WGS * 4) void rsx_pass16_kernel(const 
 struct Pass16aCfg {
 	static constexpr int BLOCK = 1024, KPT = 24, TILE = BLOCK * KPT;
 	static constexpr u32 ATOM = 32;    // values per 64-byte atom
-	static constexpr u32 BACK = 256;   // values at the end of every slot for what is carried when a range ends
+	static constexpr u32 BACK = 128;   // values at the end of every slot for what is carried when a range ends (LEAF16_BACK, rsx_leaf16.hpp):
+	                                   // up to four workgroups' 31 per digit -- a bucket's tiles are shared by three at most
 	static constexpr int STAGE = TILE + 256 * 14;   // + what the 16-byte alignment of 256 runs can cost
 };
 
 struct Pass16aSmem {
 	__attribute__((aligned(16))) unsigned short stage[Pass16aCfg::STAGE];
 	__attribute__((aligned(16))) unsigned short carry[256][32];
-	u32 cell[256];      // per digit: count, then the run's cursor (tile-local)
+	u32 cell[2][256];   // per digit: count, then the run's cursor (tile-local); tiles alternate between the two (the other is zeroed meanwhile)
 	u32 delta[256];     // slot position of a body value minus its tile-local position
 	u32 info[256];      // carried before (6 bits) | head (6) | tail (6) | atom completed (1), for the copying threads
 	unsigned short rbeg[256], bbeg[256], bend[256];   // the run, and the part of it that goes out as whole atoms (the body)
@@ -267,7 +268,7 @@ struct Pass16aSmem {
 };
 
 // cursors: [65536] front cursors, then [65536] back cursors (zeroed by rsx_blind_precheck_kernel with the status words).
-template <typename KT, int DIG>
+template <typename KT, int DIG, bool PREFETCH = false>
 __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const KT *__restrict__ kin, const KT *__restrict__ kin_hi,
                                                                           u32 lo_slots, unsigned short *__restrict__ kout,
                                                                           const SegTile *__restrict__ tiles,
@@ -288,16 +289,17 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 	const u32 shift = ctl->shift2;
 	const u32 gran = ctl->leaf16 ? C::ATOM : 1u;
 	__shared__ Pass16aSmem sm;
-	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-	const u32 cd = tid >> 2, part = tid & 3u;   // the copying threads: digit, quarter of an atom
+	const u32 tid0 = threadIdx.x;
 	auto sidx = [](u32 pos) { return stage_swz<true>(pos * 2u); };   // byte offset of staged value `pos`
 	auto staged = [&](u32 pos) -> unsigned short & { return *(unsigned short *)((char *)sm.stage + sidx(pos)); };
 	u32 cc = 0;                // digit thread: values of its digit carried from the tiles before
 	u32 bucket = tiles[t0].bucket;
-	if (tid < 256)
-		sm.cell[tid] = 0;
+	if (tid0 < 256)
+		sm.cell[0][tid0] = 0;
 	// what is carried goes to the back of its slot (the range ends, or the next tile lies in another bucket)
 	auto flush = [&]() {
+		const u32 tid = tid0, cd = tid >> 2, part = tid & 3u;
+		__syncthreads();   // (the tile before is through: its tables are free, what it carries on is in place)
 		if (tid < 256) {
 			u32 inf = 0, dest = 0;
 			if (cc) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 		__syncthreads();
 		{
 			const u32 n = sm.info[cd], dest = sm.delta[cd];
-#pragma unroll
+#pragma unroll 2
 			for (u32 e = 0; e < 8; ++e) {
 				const u32 k = part * 8u + e;
 				if (k < n)
@@ -327,18 +329,12 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 		__syncthreads();
 	};
 	__syncthreads();
-	for (u32 t = t0; t < t1; ++t) {
+	KT keep[KPT];
+	// the keys of tile t into keep[] (as they lie in memory; only issued here)
+	auto request = [&](const u32 t, const u32 tid) {
 		const SegTile st = tiles[t];
-		if (st.bucket != bucket) {
-			flush();
-			bucket = st.bucket;
-		}
-		const u32 cnt = st.cnt;
-		const KT *p = ((kin_hi && bucket >= lo_slots) ? kin_hi : kin) + st.beg;
-		// ---- the tile's keys (any key in any lane), derived once, and the digits' counts
-		KT keep[KPT];
-		const bool full = cnt == (u32)TILE;
-		if (full && (((uintptr_t)p) & 15) == 0) {
+		const KT *p = ((kin_hi && st.bucket >= lo_slots) ? kin_hi : kin) + st.beg;
+		if (st.cnt == (u32)TILE && (((uintptr_t)p) & 15) == 0) {
 			typedef KT vec_t __attribute__((ext_vector_type(4)));
 			const vec_t *vp = (const vec_t *)p + tid;
 #pragma unroll
@@ -352,9 +348,35 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 #pragma unroll
 			for (int r = 0; r < KPT; ++r) {
 				const u32 o = tid + r * BLOCK;
-				keep[r] = o < cnt ? p[o] : (KT)0;
+				keep[r] = o < st.cnt ? p[o] : (KT)0;
 			}
 		}
+	};
+	// (the two workgroups of a CU start half a tile apart: started together they would load, rank and store in step)
+	if (blockIdx.x >= gridDim.x / 2)
+		__builtin_amdgcn_s_sleep(127);   // (about 8 k cycles)
+	// PREFETCH (probe): the next tile's keys are requested before this tile is written out.  With 64 registers per lane the
+	// compiler then spills the arriving keys to scratch (54-85 dwords) -- the second workgroup of the CU is the overlap.
+	if constexpr (PREFETCH)
+		request(t0, tid0);
+	for (u32 t = t0; t < t1; ++t) {
+		// (everything a tile derives from the thread index is derived from an opaque copy of it, made per tile: as loop invariants
+		// the LDS addresses of a dozen tables would be hoisted in front of the loop and spilled there)
+		u32 tid = tid0;
+		asm volatile("" : "+v"(tid));
+		const u32 lane = tid & 63, wid = tid >> 6;
+		const u32 cd = tid >> 2, part = tid & 3u;   // the copying threads: digit, quarter of an atom
+		u32 *const cell = sm.cell[(t - t0) & 1u];
+		const SegTile st = tiles[t];
+		if (st.bucket != bucket) {
+			flush();
+			bucket = st.bucket;
+		}
+		const u32 cnt = st.cnt;
+		const bool full = cnt == (u32)TILE;
+		// ---- the tile's keys (any key in any lane), derived once, and the digits' counts
+		if constexpr (!PREFETCH)
+			request(t, tid);
 		if constexpr (DIG != 1) {
 #pragma unroll
 			for (int r = 0; r < KPT; ++r)
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 #pragma unroll
 			for (int r = 0; r < KPT; ++r) {
 				if (FULL || tid + r * BLOCK < cnt)
-					atomicAdd(&sm.cell[(u32)(keep[r] >> shift) & 0xFFu], 1u);
+					atomicAdd(&cell[(u32)(keep[r] >> shift) & 0xFFu], 1u);
 			}
 		};
 		if (full)
@@ -381,7 +403,7 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 		{
 			u32 rlen = 0, rstart = 0;
 			if (tid < 256) {
-				const u32 c = sm.cell[tid];
+				const u32 c = cell[tid];
 				u32 h, body = 0, tail = 0, atom = 0;
 				const bool enough = cc + c >= gran;
 				if (enough) {
@@ -417,7 +439,8 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 					rstart += sm.wsum[k];
 				const u32 inf = sm.info[tid];
 				const u32 rb = rstart + (inf >> 20), bb = rb + ((inf >> 6) & 63u), be = bb + sm.bend[tid];
-				sm.cell[tid] = rb;
+				cell[tid] = rb;
+				sm.cell[((t - t0) & 1u) ^ 1u][tid] = 0;   // (the next tile's counters: last used as the cursors of the tile before, three barriers ago)
 				sm.rbeg[tid] = (unsigned short)rb;
 				sm.bbeg[tid] = (unsigned short)bb;
 				sm.bend[tid] = (unsigned short)be;
@@ -451,7 +474,7 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 				for (int r = 0; r < 8; ++r) {
 					pos[r] = 0;
 					if (FULL || tid + (r0 + r) * BLOCK < cnt)
-						pos[r] = __hip_atomic_fetch_add(&sm.cell[(u32)(keep[r0 + r] >> shift_b) & 0xFFu], 1u, __ATOMIC_RELAXED,
+						pos[r] = __hip_atomic_fetch_add(&cell[(u32)(keep[r0 + r] >> shift_b) & 0xFFu], 1u, __ATOMIC_RELAXED,
 						                                __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 #pragma unroll
@@ -467,28 +490,43 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 			stage_keys(std::false_type{});
 		__syncthreads();
 
+		// the next tile's keys are requested now -- the registers are free, and they cross the memory system while this tile is
+		// written out
+		if constexpr (PREFETCH) {
+			if (t + 1 < t1)
+				request(t + 1, tid);
+		}
 		// ---- out: the completed atoms (a quarter per copying thread: carried values, then the head of the run) ...
 		{
 			const u32 inf = sm.info[cd];
 			const u32 ccd = inf & 63u, hd = (inf >> 6) & 63u, atomd = (inf >> 18) & 1u;
 			if (atomd) {
 				const u32 rb = sm.rbeg[cd];
-				u32 w[4] = {0, 0, 0, 0};
+				u64 qlo = 0, qhi = 0;
+				// (four values at a time: unrolled eight-fold, the addresses and values in flight cost the registers the next tile's
+				// keys are arriving in)
+#pragma unroll 1
+				for (u32 half = 0; half < 2u; ++half) {
+					u64 acc = 0;
 #pragma unroll
-				for (u32 e = 0; e < 8; ++e) {
-					const u32 k = part * 8u + e;
-					const u32 v = k < ccd ? (u32)sm.carry[cd][k] : (u32)staged(rb + (k - ccd));
-					w[e >> 1] |= v << (16u * (e & 1u));
+					for (u32 e = 0; e < 4; ++e) {
+						const u32 k = part * 8u + half * 4u + e;
+						const u32 v = k < ccd ? (u32)sm.carry[cd][k] : (u32)staged(rb + (k - ccd));
+						acc |= (u64)v << (16u * e);
+					}
+					if (half)
+						qhi = acc;
+					else
+						qlo = acc;
 				}
 				(void)hd;
 				typedef u32x4 avec_t __attribute__((aligned(16)));
-				*(avec_t *)(kout + (u32)(sm.delta[cd] + sm.bbeg[cd] - C::ATOM + part * 8u)) = u32x4{w[0], w[1], w[2], w[3]};
+				*(avec_t *)(kout + (u32)(sm.delta[cd] + sm.bbeg[cd] - C::ATOM + part * 8u)) =
+				    u32x4{(u32)qlo, (u32)(qlo >> 32), (u32)qhi, (u32)(qhi >> 32)};
 			}
 		}
 		// ... and the bodies: every group of eight staged values that lies in one is a quarter of an aligned atom
 		// (granule 1: runs of any length -- the last group of a body goes value by value)
-		if (tid < 256)
-			sm.cell[tid] = 0;   // (the next tile's counts: the staging atomics are through, the next count lies behind two barriers)
 		{
 			const u32 total = (u32)__builtin_amdgcn_readfirstlane((int)sm.wsum[0]) + sm.wsum[1] + sm.wsum[2] + sm.wsum[3];
 #pragma unroll 1
@@ -509,20 +547,20 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 				}
 			}
 		}
-		__syncthreads();
-		// ---- what stays: the tail of the run (or, with too few values for an atom, all of the run behind what was carried)
+		// ---- what stays: the tail of the run (or, with too few values for an atom, all of the run behind what was carried).  (No
+		// barrier in front: carry[d][8 part ..] was read for the atom above by this very thread.  None behind: the next tile stages
+		// -- and reads the carried values -- behind three barriers of its own.)
 		{
 			const u32 inf = sm.info[cd];
 			const u32 ccd = inf & 63u, hd = (inf >> 6) & 63u, taild = (inf >> 12) & 63u, fulld = (inf >> 19) & 1u;
 			const u32 from = fulld ? sm.bend[cd] : sm.rbeg[cd], to = fulld ? 0u : ccd, n = fulld ? taild : hd;
-#pragma unroll
+#pragma unroll 2
 			for (u32 e = 0; e < 8; ++e) {
 				const u32 k = part * 8u + e;
 				if (k < n)
 					sm.carry[cd][to + k] = staged(from + k);
 			}
 		}
-		__syncthreads();
 	}
 	flush();
 }
