@@ -1140,6 +1140,7 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 	// one workgroup per bucket at level 1; level 2: a workgroup per table entry (0.569 against 0.585 ms for 2^28 keys with
 	// 8192 persistent ones, tools/ubench/leaf_probe; RSX_LEAF_GRID to probe other grids)
 	const unsigned grid_s = level == HYB_TWO_LEVEL ? env().leaf_grid : 256u;
+	const unsigned grid_1 = 65536u;   // the kernels of rsx_leaf16.hpp take one leaf per workgroup (wave, row): the grid IS the table (LEAF_ONE_PER_GROUP)
 	const unsigned grid_b = 256u;
 	const LeafSeg *segtab = level == HYB_TWO_LEVEL ? (const LeafSeg *)((char *)c.seg.p + c.seg_segtab_off) : nullptr;
 	const SegCtl *ctl = (const SegCtl *)c.seg.p;
@@ -1158,14 +1159,14 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			// (three shapes by the slots' capacity, as the pairs' leaves: a leaf's fixed costs follow its shape)
 #define RSX_LEAFK(K4, K8)                                                                                                      \
 	do {                                                                                                                       \
-		hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4>), dim3(grid_s), dim3(K4::BLOCK), 0, c.stream, src, aux,               \
+		hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4>), dim3(grid_1), dim3(K4::BLOCK), 0, c.stream, src, aux,               \
 		                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo,               \
 		                   (u32)env().leaf16_maxbin);                                                                          \
-		hipLaunchKernelGGL((rsx_leafk_kernel<KT, u64, K8>), dim3(grid_s), dim3(K8::BLOCK), 0, c.stream, src, aux,               \
+		hipLaunchKernelGGL((rsx_leafk_kernel<KT, u64, K8>), dim3(grid_1), dim3(K8::BLOCK), 0, c.stream, src, aux,               \
 		                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K8::CAP, slots, c.slack_cap, redo,               \
 		                   (u32)env().leaf16_maxbin);                                                                          \
 		if (narrow_slots_ok<KT>(c.slack_cap))   /* four-byte slots (SegCtl::narrow) */                                          \
-			hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4, true>), dim3(grid_s), dim3(K4::BLOCK), 0, c.stream, src, aux,     \
+			hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4, true>), dim3(grid_1), dim3(K4::BLOCK), 0, c.stream, src, aux,     \
 			                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo,           \
 			                   (u32)env().leaf16_maxbin);                                                                      \
 	} while (0)
@@ -1183,8 +1184,19 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 				RSX_LEAFK(K1, K1);
 			else if (c.slack_cap <= (u32)K2::CAP)
 				RSX_LEAFK(K2, K2);
-			else
-				RSX_LEAFK(K4, K8);
+			else {
+				// the 5120-key shape (arrays above 2^27 keys: BASELINE.json's cfg 3): the 8-byte-carried leaves by their own kernel
+				hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4>), dim3(grid_1), dim3(K4::BLOCK), 0, c.stream, src, aux,
+				                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo,
+				                   (u32)env().leaf16_maxbin);
+				hipLaunchKernelGGL((rsx_leafk8_kernel<KT, u64, LeafK8Cfg>), dim3(grid_1), dim3(LeafK8Cfg::BLOCK), 0, c.stream, src, aux,
+				                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)LeafK8Cfg::CAP, slots, c.slack_cap, redo,
+				                   (u32)env().leaf16_maxbin);
+				if (narrow_slots_ok<KT>(c.slack_cap))
+					hipLaunchKernelGGL((rsx_leafk_kernel<KT, u32, K4, true>), dim3(grid_1), dim3(K4::BLOCK), 0, c.stream, src, aux,
+					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)K4::CAP, slots, c.slack_cap, redo,
+					                   (u32)env().leaf16_maxbin);
+			}
 #undef RSX_LEAFK
 			typedef LeafCfg<u32, 4, 32, 3, true, false> N;
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, N, u32>), dim3(2048), dim3(N::BLOCK), 0, c.stream, src, aux, (u64)n,
@@ -1220,13 +1232,13 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 				// (no list, no second launch: the wave kernel goes on until its leaf is in order)
 				typedef Leaf16QCfg<4> Q256;            // slots of up to 256 values (arrays of up to ~13 Mi keys): four leaves per wave
 				if (c.slack_cap <= (u32)Q256::CAP && !env().no_leaf16q)
-					hipLaunchKernelGGL((rsx_leaf16q_kernel<KT, Q256>), dim3(grid_s / Q256::ROWS), dim3(Q256::BLOCK), 0, c.stream, src, aux,
+					hipLaunchKernelGGL((rsx_leaf16q_kernel<KT, Q256>), dim3(grid_1 / Q256::ROWS), dim3(Q256::BLOCK), 0, c.stream, src, aux,
 					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)Q256::CAP, (const uint16_t *)slots, c.slack_cap);
 				else if (c.slack_cap <= (u32)W512::CAP)
-					hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W512>), dim3(grid_s / W512::NW), dim3(W512::BLOCK), 0, c.stream, src, aux,
+					hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W512>), dim3(grid_1 / W512::NW), dim3(W512::BLOCK), 0, c.stream, src, aux,
 					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)W512::CAP, (const uint16_t *)slots, c.slack_cap);
 				else
-					hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W1k>), dim3(grid_s / W1k::NW), dim3(W1k::BLOCK), 0, c.stream, src, aux,
+					hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W1k>), dim3(grid_1 / W1k::NW), dim3(W1k::BLOCK), 0, c.stream, src, aux,
 					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)W1k::CAP, (const uint16_t *)slots, c.slack_cap);
 				HIP_TRY(hipGetLastError());
 				return RSX_OK;
@@ -1236,9 +1248,9 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			                   segtab, wctl, ka, 0u, (u32)CFG::CAP, (const uint16_t *)slots, c.slack_cap, redo,                \
 			                   (u32)env().leaf16_maxbin)
 			if (c.slack_cap <= (u32)L2k::CAP)
-				RSX_LAUNCH_L16(rsx_leaf16_kernel, L2k, grid_s);
+				RSX_LAUNCH_L16(rsx_leaf16_kernel, L2k, grid_1);
 			else
-				RSX_LAUNCH_L16(rsx_leaf16_kernel, L5k, grid_s);
+				RSX_LAUNCH_L16(rsx_leaf16_kernel, L5k, grid_1);
 #undef RSX_LAUNCH_L16
 			typedef typename LeafShapes<KT>::Fit F_;
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F_, uint16_t, true>), dim3(4096), dim3(F_::BLOCK), 0, c.stream, src, aux,
@@ -2323,7 +2335,7 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 			typedef LeafKCfg<128, 1280, 6, 10> P1;
 			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
 #define RSX_LEAFP(P) \
-	hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P>), dim3(env().leaf_grid), dim3(P::BLOCK), 0, c.stream, (const KT *)c.slack.p, \
+	hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P>), dim3(65536u), dim3(P::BLOCK), 0, c.stream, (const KT *)c.slack.p, \
 	                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab, ctl, ka, redo, \
 	                   (u32)env().leaf16_maxbin)
 			typedef LeafKCfg<64, 256, 8, 9> P0;    // slots of up to 256 pairs: a wave per leaf

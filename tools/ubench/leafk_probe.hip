@@ -155,6 +155,13 @@ template <typename C> void launch_old(u64 *out, unsigned grid)
 	hipLaunchKernelGGL((rsx_leafk_kernel<u64, u64, C>), dim3(grid), dim3(C::BLOCK), 0, 0, out, (u64 *)nullptr, (const Plan *)d_plan,
 	                   (const LeafSeg *)d_seg, d_ctl, ka, 0u, (u32)C::CAP, (const u64 *)d_slots, cap, d_redo, 25u);
 }
+static void launch_k8(u64 *out, unsigned grid)
+{
+	KdfArgs<u64> ka{0, 0, 0};
+	hipLaunchKernelGGL((rsx_leafk8_kernel<u64, u64, LeafK8Cfg>), dim3(grid), dim3(LeafK8Cfg::BLOCK), 0, 0, out, (u64 *)nullptr,
+	                   (const Plan *)d_plan, (const LeafSeg *)d_seg, d_ctl, ka, 0u, (u32)LeafK8Cfg::CAP, (const u64 *)d_slots, cap,
+	                   d_redo, 25u);
+}
 template <typename C> void launch_new(u64 *out, unsigned grid)
 {
 	KdfArgs<u64> ka{0, 0, 0};
@@ -213,7 +220,8 @@ int main(int argc, char **argv)
 	CK(hipMemcpy(d_ctl, &c, sizeof c, hipMemcpyHostToDevice));
 	printf("n = %zu u64 keys in %u slots of %u keys (%u +- 64 in each), mode %u\n", n, nleaf, cap, per, mode);
 	typedef LeafKCfg<512, 5120, 8, 12> K8;
-	bench("rsx_leafk_kernel<u64, u64, <512, 5120, 8, 12>> (csrc)", nleaf, true, [&](u64 *o, unsigned g) { launch_old<K8>(o, g); });
+	bench("rsx_leafk_kernel<u64, u64, <512, 5120, 8, 12>> (csrc, general)", nleaf, true, [&](u64 *o, unsigned g) { launch_old<K8>(o, g); });
+	bench("rsx_leafk8_kernel (csrc: 6-byte staging, 16-byte loads)", nleaf, false, [&](u64 *o, unsigned g) { launch_k8(o, g); });
 #define NEW(GRID, ...) bench("leafk2 <" #__VA_ARGS__ ">", GRID, false, [&](u64 *o, unsigned g) { launch_new<LeafK2Cfg<__VA_ARGS__>>(o, g); })
 	NEW(nleaf, 512, 5120, 6, 12, false);
 	NEW(nleaf, 512, 5120, 6, 12, true);
