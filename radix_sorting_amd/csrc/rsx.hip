@@ -13,6 +13,7 @@
 #include "rsx_hybrid.hpp"
 #include "rsx_leaf16.hpp"
 #include "rsx_pass16.hpp"
+#include "rsx_pass32.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -118,6 +119,7 @@ struct Env {
 	bool no_shift = false;           // RSX_NO_SHIFT=1: the MSB digits of a sort without a histogram are whole bytes (the two highest kept columns) always
 	bool no_pass16 = false;          // RSX_NO_PASS16=1: the level-2 pass into two-byte slots is rsx_scatter2_kernel<..., KTO = u16, SEG> as in round 4 (rsx_pass16.hpp)
 	unsigned pass16_wgs = 2;         // RSX_PASS16_WGS=1: ... one workgroup per CU (probe)
+	bool no_pass32a = false;         // RSX_NO_PASS32A=1: the level-1 pass of such a sort is rsx_scatter2_kernel<..., SEG> with its look-back chain (rsx_pass32.hpp)
 	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
 	bool no_leaf16 = false;          // RSX_NO_LEAF16=1: two-byte slots are sorted by rsx_leaf_sort_kernel (two LDS passes) as in round 3
@@ -165,6 +167,7 @@ struct Env {
 		no_leaf16 = is_one("RSX_NO_LEAF16");
 		no_pass16 = is_one("RSX_NO_PASS16");
 		no_pass16a = is_one("RSX_NO_PASS16A");
+		no_pass32a = is_one("RSX_NO_PASS32A");
 		pass16_wgs = 2;
 		if (const char *e = getenv("RSX_PASS16_WGS"))
 			pass16_wgs = atoi(e) == 1 ? 1u : 2u;
@@ -1465,7 +1468,7 @@ template <typename KT> int seg_layout(Ctx &c, size_t n)
 	c.seg_status_off = c.seg_hist_off + hist_bytes;
 	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
 	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
-	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 257 : rows;   // (rsx_pass16a_kernel's tiles are smaller)
+	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 514 : rows;   // (rsx_pass16a_kernel's tiles are smaller; a bucket may end in a tile of its own for what lies at its slot's end)
 	c.seg_btile_off = c.seg_tiles_off + tile_rows * sizeof(SegTile);
 	c.seg_redo_off = c.seg_btile_off + 260 * sizeof(u32);   // the leaves rsx_leaf16_kernel leaves to rsx_leaf_sort_kernel
 	return c.seg.ensure(c.seg_redo_off + 65536 * sizeof(u32));
@@ -1745,11 +1748,43 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	                   (u32)(sizeof(KT) == 4 && dense_slots<KT>(c) && !env().no_leaf16 && !env().no_shift ? 1 : 0),
 	                   // 8-byte keys in slots rsx_leafk_kernel takes: four-byte slots where the leaves' columns lie in the low word
 	                   (u32)(narrow_slots_ok<KT>(cap2) ? 1 : 0));
-	RSX_TRY(launch_seg_pass<KT>(c, src, lo ? aux : nullptr, n, ka, -2, 1));
+	// 4-byte keys from 64 Mi keys on: the level-1 pass in whole 64-byte atoms (rsx_pass32a_kernel: a workgroup per CU takes a range
+	// of tiles and carries what does not fill an atom; a bucket then lies at both ends of its slot)
 	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
+	bool atoms1 = false;
+	if constexpr (sizeof(KT) == 4) {
+		// (only in front of rsx_pass16a_kernel, which has no chain: a bucket that lies at both ends of its slot is one tile more, and
+		// the chained level-2 passes have a row of status words per tile of the ordinary count)
+		atoms1 = atoms && !env().no_pass32a && n >= ((size_t)1 << 26) && cap1 >= (u32)Pass32aCfg::TILE + 2 * PASS32_BACK;
+		if (atoms1) {
+			// one base for the stores, the parts' offsets in the slots' places (as launch_seg_pass does for the chained pass)
+			u32 off_lo = 0, off_hi = 0;
+			KT *kbase = (KT *)c.slack1.p;
+			if (lo) {
+				const uintptr_t lo_a = (uintptr_t)aux, hi_a = (uintptr_t)c.slack1.p - (size_t)lo * cap1 * sizeof(KT);
+				const uintptr_t base_a = std::min(lo_a, hi_a);
+				off_lo = (u32)((lo_a - base_a) / sizeof(KT));
+				off_hi = (u32)((hi_a - base_a) / sizeof(KT));
+				kbase = (KT *)base_a;
+			}
+			u32 *cur1 = (u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256);
+			u32 *ovf = &((SegCtl *)c.seg.p)->overflow;
+			const bool plain = ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0;
+			ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
+			if (plain)
+				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIG_PLAIN>), dim3(256), dim3(Pass32aCfg::BLOCK), 0, c.stream, (const KT *)src, (u64)n,
+				                   kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka);
+			else
+				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIG_GENERIC>), dim3(256), dim3(Pass32aCfg::BLOCK), 0, c.stream, (const KT *)src, (u64)n,
+				                   kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka);
+			HIP_TRY(hipGetLastError());
+		}
+	}
+	if (!atoms1)
+		RSX_TRY(launch_seg_pass<KT>(c, src, lo ? aux : nullptr, n, ka, -2, 1));
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   atoms ? (u32)Pass16aCfg::TILE : (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
-	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0);
+	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0, atoms1 ? PASS32_BACK : 0u);
 	RSX_TRY(launch_seg_pass<KT>(c, lo ? aux : nullptr, nullptr, n, ka, -2, 2));
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
                                                             u32 tile, SegTile *__restrict__ tiles, SegCtl *__restrict__ ctl,
                                                             u32 *__restrict__ btile,   // [257]: bucket k's tiles are [btile[k], btile[k + 1])
                                                             u64 *__restrict__ off1_out = nullptr, u32 blind_cap = 0,
-                                                            const u32 *__restrict__ status0 = nullptr, u32 ntiles0 = 0)
+                                                            const u32 *__restrict__ status0 = nullptr, u32 ntiles0 = 0,
+                                                            u32 back_cap = 0)
 {
 	// blind_cap != 0 (a sort without a histogram): no offsets exist.  The inclusive prefix of the LAST tile of the level-1 pass
 	// (rsx_scatter2_kernel, SCATTER_BLIND_TOP; status0) is the size of every bucket; bucket k lies in ITS SLOT of blind_cap keys
@@ -111,11 +112,19 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
 	// (radix_sort.hpp:72-80) -- goes to off1_out[256]; a slot that overflowed ends the attempt.
 	if (plan->hyb != HYB_TWO_LEVEL || (blind_cap && ctl->blind != BLIND_GO))
 		return;
-	__shared__ u32 s_size[256], s_tb[257], s_beg[256], s_w[4];
+	__shared__ u32 s_size[256], s_tb[257], s_beg[256], s_w[4], s_back[256];
 	const u32 d = threadIdx.x;
-	u32 size;
+	u32 size, back = 0;
 	if (blind_cap) {
-		size = __hip_atomic_load(status0 + ((u64)(ntiles0 - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & StatusBits<u32>::VALMASK;
+		if (back_cap) {
+			// back_cap != 0: the level-1 pass was rsx_pass32a_kernel (rsx_pass32.hpp) -- no chain; bucket d lies at BOTH ends of its slot:
+			// status0[d] keys from the slot's beginning on, status0[256 + d] in its last back_cap places (the slot's two cursors)
+			size = __hip_atomic_load(status0 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			back = __hip_atomic_load(status0 + 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			size += back;
+		} else {
+			size = __hip_atomic_load(status0 + ((u64)(ntiles0 - 1) * 256 + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & StatusBits<u32>::VALMASK;
+		}
 		const bool over = size > blind_cap || ctl->overflow != 0;
 		u32 tot1;
 		const u32 o = block_scan_256(size, s_w, tot1);
@@ -134,8 +143,10 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
 		s_beg[d] = (u32)b;
 	}
 	s_size[d] = size;
+	s_back[d] = back;
 	u32 total;
-	const u32 tb = block_scan_256((size + tile - 1) / tile, s_w, total);
+	// (a bucket's tiles: those of its front part, then ONE for what lies at the slot's end -- at most back_cap keys, less than a tile)
+	const u32 tb = block_scan_256((size - back + tile - 1) / tile + (back ? 1u : 0u), s_w, total);
 	s_tb[d] = tb;
 	if (d == 0) {
 		s_tb[256] = total;
@@ -160,9 +171,15 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
 			++lo;
 		const u32 k = lo, j = t - s_tb[k];
 		SegTile st;
-		st.beg = s_beg[k] + j * tile;
-		const u32 left = s_size[k] - j * tile;
-		st.cnt = left < tile ? left : tile;
+		const u32 front = s_size[k] - s_back[k];
+		if (j * tile < front) {
+			st.beg = s_beg[k] + j * tile;
+			const u32 left = front - j * tile;
+			st.cnt = left < tile ? left : tile;
+		} else {
+			st.beg = s_beg[k] + blind_cap - back_cap;
+			st.cnt = s_back[k];
+		}
 		st.bucket = k;
 		st.first = s_tb[k];
 		tiles[t] = st;
