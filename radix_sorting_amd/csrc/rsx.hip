@@ -119,6 +119,7 @@ struct Env {
 	bool no_shift = false;           // RSX_NO_SHIFT=1: the MSB digits of a sort without a histogram are whole bytes (the two highest kept columns) always
 	bool no_pass16 = false;          // RSX_NO_PASS16=1: the level-2 pass into two-byte slots is rsx_scatter2_kernel<..., KTO = u16, SEG> as in round 4 (rsx_pass16.hpp)
 	unsigned pass16_wgs = 2;         // RSX_PASS16_WGS=1: ... one workgroup per CU (probe)
+	bool no_packed_keys = false;     // RSX_NO_PACKED_KEYS=1: rank sorts without a histogram go by byte columns only (SegCtl::compact never set)
 	bool no_pass32a = false;         // RSX_NO_PASS32A=1: the level-1 pass of such a sort is rsx_scatter2_kernel<..., SEG> with its look-back chain (rsx_pass32.hpp)
 	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
@@ -168,6 +169,7 @@ struct Env {
 		no_pass16 = is_one("RSX_NO_PASS16");
 		no_pass16a = is_one("RSX_NO_PASS16A");
 		no_pass32a = is_one("RSX_NO_PASS32A");
+		no_packed_keys = is_one("RSX_NO_PACKED_KEYS");
 		pass16_wgs = 2;
 		if (const char *e = getenv("RSX_PASS16_WGS"))
 			pass16_wgs = atoi(e) == 1 ? 1u : 2u;
@@ -1771,6 +1773,8 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 			u32 *ovf = &((SegCtl *)c.seg.p)->overflow;
 			const bool plain = ka.fmask == 0 && ka.sflip == 0 && ka.desc == 0;
 			ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
+			// (probed and not kept: Pass32aCfgT<12> -- 12 Ki-key tiles, 81 KB of LDS, two workgroups per CU, no prefetch: 0.534-0.543 ms
+			// for 2^28 keys where this shape takes 0.470-0.477 on the same box, profiles/r05/pass32a_probe.txt)
 			if (plain)
 				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIG_PLAIN>), dim3(256), dim3(Pass32aCfg::BLOCK), 0, c.stream, (const KT *)src, (u64)n,
 				                   kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka);
@@ -2325,7 +2329,11 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	c.host_segctl->mode = SEG_MODE_NONE;
 	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, kin, (u64)n, ka, ctl, c.plan(),
 	                   c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
-	                   (u32)sizeof(KT));   // (every column kept: the callers' parity rule below counts on it)
+	                   (u32)sizeof(KT),   // (every column kept: the callers' parity rule below counts on it)
+	                   0u, 0u,
+	                   // rank sorts (no keys wanted back): keys whose byte columns do not spread but whose VARYING bits would, packed
+	                   // together, go by those (SegCtl::compact, README.md:716-758)
+	                   (u32)((vin == nullptr && kfinal == nullptr && !env().no_packed_keys) ? 1 : 0));
 	SegArgs sa{};
 	sa.ctl = ctl;
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);

@@ -59,8 +59,41 @@ struct SegCtl {
 	// of every DERIVED key into its slots (four bytes per key instead of eight) and rsx_leafk_kernel's SLOT32 form reads them;
 	// the upper word comes back from key0, the constant columns and the slot's two digits
 	u32 narrow;
+	// Rank sorts of 4-byte keys whose VARYING bits are few (README.md:716-758, key compaction: f32 & 0xFFF000FF, BASELINE.json's
+	// cfg 4 (iii), varies in 20 bits -- and its byte columns hold 2, 32 and 256 values, which no slot scheme by bytes takes):
+	// the level-1 pass packs the bits in which the sampled keys differ from the first key into the low `compact` bits of an
+	// unsigned key (up to four runs of bits: cpiece[] = source shift | width << 8 | destination shift << 16; the KDF's flips applied
+	// in the packed space: dropping bits that are the same in every key does not change the order), writes THAT into its slots, and
+	// every kernel behind it sorts plain unsigned keys whose digits lie below bit `compact` (shift1 / shift2).  A key that
+	// differs from the first one (craw0, as the caller wrote it) outside the varying bits (cvnot) calls the attempt off, as a
+	// column taken for constant that is not (cmask) does for the byte scheme.  0: no compaction.
+	u32 compact;
+	u32 cpiece[4];
+	u32 craw0, cvnot;
 };
 enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
+
+// the packed key of `raw` (SegCtl::compact): the varying bits' runs moved together, then the KDF's flips in the packed space
+// (fneg: a float key with its sign bit set; top: the packed position of the sign bit, if it varies; desc: descending order)
+template <typename KT>
+__device__ __forceinline__ u32 compact_key(u32 raw, const u32 (&piece)[4], u32 nb, const KdfArgs<KT> ka)
+{
+	u32 c = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const u32 p = piece[i];
+		c |= __builtin_amdgcn_ubfe(raw, p & 31u, (p >> 8) & 63u) << (p >> 16);
+	}
+	const u32 all = nb >= 32u ? ~0u : (1u << nb) - 1u;
+	// which packed bits the KDF flips: every one for a negative float and for descending order; the sign bit's packed place
+	// (the top packed bit, if the sign varies at all) for signed keys and non-negative floats
+	const bool neg = ka.fmask != 0 && (raw >> 31) != 0;
+	const u32 top = (piece[0] & 31u) + ((piece[0] >> 8) & 63u) == 32u ? 1u << (nb - 1u) : 0u;   // (piece 0 is the highest run)
+	u32 flip = neg ? all : (ka.sflip ? top : 0u);
+	if (ka.desc)
+		flip ^= all;
+	return c ^ flip;
+}
 
 // A leaf's keys: [beg, beg + cnt), sorted by the `ncols` lowest kept columns.  Level 2: a (digit, digit) bucket (ncols = all
 // columns below the level-2 one) or a run of small neighbouring ones of the same level-1 bucket (one column more).
@@ -506,7 +539,7 @@ template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka,
                                                                   SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
                                                                   Plan *host_plan, u32x4 *__restrict__ z, u64 nz, u32 min_cols,
-                                                                  u32 allow_shift = 0, u32 allow_narrow = 0)
+                                                                  u32 allow_shift = 0, u32 allow_narrow = 0, u32 allow_compact = 0)
 {
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
@@ -648,6 +681,76 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		}
 		__syncthreads();
 	}
+	// ---- rank sorts of 4-byte keys (allow_compact): would the keys' VARYING bits, packed together, spread evenly?  (SegCtl::compact)
+	__shared__ u32 s_vraw, s_cnb, s_cpiece[4], s_cmax[2];
+	if constexpr (W == 4) {
+		if (allow_compact) {
+			const u32 raw0 = (u32)src[0];
+			u32 raw[S];
+			u32 v = 0;
+#pragma unroll
+			for (u32 e = 0; e < S; ++e) {
+				raw[e] = (u32)src[i0 + e];
+				v |= raw[e] ^ raw0;
+			}
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1)
+				v |= (u32)__shfl_xor((int)v, off);
+			if (tid == 0)
+				s_vraw = s_cnb = s_cmax[0] = s_cmax[1] = 0;
+			if (tid < 512)
+				(&hs[0][0])[tid] = 0;
+			__syncthreads();
+			if ((tid & 63) == 0)
+				atomicOr(&s_vraw, v);
+			__syncthreads();
+			if (tid == 0) {
+				// the runs of varying bits, highest first; their packed places, highest first
+				u32 vv = s_vraw, np = 0, nb = (u32)__popc(vv), left = nb;
+				bool ok = nb >= 17u && nb <= 30u;
+				u32 pc[4] = {0, 0, 0, 0};
+				while (vv && ok) {
+					const u32 hi = 31u - (u32)__builtin_clz(vv);            // top bit of the highest run
+					const u32 below = ~vv & ((2u << hi) - 1u);              // the bits below it that do NOT vary
+					const u32 lo = below ? 32u - (u32)__builtin_clz(below) : 0u;   // the run is bits lo .. hi
+					const u32 w = hi - lo + 1u;
+					if (np == 4) {
+						ok = false;
+						break;
+					}
+					left -= w;
+					pc[np++] = lo | (w << 8) | (left << 16);
+					vv &= lo ? (1u << lo) - 1u : 0u;
+				}
+				for (u32 i = 0; i < 4; ++i)
+					s_cpiece[i] = pc[i];
+				s_cnb = ok ? nb : 0u;
+			}
+			__syncthreads();
+			const u32 cnb = s_cnb;
+			if (cnb) {
+				const u32 pc[4] = {s_cpiece[0], s_cpiece[1], s_cpiece[2], s_cpiece[3]};
+#pragma unroll
+				for (u32 e = 0; e < S; ++e) {
+					const u32 c = compact_key<KT>(raw[e], pc, cnb, ka);
+					atomicAdd(&hs[0][(c >> (cnb - 8u)) & 0xFFu], 1u);
+					atomicAdd(&hs[1][(c >> (cnb - 16u)) & 0xFFu], 1u);
+				}
+			}
+			__syncthreads();
+			if (cnb) {
+				u32 ms = tid < 512 ? (&hs[0][0])[tid] : 0u;
+#pragma unroll
+				for (int off = 32; off > 0; off >>= 1) {
+					const u32 ys = __shfl_xor(ms, off);
+					ms = ys > ms ? ys : ms;
+				}
+				if ((tid & 63) == 0 && tid < 512)
+					atomicMax(&s_cmax[tid >> 8], ms);
+			}
+			__syncthreads();
+		}
+	}
 	if (tid == 0) {
 		bool go = s_desc != 0;
 		u32 nk = 0, cols[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -675,11 +778,28 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		const u32 max12_ok = 3 * (NS / nbins12) + 18u;
 		if (shift1 & 7u)
 			go = go && s_max12 <= max12_ok;
+		// the byte scheme does not take these keys, their packed varying bits would (all four columns kept, so that the ranks end in
+		// the half the reference's parity rule names for four passes, radix_sort_rank.hpp:91; unsorted; both packed MSB digits even)
+		u32 compact = 0;
+		if constexpr (W == 4) {
+			if (!go && allow_compact && s_cnb && s_desc != 0 && nk == 4 && s_cmax[0] <= 2 * NS / 256 && s_cmax[1] <= 2 * NS / 256) {
+				compact = s_cnb;
+				go = true;
+				shift1 = compact - 8u;
+				shift2 = compact - 16u;
+				cmask = 0;   // (what must not vary is checked on the keys as the caller wrote them: cvnot)
+			}
+		}
+		ctl->compact = compact;
+		for (u32 i = 0; i < 4; ++i)
+			ctl->cpiece[i] = compact ? s_cpiece[i] : 0u;
+		ctl->craw0 = compact ? (u32)src[0] : 0u;
+		ctl->cvnot = compact ? ~s_vraw : 0u;
 		ctl->ntiles = ctl->mode = ctl->maxleaf = ctl->done = ctl->nleaf = ctl->overflow = ctl->nredo = 0;   // (nobody else zeroes the control block)
 		ctl->blind = go ? BLIND_GO : BLIND_FAILED;
 		// NS samples over 4096 bins: two per bin on average, the fullest holds ten or eleven; a leaf of 4096 keys sees half of
 		// what the sample sees, and rsx_leaf16_kernel takes bins of up to 25 keys
-		ctl->leaf16 = s_max12 <= max12_ok ? 1u : 0u;
+		ctl->leaf16 = (s_max12 <= max12_ok || compact) ? 1u : 0u;   // (packed keys: the leaves' own test of their bins decides)
 		// (8-byte keys, the leaves' columns all in the low word, their bins even: the leaves that read four-byte slots)
 		ctl->narrow = (W == 8 && allow_narrow && go && nk >= 4 && cols[nk - 3] <= 3u && s_max12 <= max12_ok) ? 1u : 0u;
 		ctl->shift1 = shift1;
@@ -1132,6 +1252,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 	static_assert(KPT % G == 0, "whole groups of rounds");
 	if (plan->hyb != level || (level == HYB_TWO_LEVEL && ctl->mode != SEG_MODE_LEAVES))
 		return;
+	if (level == HYB_TWO_LEVEL && ctl->compact)
+		ka.fmask = ka.sflip = ka.desc = 0;   // (the slots hold packed keys, SegCtl::compact: plain unsigned)
 	u32 colpack = 0;
 #pragma unroll
 	for (int k = 0; k < 8; ++k)

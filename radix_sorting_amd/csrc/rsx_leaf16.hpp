@@ -1419,6 +1419,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 	const u32 mode = ctl->mode, nseg = ctl->nleaf, on = ctl->leaf16, maxleaf = ctl->maxleaf;
 	if (hyb != HYB_TWO_LEVEL || ncols != 4 || mode != SEG_MODE_LEAVES || !on || maxleaf > (u32)CAP)
 		return;
+	// SegCtl::compact (rsx_hybrid.hpp): the slots hold PACKED keys -- plain unsigned, their own derived keys -- of which the low
+	// LB = SegCtl::shift2 bits are the leaf's to sort by (16 without compaction: the two low byte columns).  The compound is the
+	// leaf's bits above the pair's position in the slot, left-aligned: its top twelve bits -- the bins -- then spread over the
+	// leaf's bits and, where those are fewer than twelve, the top bits of the position.
+	const u32 LB = ctl->compact ? ctl->shift2 : 16u;
+	if (ctl->compact)
+		ka.fmask = ka.sflip = ka.desc = 0;
+	const u32 shk = 32u - LB, shi = 19u - LB;   // (the position's thirteen bits right below the leaf's: no unused bit between them dilutes the bins)
 	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
 	__shared__ __attribute__((aligned(16))) u32 stage[16 * S + 64];   // the compounds, transposed (LeafKCfg::S)
 	__shared__ __attribute__((aligned(16))) VT pay[CAP];
@@ -1458,7 +1466,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 				*(u32x4 *)&pay[e0] = vv[j];
 #pragma unroll
 			for (int e = 0; e < 4; ++e)
-				kv[j][e] = (kdf_apply((KT)kv[j][e], ka) << 16) | (e0 + e);
+				kv[j][e] = (kdf_apply((KT)kv[j][e], ka) << shk) | ((e0 + e) << shi);
 		}
 		__syncthreads();
 		auto cell_of = [&](u32 c, bool valid, u32 &sh) -> u32 * {
@@ -1584,8 +1592,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
 					const u32 x = stage[at(i0 + e)];
-					pv[e] = pay[(x & 0xFFFFu) < (u32)CAP ? (x & 0xFFFFu) : 0u];   // (behind the leaf's end: padding)
-					kk[e] = kdf_invert((KT)(upper | (x >> 16)), ka);
+					const u32 pi = (x >> shi) & 0x1FFFu;                  // (the pair's position in the slot: thirteen bits)
+					pv[e] = pay[pi < (u32)CAP ? pi : 0u];                  // (behind the leaf's end: padding)
+					kk[e] = kdf_invert((KT)(upper | (x >> 16)), ka);       // (keys out: key + payload sorts, never packed)
 				}
 				if (i0 + 4 <= cnt) {
 					store_chunk<VT, 4>(vo + i0, pv);

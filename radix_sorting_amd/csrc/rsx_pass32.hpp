@@ -23,37 +23,39 @@
 
 namespace rsx {
 
-struct Pass32aCfg {
-	static constexpr int BLOCK = 1024, KPT = 28, TILE = BLOCK * KPT;
+template <int KPT_ = 28> struct Pass32aCfgT {
+	static constexpr int BLOCK = 1024, KPT = KPT_, TILE = BLOCK * KPT;
+	static constexpr int WPE = KPT_ <= 12 ? 8 : 4;   // (12 keys per lane: 81 KB of LDS, two workgroups per CU, 64 registers)
+	static constexpr int SB = KPT_ % 7 == 0 ? 7 : 6;  // staging atomics in flight
 	static constexpr u32 ATOM = 16;     // keys per 64-byte atom
-	static constexpr u32 BACK = 4096;   // keys at the end of every slot for what is carried when a range ends (256 workgroups x 15)
+	static constexpr u32 BACK = 8192;   // keys at the end of every slot for what is carried when a range ends (up to 512 workgroups x 15)
 	static constexpr int STAGE = TILE + 256 * 6;   // + what the 16-byte alignment of 256 runs can cost
 };
+typedef Pass32aCfgT<28> Pass32aCfg;
 constexpr u32 PASS32_BACK = Pass32aCfg::BACK;
 
-template <typename KT> struct Pass32aSmem {
-	__attribute__((aligned(16))) KT stage[Pass32aCfg::STAGE];
+template <typename KT, typename C> struct Pass32aSmem {
+	__attribute__((aligned(16))) KT stage[C::STAGE];
 	__attribute__((aligned(16))) KT carry[256][16];
 	u32 cell[2][256];   // per digit: count, then the run's cursor (tile-local); tiles alternate between the two
 	u32 delta[256];     // slot position of a body key minus its tile-local position
 	u32 info[256];      // carried before (5 bits) | head (5) | tail (5) | atom completed | enough for an atom | offset in the region
 	unsigned short rbeg[256], bbeg[256], bend[256];
-	unsigned char group_digit[Pass32aCfg::STAGE / 4];
+	unsigned char group_digit[C::STAGE / 4];
 	u32 wsum[4];
 };
 
 // kout: the lower of the two arrays the slots lie in; slot d starts (d < lo_slots ? off_lo : off_hi) + d * cap keys from there
 // (SegArgs, rsx_scatter2.hpp).  cursors: [256] front cursors, [256] back cursors (zeroed by rsx_blind_precheck_kernel).
-template <typename KT, int DIG, bool PREFETCH = true>
-__global__ __launch_bounds__(Pass32aCfg::BLOCK, 4) void rsx_pass32a_kernel(const KT *__restrict__ kin, u64 n, KT *__restrict__ kout,
+template <typename KT, int DIG, bool PREFETCH = true, typename C = Pass32aCfg>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT *__restrict__ kin, u64 n, KT *__restrict__ kout,
                                                                           u32 lo_slots, u32 off_lo, u32 off_hi, u32 cap,
                                                                           const SegCtl *__restrict__ ctl,
                                                                           u32 *__restrict__ cursors, u32 *__restrict__ overflow,
                                                                           KdfArgs<KT> ka)
 {
 	static_assert(sizeof(KT) == 4, "4-byte keys");
-	typedef Pass32aCfg C;
-	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE;
+	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
 	if (ctl->blind != BLIND_GO)
 		return;   // (the sample has called the attempt off: rsx_hybrid.hpp)
 	const u32 ntiles = (u32)((n + TILE - 1) / TILE);
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(Pass32aCfg::BLOCK, 4) void rsx_pass32a_kernel(const
 		return;
 	const u32 shift = ctl->shift1;
 	const KT cmask = (KT)ctl->cmask_lo, key0 = (KT)ctl->key0_lo;   // the bits the sample took for constant, and the first key's (derived)
-	__shared__ Pass32aSmem<KT> sm;
+	__shared__ Pass32aSmem<KT, C> sm;
 	const u32 tid0 = threadIdx.x;
 	auto sidx = [](u32 pos) { return stage_swz<true>(pos * 4u); };
 	auto staged = [&](u32 pos) -> KT & { return *(KT *)((char *)sm.stage + sidx(pos)); };
@@ -200,10 +202,10 @@ __global__ __launch_bounds__(Pass32aCfg::BLOCK, 4) void rsx_pass32a_kernel(const
 		auto stage_keys = [&](auto full_c) {
 			constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-			for (int r0 = 0; r0 < KPT; r0 += 7) {
-				u32 pos[7];
+			for (int r0 = 0; r0 < KPT; r0 += SB) {
+				u32 pos[SB];
 #pragma unroll
-				for (int r = 0; r < 7; ++r) {
+				for (int r = 0; r < SB; ++r) {
 					pos[r] = 0;
 					if (FULL || tid + (r0 + r) * BLOCK < cnt) {
 						const KT k = DIG == 1 ? keep[r0 + r] : kdf_apply(keep[r0 + r], ka);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(Pass32aCfg::BLOCK, 4) void rsx_pass32a_kernel(const
 					}
 				}
 #pragma unroll
-				for (int r = 0; r < 7; ++r) {
+				for (int r = 0; r < SB; ++r) {
 					if (FULL || tid + (r0 + r) * BLOCK < cnt)
 						staged(pos[r]) = keep[r0 + r];
 				}

@@ -178,10 +178,29 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	u32 dcol = 0;
 	u32 seg_slot = 0;
 	KT bl_cmask = 0, bl_key0 = 0;   // SCATTER_BLIND_TOP: the columns taken for constant and the first key (derived): checked on every key
+	// SegCtl::compact (rank sorts of 4-byte keys whose varying bits are few, rsx_hybrid.hpp): the level-1 pass packs them and every
+	// pass behind it sorts the packed keys -- plain unsigned keys, whatever the caller's type
+	constexpr bool CAN_COMPACT = SEG && sizeof(KT) == 4 && val_bytes<VT>::value == 4 && std::is_same<KTO, KT>::value;
+	u32 cp_nb = 0, cp_raw0 = 0, cp_vnot = 0;
+	u32 cp_piece[4] = {0, 0, 0, 0};
+	const KdfArgs<KT> ka_raw = ka;
 	if constexpr (SEG) {
 		if ((flags & SCATTER_BLIND) && seg.ctl->blind != BLIND_GO)
 			return;   // (a sort without a histogram that has been called off: rsx_hybrid.hpp)
 		const u32 mode = seg.ctl->mode;
+		if constexpr (CAN_COMPACT) {
+			if ((flags & SCATTER_BLIND) && seg.ctl->compact) {
+				cp_nb = seg.ctl->compact;
+				if (flags & SCATTER_BLIND_TOP) {
+					cp_raw0 = seg.ctl->craw0;
+					cp_vnot = seg.ctl->cvnot;
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+						cp_piece[i] = seg.ctl->cpiece[i];
+				}
+				ka.fmask = ka.sflip = ka.desc = 0;   // (what is ranked from here on is a packed key: its own derived key)
+			}
+		}
 		if (flags & SCATTER_BLIND_TOP) {
 			// the level-1 pass of such a sort: by the highest column the sample proved kept, no offsets
 			seg_slot = 0;
@@ -568,6 +587,18 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 								atomicOr(seg.overflow, 1u);
 						}
 					}
+					if constexpr (CAN_COMPACT) {
+						if (cp_nb && (flags & SCATTER_BLIND_TOP)) {   // (uniform) the keys as the caller wrote them -> packed keys
+							u32 bad = 0;
+#pragma unroll
+							for (int r = 0; r < KPT; ++r) {
+								bad |= ((u32)keep[r] ^ cp_raw0) & cp_vnot;
+								keep[r] = (KT)compact_key<KT>((u32)keep[r], cp_piece, cp_nb, ka_raw);
+							}
+							if (__ballot(bad != 0) && lane == 0)
+								atomicOr(seg.overflow, 1u);   // (a bit the sample took for constant varies: the attempt is lost)
+						}
+					}
 #pragma unroll
 					for (int r = 0; r < KPT; ++r) {
 						const u32 d = digit2<DIG>(keep[r], ka, shift);
@@ -595,6 +626,19 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 						for (int r = 0; r < KPT; ++r)
 							if (wo + r * 64 < cnt)
 								bad |= ((DIG == DIG_PLAIN ? keep[r] : kdf_apply(keep[r], ka)) ^ bl_key0) & bl_cmask;
+						if (__ballot(bad != 0) && lane == 0)
+							atomicOr(seg.overflow, 1u);
+					}
+				}
+				if constexpr (CAN_COMPACT) {
+					if (cp_nb && (flags & SCATTER_BLIND_TOP)) {
+						u32 bad = 0;
+#pragma unroll
+						for (int r = 0; r < KPT; ++r) {
+							if (wo + r * 64 < cnt)
+								bad |= ((u32)keep[r] ^ cp_raw0) & cp_vnot;
+							keep[r] = (KT)compact_key<KT>((u32)keep[r], cp_piece, cp_nb, ka_raw);
+						}
 						if (__ballot(bad != 0) && lane == 0)
 							atomicOr(seg.overflow, 1u);
 					}

@@ -300,3 +300,60 @@ def test_f32_ranks_stable_through_the_compound_leaves(shape, monkeypatch):
     assert info.hybrid == 5, (shape, info.hybrid)
     assert info.result_in_aux == want_aux
     assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), shape
+
+
+@pytest.mark.parametrize("case", ["f32 & 0xFFF000FF, 16 Mi", "f32 & 0xFFF000FF, 96 Mi", "f32 & 0xFFF000FF desc, 24 Mi", "i32 three runs, 40 Mi",
+                                  "u32 four runs, 20 Mi"])
+def test_rank_sort_by_packed_varying_bits(case):
+    """Rank sorts of keys whose byte columns do not spread but whose VARYING bits, packed together, do (README.md:716-758;
+    BASELINE.json's cfg 4 (iii): f32 & 0xFFF000FF -- 2, 32 and 256 values per column, 20 varying bits): the sample finds the varying
+    bits, the level-1 pass packs them (and checks every key against the others), and the sort goes without a histogram on the
+    packed keys (SegCtl::compact).  Ranks as the oracle's, ties in index order (every key 16 .. 4096 times), the route asserted."""
+    name, size = case.rsplit(", ", 1)
+    n = int(size.split()[0]) * MI + 77
+    dt, order, mask = ol.F32, ol.ASC, 0xFFF000FF
+    if name.endswith("desc"):
+        order = ol.DESC
+    elif name.startswith("i32"):
+        dt, mask = ol.I32, 0xFF0FF0FC                     # runs 31-24, 19-12, 7-2: 22 varying bits, every byte column kept
+    elif name.startswith("u32"):
+        dt, mask = ol.U32, 0xF0F0FF0F                     # runs 31-28, 23-20, 15-8, 3-0: 20 varying bits
+    a = ol.splitmix_fill(n, dt, 5100 + len(case), mask).view(np.uint32).copy()
+    want, want_aux = ol.want_ranks(a, dt, order, big=1 << 22)
+    bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(bits, ib, dtype=dt, order=order)
+    torch.cuda.synchronize()
+    assert info.hybrid == 5, (case, info.hybrid)
+    assert info.result_in_aux == want_aux == 0
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), case
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), a), case          # the keys are only read
+
+
+@pytest.mark.parametrize("case", ["five runs", "one key differs outside the varying bits", "fifteen varying bits", "key + payload"])
+def test_packed_keys_are_not_for_everybody(case):
+    """What the packing does not take falls back to the histogram-first sort: more than four runs of varying bits; fewer than 17
+    varying bits; a key that differs from the first one in a bit the sample saw constant (found by the level-1 pass on EVERY key:
+    the attempt is called off after that pass); key + payload sorts (the caller wants the keys back)."""
+    n = 16 * MI + 5
+    mask = {"five runs": 0xF8F8F8F9, "fifteen varying bits": 0xFE0000FF}.get(case, 0xFFF000FF)
+    a = ol.splitmix_fill(n, ol.F32, 5200 + len(case), mask).view(np.uint32).copy()
+    if case.startswith("one key"):
+        a[n - 12345] ^= np.uint32(0x00004000)
+    want, want_aux = ol.want_ranks(a, ol.F32, ol.ASC, big=1 << 22)
+    bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    if case == "key + payload":
+        vals = torch.arange(n, dtype=torch.int32, device="cuda")
+        ka, va = torch.empty_like(bits), torch.empty_like(vals)
+        kr, vr, info = rsa.radix_sort_pairs(bits, ka, vals, va, dtype=rsa.F32)
+        torch.cuda.synchronize()
+        assert info.hybrid == 0, info.hybrid
+        assert np.array_equal(vr.cpu().numpy().view(np.uint32), want)
+        assert np.array_equal(kr.cpu().numpy().view(np.uint32), a[want])
+        return
+    ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert info.hybrid == 0, (case, info.hybrid)
+    assert info.result_in_aux == want_aux
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), case
