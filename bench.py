@@ -309,6 +309,15 @@ def main():
         ok = bool(okt.item())
     if not ok:
         raise SystemExit("bench: output of the last step is not sorted")
+    # per-phase GPU time of the LAST step, max over ranks (split / exchange / sort; the chunk pipeline overlaps the last two):
+    # a first run on several GPUs should explain itself
+    phase_max = None
+    if sharded and isinstance(last[1], dict) and callable(last[1].get("phases")):
+        ph = last[1]["phases"]() or {}
+        names = ["split_ms", "exchange_ms", "sort_ms", "exchange_and_sort_ms", "total_ms"]
+        vec = torch.tensor([float(ph.get(k, -1.0)) for k in names], dtype=torch.float64, device=dev)
+        dist.all_reduce(vec, op=dist.ReduceOp.MAX)
+        phase_max = {k: float(v) for k, v in zip(names, vec.tolist()) if v >= 0}
 
     if sharded:
         # RCCL writes its version banner to the C stdout (NCCL_DEBUG=VERSION on the GPU boxes): push it out on every rank
@@ -429,6 +438,10 @@ def main():
             out["host"] = {"ms_split_and_counts_last_step": last[1]["host_ms_split_and_counts"],
                            "ms_submit_exchange_and_sorts_last_step": last[1]["host_ms_submit_exchange_and_sorts"],
                            "chunks": last[1].get("chunks"), "heavy_digits": last[1].get("heavy_digits")}
+        if sharded and isinstance(last[1], dict):
+            out["multi"] = {"phases_last_step_max_over_ranks_ms": phase_max, "safe_mode": bool(last[1].get("safe_mode")),
+                            "safe_why": last[1].get("safe_why"), "overlap_stream": last[1].get("overlap_stream"),
+                            "imbalance": last[1].get("imbalance")}
         if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

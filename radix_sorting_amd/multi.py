@@ -68,6 +68,23 @@ def choose_splitters(top_hist, world):
 
 
 _OVERLAP_STREAMS = {}      # (device, group, to_self) -> stream or None (HipEngine.overlap_stream)
+# RSX_MULTI_SAFE=1 -- and, once set by a failure, for the rest of the process --: the exchange is ONE all_to_all_single and ONE
+# local sort, no sub-ranges, no grouped send/recv, no second stream, no calibration.  Nothing of the chunk pipeline below has
+# run on more than one physical GPU yet; this is what a first contact with eight ranks falls back to.
+_SAFE = {"latched": False, "why": None}
+
+
+def safe_mode():
+    return os.environ.get("RSX_MULTI_SAFE", "") == "1" or _SAFE["latched"]
+
+
+def _agree_failed(failed, group, device):
+    """Every rank learns whether ANY rank failed (one small all-reduce): the ranks must leave the pipeline together."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
 
 
 def count_matrix(hists, lut, world):
@@ -351,12 +368,21 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     nchunks = max(1, min(int(chunks), 64))
     if split_slices is None:
         split_slices = int(os.environ.get("RSX_MULTI_SPLIT_SLICES", "1"))
+    if safe_mode():
+        nchunks = 1
     nslices = max(1, min(int(split_slices), 16)) if nchunks > 1 else 1
+    on_gpu = shard.is_cuda
+    ev = (lambda: torch.cuda.Event(enable_timing=True)) if on_gpu else (lambda: None)
+    e_begin, e_split, e_xchg, e_end = ev(), ev(), ev(), ev()
+    if on_gpu:
+        e_begin.record()
     hists, column, heavy, levels, sliced = split_plan(shard, part, engine, group, world,
                                                       tmp=scratch.get("aux") if scratch else None, slices=nslices)
     if sliced is None:
         nslices = 1
     t_planned = time.perf_counter()     # (includes the split pass's one synchronisation and the gather of the counts)
+    if on_gpu:
+        e_split.record()
     local_hist = hists[rank]
     lut = choose_splitters(hists.sum(axis=0), world)
     matrix = count_matrix(hists, lut, world)          # matrix[s, d]: keys rank s sends to rank d
@@ -375,14 +401,35 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # every key width works on every backend), and as soon as they are in, they are sorted in place while the next
     # sub-range is on the links.  The split shard is in digit order: piece (destination d, sub-range j) of this rank is
     # part[first[a] : first[b]] for the digits [a, b) of that sub-range.  Receive layout: sub-range major, source minor.
-    if nchunks == 1:
+    def phases():
+        """GPU time of the step's phases on this rank (ms; needs a synchronisation: called by bench.py after its own)"""
+        if not on_gpu:
+            return None
+        torch.cuda.synchronize()
+        out = {"split_ms": e_begin.elapsed_time(e_split), "total_ms": e_begin.elapsed_time(e_end)}
+        if e_xchg.query():
+            out["exchange_ms"] = e_split.elapsed_time(e_xchg)
+            out["sort_ms"] = e_xchg.elapsed_time(e_end)
+        else:
+            out["exchange_and_sort_ms"] = e_split.elapsed_time(e_end)   # (the chunk pipeline overlaps the two)
+        return out
+
+    def one_exchange():
         es = shard.element_size()
         dist.all_to_all_single(recv.view(torch.uint8), part.view(torch.uint8),
                                output_split_sizes=[int(x) * es for x in recv_counts],
                                input_split_sizes=[int(x) * es for x in send_counts], group=group)
+        if on_gpu:
+            e_xchg.record()
         if n_recv > 1:
             engine.sort_inplace_async(recv, aux)
+        if on_gpu:
+            e_end.record()
+
+    if nchunks == 1:
+        one_exchange()
         return recv, {"sent": int(send_counts.sum() - send_counts[rank]), "received": n_recv, "local_info": None, "lut": lut,
+                      "safe_mode": safe_mode(), "safe_why": _SAFE["why"], "phases": phases,
                       "split_column": column, "heavy_digits": heavy, "refine_levels": levels, "chunks": 1,
                       "send_counts": send_counts, "recv_counts": recv_counts,
                       "imbalance": float(matrix.sum(axis=0).max()) * world / max(float(matrix.sum()), 1.0)}
@@ -396,7 +443,23 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     part_b, recv_b = part.view(torch.uint8), recv.view(torch.uint8)
     lut64 = lut.astype(np.int64)
     mine_digits = lut64 == rank
-    side = engine.overlap_stream(group, force_exchange) if hasattr(engine, "overlap_stream") else None
+    # first contact: the calibration (a 20 ms spin and four dummy exchanges) and the grouped send/recv below are what has never
+    # run between physical GPUs.  A rank on which either raises tells the others (one all-reduce) and ALL of them finish this
+    # sort -- and every later one -- the safe way: `part` is intact, the single all-to-all rewrites every byte of `recv`.
+    side, failed, why = None, False, None
+    if hasattr(engine, "overlap_stream"):
+        try:
+            side = engine.overlap_stream(group, force_exchange)
+        except Exception as exc:      # noqa: BLE001
+            failed, why = True, "overlap_stream: %r" % (exc,)
+        if on_gpu and dist.is_initialized() and _agree_failed(failed, group, shard.device):
+            _SAFE["latched"], _SAFE["why"] = True, why or "another rank's calibration failed"
+            one_exchange()
+            return recv, {"sent": int(send_counts.sum() - send_counts[rank]), "received": n_recv, "local_info": None, "lut": lut,
+                          "safe_mode": True, "safe_why": _SAFE["why"], "phases": phases, "split_column": column,
+                          "heavy_digits": heavy, "refine_levels": levels, "chunks": 1, "send_counts": send_counts,
+                          "recv_counts": recv_counts,
+                          "imbalance": float(matrix.sum(axis=0).max()) * world / max(float(matrix.sum()), 1.0)}
     main = torch.cuda.current_stream() if side is not None else None
     # receive layout: sub-range major, then source rank, then part (= global index order inside a source rank)
     roffs = np.zeros((nchunks, world, nslices + 1), dtype=np.int64)
@@ -435,7 +498,12 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # sub-range j+1 is submitted before sub-range j is sorted: with the sorts on a stream of their own (another hardware
     # queue than RCCL's) the two overlap; on a shared queue the order of submission is simply the order of execution.
     # A sliced split: part 0's pieces of sub-range 0 go out first, THEN the rest of the shard is split (under them).
-    works0 = exchange(0, [0])
+    try:
+        works0 = exchange(0, [0])
+    except Exception as exc:      # noqa: BLE001  (the first grouped send/recv: nothing has been waited for yet)
+        _SAFE["latched"], _SAFE["why"] = True, "batch_isend_irecv: %r" % (exc,)
+        raise RuntimeError("the grouped send/recv of the chunk pipeline failed (%r); RSX_MULTI_SAFE is now latched for this process: "
+                           "the next distributed_sort uses one all_to_all_single" % (exc,)) from exc
     if sliced:
         for fn in sliced["pending"]:
             fn()
@@ -459,12 +527,14 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
                 engine.sort_inplace_async(recv[begin:end], aux[begin:end])
     if side is not None:
         main.wait_stream(side)
+    if on_gpu:
+        e_end.record()
     sent = int(send_counts.sum() - send_counts[rank])
     t_submitted = time.perf_counter()
     return recv, {"host_ms_split_and_counts": (t_planned - t_enter) * 1e3, "host_ms_submit_exchange_and_sorts": (t_submitted - t_planned) * 1e3,
                   "sent": sent, "received": n_recv, "local_info": None, "lut": lut, "split_column": column,
                   "heavy_digits": heavy, "refine_levels": levels, "chunks": nchunks, "split_slices": nslices,
-                  "overlap_stream": side is not None,
+                  "overlap_stream": side is not None, "safe_mode": False, "safe_why": None, "phases": phases,
                   "send_counts": send_counts, "recv_counts": recv_counts,
                   # the largest rank's share of the keys over the fair share (1.0 = balanced): what is left of the skew
                   "imbalance": float(matrix.sum(axis=0).max()) * world / max(float(matrix.sum()), 1.0)}

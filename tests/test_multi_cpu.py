@@ -335,3 +335,37 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert any("noise from rank 1" in l for l in lines[:-1])
     bad = subprocess.run([sys.executable, "-c", driver, "--fail"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+
+
+def _safe_worker(rank, world, port, n_per_rank, seed, outdir, latch):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if not latch:
+        os.environ["RSX_MULTI_SAFE"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = n_per_rank[rank]
+        first = sum(n_per_rank[:rank])
+        whole = ol.splitmix_fill(sum(n_per_rank), ol.U32, seed, 0xFFFFFFFF)
+        shard = torch.from_numpy(whole[first:first + n].view(np.int32).copy())
+        if latch:      # what a failure of the chunk pipeline leaves behind: every later sort of the process is the safe one
+            multi._SAFE["latched"], multi._SAFE["why"] = True, "test"
+        res, stats = multi.distributed_sort(shard, OracleEngine(ol.U32, 0), chunks=4, split_slices=2)
+        assert stats["safe_mode"] and stats["chunks"] == 1, stats
+        np.save(os.path.join(outdir, "out%d.npy" % rank), res.numpy().view(np.uint32).copy())
+    finally:
+        multi._SAFE["latched"], multi._SAFE["why"] = False, None
+        os.environ.pop("RSX_MULTI_SAFE", None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("latch", [False, True], ids=["RSX_MULTI_SAFE=1", "latched by a failure"])
+def test_safe_mode_is_one_exchange_and_one_sort(tmp_path, latch):
+    """RSX_MULTI_SAFE=1 (or the latch a failed first contact sets): whatever chunks / slices were asked for, the exchange is one
+    all_to_all_single and the local sort one sort -- and the result is the same (README.md:647-650)."""
+    world, n_per_rank, seed = 3, [30000, 30111, 29950], 55
+    port = _free_port()
+    mp.spawn(_safe_worker, args=(world, port, n_per_rank, seed, str(tmp_path), latch), nprocs=world, join=True)
+    want, _, _ = ol.oracle_sort(ol.splitmix_fill(sum(n_per_rank), ol.U32, seed, 0xFFFFFFFF), ol.U32, 0)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "out%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got, want)
