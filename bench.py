@@ -87,11 +87,11 @@ def kernel_classes(how):
     two_level = how in (2, 4, 5)
     return {
         "hist": ("rsx_hist_kernel<u32> (all columns' counts + the pre-sorted test, radix_sort.hpp:47-58)", ["rsx_hist_kernel<u32"]),
-        "scatter": (("rsx_scatter2_kernel<u32,NoVal,...,SEG> (level-1 pass: whole keys into 256 slots)", ["rsx_scatter2_kernel<u32, NoVal", "u32, true>"])
+        "scatter": (("rsx_pass32a_kernel<u32> (level-1 pass: whole keys into 256 slots, whole 64-byte atoms)", ["rsx_pass32a_kernel<u32"])
                     if how == 5 else
                     ("rsx_scatter2_kernel<u32,NoVal,u32> (one stable pass by an 8-bit column, radix_sort.hpp:82-90)", ["rsx_scatter2_kernel<u32, NoVal", "u32, false>"])),
-        "narrow": ("rsx_scatter2_kernel<u32,NoVal,...,KTO=u16,SEG> (level-2 pass: two bytes per key into 65536 slots)",
-                   ["rsx_scatter2_kernel<u32, NoVal", "u16, true>"]),
+        "narrow": ("rsx_pass16a_kernel<u32> (level-2 pass: two bytes per key into 65536 slots, whole 64-byte atoms)",
+                   ["rsx_pass16a_kernel<u32"]),
         "leaf": (("rsx_leaf16_kernel<u32,Leaf16Cfg<256,5120,8,12>> (two-byte slots in, sorted keys out; + the list launch of rsx_leaf_sort_kernel)",
                   ["rsx_leaf16_kernel<u32"]) if how == 5 else
                  ("rsx_leaf_sort_kernel<u32> (%s)" % ("65536 buckets" if two_level else "256 buckets"), ["rsx_leaf_sort_kernel<u32"])),

@@ -166,7 +166,7 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * enqueued first and the histogram-first kernels behind it do nothing if it went through.  That attempt works in d_scratch
  * (once its sample has proven the input unsorted) and in slots in the (device, stream) workspace: 0.25 n + 0.625 n .. 1.25 n
  * keys of device memory (see "Scratch memory" above); rsx_sort_inplace_async_ws, whose state lies in the caller's
- * workspace, never makes it.  rsx_sort_pairs_inplace_async and rsx_sort_rank_inplace_async (4-byte keys with 4-byte
+ * workspace, makes it when the workspace was sized by rsx_workspace_bytes_fast (below).  rsx_sort_pairs_inplace_async and rsx_sort_rank_inplace_async (4-byte keys with 4-byte
  * payloads / indices, 16 Mi .. 2^28 pairs) make the same attempt; rsx_async_route reports the last call's route for them too. */
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
                            void *stream);
@@ -185,6 +185,13 @@ int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dty
  * move, and graphs with different workspaces may replay on any streams. */
 int rsx_sort_inplace_async_ws(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
                               void *d_workspace, size_t workspace_bytes, void *stream);
+/* Round 5: a workspace of rsx_workspace_bytes_fast(n, dtype) bytes (0.25 n + 0.63 n .. 1.25 n keys more than the minimum:
+ * the slots of a sort without a histogram) lets rsx_sort_inplace_async_ws make that attempt INSIDE the workspace, so a graph
+ * that is kept runs on the route of DESIGN.md 4c like every other sort (4- and 8-byte keys, 4 Mi .. 2^30 keys).  A smaller
+ * workspace (at least rsx_workspace_bytes) works as before: histogram first.  rsx_async_route_ws reads the route the last sort
+ * (or replay) in that workspace took (it waits for `stream`): 5, 1 or 0 as rsx_async_route. */
+size_t rsx_workspace_bytes_fast(size_t n, rsx_dtype dtype);
+int rsx_async_route_ws(const void *d_workspace, size_t workspace_bytes, size_t n, rsx_dtype dtype, void *stream, uint32_t *route);
 int rsx_sort_pairs_inplace_async_ws(void *d_keys, void *d_keys_scratch, void *d_vals, void *d_vals_scratch,
                                     size_t n, rsx_dtype dtype, size_t payload_bytes, rsx_order order,
                                     void *d_workspace, size_t workspace_bytes, void *stream);

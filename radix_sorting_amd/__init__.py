@@ -62,6 +62,8 @@ ABI = [
     ("rsx_release_stream", None, [_VP]),
     ("rsx_sort_inplace_async", _I, [_VP, _VP, _SZ, _I, _I, _VP]),
     ("rsx_sort_inplace_async_ws", _I, [_VP, _VP, _SZ, _I, _I, _VP, _SZ, _VP]),
+    ("rsx_workspace_bytes_fast", _SZ, [_SZ, _I]),
+    ("rsx_async_route_ws", _I, [_VP, _SZ, _SZ, _I, _VP, C.POINTER(C.c_uint32)]),
     ("rsx_sort_pairs_inplace_async_ws", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP, _SZ, _VP]),
     ("rsx_sort_pairs_inplace_async", _I, [_VP, _VP, _VP, _VP, _SZ, _I, _SZ, _I, _VP]),
     ("rsx_capture_histogram", _I, [_VP, _SZ]),
@@ -235,6 +237,20 @@ def radix_sort_inplace_async(buf, scratch, dtype=None, order=ASCENDING, stream=N
     _same_shape(buf, scratch, "scratch")
     check(lib().rsx_sort_inplace_async(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream)))
     return buf
+
+
+def workspace_bytes_fast(n, dtype):
+    """rsx_workspace_bytes_fast: a workspace that also holds the slots of a sort without a histogram (the *_ws sort then takes
+    that route inside it)."""
+    return int(lib().rsx_workspace_bytes_fast(n, dtype))
+
+
+def async_route_ws(workspace, n, dtype, stream=None):
+    """rsx_async_route_ws: the route the last rsx_sort_inplace_async_ws in `workspace` took (waits for the stream)."""
+    r = C.c_uint32(0)
+    check(lib().rsx_async_route_ws(workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, dtype, _stream_ptr(stream),
+                                   C.byref(r)))
+    return int(r.value)
 
 
 def workspace_bytes(n, dtype, payload_bytes=0):

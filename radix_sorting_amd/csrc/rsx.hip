@@ -321,6 +321,7 @@ struct Ctx {
 	// kernels enqueued behind it that there is nothing left to do
 	const SegCtl *pass_gate = nullptr;
 	bool async_tried_blind = false;   // ... whether the last rsx_sort_inplace_async of this context enqueued such an attempt
+	bool ws_blind = false;            // a context in a caller's workspace that has room for the slots of a sort without a histogram (borrow_ctx)
 	bool async_small = false;         // ... or was the one-launch sort of a small array (rsx_async_route: 0, whatever the device's words say)
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
 	DevBuf vsum;        // RSX_VERIFY=2: [descents, sum, mix] of the input and of the result
@@ -1460,6 +1461,18 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 }
 
 // where the parts of a two-level sort's device-side state lie in c.seg
+// bytes of c.seg for a two-level sort of n keys (seg_layout below)
+template <typename KT> size_t seg_bytes(size_t n)
+{
+	typedef Sc2Cfg<KT, NoVal> C2;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const size_t st_bytes = 256 + rows * 256 * 4;
+	const size_t hist_bytes = (size_t)256 * (sizeof(KT) - 1) * 256 * sizeof(u32);
+	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 514 : rows;
+	return 256 + hist_bytes + (sizeof(KT) - 1) * st_bytes + 65536 * sizeof(LeafSeg) + tile_rows * sizeof(SegTile) + 260 * sizeof(u32) +
+	       65536 * sizeof(u32);
+}
+
 template <typename KT> int seg_layout(Ctx &c, size_t n)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
@@ -1475,6 +1488,41 @@ template <typename KT> int seg_layout(Ctx &c, size_t n)
 	c.seg_redo_off = c.seg_btile_off + 260 * sizeof(u32);   // the leaves rsx_leaf16_kernel leaves to rsx_leaf_sort_kernel
 	return c.seg.ensure(c.seg_redo_off + 65536 * sizeof(u32));
 }
+
+// What a sort of n keys WITHOUT a histogram needs on top of that (blind_enqueue): the level-1 slots that do not fit the
+// caller's second buffer, the level-2 slots, the control block / tables / status words of the two passes.
+template <typename KT> void blind_sizes(size_t n, size_t *gscan, size_t *seg, size_t *slack1, size_t *slack)
+{
+	typedef Sc2Cfg<KT, NoVal> C2;
+	const u32 cap1 = slot_cap_for((u32)(n >> 8)), cap2 = slot_cap_for((u32)(n >> 16));
+	const u32 lo = cap1 >= (u32)C2::TILE ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
+	const size_t slot2 = (sizeof(KT) == 4 && cap2 <= (u32)LeafShapes<KT>::Fit::CAP) ? 2 : sizeof(KT);
+	*gscan = 256 * sizeof(u64);
+	*seg = (seg_bytes<KT>(n) + 255) & ~(size_t)255;
+	*slack1 = ((((size_t)(256 - lo) * cap1 + C2::TILE) * sizeof(KT)) + 255) & ~(size_t)255;
+	*slack = ((((size_t)65536 * cap2 + C2::TILE) * slot2) + 255) & ~(size_t)255;
+}
+
+// ... handed to the context if the workspace has it (rsx_workspace_bytes_fast): the attempt is then made inside the workspace
+template <typename KT> void borrow_blind(Ctx &v, char *p, char *ws_end, size_t n)
+{
+	if constexpr (sizeof(KT) >= 4) {
+		size_t g, sg, s1, s2;
+		blind_sizes<KT>(n, &g, &sg, &s1, &s2);
+		p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+		if (n < ((size_t)1 << 22) || n >= ((size_t)1 << 30) || p + g + sg + s1 + s2 > ws_end)
+			return;
+		v.gscan.borrow(p, g);
+		p += g;
+		v.seg.borrow(p, sg);
+		p += sg;
+		v.slack1.borrow(p, s1);
+		p += s1;
+		v.slack.borrow(p, s2);
+		v.ws_blind = true;
+	}
+}
+
 
 // The second level of a two-level sort.  Pass 1 (by the highest kept column, src -> aux) is on its way; `plan` says so.
 // Ends with the sorted keys in the buffer the reference's parity rule names (radix_sort.hpp:92); *result says which.
@@ -1649,8 +1697,9 @@ template <typename KT> bool async_blind_ok(Ctx &c, size_t n)
 {
 	if constexpr (sizeof(KT) < 4)
 		return false;
-	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() || c.small.external ||
-	    env().no_speculation)
+	// (a caller's workspace: only one that was sized for the slots as well, rsx_workspace_bytes_fast)
+	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() ||
+	    (c.small.external && !c.ws_blind) || env().no_speculation)
 		return false;
 	// (blind_wanted's floors, except that 4-byte keys start at 9 Mi here: at 8 Mi the empty launches of the gated histogram-first
 	// kernels behind the attempt make it 153 us against 138 for one pass per column; the blocking sort: 127 against 135-139)
@@ -1736,9 +1785,11 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	LeafSeg *segtab = (LeafSeg *)((char *)c.seg.p + c.seg_segtab_off);
 	u32 *btile = (u32 *)((char *)c.seg.p + c.seg_btile_off);
 	u64 *off1 = (u64 *)c.gscan.p;
-	if (!c.seg_ev)
+	// (a context in a caller's workspace has neither a pinned control block nor an event: nobody reads a verdict there)
+	if (!c.seg_ev && !c.small.external)
 		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
-	c.host_segctl->mode = SEG_MODE_NONE;
+	if (c.host_segctl)
+		c.host_segctl->mode = SEG_MODE_NONE;
 	c.slack1_cap = cap1;
 	c.slack_cap = cap2;
 	// the sample (workgroup 0: control block, plan) and the zeroing of both passes' status words, one launch
@@ -1794,7 +1845,8 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
 	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, atoms ? 2u : 1u);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
+	if (c.seg_ev)
+		HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	u32 leaf_shape = LeafShapes<KT>::shape_for_slots(cap2);
 	if (dense_slots<KT>(c))
 		leaf_shape |= 0x100u;   // (the leaves read 2-byte slots: the cut shapes have that variant)
@@ -2993,7 +3045,7 @@ namespace {
 
 // A context whose device state lies in the caller's workspace: [flags 256][plan 64 + pad][histogram][status regions]
 // [histogram rows].  Everything a captured graph of the *_ws entry points refers to is inside that workspace.
-int borrow_ctx(Ctx &v, void *stream, void *ws, size_t ws_bytes, size_t n, size_t kb, size_t status_total)
+int borrow_ctx(Ctx &v, void *stream, void *ws, size_t ws_bytes, size_t n, size_t kb, size_t status_total, char **end = nullptr)
 {
 	// (no context of the library's own is created or touched: the call may be inside a stream capture, where nothing may
 	// be allocated; the device self-check has run when any other entry point was used before, otherwise it runs now)
@@ -3032,6 +3084,8 @@ int borrow_ctx(Ctx &v, void *stream, void *ws, size_t ws_bytes, size_t n, size_t
 	v.status.borrow(p, (status_total + 255) & ~(size_t)255);
 	p += (status_total + 255) & ~(size_t)255;
 	v.hpart.borrow(p, hpart_bytes);
+	if (end)
+		*end = p + hpart_bytes;
 	return RSX_OK;
 }
 
@@ -3069,8 +3123,54 @@ int rsx_sort_inplace_async_ws(void *d_buf, void *d_scratch, size_t n, rsx_dtype 
 	Ctx view;
 	size_t status_total = 0;
 	RSX_DISPATCH_KT(dtype, status_total = (status_bytes<KT, NoVal>(n) * sizeof(KT)));
-	RSX_TRY(borrow_ctx(view, stream, d_workspace, workspace_bytes, n, kb, status_total));
+	char *end = nullptr;
+	RSX_TRY(borrow_ctx(view, stream, d_workspace, workspace_bytes, n, kb, status_total, &end));
+	// a workspace sized by rsx_workspace_bytes_fast also holds the slots of a sort without a histogram: the attempt is made in it
+	RSX_DISPATCH_KT(dtype, borrow_blind<KT>(view, end, (char *)d_workspace + workspace_bytes, n));
+	AsyncScope async_scope((hipStream_t)stream);
 	RSX_DISPATCH_KT(dtype, return sort_keys_inplace_async<KT>(view, (KT *)d_buf, (KT *)d_scratch, n, dtype, order));
+	return RSX_OK;
+}
+
+size_t rsx_workspace_bytes_fast(size_t n, rsx_dtype dtype)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!kb)
+		return 0;
+	size_t g = 0, sg = 0, s1 = 0, s2 = 0;
+	if (kb >= 4 && n >= ((size_t)1 << 22) && n < ((size_t)1 << 30)) {
+		if (kb == 4)
+			blind_sizes<u32>(n, &g, &sg, &s1, &s2);
+		else
+			blind_sizes<u64>(n, &g, &sg, &s1, &s2);
+	}
+	return ((rsx_workspace_bytes(n, dtype, 0) + 255) & ~(size_t)255) + 256 + g + sg + s1 + s2;
+}
+
+int rsx_async_route_ws(const void *d_workspace, size_t workspace_bytes, size_t n, rsx_dtype dtype, void *stream, uint32_t *route)
+{
+	const size_t kb = dtype_size(dtype);
+	if (!route || !d_workspace || !kb)
+		return fail(RSX_EINVAL, "rsx_async_route_ws: bad argument");
+	*route = 0;
+	HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+	Plan plan;
+	HIP_TRY(hipMemcpy(&plan, (const char *)d_workspace + 64, sizeof(plan), hipMemcpyDeviceToHost));
+	// (the layout of borrow_ctx / borrow_blind: the control block of the attempt lies behind the histogram kernel's rows and gscan)
+	size_t status_total = 0;
+	RSX_DISPATCH_KT(dtype, status_total = (status_bytes<KT, NoVal>(n) * sizeof(KT)));
+	const size_t minimal = 512 + kb * 256 * sizeof(u64) + ((status_total + 255) & ~(size_t)255) + (size_t)512 * kb * 256 * sizeof(u32);
+	if (kb >= 4 && workspace_bytes >= rsx_workspace_bytes_fast(n, dtype) && n >= ((size_t)1 << 22) && n < ((size_t)1 << 30)) {
+		const char *p = (const char *)(((uintptr_t)d_workspace + minimal + 255) & ~(uintptr_t)255) + 256 * sizeof(u64);
+		SegCtl ctl;
+		HIP_TRY(hipMemcpy(&ctl, p, sizeof(ctl), hipMemcpyDeviceToHost));
+		if (ctl.mode == SEG_MODE_LEAVES && ctl.blind == BLIND_GO) {
+			*route = 5;
+			return RSX_OK;
+		}
+	}
+	if (!plan.sorted && plan.hyb == HYB_ONE_LEVEL)
+		*route = 1;
 	return RSX_OK;
 }
 

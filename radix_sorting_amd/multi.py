@@ -401,13 +401,15 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # every key width works on every backend), and as soon as they are in, they are sorted in place while the next
     # sub-range is on the links.  The split shard is in digit order: piece (destination d, sub-range j) of this rank is
     # part[first[a] : first[b]] for the digits [a, b) of that sub-range.  Receive layout: sub-range major, source minor.
+    recorded = {"xchg": False}
+
     def phases():
         """GPU time of the step's phases on this rank (ms; needs a synchronisation: called by bench.py after its own)"""
         if not on_gpu:
             return None
         torch.cuda.synchronize()
         out = {"split_ms": e_begin.elapsed_time(e_split), "total_ms": e_begin.elapsed_time(e_end)}
-        if e_xchg.query():
+        if recorded["xchg"]:
             out["exchange_ms"] = e_split.elapsed_time(e_xchg)
             out["sort_ms"] = e_xchg.elapsed_time(e_end)
         else:
@@ -421,6 +423,7 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
                                input_split_sizes=[int(x) * es for x in send_counts], group=group)
         if on_gpu:
             e_xchg.record()
+            recorded["xchg"] = True
         if n_recv > 1:
             engine.sort_inplace_async(recv, aux)
         if on_gpu:

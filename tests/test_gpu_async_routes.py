@@ -160,8 +160,11 @@ def test_ranks_and_pairs_without_histogram_on_the_device(n):
     half = twice.copy()
     half[::2] &= np.uint32(0x00FFFFFF)                                      # a dominant top digit
     const_col = twice & np.uint32(0xFFFF00FF)                               # column 1 constant: three kept columns
-    cases = (("uniform, ties", twice, 5), ("dominant top digit", half, 0), ("constant column", const_col, 0))
-    for name, a, want_route in (cases if n < (1 << 25) else cases[:2]):
+    # (routes of the rank sort / of the key + payload sort.  "constant column": the f32 KDF makes the constant byte 0x00 or 0xFF by
+    # the sign, so all four columns are kept; no byte scheme takes a column with two values, but the RANK sort packs the 24
+    # varying bits -- SegCtl::compact, round 5 -- and stays on route 5; the pair sort wants its keys back and does not)
+    cases = (("uniform, ties", twice, 5, 5), ("dominant top digit", half, 0, 0), ("constant column", const_col, 5, 0))
+    for name, a, want_route, want_pair_route in (cases if n < (1 << 25) else cases[:2]):
         a = np.ascontiguousarray(a)
         want, _ = ol.want_ranks(a, ol.F32, big=1 << 22)
         bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
@@ -176,7 +179,7 @@ def test_ranks_and_pairs_without_histogram_on_the_device(n):
         ks, vs = torch.empty_like(bits), torch.empty_like(vals)
         rsa.radix_sort_pairs_inplace_async(bits, ks, vals, vs, dtype=rsa.F32)
         route = rsa.async_route()
-        assert route == want_route, (name, "pairs", route)
+        assert route == want_pair_route, (name, "pairs", route)
         assert np.array_equal(vals.cpu().numpy().view(np.uint32), want), (name, "pairs")
         assert np.array_equal(bits.cpu().numpy().view(np.uint32), a.view(np.uint32)[want]), (name, "pairs' keys")
         del vals, ks, vs, bits
@@ -210,3 +213,50 @@ def test_rank_routes_inside_one_captured_graph():
         want, _ = ol.want_ranks(a, ol.U32, big=1 << 22)
         assert np.array_equal(ib[:n].cpu().numpy().view(np.uint32), want), name
     rsa.release_stream(s)
+
+
+@pytest.mark.parametrize("dt,n", [(ol.U32, (1 << 25) + 33), (ol.U64, (1 << 24) + 9)], ids=["u32-32Mi", "u64-16Mi"])
+def test_a_kept_graph_takes_the_fast_route_inside_its_own_workspace(dt, n):
+    """rsx_sort_inplace_async_ws with a workspace of rsx_workspace_bytes_fast: the slots of the sort without a histogram lie in
+    the CALLER's workspace, so a graph that is kept -- nothing it touches can move -- runs on route 5 like every other sort
+    (round 4: "never makes the attempt").  One capture, replayed on inputs that take routes 5, 0 (a dominant top digit), 0 (sorted), 5;
+    a second graph with its own workspace replays in between; results against the oracle, routes read back from the workspace."""
+    carrier = torch.int32 if ol.DTYPE_SIZE[dt] == 4 else torch.int64
+    full = (1 << (8 * ol.DTYPE_SIZE[dt])) - 1
+    s = torch.cuda.Stream()
+    graphs = []
+    for k in range(2):
+        buf = torch.empty(n, dtype=carrier, device="cuda")
+        scratch = torch.empty_like(buf)
+        ws = torch.empty(rsa.workspace_bytes_fast(n, dt), dtype=torch.uint8, device="cuda")
+        assert ws.numel() > rsa.workspace_bytes(n, dt) + n * ol.DTYPE_SIZE[dt] // 4
+        with torch.cuda.stream(s):
+            rsa.fill_splitmix(buf, seed=1 + k, stream=s)
+            rsa.radix_sort_inplace_async_ws(buf, scratch, ws, dtype=dt, stream=s)     # (the library's first use outside a capture)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            rsa.radix_sort_inplace_async_ws(buf, scratch, ws, dtype=dt, stream=torch.cuda.current_stream())
+        graphs.append((g, buf, scratch, ws))
+    base = ol.splitmix_fill(n, dt, 7700, full)
+    half = base.copy()
+    half[::2] &= ol.NP_BITS[dt](full >> 8)
+    cases = [("uniform", base, 5), ("top digit dominant", half, 0), ("sorted", np.sort(base), 0), ("uniform again", base[::-1].copy(), 5)]
+    for i, (name, a, want_route) in enumerate(cases):
+        g, buf, scratch, ws = graphs[i & 1]
+        a = np.ascontiguousarray(a)
+        buf.copy_(to_dev(a))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert rsa.async_route_ws(ws, n, dt, s) == want_route, name
+        want, _, _ = ol.oracle_sort(a, dt)
+        assert np.array_equal(buf.cpu().numpy().view(ol.NP_BITS[dt]), want), name
+    # a workspace of the old size still works: histogram first
+    g, buf, scratch, _ = graphs[0]
+    small = torch.empty(rsa.workspace_bytes(n, dt), dtype=torch.uint8, device="cuda")
+    buf.copy_(to_dev(base))
+    rsa.radix_sort_inplace_async_ws(buf, scratch, small, dtype=dt)
+    torch.cuda.synchronize()
+    assert rsa.async_route_ws(small, n, dt) == 0
+    assert np.array_equal(buf.cpu().numpy().view(ol.NP_BITS[dt]), ol.oracle_sort(base, dt)[0])

@@ -61,6 +61,12 @@ def algorithmic_bytes(name):
         if t[-1] == "true" and len(t) >= 3 and t[-2] in SIZES:      # <KT, shape, CT, DENSE>: the slots hold CT-wide values
             return N * (SIZES[t[-2]] + SIZES.get(t[0], 0))
         return N * 2 * SIZES.get(t[0], 0)
+    if "rsx_pass32a_kernel" in name and t:        # round 5: the level-1 pass in whole atoms: keys in, keys out
+        return N * 2 * SIZES.get(t[0], 0)
+    if ("rsx_pass16a_kernel" in name or "rsx_pass16_kernel" in name) and t:   # the level-2 pass: keys in, two bytes per key out
+        return N * (SIZES.get(t[0], 0) + 2)
+    if "rsx_leafk8_kernel" in name and t:         # 8-byte keys carried as 8-byte values: whole keys in and out
+        return N * 2 * SIZES.get(t[0], 0)
     if "rsx_leafk_kernel" in name and t:          # whole 8-byte keys in and out (rsx_leaf16.hpp); SLOT32: four-byte slots in
         if t[-1] == "true":
             return N * (4 + SIZES.get(t[0], 0))
