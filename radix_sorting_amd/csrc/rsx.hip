@@ -1231,7 +1231,10 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
 			SegCtl *wctl = (SegCtl *)c.seg.p;
 			typedef Leaf16Cfg<256, 5120, 8, 12> L5k;
-			typedef Leaf16Cfg<256, 2560, 8, 11> L2k;
+			// (128 threads per leaf for slots of up to 2560 values -- arrays of 52 Mi .. 128 Mi keys: a 1280-value leaf keeps 80 lanes
+			// busy in the register passes, and sixteen small workgroups per CU overlap better than eight: tools/ubench/leaf16_probe,
+			// profiles/r05/leaf16_probe_mid.txt: 56 Mi keys 0.118 against 0.163 ms, 128 Mi 0.214 against 0.252)
+			typedef Leaf16Cfg<128, 2560, 8, 11> L2k;
 			typedef Leaf16WCfg<1024, 10, 4> W1k;   // small slots (arrays of up to ~50 Mi keys): a wave per leaf
 			typedef Leaf16WCfg<512, 9, 4> W512;
 			if (c.slack_cap <= (u32)W1k::CAP) {
@@ -1808,7 +1811,9 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	if constexpr (sizeof(KT) == 4) {
 		// (only in front of rsx_pass16a_kernel, which has no chain: a bucket that lies at both ends of its slot is one tile more, and
 		// the chained level-2 passes have a row of status words per tile of the ordinary count)
-		atoms1 = atoms && !env().no_pass32a && n >= ((size_t)1 << 26) && cap1 >= (u32)Pass32aCfg::TILE + 2 * PASS32_BACK;
+		// (from 96 Mi keys: tools/atoms_threshold_probe.py, profiles/r05/atoms_threshold_probe.txt -- level with the chained pass at
+		// 64-80 Mi, 1 % ahead at 96 Mi, 3.3 % at 2^28; the level-2 pass in atoms pays from its first size, 52 Mi)
+		atoms1 = atoms && !env().no_pass32a && n >= ((size_t)3 << 25) && cap1 >= (u32)Pass32aCfg::TILE + 2 * PASS32_BACK;
 		if (atoms1) {
 			// one base for the stores, the parts' offsets in the slots' places (as launch_seg_pass does for the chained pass)
 			u32 off_lo = 0, off_hi = 0;

@@ -152,7 +152,8 @@ template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12, int SKIP_ = 0> struct
 	static constexpr u32 MAXBIN2 = 25;   // ... and four passes (ceil((m - 1) / 8) + 1 passes for a bin of m keys)
 	static_assert(NBITS >= 10 && NBITS <= 12, "");
 	static_assert(CAP % 16 == 0 && CAP <= 8192, "whole chunks; bin starts fit 16 bits");
-	static_assert(BLOCK == 256 || BLOCK == 512, "one or two vectors of cells per thread");
+	static_assert(PLANES == 1 || PLANES == 2, "one or two vectors of cells per thread");
+	static_assert(NCELLW == 4 * BLOCK * PLANES, "every cell in some thread's vectors");
 };
 
 // segtab[s].slot names the slot (of slack_cap two-byte values) leaf s reads; the sorted keys go to out + segtab[s].beg.

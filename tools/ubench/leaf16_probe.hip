@@ -231,9 +231,27 @@ int main(int argc, char **argv)
 			WAVE(512, 9, 8, nleaf / 8);
 		}
 	}
+	if (cap <= 1536) {
+		NEW(128, 1536, 8, 11, nleaf);
+		NEW(128, 1536, 8, 10, nleaf);
+	}
+	if (cap <= 2048) {
+		NEW(128, 2048, 8, 11, nleaf);
+		NEW(256, 2048, 8, 11, nleaf);
+	}
 	if (cap <= 2560) {
+		NEW(128, 2560, 8, 11, nleaf);
 		NEW(256, 2560, 8, 11, nleaf);
 		NEW(256, 2560, 8, 11, 8192);
+	}
+	if (cap > 2560 && cap <= 3840) {
+		NEW(256, 3840, 8, 12, nleaf);
+		NEW(128, 3840, 8, 11, nleaf);
+		NEW(256, 3840, 8, 11, nleaf);
+	}
+	if (cap > 2560) {
+		NEW(128, 5120, 8, 11, nleaf);
+		NEW(256, 5120, 8, 11, nleaf);
 	}
 	NEW(256, 5120, 8, 12, nleaf);
 	if (cap > 2560) {

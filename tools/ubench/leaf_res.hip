@@ -22,7 +22,7 @@ INST_P(LeafKCfg<128, 1280, 6, 10>);
 INST_P(LeafKCfg<64, 512, 8, 10>);
 INST_P(LeafKCfg<64, 256, 8, 9>);
 INST_16(Leaf16Cfg<256, 5120, 8, 12>);
-INST_16(Leaf16Cfg<256, 2560, 8, 11>);
+INST_16(Leaf16Cfg<128, 2560, 8, 11>);
 INST_16W(Leaf16WCfg<1024, 10, 4>);
 INST_16W(Leaf16WCfg<512, 9, 4>);
 INST_16Q(Leaf16QCfg<4>);
