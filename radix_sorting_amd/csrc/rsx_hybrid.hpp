@@ -70,6 +70,12 @@ struct SegCtl {
 	u32 compact;
 	u32 cpiece[4];
 	u32 craw0, cvnot;
+	// ckind == 1: FLOATS ON A GRID.  f32 keys that are all whole multiples of one power of two and smaller than another --
+	// measurements, prices, normalised values: BASELINE.json's cfg 4 (ii), (int24 - 2^23) x 2^-23, whose sign-and-exponent byte
+	// holds 87 % of the keys in four values -- are fixed-point numbers: key x 2^-e0 (cpiece[0]: that factor's bits) is an integer
+	// of `compact` bits, in the keys' order, and spreads as evenly as the values do.  The level-1 pass converts (and checks every
+	// key: finite, on the grid, in range, not -0.0, which the reference orders before +0.0 and an integer cannot).
+	u32 ckind;
 };
 enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
 
@@ -127,6 +133,23 @@ __device__ __forceinline__ u32 block_scan_256(u32 v, u32 *s_w, u32 &tot)
 	tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 	__syncthreads();
 	return base + x - v;
+}
+
+// the fixed-point key of the float `raw` (SegCtl::ckind == 1): raw x scale as an integer of nb bits, offset to unsigned; `bad` is set
+// for a key that is not finite, not on the grid, out of range, or -0.0
+// (nonneg: no key is negative -- the sample saw none, every key is checked --: the integers are the keys, no offset, one bit less)
+__device__ __forceinline__ u32 fixedpoint_key(u32 raw, u32 scale_bits, u32 nb, bool nonneg, bool desc, u32 &bad)
+{
+	const float tf = __uint_as_float(raw) * __uint_as_float(scale_bits);   // (exact: a power of two; overflow -> inf fails the range test)
+	const float hi = __uint_as_float((127u + nb - (nonneg ? 0u : 1u)) << 23);   // 2^nb or 2^(nb - 1)
+	const float lo = nonneg ? 0.0f : -hi;
+	const int t = (int)tf;
+	if (!(tf >= lo && tf < hi) || (float)t != tf || raw == 0x80000000u)   // (NaN fails the first test)
+		bad |= 1u;
+	u32 key = nonneg ? (u32)t : (u32)(t + (int)(1u << (nb - 1u)));
+	if (desc)
+		key = ~key & ((1u << nb) - 1u);
+	return key;
 }
 
 // ---- tiles of the segmented passes ----------------------------------------------------------------------------------
@@ -682,7 +705,7 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		__syncthreads();
 	}
 	// ---- rank sorts of 4-byte keys (allow_compact): would the keys' VARYING bits, packed together, spread evenly?  (SegCtl::compact)
-	__shared__ u32 s_vraw, s_cnb, s_cpiece[4], s_cmax[2];
+	__shared__ u32 s_vraw, s_cnb, s_cpiece[4], s_cmax[2], s_fx[3], s_fxnb, s_fxscale, s_ckind;
 	if constexpr (W == 4) {
 		if (allow_compact) {
 			const u32 raw0 = (u32)src[0];
@@ -697,7 +720,7 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 			for (int off = 32; off > 0; off >>= 1)
 				v |= (u32)__shfl_xor((int)v, off);
 			if (tid == 0)
-				s_vraw = s_cnb = s_cmax[0] = s_cmax[1] = 0;
+				s_vraw = s_cnb = s_cmax[0] = s_cmax[1] = s_ckind = s_fxnb = s_fxscale = 0;
 			if (tid < 512)
 				(&hs[0][0])[tid] = 0;
 			__syncthreads();
@@ -749,6 +772,84 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 					atomicMax(&s_cmax[tid >> 8], ms);
 			}
 			__syncthreads();
+			// ---- floats on a grid (SegCtl::ckind == 1), where the packed bits do not spread
+			const bool packed_ok = s_cnb && s_cmax[0] <= 2 * NS / 256 && s_cmax[1] <= 2 * NS / 256;
+			if (!packed_ok && ka.fmask != 0) {
+				u32 lo = 0xFFFFFFFFu, hi = 0, flags = 0;   // lowest set bit's weight / magnitude bound (both + 256), not finite | -0.0
+#pragma unroll
+				for (u32 e = 0; e < S; ++e) {
+					const u32 E = (raw[e] >> 23) & 0xFFu, M = raw[e] & 0x7FFFFFu;
+					flags |= (E == 255u || raw[e] == 0x80000000u) ? 1u : 0u;
+					flags |= (raw[e] >> 31) ? 2u : 0u;
+					if (raw[e] & 0x7FFFFFFFu) {
+						const u32 mant = E ? (M | 0x800000u) : M, Ee = E ? E : 1u;
+						const u32 w = 256u + Ee - 150u + (u32)__builtin_ctz(mant);
+						lo = w < lo ? w : lo;
+						const u32 t = 256u + Ee - 126u;
+						hi = t > hi ? t : hi;
+					}
+				}
+#pragma unroll
+				for (int off = 32; off > 0; off >>= 1) {
+					const u32 a = (u32)__shfl_xor((int)lo, off), b = (u32)__shfl_xor((int)hi, off);
+					lo = a < lo ? a : lo;
+					hi = b > hi ? b : hi;
+					flags |= (u32)__shfl_xor((int)flags, off);
+				}
+				if (tid == 0) {
+					s_fx[0] = 0xFFFFFFFFu;
+					s_fx[1] = s_fx[2] = 0;
+					s_cmax[0] = s_cmax[1] = 0;
+					s_fxnb = 0;
+				}
+				if (tid < 512)
+					(&hs[0][0])[tid] = 0;
+				__syncthreads();
+				if ((tid & 63) == 0) {
+					atomicMin(&s_fx[0], lo);
+					atomicMax(&s_fx[1], hi);
+					atomicOr(&s_fx[2], flags);
+				}
+				__syncthreads();
+				if (tid == 0 && (s_fx[2] & 1u) == 0 && s_fx[1] > s_fx[0]) {
+					const int e0 = (int)s_fx[0] - 256, e1 = (int)s_fx[1] - 256;
+					const int nb = e1 - e0 + ((s_fx[2] & 2u) ? 1 : 0);   // (a sign bit only if some key is negative)
+					if (nb >= 17 && nb <= 30 && 127 - e0 >= 1 && 127 - e0 <= 254) {
+						s_fxnb = (u32)nb;
+						s_fxscale = (u32)(127 - e0) << 23;
+					}
+				}
+				__syncthreads();
+				const u32 fnb = s_fxnb;
+				if (fnb) {
+					const u32 sc = s_fxscale;
+					u32 bad = 0;
+#pragma unroll
+					for (u32 e = 0; e < S; ++e) {
+						const u32 c = fixedpoint_key(raw[e], sc, fnb, (s_fx[2] & 2u) == 0, ka.desc != 0, bad);
+						atomicAdd(&hs[0][(c >> (fnb - 8u)) & 0xFFu], 1u);
+						atomicAdd(&hs[1][(c >> (fnb - 16u)) & 0xFFu], 1u);
+					}
+					(void)bad;   // (the sample's own keys lie on the grid it was made from)
+				}
+				__syncthreads();
+				if (fnb) {
+					u32 ms = tid < 512 ? (&hs[0][0])[tid] : 0u;
+#pragma unroll
+					for (int off = 32; off > 0; off >>= 1) {
+						const u32 ys = __shfl_xor(ms, off);
+						ms = ys > ms ? ys : ms;
+					}
+					if ((tid & 63) == 0 && tid < 512)
+						atomicMax(&s_cmax[tid >> 8], ms);
+				}
+				__syncthreads();
+				if (tid == 0 && fnb) {
+					s_cnb = fnb;           // (the decision below reads s_cnb / s_cmax: now the grid's)
+					s_ckind = 1;
+				}
+				__syncthreads();
+			}
 		}
 	}
 	if (tid == 0) {
@@ -791,8 +892,9 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 			}
 		}
 		ctl->compact = compact;
+		ctl->ckind = compact ? s_ckind : 0u;
 		for (u32 i = 0; i < 4; ++i)
-			ctl->cpiece[i] = compact ? s_cpiece[i] : 0u;
+			ctl->cpiece[i] = compact ? (s_ckind ? (i == 0 ? s_fxscale : i == 1 ? ((s_fx[2] & 2u) ? 0u : 1u) : 0u) : s_cpiece[i]) : 0u;   // (grid: the factor, "no key is negative")
 		ctl->craw0 = compact ? (u32)src[0] : 0u;
 		ctl->cvnot = compact ? ~s_vraw : 0u;
 		ctl->ntiles = ctl->mode = ctl->maxleaf = ctl->done = ctl->nleaf = ctl->overflow = ctl->nredo = 0;   // (nobody else zeroes the control block)

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// SegCtl::compact (rank sorts of 4-byte keys whose varying bits are few, rsx_hybrid.hpp): the level-1 pass packs them and every
 	// pass behind it sorts the packed keys -- plain unsigned keys, whatever the caller's type
 	constexpr bool CAN_COMPACT = SEG && sizeof(KT) == 4 && val_bytes<VT>::value == 4 && std::is_same<KTO, KT>::value;
-	u32 cp_nb = 0, cp_raw0 = 0, cp_vnot = 0;
+	u32 cp_nb = 0, cp_raw0 = 0, cp_vnot = 0, cp_kind = 0;
 	u32 cp_piece[4] = {0, 0, 0, 0};
 	const KdfArgs<KT> ka_raw = ka;
 	if constexpr (SEG) {
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				if (flags & SCATTER_BLIND_TOP) {
 					cp_raw0 = seg.ctl->craw0;
 					cp_vnot = seg.ctl->cvnot;
+					cp_kind = seg.ctl->ckind;
 #pragma unroll
 					for (int i = 0; i < 4; ++i)
 						cp_piece[i] = seg.ctl->cpiece[i];
@@ -592,8 +593,12 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 							u32 bad = 0;
 #pragma unroll
 							for (int r = 0; r < KPT; ++r) {
-								bad |= ((u32)keep[r] ^ cp_raw0) & cp_vnot;
-								keep[r] = (KT)compact_key<KT>((u32)keep[r], cp_piece, cp_nb, ka_raw);
+								if (cp_kind) {   // (uniform) floats on a grid: the key as a fixed-point integer
+									keep[r] = (KT)fixedpoint_key((u32)keep[r], cp_piece[0], cp_nb, cp_piece[1] != 0, ka_raw.desc != 0, bad);
+								} else {
+									bad |= ((u32)keep[r] ^ cp_raw0) & cp_vnot;
+									keep[r] = (KT)compact_key<KT>((u32)keep[r], cp_piece, cp_nb, ka_raw);
+								}
 							}
 							if (__ballot(bad != 0) && lane == 0)
 								atomicOr(seg.overflow, 1u);   // (a bit the sample took for constant varies: the attempt is lost)
@@ -635,9 +640,16 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 						u32 bad = 0;
 #pragma unroll
 						for (int r = 0; r < KPT; ++r) {
-							if (wo + r * 64 < cnt)
-								bad |= ((u32)keep[r] ^ cp_raw0) & cp_vnot;
-							keep[r] = (KT)compact_key<KT>((u32)keep[r], cp_piece, cp_nb, ka_raw);
+							if (cp_kind) {
+								u32 b2 = 0;
+								keep[r] = (KT)fixedpoint_key((u32)keep[r], cp_piece[0], cp_nb, cp_piece[1] != 0, ka_raw.desc != 0, b2);
+								if (wo + r * 64 < cnt)
+									bad |= b2;
+							} else {
+								if (wo + r * 64 < cnt)
+									bad |= ((u32)keep[r] ^ cp_raw0) & cp_vnot;
+								keep[r] = (KT)compact_key<KT>((u32)keep[r], cp_piece, cp_nb, ka_raw);
+							}
 						}
 						if (__ballot(bad != 0) && lane == 0)
 							atomicOr(seg.overflow, 1u);

@@ -18,7 +18,7 @@ N = 1 << 28
 # the routes (rsx_info.hybrid) BASELINE.json's configurations take at this size: 5 = no histogram, two MSB passes into slots and
 # leaves; 0 = histogram and one pass per kept column (the skewed inputs); DESIGN.md 4b / 4c
 ZIPF_ROUTE = 0
-RANK_ROUTE = {"random_bits": 5, "uniform_pm1": 0, "duplicate_heavy": 5}   # (duplicate_heavy: by its packed varying bits, SegCtl::compact)
+RANK_ROUTE = {"random_bits": 5, "uniform_pm1": 5, "duplicate_heavy": 5}   # (duplicate_heavy: by its packed varying bits, SegCtl::compact; uniform_pm1: floats on a grid as fixed-point integers, SegCtl::ckind)
 SIGN64 = -(1 << 63)
 SIGN32 = -(1 << 31)
 

@@ -357,3 +357,44 @@ def test_packed_keys_are_not_for_everybody(case):
     assert info.hybrid == 0, (case, info.hybrid)
     assert info.result_in_aux == want_aux
     assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), case
+
+
+def _grid_floats(n, seed):
+    """SURVEY.md 8d cfg 4 (ii): (int24 - 2^23) * 2^-23, uniform in [-1, 1) on a grid of 2^-23 (exact on every platform)"""
+    r = ol.splitmix_fill(n, ol.U64, seed, (1 << 64) - 1).view(np.uint64)
+    k = ((r >> np.uint64(40)) & np.uint64(0xFFFFFF)).astype(np.int64) - (1 << 23)
+    return (k.astype(np.float32) * np.float32(2.0 ** -23)).view(np.uint32).copy()
+
+
+@pytest.mark.parametrize("case", ["[-1, 1) on a grid of 2^-23", "the same, descending", "prices: cents up to 40000.00", "one -0.0", "one NaN",
+                                  "one key off the grid"])
+def test_rank_sort_of_floats_on_a_grid(case):
+    """f32 keys that are whole multiples of one power of two (BASELINE.json's cfg 4 (ii); measurements, prices) are fixed-point
+    numbers: the sample finds the grid and the range, the level-1 pass converts every key (and checks it), and the rank sort goes
+    without a histogram on integers that spread as the values do (SegCtl::ckind).  A key that is not on the grid, not finite, or
+    -0.0 (which the reference orders before +0.0) calls the attempt off: the histogram-first sort then gives the same ranks."""
+    n = 24 * MI + 11
+    order, want_route = ol.ASC, 5
+    a = _grid_floats(n, 5300 + len(case))
+    if case.endswith("descending"):
+        order = ol.DESC
+    elif case.startswith("prices"):
+        r = ol.splitmix_fill(n, ol.U32, 5301, 0xFFFFFFFF).view(np.uint32)
+        a = ((r % np.uint32(4000001)).astype(np.float32) * np.float32(1.0 / 128.0)).view(np.uint32).copy()   # multiples of 2^-7 up to 31250
+    elif case == "one -0.0":
+        a[n // 3] = np.uint32(0x80000000)
+        want_route = 0
+    elif case == "one NaN":
+        a[n // 5] = np.uint32(0x7FC00001)
+        want_route = 0
+    elif case == "one key off the grid":
+        a[n - 777] = np.float32(0.3).view(np.uint32)       # 0.3 is no multiple of 2^-23 (a few of its low bits lie below the grid)
+        want_route = 0
+    want, want_aux = ol.want_ranks(a, ol.F32, order, big=1 << 22)
+    bits = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32, order=order)
+    torch.cuda.synchronize()
+    assert info.hybrid == want_route, (case, info.hybrid)
+    assert info.result_in_aux == want_aux
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), case
