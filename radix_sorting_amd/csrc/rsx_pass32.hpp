@@ -34,7 +34,7 @@ template <int KPT_ = 28> struct Pass32aCfgT {
 typedef Pass32aCfgT<28> Pass32aCfg;
 constexpr u32 PASS32_BACK = Pass32aCfg::BACK;
 
-template <typename KT, typename C> struct Pass32aSmem {
+template <typename KT, typename C, bool SPLITTERS = false> struct Pass32aSmem {
 	__attribute__((aligned(16))) KT stage[C::STAGE];
 	__attribute__((aligned(16))) KT carry[256][16];
 	u32 cell[2][256];   // per digit: count, then the run's cursor (tile-local); tiles alternate between the two
@@ -43,6 +43,8 @@ template <typename KT, typename C> struct Pass32aSmem {
 	unsigned short rbeg[256], bbeg[256], bend[256];
 	unsigned char group_digit[C::STAGE / 4];
 	u32 wsum[4];
+	KT spl[SPLITTERS ? 256 : 1];   // DIG == 2 (probe): 255 ascending splitters; a key's bucket is the number of splitters <= it
+	unsigned char tbl[SPLITTERS ? 4104 : 4];   // DIG == 2: the bucket of the first key of every 2^-12 of the key range (and 255 behind the last)
 };
 
 // kout: the lower of the two arrays the slots lie in; slot d starts (d < lo_slots ? off_lo : off_hi) + d * cap keys from there
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
                                                                           u32 lo_slots, u32 off_lo, u32 off_hi, u32 cap,
                                                                           const SegCtl *__restrict__ ctl,
                                                                           u32 *__restrict__ cursors, u32 *__restrict__ overflow,
-                                                                          KdfArgs<KT> ka)
+                                                                          KdfArgs<KT> ka, const KT *__restrict__ splitters = nullptr)
 {
 	static_assert(sizeof(KT) == 4, "4-byte keys");
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
@@ -65,15 +67,51 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 		return;
 	const u32 shift = ctl->shift1;
 	const KT cmask = (KT)ctl->cmask_lo, key0 = (KT)ctl->key0_lo;   // the bits the sample took for constant, and the first key's (derived)
-	__shared__ Pass32aSmem<KT, C> sm;
+	__shared__ Pass32aSmem<KT, C, DIG == 2> sm;
 	const u32 tid0 = threadIdx.x;
 	auto sidx = [](u32 pos) { return stage_swz<true>(pos * 4u); };
 	auto staged = [&](u32 pos) -> KT & { return *(KT *)((char *)sm.stage + sidx(pos)); };
 	auto slot_base = [&](u32 d) { return (d < lo_slots ? off_lo : off_hi) + d * cap; };
 	u32 cc = 0;   // digit thread: keys of its digit carried from the tiles before
-	if (tid0 < 256)
+	if (tid0 < 256) {
 		sm.cell[0][tid0] = 0;
+		if constexpr (DIG == 2)
+			sm.spl[tid0] = tid0 < 255 ? splitters[tid0] : (KT)~(KT)0;
+	}
 	__syncthreads();
+	// DIG == 2 (tools/ubench/pass32_probe.hip: what a level-1 pass by 255 SAMPLED SPLITTERS instead of a byte would cost -- the
+	// review's question for keys no byte scheme spreads).  A key's bucket: a table by its top 12 bits gives the buckets its 2^-12 of
+	// the key range touches, a search among those splitters the rest (no step at all where the range holds no splitter); found once
+	// per key, kept as a byte for the staging phase.
+	auto search_all = [&](KT k) -> u32 {
+		u32 d = 0;
+#pragma unroll
+		for (u32 step = 128; step >= 1; step >>= 1)
+			d += k >= sm.spl[d + step - 1] ? step : 0u;
+		return d;
+	};
+	if constexpr (DIG == 2) {
+		for (u32 c = tid0; c <= 4096u; c += BLOCK)
+			sm.tbl[c] = (unsigned char)(c == 4096u ? 255u : search_all((KT)c << 20));
+		__syncthreads();
+	}
+	auto bucket_of = [&](KT k, u32 sh) -> u32 {
+		if constexpr (DIG == 2) {
+			const u32 c = (u32)(k >> 20);
+			u32 lo = sm.tbl[c], hi = sm.tbl[c + 1];
+			while (lo < hi) {
+				const u32 mid = (lo + hi) >> 1;
+				if (k >= sm.spl[mid])
+					lo = mid + 1;
+				else
+					hi = mid;
+			}
+			return lo;
+		} else {
+			return (u32)(k >> sh) & 0xFFu;
+		}
+	};
+	u32 bkp[DIG == 2 ? (KPT + 3) / 4 : 1];   // DIG == 2: the keys' buckets, a byte each
 	KT keep[KPT];
 	auto request = [&](const u32 t, const u32 tid) {
 		const u64 beg = (u64)t * TILE;
@@ -121,7 +159,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 				if (FULL || tid + r * BLOCK < cnt) {
 					const KT k = DIG == 1 ? keep[r] : kdf_apply(keep[r], ka);
 					bad |= (k ^ key0) & cmask;
-					atomicAdd(&cell[(u32)(k >> shift) & 0xFFu], 1u);
+					const u32 b = bucket_of(k, shift);
+					if constexpr (DIG == 2)
+						bkp[r >> 2] = (r & 3) ? bkp[r >> 2] | (b << (8 * (r & 3))) : b;
+					atomicAdd(&cell[b], 1u);
 				}
 			}
 			if (__ballot(bad != 0) && lane == 0)
@@ -209,7 +250,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 					pos[r] = 0;
 					if (FULL || tid + (r0 + r) * BLOCK < cnt) {
 						const KT k = DIG == 1 ? keep[r0 + r] : kdf_apply(keep[r0 + r], ka);
-						pos[r] = __hip_atomic_fetch_add(&cell[(u32)(k >> shift_b) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						u32 b;
+						if constexpr (DIG == 2)
+							b = (bkp[(r0 + r) >> 2] >> (8 * ((r0 + r) & 3))) & 0xFFu;
+						else
+							b = bucket_of(k, shift_b);
+						pos[r] = __hip_atomic_fetch_add(&cell[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
 #pragma unroll
