@@ -14,6 +14,7 @@
 #include "rsx_leaf16.hpp"
 #include "rsx_pass16.hpp"
 #include "rsx_pass32.hpp"
+#include "rsx_leafc.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -123,6 +124,8 @@ struct Env {
 	bool no_pass32a = false;         // RSX_NO_PASS32A=1: the level-1 pass of such a sort is rsx_scatter2_kernel<..., SEG> with its look-back chain (rsx_pass32.hpp)
 	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
+	bool no_leafc = false;           // RSX_NO_LEAFC=1: no two-byte slots of more than 5120 values (rsx_leafc.hpp): sorts without a histogram of 4-byte keys end below 2^30 keys and their larger leaves sort whole keys, as in round 4
+	unsigned force_leafc = 0;        // RSX_FORCE_LEAFC=1|2|3 (tests): two-byte slots of ANY size take the leaves of the large ones -- 1 the counting leaves at once, 2 / 3 rsx_leaf16_kernel's 10240- / 20480-value shape and the counting leaves behind it
 	bool no_leaf16 = false;          // RSX_NO_LEAF16=1: two-byte slots are sorted by rsx_leaf_sort_kernel (two LDS passes) as in round 3
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
@@ -166,6 +169,9 @@ struct Env {
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
+		no_leafc = is_one("RSX_NO_LEAFC");
+		if (const char *e = getenv("RSX_FORCE_LEAFC"))
+			force_leafc = (unsigned)atoi(e);
 		no_pass16 = is_one("RSX_NO_PASS16");
 		no_pass16a = is_one("RSX_NO_PASS16A");
 		no_pass32a = is_one("RSX_NO_PASS32A");
@@ -1122,10 +1128,22 @@ template <typename KT> bool narrow_slots_ok(u32 cap2)
 // Sorts without a histogram of 4-byte keys (all four columns kept): the level-2 pass writes only the low two bytes of the
 // derived keys into its slots and the leaves put the rest back from the slot's digits (RSX_NO_DENSE_SLOTS=1: whole keys).
 // (where the slots fit the leaf shape that reads them: up to 5120 keys each, 2^28 keys in all)
+// the largest two-byte slot there are leaves for: rsx_leaf16_kernel's 5120 values; round 5: 40960 (slots of 2^31 keys) with the
+// counting leaves of rsx_leafc.hpp behind larger shapes of that kernel
+constexpr u32 LEAFC_CAP = 40960;
+template <typename KT> u32 dense_cap_max()
+{
+	if (sizeof(KT) != 4)
+		return 0u;
+	const bool big = !env().no_leafc && !env().no_leaf16 && !env().no_pass16 && !env().no_pass16a && !env().no_unstable;
+	return big ? LEAFC_CAP : (u32)LeafShapes<KT>::Fit::CAP;
+}
 template <typename KT> bool dense_slots(const Ctx &c)
 {
-	if (sizeof(KT) != 4 || env().no_dense_slots || c.slack_cap == 0 || c.slack_cap > (u32)LeafShapes<KT>::Fit::CAP)
+	if (sizeof(KT) != 4 || env().no_dense_slots || c.slack_cap == 0 || c.slack_cap > dense_cap_max<KT>())
 		return false;
+	if (c.slack_cap > (u32)LeafShapes<KT>::Fit::CAP)
+		return true;   // (rsx_leafc.hpp: on unless dense_cap_max says otherwise)
 	// round 4: rsx_leaf16_kernel (rsx_leaf16.hpp) sorts two-byte slots of every size up to 5120 values faster than the
 	// leaves of whole keys are sorted (tools/ubench/leaf16_probe: 2^28 keys 0.39 against 0.67 ms, 2^27 0.25 against 0.46)
 	if (!env().no_leaf16)
@@ -1230,6 +1248,36 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			// alone (a list; or everything, if the sample saw the low sixteen bits cluster) goes through the two LDS passes
 			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
 			SegCtl *wctl = (SegCtl *)c.seg.p;
+			if (c.slack_cap > 5120u || (env().force_leafc && c.slack_cap <= LEAFC_CAP)) {
+				const unsigned force = env().force_leafc;
+				// round 5, arrays beyond 2^28 keys (rsx_leafc.hpp).  Slots of up to 20480 values (2^30 keys): rsx_leaf16_kernel in a larger
+				// shape -- 13 or 14 bits name a value's bin, 512 or 1024 threads to a leaf --, and behind it the counting leaves for what
+				// it leaves alone; larger slots (2^31 keys: 32 Ki values each): the counting leaves at once.  tools/ubench/leafc_probe,
+				// profiles/r05/leafc_probe.txt: 2^29 keys 0.81 ms against 1.78 counting, 2^30 1.80 against 2.35, 2^31 4.33 against 3.20.
+				typedef Leaf16Cfg<512, 10240, 8, 13> L10k;
+				typedef Leaf16Cfg<1024, 20480, 8, 14> L20k;
+				const unsigned grid_c = 256u;   // (a workgroup per CU: the cells fill the LDS)
+#define RSX_LAUNCH_LC(NVEC, REDO)                                                                                           \
+				hipLaunchKernelGGL((rsx_leafc_kernel<KT, LeafCCfg<NVEC>>), dim3(grid_c), dim3(LeafCCfg<NVEC>::BLOCK), 0, c.stream, src, aux, \
+				                   (const Plan *)c.plan(), segtab, ctl, ka, 0u, (u32)LeafCCfg<NVEC>::CAP, (const uint16_t *)slots,     \
+				                   c.slack_cap, (const u32 *)(REDO))
+				if (force ? force == 2 && c.slack_cap <= (u32)L10k::CAP : c.slack_cap <= (u32)L10k::CAP) {
+					hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L10k>), dim3(grid_1), dim3(L10k::BLOCK), 0, c.stream, src, aux,
+					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L10k::CAP, (const uint16_t *)slots, c.slack_cap,
+					                   redo, (u32)env().leaf16_maxbin);
+					RSX_LAUNCH_LC(2, redo);
+				} else if (force ? force >= 2 && c.slack_cap <= (u32)L20k::CAP : c.slack_cap <= (u32)L20k::CAP) {
+					hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L20k>), dim3(grid_1), dim3(L20k::BLOCK), 0, c.stream, src, aux,
+					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L20k::CAP, (const uint16_t *)slots, c.slack_cap,
+					                   redo, (u32)env().leaf16_maxbin);
+					RSX_LAUNCH_LC(3, redo);
+				} else {
+					RSX_LAUNCH_LC(5, nullptr);
+				}
+#undef RSX_LAUNCH_LC
+				HIP_TRY(hipGetLastError());
+				return RSX_OK;
+			}
 			typedef Leaf16Cfg<256, 5120, 8, 12> L5k;
 			// (128 threads per leaf for slots of up to 2560 values -- arrays of 52 Mi .. 128 Mi keys: a 1280-value leaf keeps 80 lanes
 			// busy in the register passes, and sixteen small workgroups per CU overlap better than eight: tools/ubench/leaf16_probe,
@@ -1499,7 +1547,7 @@ template <typename KT> void blind_sizes(size_t n, size_t *gscan, size_t *seg, si
 	typedef Sc2Cfg<KT, NoVal> C2;
 	const u32 cap1 = slot_cap_for((u32)(n >> 8)), cap2 = slot_cap_for((u32)(n >> 16));
 	const u32 lo = cap1 >= (u32)C2::TILE ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
-	const size_t slot2 = (sizeof(KT) == 4 && cap2 <= (u32)LeafShapes<KT>::Fit::CAP) ? 2 : sizeof(KT);
+	const size_t slot2 = (sizeof(KT) == 4 && cap2 <= dense_cap_max<KT>()) ? 2 : sizeof(KT);
 	*gscan = 256 * sizeof(u64);
 	*seg = (seg_bytes<KT>(n) + 255) & ~(size_t)255;
 	*slack1 = ((((size_t)(256 - lo) * cap1 + C2::TILE) * sizeof(KT)) + 255) & ~(size_t)255;
@@ -1646,6 +1694,16 @@ inline void blind_refresh(Ctx &c)
 			c.blind_skip[k] = c.blind_backoff[k] = 0;
 	}
 }
+// Where the keys-only sorts without a histogram end: 2^30 keys (32-bit offsets in the leaf and tile tables; level-2 slots of more
+// than 32 Ki whole keys have no leaf) -- or, 4-byte keys in two-byte slots (rsx_leafc.hpp: slots of up to 40960 values), where the
+// mean level-2 slot passes 32 Ki: 2^31 + 65536 keys.  Every offset of such a sort still fits 32 bits: 257 level-1 slots of
+// 1.25 x 2^23 keys, 65537 level-2 slots of 40960 values, positions below 2^32.
+template <typename KT> size_t blind_keys_end()
+{
+	if (sizeof(KT) == 4 && dense_cap_max<KT>() >= LEAFC_CAP)
+		return (size_t)32769 << 16;
+	return (size_t)1 << 30;
+}
 template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes = 0, bool rank = false)
 {
 	if constexpr (sizeof(KT) < 4)
@@ -1653,7 +1711,7 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 	if (env().no_blind || env().no_slack || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() ||
 	    c.small.external || env().no_speculation)
 		return false;
-	if (n < ((size_t)1 << 22) || n >= ((size_t)1 << 30))
+	if (n < ((size_t)1 << 22) || n >= (payload_bytes || rank ? (size_t)1 << 30 : blind_keys_end<KT>()))
 		return false;
 	if (payload_bytes) {
 		// 4-byte keys with 4-byte payloads, 16 Mi .. 2^28 pairs.  Round 3: from 96 Mi (one leaf shape, 5120 pairs, whose fixed
@@ -1711,7 +1769,7 @@ template <typename KT> bool async_blind_ok(Ctx &c, size_t n)
 		floor_keys = (size_t)1 << env().blind_min_log2;
 	floor_keys = std::min(floor_keys, (size_t)1 << env().two_level_min_log2);
 	blind_refresh(c);
-	return n >= std::max(floor_keys, (size_t)1 << 22) && n < ((size_t)1 << 30);
+	return n >= std::max(floor_keys, (size_t)1 << 22) && n < (c.ws_blind ? (size_t)1 << 30 : blind_keys_end<KT>());
 }
 // ... for key + payload and rank sorts (4-byte keys, 4-byte payloads: blind_wanted's window, without its back-off)
 template <typename KT> bool async_pairs_blind_ok(Ctx &c, size_t n, size_t payload_bytes)
@@ -1732,7 +1790,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
 	const u32 cap1 = slot_cap_for(mean1), cap2 = slot_cap_for(mean2);
-	if (cap2 > (u32)LeafShapes<KT>::Big::CAP)
+	if (cap2 > std::max((u32)LeafShapes<KT>::Big::CAP, dense_cap_max<KT>()))
 		return RSX_OK;
 	if (c.blind_no_room)
 		return RSX_OK;

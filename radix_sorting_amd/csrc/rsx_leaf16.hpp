@@ -150,8 +150,11 @@ template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12, int SKIP_ = 0> struct
 	static constexpr int PLANES = NCELLW / 4 / BLOCK;            // 16-byte vectors of cells per thread
 	static constexpr u32 MAXBIN = 9;     // the largest bin two passes over 16-value chunks put right
 	static constexpr u32 MAXBIN2 = 25;   // ... and four passes (ceil((m - 1) / 8) + 1 passes for a bin of m keys)
-	static_assert(NBITS >= 10 && NBITS <= 12, "");
-	static_assert(CAP % 16 == 0 && CAP <= 8192, "whole chunks; bin starts fit 16 bits");
+	// who takes the leaves this kernel leaves alone: rsx_leaf_sort_kernel (byte columns only: with MSB digits at other bit positions
+	// this kernel has to go on until the leaf is in order) or, behind the shapes for more than 5120 values, rsx_leafc_kernel (any digits)
+	static constexpr bool REDO_ANY_SHIFT = CAP > 5120;
+	static_assert(NBITS >= 10 && NBITS <= 14, "");
+	static_assert(CAP % 16 == 0 && CAP <= 40960, "whole chunks; bin starts fit 16 bits");
 	static_assert(PLANES == 1 || PLANES == 2, "one or two vectors of cells per thread");
 	static_assert(NCELLW == 4 * BLOCK * PLANES, "every cell in some thread's vectors");
 };
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 #pragma unroll
 			for (int w = 1; w < NW; ++w)
 				mx = mx > wmax[w] ? mx : wmax[w];
-			if (mx > maxbin2 && !(sh1 & 7u)) {
+			if (mx > maxbin2 && (C::REDO_ANY_SHIFT || !(sh1 & 7u))) {
 				// a bin too large for the register passes: the leaf goes to rsx_leaf_sort_kernel (nothing was written) -- which
 				// sorts by byte columns: with MSB digits at other bit positions this kernel goes on until the leaf is in order
 				if (tid == 0)

@@ -39,3 +39,19 @@ def test_two_levels_with_medium_leaves_at_2p29_keys(no_blind, route):
                          text=True, timeout=900, env=dict(os.environ, RSX_NO_BLIND=no_blind))
     assert out.returncode == 0 and ("route %d" % route) in out.stdout and "sorted True" in out.stdout and \
         "preserved True" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("log2n,extra,free_gib", [(30, 7, 24), (31, 4097, 44)], ids=["2^30", "2^31"])
+def test_two_levels_without_histogram_up_to_2p31_keys(log2n, extra, free_gib):
+    """2^30 and 2^31 u32 keys keep the route of BASELINE.json's headline (two MSB passes without a histogram, leaves): the
+    level-2 slots hold two-byte values -- 16 Ki of them at 2^30 keys (rsx_leaf16_kernel's 20480-value shape), 32 Ki at 2^31 (the
+    counting leaves, csrc/rsx_leafc.hpp); every offset still fits 32 bits.  Sortedness and checksums on the device."""
+    rsa.require_gpu()
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < free_gib * (1 << 30):
+        pytest.skip("needs %d GiB of free HBM" % free_gib)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_sort_check.py"), str(log2n), str(extra)], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "route 5" in out.stdout and "sorted True" in out.stdout and "preserved True" in out.stdout, \
+        out.stdout + out.stderr

@@ -191,6 +191,39 @@ def test_u32_low_bits_clustered_everywhere_keeps_the_route_and_changes_the_leave
     _sort_and_compare(a, ol.U32, ol.ASC, 5, "low bits & 0xFC0F")
 
 
+@pytest.mark.parametrize("force", ["1", "2", "3"], ids=["counting", "10240-value shape + counting", "20480-value shape + counting"])
+@pytest.mark.parametrize("case", ["uniform", "constant top bits, descending", "low bits clustered in some buckets", "low bits clustered everywhere",
+                                  "few values"])
+def test_u32_leaves_of_the_large_slots(case, force, monkeypatch):
+    """Arrays beyond 2^28 keys leave two-byte slots of more than 5120 values: rsx_leaf16_kernel in its 10240- / 20480-value shapes
+    with the counting leaves (rsx_leafc_kernel) behind them, the counting leaves alone for the slots of 2^31 keys
+    (csrc/rsx_leafc.hpp; the reference's last two passes, radix_sort.hpp:82-90).  Those sizes are beyond the oracle
+    (tests/test_gpu_big.py checks them by properties), so RSX_FORCE_LEAFC sends the slots of 160 Mi keys (3328 values) through
+    the same three launches: bit for bit, route asserted.  Clustered low bits: the larger shapes leave such leaves to the
+    counting kernel's list launch -- or all of them, when the sample sees the clustering."""
+    monkeypatch.setenv("RSX_FORCE_LEAFC", force)
+    n = 160 * MI + 77
+    dt, order = ol.U32, ol.ASC
+    if case == "uniform":
+        a = ol.splitmix_fill(n, ol.F32, 5100, 0xFFFFFFFF)
+        dt = ol.F32
+    elif case == "constant top bits, descending":
+        a = np.ascontiguousarray(ol.splitmix_fill(n, ol.U32, 5101, 0x1FFFFFFF).view(np.uint32) | np.uint32(0xE0000000))
+        order = ol.DESC
+    elif case == "low bits clustered in some buckets":
+        a = ol.splitmix_fill(n, ol.U32, 5102, 0xFFFFFFFF).view(np.uint32).copy()
+        top = a >> 16
+        a[(top % 97) == 5] &= np.uint32(0xFFFF0FF0)
+        a[(top % 389) == 7] &= np.uint32(0xFFFF000F)
+        a[(top % 1009) == 11] &= np.uint32(0xFFFF0000)      # every value of the leaf the same
+    elif case == "low bits clustered everywhere":
+        a = ol.splitmix_fill(n, ol.U32, 5103, 0xFFFFFC0F)
+    else:
+        a = ol.splitmix_fill(n, ol.I32, 5104, 0xFFFFF00F)   # 256 values of the low sixteen bits: thirteen of each in every leaf
+        dt = ol.I32
+    _sort_and_compare(a, dt, order, 5, (case, force))
+
+
 @pytest.mark.parametrize("n_mi,mask", [(5, 0xFFFFFFFFFFFFFFFF), (6, 0xFFFFFFFFFF), (9, 0xFFFFFFFFFFFFFFFF), (20, 0xFFFFFFFFFFFFFFFF), (48, 0xFFFFFFFFFFFFFFFF),
                                        (96, 0xFFFFFFFFFFFFFFFF), (160, 0xFFFFFFFFFFFFFFFF), (12, 0xFFFFFFFFFF), (48, 0xFFFFFFFFFF), (96, 0xFFFFFFFFFF),
                                        (24, 0xFFFFFFFF), (96, 0xFFFFFFFF)])
