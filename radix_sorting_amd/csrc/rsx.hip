@@ -125,7 +125,7 @@ struct Env {
 	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
 	bool no_leafc = false;           // RSX_NO_LEAFC=1: no two-byte slots of more than 5120 values (rsx_leafc.hpp): sorts without a histogram of 4-byte keys end below 2^30 keys and their larger leaves sort whole keys, as in round 4
-	unsigned force_leafc = 0;        // RSX_FORCE_LEAFC=1|2|3 (tests): two-byte slots of ANY size take the leaves of the large ones -- 1 the counting leaves at once, 2 / 3 rsx_leaf16_kernel's 10240- / 20480-value shape and the counting leaves behind it
+	unsigned force_leafc = 0;        // RSX_FORCE_LEAFC=1..6 (tests): two-byte slots of ANY size take the leaves of the large ones -- 1 the counting leaves at once, 2 / 3 / 4 / 5 / 6 rsx_leaf16_kernel's 10240- / 20480- / 6144- / 7680- / 15360-value shape and the counting leaves behind it
 	bool no_leaf16 = false;          // RSX_NO_LEAF16=1: two-byte slots are sorted by rsx_leaf_sort_kernel (two LDS passes) as in round 3
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
@@ -1254,26 +1254,45 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 				// shape -- 13 or 14 bits name a value's bin, 512 or 1024 threads to a leaf --, and behind it the counting leaves for what
 				// it leaves alone; larger slots (2^31 keys: 32 Ki values each): the counting leaves at once.  tools/ubench/leafc_probe,
 				// profiles/r05/leafc_probe.txt: 2^29 keys 0.81 ms against 1.78 counting, 2^30 1.80 against 2.35, 2^31 4.33 against 3.20.
+				// (the shapes' ladder: tools/ubench/leafc_probe at 300 M, 400 M, 2^29, 700 M, 2^30 and 1.5 x 2^30 keys,
+				// profiles/r05/leafc_probe_between.txt -- every step is 10-20 % over the next larger shape at its size)
+				typedef Leaf16Cfg<256, 6144, 8, 12> L6k;
+				typedef Leaf16Cfg<256, 7680, 8, 12> L7k;
 				typedef Leaf16Cfg<512, 10240, 8, 13> L10k;
+				typedef Leaf16Cfg<512, 15360, 8, 13> L15k;
 				typedef Leaf16Cfg<1024, 20480, 8, 14> L20k;
 				const unsigned grid_c = 256u;   // (a workgroup per CU: the cells fill the LDS)
 #define RSX_LAUNCH_LC(NVEC, REDO)                                                                                           \
 				hipLaunchKernelGGL((rsx_leafc_kernel<KT, LeafCCfg<NVEC>>), dim3(grid_c), dim3(LeafCCfg<NVEC>::BLOCK), 0, c.stream, src, aux, \
 				                   (const Plan *)c.plan(), segtab, ctl, ka, 0u, (u32)LeafCCfg<NVEC>::CAP, (const uint16_t *)slots,     \
 				                   c.slack_cap, (const u32 *)(REDO))
-				if (force ? force == 2 && c.slack_cap <= (u32)L10k::CAP : c.slack_cap <= (u32)L10k::CAP) {
-					hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L10k>), dim3(grid_1), dim3(L10k::BLOCK), 0, c.stream, src, aux,
-					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L10k::CAP, (const uint16_t *)slots, c.slack_cap,
-					                   redo, (u32)env().leaf16_maxbin);
-					RSX_LAUNCH_LC(2, redo);
-				} else if (force ? force >= 2 && c.slack_cap <= (u32)L20k::CAP : c.slack_cap <= (u32)L20k::CAP) {
-					hipLaunchKernelGGL((rsx_leaf16_kernel<KT, L20k>), dim3(grid_1), dim3(L20k::BLOCK), 0, c.stream, src, aux,
-					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)L20k::CAP, (const uint16_t *)slots, c.slack_cap,
-					                   redo, (u32)env().leaf16_maxbin);
-					RSX_LAUNCH_LC(3, redo);
-				} else {
+#define RSX_LAUNCH_L16B(CFG, NVEC)                                                                                          \
+				do {                                                                                                        \
+					hipLaunchKernelGGL((rsx_leaf16_kernel<KT, CFG>), dim3(grid_1), dim3(CFG::BLOCK), 0, c.stream, src, aux,   \
+					                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)CFG::CAP, (const uint16_t *)slots,   \
+					                   c.slack_cap, redo, (u32)env().leaf16_maxbin);                                          \
+					RSX_LAUNCH_LC(NVEC, redo);                                                                                \
+				} while (0)
+				const u32 cap = c.slack_cap;
+				// (RSX_FORCE_LEAFC, tests: 1 counting, 2 / 3 / 4 / 5 / 6 the 10240- / 20480- / 6144- / 7680- / 15360-value shape)
+				const unsigned pick = force ? force
+				                            : cap <= (u32)L6k::CAP ? 4u : cap <= (u32)L7k::CAP ? 5u : cap <= (u32)L10k::CAP ? 2u
+				                            : cap <= (u32)L15k::CAP ? 6u : cap <= (u32)L20k::CAP ? 3u : 1u;
+				if (pick == 4 && cap <= (u32)L6k::CAP)
+					RSX_LAUNCH_L16B(L6k, 2);
+				else if (pick == 5 && cap <= (u32)L7k::CAP)
+					RSX_LAUNCH_L16B(L7k, 2);
+				else if (pick == 2 && cap <= (u32)L10k::CAP)
+					RSX_LAUNCH_L16B(L10k, 2);
+				else if (pick == 6 && cap <= (u32)L15k::CAP)
+					RSX_LAUNCH_L16B(L15k, 2);
+				else if (pick == 3 && cap <= (u32)L20k::CAP)
+					RSX_LAUNCH_L16B(L20k, 3);
+				else if (cap <= (u32)LeafCCfg<4>::CAP)
+					RSX_LAUNCH_LC(4, nullptr);
+				else
 					RSX_LAUNCH_LC(5, nullptr);
-				}
+#undef RSX_LAUNCH_L16B
 #undef RSX_LAUNCH_LC
 				HIP_TRY(hipGetLastError());
 				return RSX_OK;

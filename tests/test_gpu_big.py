@@ -41,7 +41,10 @@ def test_two_levels_with_medium_leaves_at_2p29_keys(no_blind, route):
         "preserved True" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("log2n,extra,free_gib", [(30, 7, 24), (31, 4097, 44)], ids=["2^30", "2^31"])
+@pytest.mark.parametrize("log2n,extra,free_gib", [(28, 50000000, 8), (28, 130000000, 10), (29, 200000000, 16), (30, 7, 24), (30, 500000000, 34),
+                                                  (31, 4097, 44)],
+                         ids=["304 Mi (6144-value slots)", "380 Mi (7680)", "703 Mi (15360)", "2^30 (20480)", "1.47 x 2^30 (counting, 32768)",
+                              "2^31 (counting, 40960)"])
 def test_two_levels_without_histogram_up_to_2p31_keys(log2n, extra, free_gib):
     """2^30 and 2^31 u32 keys keep the route of BASELINE.json's headline (two MSB passes without a histogram, leaves): the
     level-2 slots hold two-byte values -- 16 Ki of them at 2^30 keys (rsx_leaf16_kernel's 20480-value shape), 32 Ki at 2^31 (the

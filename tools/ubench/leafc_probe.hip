@@ -86,10 +86,10 @@ __global__ void diff_kernel(const u32 *a, const u32 *b, u64 n, u64 *out)
 
 int main(int argc, char **argv)
 {
-	const int log2n = argc > 1 ? atoi(argv[1]) : 31;
+	const long long a1 = argc > 1 ? atoll(argv[1]) : 31;   // log2 of the number of keys, or the number itself
 	const u32 mode = argc > 2 ? (u32)atoi(argv[2]) : 0;
 	const unsigned grid = argc > 3 ? (unsigned)atoi(argv[3]) : 256u;
-	const size_t nkeys = (size_t)1 << log2n;
+	const size_t nkeys = a1 <= 40 ? (size_t)1 << a1 : (size_t)a1;
 	const u32 per = (u32)(nkeys >> 16), nleaf = 65536;
 	const u32 cap = ((per + per / 4 + 255) / 256) * 256;
 	uint16_t *d_slots;
@@ -213,12 +213,21 @@ int main(int argc, char **argv)
 		       nredo, (unsigned long long)chk[0], chk[1] == want[1] ? "ok" : "DIFFERENT", chk[2] == want[2] ? "ok" : "DIFFERENT");
 		fflush(stdout);
 	};
+	run16("rsx_leaf16_kernel<256, 6144, 8, 12>", Leaf16Cfg<256, 6144, 8, 12>{});
+	run16("rsx_leaf16_kernel<256, 7680, 8, 12>", Leaf16Cfg<256, 7680, 8, 12>{});
+	run16("rsx_leaf16_kernel<512, 7680, 8, 12>", Leaf16Cfg<512, 7680, 8, 12>{});
+	run16("rsx_leaf16_kernel<512, 7680, 8, 13>", Leaf16Cfg<512, 7680, 8, 13>{});
+	run16("rsx_leaf16_kernel<512, 10240, 8, 12>", Leaf16Cfg<512, 10240, 8, 12>{});
 	run16("rsx_leaf16_kernel<512, 10240, 8, 13>", Leaf16Cfg<512, 10240, 8, 13>{});
+	run16("rsx_leaf16_kernel<512, 15360, 8, 13>", Leaf16Cfg<512, 15360, 8, 13>{});
+	run16("rsx_leaf16_kernel<1024, 15360, 8, 14>", Leaf16Cfg<1024, 15360, 8, 14>{});
+	run16("rsx_leaf16_kernel<1024, 20480, 8, 13>", Leaf16Cfg<1024, 20480, 8, 13>{});
 	run16("rsx_leaf16_kernel<1024, 10240, 8, 13>", Leaf16Cfg<1024, 10240, 8, 13>{});
 	run16("rsx_leaf16_kernel<1024, 10240, 8, 14>", Leaf16Cfg<1024, 10240, 8, 14>{});
 	run16("rsx_leaf16_kernel<1024, 20480, 8, 14>", Leaf16Cfg<1024, 20480, 8, 14>{});
 	run16("rsx_leaf16_kernel<1024, 40960, 4, 14>", Leaf16Cfg<1024, 40960, 4, 14>{});
 	run("rsx_leafc_kernel<5 vectors>", LeafCCfg<5>{}, grid);
+	run("rsx_leafc_kernel<4 vectors>", LeafCCfg<4>{}, grid);
 	run("rsx_leafc_kernel<3 vectors>", LeafCCfg<3>{}, grid);
 	run("rsx_leafc_kernel<2 vectors>", LeafCCfg<2>{}, grid);
 	run("rsx_leafc_kernel<5 vectors>", LeafCCfg<5>{}, 2 * grid);
