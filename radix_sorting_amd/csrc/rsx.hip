@@ -485,6 +485,11 @@ struct ProfRec {
 	hipStream_t stream;
 	bool called_off;   // launches of an attempt the device called off (or of a route the plan did not choose): they returned at
 	                   // once or their output was discarded -- their time is booked apart, their bytes are not booked at all
+	// device-scheduled sorts (rsx_sort_inplace_async): nobody reads a verdict back while the sort is enqueued, so the record names
+	// a pinned word that receives SegCtl::mode behind the attempt (prof_verdict_slot) and which value makes it count:
+	// valid_if 1 -- the attempt's own launches: SEG_MODE_LEAVES; 2 -- the gated histogram-first launches behind it: anything else
+	const u32 *verdict = nullptr;
+	int valid_if = 0;
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -524,6 +529,59 @@ void prof_rebook(size_t mark, hipStream_t s, int kind, u64 bytes, int new_kind =
 			break;
 		}
 }
+
+// a pinned word for one device-scheduled sort's verdict (4096 per profile window; none left: the records stay as they are)
+u32 *g_prof_vblock = nullptr;
+size_t g_prof_vnext = 0;
+u32 *prof_verdict_slot()
+{
+	std::lock_guard<std::mutex> lock(g_prof_mu);
+	if (!g_prof_vblock && hipHostMalloc((void **)&g_prof_vblock, 4096 * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		g_prof_vblock = nullptr;
+		return nullptr;
+	}
+	if (g_prof_vnext >= 4096)
+		return nullptr;
+	u32 *p = g_prof_vblock + g_prof_vnext++;
+	*p = 0;
+	return p;
+}
+void prof_tag(size_t from, size_t to, hipStream_t s, const u32 *verdict, int valid_if)
+{
+	std::lock_guard<std::mutex> lock(g_prof_mu);
+	for (size_t i = from; i < to && i < g_prof.size(); ++i)
+		if (g_prof[i].stream == s) {
+			g_prof[i].verdict = verdict;
+			g_prof[i].valid_if = valid_if;
+		}
+}
+// ... around the attempt and the gated launches of a device-scheduled sort (`attempted`: an attempt was enqueued at all)
+struct ProfAsyncVerdict {
+	size_t m0 = 0, m1 = 0;
+	u32 *slot = nullptr;
+	hipStream_t stream;
+	explicit ProfAsyncVerdict(hipStream_t s) : stream(s) { m0 = prof_mark(); }
+	void attempt_enqueued(const SegCtl *ctl)
+	{
+		if (!g_prof_on)
+			return;
+		slot = prof_verdict_slot();
+		if (slot && hipMemcpyAsync(slot, &ctl->mode, sizeof(u32), hipMemcpyDeviceToHost, stream) != hipSuccess) {
+			(void)hipGetLastError();
+			slot = nullptr;
+		}
+		m1 = prof_mark();
+	}
+	void gated_enqueued()
+	{
+		if (!g_prof_on || !slot)
+			return;
+		const size_t m2 = prof_mark();
+		prof_tag(m0, m1, stream, slot, 1);
+		prof_tag(m1, m2, stream, slot, 2);
+	}
+};
 
 struct ProfScope {
 	bool on;
@@ -2247,6 +2305,7 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 	// A caller-owned workspace (rsx_sort_inplace_async_ws) has no room for slots: one level only.
 	HybCaps caps{0, 0, 0, 0};
 	int blind = 0;
+	ProfAsyncVerdict pverdict(c.stream);   // (rsx_profile books what the device chose: the attempt's launches or the ones behind it)
 	if constexpr (sizeof(KT) >= 4) {
 		if (hybrid_enabled() && !verify_mode() && !env().no_speculation) {
 			caps = hybrid_caps<KT>(n);
@@ -2255,6 +2314,8 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 				RSX_TRY(blind_enqueue<KT>(c, buf, scratch, n, ka, &blind));
 		}
 	}
+	if (blind)
+		pverdict.attempt_enqueued((const SegCtl *)c.seg.p);
 	c.pass_gate = blind ? (const SegCtl *)c.seg.p : nullptr;
 	c.async_tried_blind = blind != 0;
 	int rc = plan_phase<KT>(c, buf, n, ka, nullptr, status_total, caps);
@@ -2270,6 +2331,7 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 			RSX_TRY(launch_leaves<KT>(c, buf, scratch, n, ka, HYB_ONE_LEVEL, shapes));
 		}
 	}
+	pverdict.gated_enqueued();
 	// an odd number of kept columns leaves the result in `scratch` (radix_sort.hpp:92): bring it home
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)buf, (const unsigned char *)scratch,
 	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
@@ -2301,10 +2363,13 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 	// passes into slots and the pairs' leaves, which write (k, v) -- an attempt that is called off has only read them), the
 	// histogram-first kernels behind it gated on its verdict
 	int blind = 0;
+	ProfAsyncVerdict pverdict(c.stream);
 	if constexpr (sizeof(KT) == 4 && sizeof(VT) == 4) {
 		if (async_pairs_blind_ok<KT>(c, n, sizeof(VT)))
 			RSX_TRY((pairs_blind_enqueue<KT, VT>(c, k, v, k, v, n, ka, &blind)));
 	}
+	if (blind)
+		pverdict.attempt_enqueued((const SegCtl *)c.seg.p);
 	c.pass_gate = blind ? (const SegCtl *)c.seg.p : nullptr;
 	c.async_tried_blind = blind != 0;
 	int rc = plan_phase<KT>(c, k, n, ka, nullptr, status_total);
@@ -2312,6 +2377,7 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 		rc = scatter_pass<KT, VT>(c, k, ks, v, vs, n, 0, c.ghist(), ka, 0, c.plan(), (int)i, i);
 	c.pass_gate = nullptr;
 	RSX_TRY(rc);
+	pverdict.gated_enqueued();
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)k, (const unsigned char *)ks,
 	                   (u64)n * sizeof(KT), (const Plan *)c.plan());
 	hipLaunchKernelGGL(rsx_copy_if_odd_kernel, dim3(2048), dim3(256), 0, c.stream, (unsigned char *)v, (const unsigned char *)vs,
@@ -2983,10 +3049,13 @@ int sort_rank_inplace_async(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, 
 	// the attempt without a histogram first (4-byte keys, 4-byte indices, 16 Mi .. 2^28 keys: its leaves write the ranks to the
 	// first half), the histogram-first kernels behind it gated on its verdict -- as sort_keys_inplace_async
 	int blind = 0;
+	ProfAsyncVerdict pverdict(c.stream);
 	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
 		if (async_pairs_blind_ok<KT>(c, n, sizeof(IT)))
 			RSX_TRY((pairs_blind_enqueue<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, &blind)));
 	}
+	if (blind)
+		pverdict.attempt_enqueued((const SegCtl *)c.seg.p);
 	c.pass_gate = blind ? (const SegCtl *)c.seg.p : nullptr;
 	c.async_tried_blind = blind != 0;
 	int rc = plan_phase<KT>(c, src, n, ka, nullptr, status_total);
@@ -2996,6 +3065,7 @@ int sort_rank_inplace_async(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, 
 	c.pass_alt = nullptr;
 	c.pass_gate = nullptr;
 	RSX_TRY(rc);
+	pverdict.gated_enqueued();
 	// sorted keys: no pass ran, the ranks are 0 .. n-1 (radix_sort_rank.hpp:52,:55-57)
 	hipLaunchKernelGGL((rsx_iota_if_sorted_kernel<IT>), dim3(1024), dim3(256), 0, c.stream, ib, (u64)n, (const Plan *)c.plan());
 	HIP_TRY(hipGetLastError());
@@ -3739,6 +3809,8 @@ int rsx_profile_end(rsx_profile *out)
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(r.stop));
 		HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+		if (r.verdict && ((r.valid_if == 1) != (*r.verdict == SEG_MODE_LEAVES)))
+			r.called_off = true;
 		if (r.called_off) {
 			out->called_off_ms += ms;
 			out->called_off_launches += 1;
@@ -3763,6 +3835,7 @@ int rsx_profile_end(rsx_profile *out)
 		(void)hipEventDestroy(r.stop);
 	}
 	g_prof.clear();
+	g_prof_vnext = 0;
 	return RSX_OK;
 }
 

@@ -260,3 +260,43 @@ def test_a_kept_graph_takes_the_fast_route_inside_its_own_workspace(dt, n):
     torch.cuda.synchronize()
     assert rsa.async_route_ws(small, n, dt) == 0
     assert np.array_equal(buf.cpu().numpy().view(ol.NP_BITS[dt]), ol.oracle_sort(base, dt)[0])
+
+
+def test_the_profile_books_what_the_device_chose():
+    """rsx_profile around device-scheduled sorts (the multi-GPU path's local sorts, bench.py's roofline object): the launches of
+    the route the device did NOT take -- the gated histogram-first kernels behind an attempt that went through, the attempt's own
+    kernels when it was called off -- add no bytes and no launch to the classes, only to called_off_*; the verdict travels to a
+    pinned word behind the attempt, nobody waits for it."""
+    n = (64 << 20) + 11
+    buf = torch.empty(n, dtype=torch.int32, device="cuda")
+    scratch = torch.empty_like(buf)
+    # uniform keys: the attempt goes through -- one level-1 pass (whole keys), one level-2 pass (two bytes per key), leaves
+    rsa.fill_splitmix(buf, 9100)
+    rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32)   # (scratch memory allocated outside the window)
+    rsa.fill_splitmix(buf, 9101)
+    torch.cuda.synchronize()
+    rsa.profile_begin()
+    rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32)
+    assert rsa.async_route() == 5
+    p = rsa.profile_end()
+    assert p.hist_launches == 0 and p.hist_bytes == 0
+    assert p.scatter_launches == 1 and p.scatter_bytes == 8 * n
+    assert p.narrow_launches == 1 and p.narrow_bytes == 6 * n
+    assert p.leaf_launches >= 1 and p.leaf_bytes == 6 * n
+    assert p.called_off_launches >= 5     # histogram, four gated passes (+ the leaf shapes of the one-level route)
+    # keys with one hot top digit: the sample calls the attempt off -- the histogram and four passes are what ran
+    a = ol.splitmix_fill(n, ol.U32, 9102, 0xFFFFFFFF).view(np.uint32).copy()
+    a[::2] &= np.uint32(0x00FFFFFF)
+    buf.copy_(torch.from_numpy(a.view(np.int32)))
+    torch.cuda.synchronize()
+    rsa.profile_begin()
+    rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32)
+    route = rsa.async_route()
+    p = rsa.profile_end()
+    assert route == 0
+    assert p.hist_launches == 1 and p.hist_bytes == 4 * n
+    assert p.scatter_launches == 4 and p.scatter_bytes == 4 * 8 * n
+    assert p.narrow_launches == 0 and p.leaf_launches == 0
+    assert p.called_off_launches >= 1
+    got = buf.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, np.sort(a))
