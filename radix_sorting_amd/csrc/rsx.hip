@@ -122,6 +122,7 @@ struct Env {
 	unsigned pass16_wgs = 2;         // RSX_PASS16_WGS=1: ... one workgroup per CU (probe)
 	bool no_packed_keys = false;     // RSX_NO_PACKED_KEYS=1: rank sorts without a histogram go by byte columns only (SegCtl::compact never set)
 	bool no_pass32a = false;         // RSX_NO_PASS32A=1: the level-1 pass of such a sort is rsx_scatter2_kernel<..., SEG> with its look-back chain (rsx_pass32.hpp)
+	int pass32_prefetch = -1;        // RSX_PASS32_PREFETCH=0|1 (probe): rsx_pass32a_kernel requests a tile's keys while it writes the tile before (1) or when it starts on the tile (0); unset: by the array's size
 	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
 	bool no_leafc = false;           // RSX_NO_LEAFC=1: no two-byte slots of more than 5120 values (rsx_leafc.hpp): sorts without a histogram of 4-byte keys end below 2^30 keys and their larger leaves sort whole keys, as in round 4
@@ -170,6 +171,8 @@ struct Env {
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
 		no_leafc = is_one("RSX_NO_LEAFC");
+		if (const char *e = getenv("RSX_PASS32_PREFETCH"))
+			pass32_prefetch = e[0] == '1' ? 1 : 0;
 		if (const char *e = getenv("RSX_FORCE_LEAFC"))
 			force_leafc = (unsigned)atoi(e);
 		no_pass16 = is_one("RSX_NO_PASS16");
@@ -1966,12 +1969,22 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 			ProfScope prof(1, (u64)n * 2 * sizeof(KT), c.stream);
 			// (probed and not kept: Pass32aCfgT<12> -- 12 Ki-key tiles, 81 KB of LDS, two workgroups per CU, no prefetch: 0.534-0.543 ms
 			// for 2^28 keys where this shape takes 0.470-0.477 on the same box, profiles/r05/pass32a_probe.txt)
-			if (plain)
-				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIG_PLAIN>), dim3(256), dim3(Pass32aCfg::BLOCK), 0, c.stream, (const KT *)src, (u64)n,
-				                   kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka);
+			// (the next tile's keys requested while this tile is written out: 1 % ahead at 2^27 keys, 2-5 % BEHIND from 2^28 on -- the
+			// level-1 pass of 2^28 keys 0.485 -> 0.457 ms without, three rounds alternating in one process, tools/blind_ab.py;
+			// 380 M keys 1.975 -> 1.929 ms, 2^30 5.157 -> 5.130: reads and writes in flight together cost more than the gap between tiles)
+			const bool prefetch = env().pass32_prefetch >= 0 ? env().pass32_prefetch != 0 : n < ((size_t)3 << 26);
+#define RSX_LAUNCH_P32(DIGV, PF)                                                                                             \
+			hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIGV, PF>), dim3(256), dim3(Pass32aCfg::BLOCK), 0, c.stream, (const KT *)src, \
+			                   (u64)n, kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka)
+			if (plain && prefetch)
+				RSX_LAUNCH_P32(DIG_PLAIN, true);
+			else if (plain)
+				RSX_LAUNCH_P32(DIG_PLAIN, false);
+			else if (prefetch)
+				RSX_LAUNCH_P32(DIG_GENERIC, true);
 			else
-				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIG_GENERIC>), dim3(256), dim3(Pass32aCfg::BLOCK), 0, c.stream, (const KT *)src, (u64)n,
-				                   kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka);
+				RSX_LAUNCH_P32(DIG_GENERIC, false);
+#undef RSX_LAUNCH_P32
 			HIP_TRY(hipGetLastError());
 		}
 	}

@@ -9,9 +9,10 @@ def main():
     rsa.require_gpu()
     dev = torch.device("cuda:0")
     print(f"{'n':>11} {'us per sort':>12} {'Mkeys/s':>10} {'inplace_async':>14}")
-    for lg in range(8, 29):
+    top = int(sys.argv[1]) if len(sys.argv) > 1 else 31   # log2 of the largest size
+    for lg in range(8, top + 1):
         for n in ((1 << lg), (1 << lg) + (1 << lg) // 2):
-            if n > (1 << 28):
+            if n > (1 << top):
                 continue
             reps = max(3, min(200, (1 << 26) // n))
             bufs = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]

@@ -4,6 +4,7 @@
 namespace rsx {
 template __global__ void rsx_pass32a_kernel<u32, DIG_PLAIN, true>(const u32 *, u64, u32 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u32>, const u32 *);
 template __global__ void rsx_pass32a_kernel<u32, DIG_GENERIC, true>(const u32 *, u64, u32 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u32>, const u32 *);
+template __global__ void rsx_pass32a_kernel<u32, DIG_GENERIC, false>(const u32 *, u64, u32 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u32>, const u32 *);
 template __global__ void rsx_pass32a_kernel<u32, DIG_PLAIN, false>(const u32 *, u64, u32 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u32>, const u32 *);
 template __global__ void rsx_pass32a_kernel<u32, 2, true>(const u32 *, u64, u32 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u32>, const u32 *);
 }
