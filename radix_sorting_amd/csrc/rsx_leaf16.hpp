@@ -1211,7 +1211,25 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk8_kernel(KT *__rest
 		const u32 cnt = ls.cnt, slot = ls.slot;
 		if (cnt != 0) {
 			const KT *q = slot ? slots + (u64)(slot - 1) * slack_cap : (const KT *)src + ls.beg;
-			CT kv[NK];
+			// the leaf's values in registers.  P6: 48 bits each, kept as the upper 32 (kh) and the lower 16 of two neighbours in one
+			// register (kl) -- fifteen registers for ten values instead of twenty: with 64 to a lane (four workgroups per CU) the
+			// whole values spilled four of them (20 bytes of scratch per lane, 1.22 x the bytes: profiles/r05/configs, first run)
+			CT kv[P6 ? 1 : NK];
+			u32 kh[P6 ? NK : 1], kl[P6 ? (NK + 1) / 2 : 1];
+			auto set = [&](int j, KT k) {
+				if constexpr (P6) {
+					kh[j] = (u32)(k >> 16);
+					kl[j >> 1] = (j & 1) ? (kl[j >> 1] | ((u32)k << 16)) : ((u32)k & 0xFFFFu);
+				} else {
+					kv[j] = (CT)k;
+				}
+			};
+			auto val = [&](int j) -> CT {
+				if constexpr (P6)
+					return (CT)(((u64)kh[j] << 16) | ((kl[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+				else
+					return kv[j];
+			};
 			const KT first = kdf_apply(q[0], ka);
 			// element index of register j (VLOAD: lane t holds elements 2 t, 2 t + 1 of every 2 * BLOCK: a slot starts on a 16-byte
 			// boundary and its capacity is even, so the second element of a vector is the slot's own even behind the last key)
@@ -1225,14 +1243,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk8_kernel(KT *__rest
 					kvec_t x = {0, 0};
 					if (e < cnt)
 						x = *(const kvec_t *)(q + e);
-					kv[j] = (CT)(P6 ? (kdf_apply(x[0], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(x[0], ka));
-					kv[j + 1] = (CT)(P6 ? (kdf_apply(x[1], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(x[1], ka));
+					set(j, P6 ? (kdf_apply(x[0], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(x[0], ka));
+					set(j + 1, P6 ? (kdf_apply(x[1], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(x[1], ka));
 				}
 			} else {
 #pragma unroll
 				for (int j = 0; j < NK; ++j) {
 					const u32 e = tid + BLOCK * j;
-					kv[j] = e < cnt ? (CT)(P6 ? (kdf_apply(q[e], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(q[e], ka)) : (CT)0;
+					set(j, e < cnt ? (P6 ? (kdf_apply(q[e], ka) & (KT)0xFFFFFFFFFFFFull) : kdf_apply(q[e], ka)) : (KT)0);
 				}
 			}
 			{
@@ -1254,13 +1272,13 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk8_kernel(KT *__rest
 #pragma unroll
 				for (int j = 0; j < NK; ++j)
 					if (elem_of(j) < cnt)
-						put_at(elem_of(j), kv[j]);
+						put_at(elem_of(j), val(j));
 			} else {
 #pragma unroll
 				for (int j = 0; j < NK; ++j) {
 					if ((C::VLOAD ? 2 * BLOCK * (j >> 1) : BLOCK * j) < (int)cnt) {
 						u32 sh;
-						u32 *a = cell_of(kv[j], elem_of(j) < cnt, sh);
+						u32 *a = cell_of(val(j), elem_of(j) < cnt, sh);
 						__hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
@@ -1330,12 +1348,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk8_kernel(KT *__rest
 						if ((C::VLOAD ? 2 * BLOCK * (j >> 1) : BLOCK * j) < (int)cnt) {
 							const bool valid = elem_of(j) < cnt;
 							u32 sh;
-							u32 *a = cell_of(kv[j], valid, sh);
+							u32 *a = cell_of(val(j), valid, sh);
 							const u32 old = __hip_atomic_fetch_add(a, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 							const u32 pos = (old >> sh) & 0xFFFFu;
 							if constexpr (P6) {
-								st_hi[valid ? at(pos) : 16 * S + lane] = (u32)((u64)kv[j] >> 16);
-								st_lo[valid ? (pos & 15u) * (u32)S2 + (pos >> 4) : 16 * S2 + lane] = (unsigned short)kv[j];
+								st_hi[valid ? at(pos) : 16 * S + lane] = kh[j];
+								st_lo[valid ? (pos & 15u) * (u32)S2 + (pos >> 4) : 16 * S2 + lane] = (unsigned short)(kl[j >> 1] >> (16 * (j & 1)));
 							} else {
 								stage[valid ? at(pos) : 16 * S + lane] = kv[j];
 							}
