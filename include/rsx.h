@@ -34,9 +34,12 @@
  *   caller's SECOND buffer (keys-only sorts: the sample has proven the input unsorted before anything is written, so that
  *   buffer belongs to the sort as in the reference, radix_sort.hpp:82-92; the early exits leave it untouched as before) and
  *   the other 52 -- 0.25 n keys -- in scratch memory, and 65536 slots of 1.25 n / 65536 keys for the second pass (two bytes per
- *   key for 4-byte keys: 0.63 n keys' worth).  Measured (tools/footprint_probe.py): 2^28 u32 keys 1.06 GiB in all (round 3:
- *   2.1), 2^27 u64 keys 1.58 (2.9).  Key + payload and rank sorts keep all their level-1 slots, keys and payloads, in scratch
- *   memory.  If an allocation fails the sort takes the histogram-first
+ *   key for 4-byte keys: 0.63 n keys' worth -- keys-only sorts of 4-byte keys up to 2^31 keys, round 5).  Buffers grow in steps
+ *   of an eighth of the next power of two (a slightly larger n does not reallocate), the new one is allocated before the old
+ *   one is freed, and nothing grows or is released inside a stream capture or a *_inplace_async call.  Measured
+ *   (tools/footprint_probe.py, profiles/r05/footprint_probe.txt): 2^28 u32 keys 1.17 GiB in all, 2^27 u64 keys 1.72, 2^28 u64
+ *   keys 3.43; 2^28 f32 keys -> ranks or key + payload pairs 5.5 GiB (those sorts keep all their level-1 slots, keys and
+ *   payloads, in scratch memory).  If an allocation fails the sort takes the histogram-first
  *   route and the (device, stream) context does not ask again until rsx_reload_env() or rsx_release_stream();
  *   RSX_NO_BLIND=1 never asks.
  *
@@ -65,6 +68,12 @@
  *                           64-byte atoms (rsx_pass16a_kernel); RSX_NO_PASS32A=1: the level-1 pass is the chained kernel of round 4
  *                           (rsx_scatter2_kernel) instead of rsx_pass32a_kernel; RSX_NO_PASS16=1: so is the level-2 pass;
  *                           RSX_PASS16_WGS=1, RSX_PASS16_DBG=1|2: probes of rsx_pass16_kernel (DBG gives WRONG output);
+ *   RSX_PASS32_PREFETCH=0|1 (probe) rsx_pass32a_kernel requests the next tile's keys while it writes the current one (default: below
+ *                           192 Mi keys only);
+ *   RSX_NO_LEAFC=1          no two-byte slots of more than 5120 values: keys-only sorts of 4-byte keys beyond 2^28 keys run as in
+ *                           round 4 (whole-key slots up to 2^30 keys, one pass per column beyond; rsx_leafc.hpp);
+ *   RSX_FORCE_LEAFC=1..6    (tests) two-byte slots of any size go through the leaves of the large ones: 1 the counting leaves,
+ *                           2 .. 6 rsx_leaf16_kernel's 10240- / 20480- / 6144- / 7680- / 15360-value shape + the counting leaves' list launch;
  *   RSX_NO_PACKED_KEYS=1    rank sorts without a histogram go by byte columns only: neither the keys' packed varying bits nor, for
  *                           floats on a grid, their fixed-point integers are tried (SegCtl::compact);
  *   RSX_NO_UNSTABLE=1       the MSB passes of a sort without a histogram rank per wave (stable) as every other pass does;
