@@ -355,7 +355,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 		if constexpr (!(C::SKIP & 1)) {
 			// ---- the low four bits: chunks of 16 values at 16 i (sorted), then at 16 i + 8 (two sorted halves: merged), and
 			// twice more for bins of more than MAXBIN keys (evenly spread keys: one leaf in two thousand)
-			const u32 npass = mx <= C::MAXBIN ? 2u : mx <= C::MAXBIN2 ? 4u : 2u * (((mx + 6) / 8 + 2) / 2);   // ceil((m - 1) / 8) + 1 passes for a bin of m
+			// ceil((m - 1) / 8) + 1 passes for a bin of m: the blocks of eight it can span (2 up to 9 values, 3 up to 17, 4 up to 25)
+			const u32 npass = mx <= C::MAXBIN ? 2u : mx <= 17u ? 3u : mx <= C::MAXBIN2 ? 4u : 2u * (((mx + 6) / 8 + 2) / 2);
 			for (u32 pass = 0; pass < npass; ++pass) {
 				const u32 off = 8 * (pass & 1);
 #pragma unroll
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 			if (mx > maxbin2)
 				batcher_sort_lds<BLOCK>(stage, cnt, at);   // (bins too full for the register passes: the network over the whole leaf)
 		}
-		const u32 npass = (SLOT32 && mx > maxbin2) ? 0u : mx > C::MAXBIN ? 4u : 2u;
+		const u32 npass = (SLOT32 && mx > maxbin2) ? 0u : mx > 17u ? 4u : mx > C::MAXBIN ? 3u : 2u;   // (a bin of up to 9 / 17 / 25 values spans 2 / 3 / 4 blocks of eight)
 		for (u32 pass = 0; pass < npass; ++pass) {
 			const u32 off = 8 * (pass & 1);
 #pragma unroll
@@ -1366,7 +1367,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk8_kernel(KT *__rest
 					put_at(cnt + tid, P6 ? (CT)0xFFFFFFFFFFFFull : (CT)~(CT)0);
 				__syncthreads();
 				if constexpr (!(C::SKIP & 1)) {
-					const u32 npass = mx > C::MAXBIN ? 4u : 2u;
+					const u32 npass = mx > 17u ? 4u : mx > C::MAXBIN ? 3u : 2u;
 					for (u32 pass = 0; pass < npass; ++pass) {
 #pragma unroll
 						for (int r = 0; r < NCH; ++r) {
@@ -1582,7 +1583,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 		if (tid < 32)
 			stage[at(cnt + tid)] = ~0u;
 		__syncthreads();
-		const u32 npass = mx > C::MAXBIN ? 4u : 2u;
+		// (a bin of up to 9 / 17 / 25 compounds spans 2 / 3 / 4 blocks of eight: as many passes.  Packed keys with few bits left for
+		// the leaves -- cfg 4 (iii): four -- fill their bins from 32 neighbouring positions each, 10-11 in the fullest: three passes)
+		const u32 npass = mx > 17u ? 4u : mx > C::MAXBIN ? 3u : 2u;
 		for (u32 pass = 0; pass < npass; ++pass) {
 			const u32 off = 8 * (pass & 1);
 #pragma unroll
