@@ -1451,11 +1451,16 @@ template <typename KT> bool pass16a_wanted(const Ctx &c)
 // j == -2: the slack attempt (aux -> the slots of c.slack, no counts needed).
 // blind (a sort without a histogram, sort_keys_blind): 1 = its level-1 pass (`aux` = the caller's array -> the 256 slots of
 // c.slack1, by the top column, status region 1), 2 = its level-2 pass (j == -2, reading c.slack1 instead of `aux`).
+// Rows of status words (and tile-table entries) a segmented pass may need beyond n / TILE: a partial tile per level-1 bucket, and
+// -- 8-byte keys, whose level-1 pass may be rsx_pass32a_kernel in front of the CHAINED level-2 pass -- one more per bucket for
+// what lies at its slot's end (rsx_seg_tiles_kernel, back_cap).
+template <typename KT> constexpr u64 seg_extra_rows() { return sizeof(KT) == 8 ? 512 : 256; }
+
 template <typename KT>
 int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, int j, int blind = 0)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
-	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + seg_extra_rows<KT>();
 	const size_t st_bytes = 256 + rows * 256 * 4;
 	char *base = (char *)c.seg.p + c.seg_status_off + (size_t)(blind == 1 ? 1 : j < 0 ? 0 : j) * st_bytes;
 	SegArgs sa{};
@@ -1504,7 +1509,7 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	if (blind && !env().no_unstable)
 		flags |= SCATTER_UNSTABLE;
 	const u32 pi = j < 0 ? 0u : (u32)j;
-	const unsigned grid = blind == 1 ? (unsigned)(rows - 256) : (unsigned)rows;
+	const unsigned grid = blind == 1 ? (unsigned)(rows - seg_extra_rows<KT>()) : (unsigned)rows;
 	const u32 shift0 = 0u;   // (every segmented pass reads its column from the device-side plan)
 #define RSX_LAUNCH_SEG(DIGV)                                                                                               \
 	hipLaunchKernelGGL((rsx_scatter2_kernel<KT, NoVal, u32, C2, false, DIGV, false, KT, true>), dim3(grid),                 \
@@ -1596,7 +1601,7 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 template <typename KT> size_t seg_bytes(size_t n)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
-	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + seg_extra_rows<KT>();
 	const size_t st_bytes = 256 + rows * 256 * 4;
 	const size_t hist_bytes = (size_t)256 * (sizeof(KT) - 1) * 256 * sizeof(u32);
 	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 514 : rows;
@@ -1607,7 +1612,7 @@ template <typename KT> size_t seg_bytes(size_t n)
 template <typename KT> int seg_layout(Ctx &c, size_t n)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
-	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + seg_extra_rows<KT>();
 	const size_t st_bytes = 256 + rows * 256 * 4;
 	const size_t hist_bytes = (size_t)256 * (sizeof(KT) - 1) * 256 * sizeof(u32);
 	c.seg_hist_off = 256;
@@ -1661,7 +1666,7 @@ template <typename KT>
 int sort_keys_two_level(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, const Plan &plan, KT **result, u32 *how)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
-	const u64 rows = (n + C2::TILE - 1) / C2::TILE + 256;
+	const u64 rows = (n + C2::TILE - 1) / C2::TILE + seg_extra_rows<KT>();
 	const size_t st_bytes = 256 + rows * 256 * 4;
 	RSX_TRY(seg_layout<KT>(c, n));
 	SegCtl *ctl = (SegCtl *)c.seg.p;
@@ -1920,7 +1925,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	RSX_TRY(seg_layout<KT>(c, n));
 	RSX_TRY(c.gscan.ensure(256 * sizeof(u64)));
 	const u64 ntiles0 = (n + C2::TILE - 1) / C2::TILE;
-	const size_t st_bytes = 256 + (ntiles0 + 256) * 256 * 4;
+	const size_t st_bytes = 256 + (ntiles0 + seg_extra_rows<KT>()) * 256 * 4;
 	SegCtl *ctl = (SegCtl *)c.seg.p;
 	SegTile *tiles = (SegTile *)((char *)c.seg.p + c.seg_tiles_off);
 	LeafSeg *segtab = (LeafSeg *)((char *)c.seg.p + c.seg_segtab_off);
@@ -1946,12 +1951,18 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	// of tiles and carries what does not fill an atom; a bucket then lies at both ends of its slot)
 	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
 	bool atoms1 = false;
-	if constexpr (sizeof(KT) == 4) {
-		// (only in front of rsx_pass16a_kernel, which has no chain: a bucket that lies at both ends of its slot is one tile more, and
-		// the chained level-2 passes have a row of status words per tile of the ordinary count)
-		// (from 96 Mi keys: tools/atoms_threshold_probe.py, profiles/r05/atoms_threshold_probe.txt -- level with the chained pass at
-		// 64-80 Mi, 1 % ahead at 96 Mi, 3.3 % at 2^28; the level-2 pass in atoms pays from its first size, 52 Mi)
-		atoms1 = atoms && !env().no_pass32a && n >= ((size_t)3 << 25) && cap1 >= (u32)Pass32aCfg::TILE + 2 * PASS32_BACK;
+	{
+		// 4-byte keys: only in front of rsx_pass16a_kernel (a bucket that lies at both ends of its slot is one tile more: that pass's
+		// tile table has room for it); from 96 Mi keys: tools/atoms_threshold_probe.py, profiles/r05/atoms_threshold_probe.txt --
+		// level with the chained pass at 64-80 Mi, 1 % ahead at 96 Mi, 3.3 % at 2^28; the level-2 pass in atoms pays from its first
+		// size, 52 Mi.
+		// 8-byte keys (atoms of eight keys, 14 Ki-key tiles): in front of the CHAINED level-2 pass, whose status words have a row
+		// more per bucket for that (seg_extra_rows); from 48 Mi keys (the same bytes) -- tools/ubench/pass32_probe, 2^28 u64 keys:
+		// 0.926 ms against 1.01 for the chained pass, 2^27: 0.447 against 0.50.
+		typedef Pass32aCfgT<sizeof(KT) == 8 ? 14 : 28> P32;
+		const size_t min32 = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)3 << 25;
+		atoms1 = (sizeof(KT) == 4 ? atoms : !env().no_unstable) && !env().no_pass32a && n >= min32 &&
+		         cap1 >= (u32)P32::TILE + 2 * PASS32_BACK;
 		if (atoms1) {
 			// one base for the stores, the parts' offsets in the slots' places (as launch_seg_pass does for the chained pass)
 			u32 off_lo = 0, off_hi = 0;
@@ -1972,17 +1983,20 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 			// (the next tile's keys requested while this tile is written out: 1 % ahead at 2^27 keys, 2-5 % BEHIND from 2^28 on -- the
 			// level-1 pass of 2^28 keys 0.485 -> 0.457 ms without, three rounds alternating in one process, tools/blind_ab.py;
 			// 380 M keys 1.975 -> 1.929 ms, 2^30 5.157 -> 5.130: reads and writes in flight together cost more than the gap between tiles)
-			const bool prefetch = env().pass32_prefetch >= 0 ? env().pass32_prefetch != 0 : n < ((size_t)3 << 26);
+			// (8-byte keys: never ahead -- 2^27 keys 0.447 against 0.455 ms, 2^28 0.926 against 0.951)
+			const bool prefetch = sizeof(KT) == 4 && (env().pass32_prefetch >= 0 ? env().pass32_prefetch != 0 : n < ((size_t)3 << 26));
 #define RSX_LAUNCH_P32(DIGV, PF)                                                                                             \
-			hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIGV, PF>), dim3(256), dim3(Pass32aCfg::BLOCK), 0, c.stream, (const KT *)src, \
+			hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIGV, PF, P32>), dim3(256), dim3(P32::BLOCK), 0, c.stream, (const KT *)src,   \
 			                   (u64)n, kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka)
-			if (plain && prefetch)
-				RSX_LAUNCH_P32(DIG_PLAIN, true);
-			else if (plain)
+			if constexpr (sizeof(KT) == 4) {
+				if (plain && prefetch)
+					RSX_LAUNCH_P32(DIG_PLAIN, true);
+				else if (!plain && prefetch)
+					RSX_LAUNCH_P32(DIG_GENERIC, true);
+			}
+			if (plain && !prefetch)
 				RSX_LAUNCH_P32(DIG_PLAIN, false);
-			else if (prefetch)
-				RSX_LAUNCH_P32(DIG_GENERIC, true);
-			else
+			else if (!prefetch)
 				RSX_LAUNCH_P32(DIG_GENERIC, false);
 #undef RSX_LAUNCH_P32
 			HIP_TRY(hipGetLastError());

@@ -27,7 +27,7 @@ template <int KPT_ = 28> struct Pass32aCfgT {
 	static constexpr int BLOCK = 1024, KPT = KPT_, TILE = BLOCK * KPT;
 	static constexpr int WPE = KPT_ <= 12 ? 8 : 4;   // (12 keys per lane: 81 KB of LDS, two workgroups per CU, 64 registers)
 	static constexpr int SB = KPT_ % 7 == 0 ? 7 : 6;  // staging atomics in flight
-	static constexpr u32 ATOM = 16;     // keys per 64-byte atom
+	static constexpr u32 ATOM = 16;     // 4-byte keys per 64-byte atom (8-byte keys: 8 -- the kernel's own ATOM)
 	static constexpr u32 BACK = 8192;   // keys at the end of every slot for what is carried when a range ends (up to 512 workgroups x 15)
 	static constexpr int STAGE = TILE + 256 * 6;   // + what the 16-byte alignment of 256 runs can cost
 };
@@ -36,12 +36,12 @@ constexpr u32 PASS32_BACK = Pass32aCfg::BACK;
 
 template <typename KT, typename C, bool SPLITTERS = false> struct Pass32aSmem {
 	__attribute__((aligned(16))) KT stage[C::STAGE];
-	__attribute__((aligned(16))) KT carry[256][16];
+	__attribute__((aligned(16))) KT carry[256][64 / sizeof(KT)];
 	u32 cell[2][256];   // per digit: count, then the run's cursor (tile-local); tiles alternate between the two
 	u32 delta[256];     // slot position of a body key minus its tile-local position
 	u32 info[256];      // carried before (5 bits) | head (5) | tail (5) | atom completed | enough for an atom | offset in the region
 	unsigned short rbeg[256], bbeg[256], bend[256];
-	unsigned char group_digit[C::STAGE / 4];
+	unsigned char group_digit[C::STAGE / (16 / sizeof(KT))];   // per 16-byte group of staged keys
 	u32 wsum[4];
 	KT spl[SPLITTERS ? 256 : 1];   // DIG == 2 (probe): 255 ascending splitters; a key's bucket is the number of splitters <= it
 	unsigned char tbl[SPLITTERS ? 4104 : 4];   // DIG == 2: the bucket of the first key of every 2^-12 of the key range (and 255 behind the last)
@@ -56,8 +56,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
                                                                           u32 *__restrict__ cursors, u32 *__restrict__ overflow,
                                                                           KdfArgs<KT> ka, const KT *__restrict__ splitters = nullptr)
 {
-	static_assert(sizeof(KT) == 4, "4-byte keys");
+	static_assert(sizeof(KT) == 4 || sizeof(KT) == 8, "4- or 8-byte keys");
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
+	constexpr u32 VEC = 16 / sizeof(KT);    // keys per 16-byte vector (what a copying thread moves: a quarter of an atom)
+	constexpr u32 ATOM = 64 / sizeof(KT);   // keys per 64-byte atom
+	static_assert(KPT % (int)VEC == 0, "whole vectors per lane");
+	static_assert(sizeof(KT) == 4 || C::STAGE * sizeof(KT) + 256 * 64 <= 150 * 1024, "8-byte keys: 14 Ki-key tiles (Pass32aCfgT<14>)");
 	if (ctl->blind != BLIND_GO)
 		return;   // (the sample has called the attempt off: rsx_hybrid.hpp)
 	const u32 ntiles = (u32)((n + TILE - 1) / TILE);
@@ -66,10 +70,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 	if (t0 >= t1)
 		return;
 	const u32 shift = ctl->shift1;
-	const KT cmask = (KT)ctl->cmask_lo, key0 = (KT)ctl->key0_lo;   // the bits the sample took for constant, and the first key's (derived)
+	// the bits the sample took for constant, and the first key's (derived)
+	const KT cmask = sizeof(KT) == 8 ? (KT)(((u64)ctl->cmask_hi << 32) | ctl->cmask_lo) : (KT)ctl->cmask_lo;
+	const KT key0 = sizeof(KT) == 8 ? (KT)(((u64)ctl->key0_hi << 32) | ctl->key0_lo) : (KT)ctl->key0_lo;
 	__shared__ Pass32aSmem<KT, C, DIG == 2> sm;
 	const u32 tid0 = threadIdx.x;
-	auto sidx = [](u32 pos) { return stage_swz<true>(pos * 4u); };
+	auto sidx = [](u32 pos) { return stage_swz<true>(pos * (u32)sizeof(KT)); };
 	auto staged = [&](u32 pos) -> KT & { return *(KT *)((char *)sm.stage + sidx(pos)); };
 	auto slot_base = [&](u32 d) { return (d < lo_slots ? off_lo : off_hi) + d * cap; };
 	u32 cc = 0;   // digit thread: keys of its digit carried from the tiles before
@@ -118,14 +124,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 		const u32 cnt = n - beg < (u64)TILE ? (u32)(n - beg) : (u32)TILE;
 		const KT *p = kin + beg;
 		if (cnt == (u32)TILE && (((uintptr_t)p) & 15) == 0) {
-			typedef KT vec_t __attribute__((ext_vector_type(4)));
+			typedef KT vec_t __attribute__((ext_vector_type(VEC)));
 			const vec_t *vp = (const vec_t *)p + tid;
 #pragma unroll
-			for (int i = 0; i < KPT / 4; ++i) {
+			for (int i = 0; i < KPT / (int)VEC; ++i) {
 				const vec_t v = vp[i * BLOCK];
 #pragma unroll
-				for (int e = 0; e < 4; ++e)
-					keep[4 * i + e] = v[e];
+				for (int e = 0; e < (int)VEC; ++e)
+					keep[(int)VEC * i + e] = v[e];
 			}
 		} else {
 #pragma unroll
@@ -181,20 +187,20 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 			if (tid < 256) {
 				const u32 c = cell[tid];
 				u32 h, body = 0, tail = 0, atom = 0;
-				const bool enough = cc + c >= C::ATOM;
+				const bool enough = cc + c >= ATOM;
 				if (enough) {
-					h = cc ? C::ATOM - cc : 0u;   // the head completes the carried atom
+					h = cc ? ATOM - cc : 0u;   // the head completes the carried atom
 					atom = cc ? 1u : 0u;
-					body = (c - h) & ~(C::ATOM - 1u);
-					tail = (c - h) & (C::ATOM - 1u);
+					body = (c - h) & ~(ATOM - 1u);
+					tail = (c - h) & (ATOM - 1u);
 				} else {
 					h = c;                        // too few for an atom: all of it joins the carried keys
 				}
-				const u32 m = atom * C::ATOM + body;
+				const u32 m = atom * ATOM + body;
 				if (m)   // (issued first: it crosses the fabric while the layout is made)
 					base = __hip_atomic_fetch_add(cursors + tid, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const u32 o = (4u - (h & 3u)) & 3u;   // the run starts `o` keys into its region: the body then starts on a 16-byte boundary
-				rlen = (o + c + 3u) & ~3u;
+				const u32 o = (VEC - (h & (VEC - 1u))) & (VEC - 1u);   // the run starts `o` keys into its region: the body then starts on a 16-byte boundary
+				rlen = (o + c + VEC - 1u) & ~(VEC - 1u);
 				sm.info[tid] = cc | (h << 5) | (tail << 10) | (atom << 15) | ((enough ? 1u : 0u) << 16) | (o << 17);
 				sm.bend[tid] = (unsigned short)body;   // (for now: the body's length)
 				cc = enough ? tail : cc + c;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 				sm.rbeg[tid] = (unsigned short)rb;
 				sm.bbeg[tid] = (unsigned short)bb;
 				sm.bend[tid] = (unsigned short)be;
-				for (u32 g = bb >> 2; g < (be + 3u) >> 2; ++g)
+				for (u32 g = bb / VEC; g < (be + VEC - 1u) / VEC; ++g)
 					sm.group_digit[g] = (unsigned char)tid;
 			}
 		}
@@ -228,13 +234,13 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 
 		// ---- stage; the digit threads first put down where their bodies go
 		if (tid < 256) {
-			const u32 atom = (sm.info[tid] >> 15) & 1u, bb = sm.bbeg[tid], m = atom * C::ATOM + (sm.bend[tid] - bb);
-			u32 dest = slot_base(tid) + base + atom * C::ATOM;   // of the body's first key
+			const u32 atom = (sm.info[tid] >> 15) & 1u, bb = sm.bbeg[tid], m = atom * ATOM + (sm.bend[tid] - bb);
+			u32 dest = slot_base(tid) + base + atom * ATOM;   // of the body's first key
 			if (m && base + m > cap - C::BACK) {
 				// the slot is too small: the attempt will be discarded (rsx_seg_tiles_kernel sees the flag).  Its keys go over the
 				// slot's own beginning -- a slot holds more than a tile (blind_enqueue) and nothing of a lost attempt is read
 				atomicOr(overflow, 1u);
-				dest = slot_base(tid) + C::ATOM;
+				dest = slot_base(tid) + ATOM;
 			}
 			sm.delta[tid] = dest - bb;
 		}
@@ -283,25 +289,25 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 			const u32 ccd = inf & 31u, atomd = (inf >> 15) & 1u;
 			if (atomd) {
 				const u32 rb = sm.rbeg[cd];
-				KT w[4];
+				typedef KT kvec_t __attribute__((ext_vector_type(VEC)));
+				typedef kvec_t avec_t __attribute__((aligned(16)));
+				kvec_t w;
 #pragma unroll
-				for (u32 e = 0; e < 4; ++e) {
-					const u32 k = part * 4u + e;
+				for (u32 e = 0; e < VEC; ++e) {
+					const u32 k = part * VEC + e;
 					w[e] = k < ccd ? sm.carry[cd][k] : staged(rb + (k - ccd));
 				}
-				typedef KT kvec_t __attribute__((ext_vector_type(4)));
-				typedef kvec_t avec_t __attribute__((aligned(16)));
-				*(avec_t *)(kout + (u32)(sm.delta[cd] + sm.bbeg[cd] - C::ATOM + part * 4u)) = kvec_t{w[0], w[1], w[2], w[3]};
+				*(avec_t *)(kout + (u32)(sm.delta[cd] + sm.bbeg[cd] - ATOM + part * VEC)) = w;
 			}
 		}
 		// ... and the bodies: every group of four staged keys that lies in one is a quarter of an aligned atom
 		{
 			const u32 total = (u32)__builtin_amdgcn_readfirstlane((int)sm.wsum[0]) + sm.wsum[1] + sm.wsum[2] + sm.wsum[3];
 #pragma unroll 1
-			for (u32 i0 = 4u * tid; i0 < total; i0 += 4u * BLOCK) {
-				const u32 d = sm.group_digit[i0 >> 2];
+			for (u32 i0 = VEC * tid; i0 < total; i0 += VEC * BLOCK) {
+				const u32 d = sm.group_digit[i0 / VEC];
 				if (i0 >= sm.bbeg[d] && i0 < sm.bend[d]) {
-					typedef KT kvec_t __attribute__((ext_vector_type(4)));
+					typedef KT kvec_t __attribute__((ext_vector_type(VEC)));
 					typedef kvec_t avec_t __attribute__((aligned(16)));
 					*(avec_t *)(kout + (u32)(sm.delta[d] + i0)) = *(const kvec_t *)((const char *)sm.stage + sidx(i0));
 				}
@@ -315,8 +321,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 			const u32 ccd = inf & 31u, hd = (inf >> 5) & 31u, taild = (inf >> 10) & 31u, enoughd = (inf >> 16) & 1u;
 			const u32 from = enoughd ? sm.bend[cd] : sm.rbeg[cd], to = enoughd ? 0u : ccd, nk = enoughd ? taild : hd;
 #pragma unroll
-			for (u32 e = 0; e < 4; ++e) {
-				const u32 k = part * 4u + e;
+			for (u32 e = 0; e < VEC; ++e) {
+				const u32 k = part * VEC + e;
 				if (k < nk)
 					sm.carry[cd][to + k] = staged(from + k);
 			}
@@ -343,8 +349,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 		__syncthreads();
 		const u32 nk = sm.info[cd], dest = sm.delta[cd];
 #pragma unroll
-		for (u32 e = 0; e < 4; ++e) {
-			const u32 k = part * 4u + e;
+		for (u32 e = 0; e < VEC; ++e) {
+			const u32 k = part * VEC + e;
 			if (k < nk)
 				kout[dest + k] = sm.carry[cd][k];
 		}

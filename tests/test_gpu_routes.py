@@ -239,6 +239,21 @@ def test_u64_without_histogram(n_mi, mask):
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64", n_mi, hex(mask)))
 
 
+@pytest.mark.parametrize("switch", [None, "RSX_NO_PASS32A"], ids=["atoms of eight keys", "the chained level-1 pass"])
+def test_u64_level1_pass_in_whole_atoms(switch, monkeypatch):
+    """8-byte keys from 48 Mi keys on: the level-1 pass writes whole 64-byte atoms (rsx_pass32a_kernel<u64>: a bucket lies at both
+    ends of its slot, the chained level-2 pass reads a tile more per bucket); RSX_NO_PASS32A=1: round 4's chained pass.  Signed
+    keys descending (the generic digit) and masked keys whose result ends in the second buffer (five kept columns)."""
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    n = 56 * MI + 4099
+    a = ol.splitmix_fill(n, ol.I64, 5200, 0xFFFFFFFFFFFFFFFF)
+    _sort_and_compare(a, ol.I64, ol.DESC, 5, ("i64 desc", switch))
+    b = ol.splitmix_fill(n, ol.U64, 5201, 0xFFFFFFFFFF)
+    info = _sort_and_compare(b, ol.U64, ol.ASC, 5, ("u64 & 0xFFFFFFFFFF", switch))
+    assert info.result_in_aux == 1
+
+
 @pytest.mark.parametrize("n_mi,maxbin", [(7, "0"), (20, "0"), (80, "0"), (7, None), (20, None)])
 def test_u64_small_leaves_lists_and_fat_bins(n_mi, maxbin, monkeypatch):
     """The smaller shapes of rsx_leafk_kernel (1280 keys / 1024 bins, 2560 / 2048): every leaf through the list launch

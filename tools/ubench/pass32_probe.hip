@@ -4,7 +4,7 @@
 // partition, so one check serves both: every key of slot d has top byte d, the slots hold n keys, their key sum and key mix are
 // the input's.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc tools/ubench/pass32_probe.hip -o tools/ubench/pass32_probe.bin
-// Run:   pass32_probe.bin [log2 n = 28] [mode: 0 uniform keys | 1 Zipf-like 32-bit keys with quantile splitters]
+// Run:   pass32_probe.bin [log2 n = 28] [mode: 0 uniform keys | 1 Zipf-like 32-bit keys with quantile splitters] [key bytes: 4 | 8]
 #include "rsx_scatter2.hpp"
 #include "rsx_pass32.hpp"
 
@@ -24,33 +24,33 @@ using namespace rsx;
 		}                                                                                 \
 	} while (0)
 
-__global__ void gen_kernel(u32 *k, u64 n, u32 mode)
+template <typename KT> __global__ void gen_kernel(KT *k, u64 n, u32 mode)
 {
 	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
 		u64 z = (i + 1) * 0x9E3779B97F4A7C15ull;
 		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
 		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
 		z ^= z >> 31;
-		u32 v = (u32)z;
-		if (mode == 1) {   // log-uniform over [2^8, 2^32): b = 9 .. 32 uniformly, then b - 1 random bits (SURVEY.md 8d cfg 3 (iv), in 32 bits)
+		KT v = (KT)z;
+		if (mode == 1 && sizeof(KT) == 4) {   // log-uniform over [2^8, 2^32): b = 9 .. 32 uniformly, then b - 1 random bits (SURVEY.md 8d cfg 3 (iv), in 32 bits)
 			const u32 b = 9 + (u32)((z >> 58) % 24);
-			v = (1u << (b - 1)) | ((u32)z & ((1u << (b - 1)) - 1u));
+			v = (KT)((1u << (b - 1)) | ((u32)z & ((1u << (b - 1)) - 1u)));
 		}
 		k[i] = v;
 	}
 }
 
 // every key of [slot d's front and back] lies between the slot's splitters; sums over all slots
-__global__ void check_kernel(const u32 *slots, const u32 *cursors, u32 cap, u32 back_cap, const u32 *spl, u64 *out)
+template <typename KT> __global__ void check_kernel(const KT *slots, const u32 *cursors, u32 cap, u32 back_cap, const KT *spl, u64 *out)
 {
 	const u32 d = blockIdx.x;
 	const u32 front = cursors[d], back = cursors[256 + d];
-	const u32 lo = d ? spl[d - 1] : 0u, hi = d < 255 ? spl[d] : 0xFFFFFFFFu;
+	const KT lo = d ? spl[d - 1] : (KT)0, hi = d < 255 ? spl[d] : (KT)~(KT)0;
 	u64 bad = 0, sum = 0, mix = 0;
 	for (u32 i = threadIdx.x; i < front + back; i += blockDim.x) {
-		const u32 k = i < front ? slots[(u64)d * cap + i] : slots[(u64)d * cap + cap - back_cap + (i - front)];
+		const KT k = i < front ? slots[(u64)d * cap + i] : slots[(u64)d * cap + cap - back_cap + (i - front)];
 		bad += (k < lo || (d < 255 && k >= hi)) ? 1 : 0;
-		sum += k;
+		sum += (u64)k;
 		mix ^= (u64)k * 0x9E3779B97F4A7C15ull;
 	}
 	atomicAdd((unsigned long long *)&out[0], bad);
@@ -60,59 +60,58 @@ __global__ void check_kernel(const u32 *slots, const u32 *cursors, u32 cap, u32 
 		atomicAdd((unsigned long long *)&out[3], (u64)front + back);
 }
 
-__global__ void sum_kernel(const u32 *k, u64 n, u64 *out)
+template <typename KT> __global__ void sum_kernel(const KT *k, u64 n, u64 *out)
 {
 	u64 sum = 0, mix = 0;
 	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-		sum += k[i];
+		sum += (u64)k[i];
 		mix ^= (u64)k[i] * 0x9E3779B97F4A7C15ull;
 	}
 	atomicAdd((unsigned long long *)&out[1], sum);
 	atomicXor((unsigned long long *)&out[2], mix);
 }
 
-int main(int argc, char **argv)
+template <typename KT, typename CFG> int run_all(int log2n, u32 mode)
 {
-	const int log2n = argc > 1 ? atoi(argv[1]) : 28;
-	const u32 mode = argc > 2 ? (u32)atoi(argv[2]) : 0;
 	const size_t n = (size_t)1 << log2n;
-	u32 *d_in, *d_slots, *d_cur, *d_ovf, *d_spl;
+	KT *d_in, *d_slots, *d_spl;
+	u32 *d_cur, *d_ovf;
 	u64 *d_chk;
 	SegCtl *d_ctl;
-	CK(hipMalloc(&d_in, n * 4));
-	hipLaunchKernelGGL(gen_kernel, dim3(2048), dim3(256), 0, 0, d_in, (u64)n, mode);
+	CK(hipMalloc(&d_in, n * sizeof(KT)));
+	hipLaunchKernelGGL((gen_kernel<KT>), dim3(2048), dim3(256), 0, 0, d_in, (u64)n, mode);
 	// splitters: the byte boundaries (mode 0), or the 255 quantiles of a sorted sample of 64 Ki keys (mode 1)
-	std::vector<u32> spl(255);
+	std::vector<KT> spl(255);
 	if (mode == 0) {
 		for (u32 i = 0; i < 255; ++i)
-			spl[i] = (i + 1) << 24;
+			spl[i] = (KT)(i + 1) << (8 * sizeof(KT) - 8);
 	} else {
-		std::vector<u32> sample(65536);
+		std::vector<KT> sample(65536);
 		for (u32 i = 0; i < 65536; ++i)
-			CK(hipMemcpy(&sample[i], d_in + (size_t)i * (n / 65536), 4, hipMemcpyDeviceToHost));
+			CK(hipMemcpy(&sample[i], d_in + (size_t)i * (n / 65536), sizeof(KT), hipMemcpyDeviceToHost));
 		std::sort(sample.begin(), sample.end());
 		for (u32 i = 0; i < 255; ++i)
 			spl[i] = sample[(i + 1) * 256];
 	}
 	const u32 mean = (u32)(n >> 8);
 	const u32 cap = ((mode == 0 ? mean + mean / 4 : 2 * mean) + 255) / 256 * 256;   // (quantile splitters from a sample: wider slots)
-	CK(hipMalloc(&d_slots, ((size_t)256 * cap + 65536) * 4));
+	CK(hipMalloc(&d_slots, ((size_t)256 * cap + 65536) * sizeof(KT)));
 	CK(hipMalloc(&d_cur, 4096));
 	CK(hipMalloc(&d_ovf, 64));
-	CK(hipMalloc(&d_spl, 1024));
+	CK(hipMalloc(&d_spl, 2048));
 	CK(hipMalloc(&d_chk, 64));
 	CK(hipMalloc(&d_ctl, sizeof(SegCtl)));
-	CK(hipMemcpy(d_spl, spl.data(), 255 * 4, hipMemcpyHostToDevice));
+	CK(hipMemcpy(d_spl, spl.data(), 255 * sizeof(KT), hipMemcpyHostToDevice));
 	SegCtl c{};
 	c.blind = BLIND_GO;
-	c.shift1 = 24;
+	c.shift1 = 8 * sizeof(KT) - 8;
 	CK(hipMemcpy(d_ctl, &c, sizeof c, hipMemcpyHostToDevice));
-	KdfArgs<u32> ka{0, 0, 0};
+	KdfArgs<KT> ka{0, 0, 0};
 	u64 want[4] = {0, 0, 0, 0};
 	CK(hipMemset(d_chk, 0, 64));
-	hipLaunchKernelGGL(sum_kernel, dim3(2048), dim3(256), 0, 0, (const u32 *)d_in, (u64)n, d_chk);
+	hipLaunchKernelGGL((sum_kernel<KT>), dim3(2048), dim3(256), 0, 0, (const KT *)d_in, (u64)n, d_chk);
 	CK(hipMemcpy(want, d_chk, 32, hipMemcpyDeviceToHost));
-	printf("n = %zu u32 keys, mode %u, slots of %u keys\n", n, mode, cap);
+	printf("n = %zu %zu-byte keys, mode %u, slots of %u keys\n", n, sizeof(KT), mode, cap);
 	auto run = [&](const char *name, int which) {
 		float best = 1e9f;
 		for (int rep = 0; rep < 5; ++rep) {
@@ -123,14 +122,15 @@ int main(int argc, char **argv)
 			CK(hipEventCreate(&e1));
 			CK(hipEventRecord(e0, 0));
 			if (which == 0)
-				hipLaunchKernelGGL((rsx_pass32a_kernel<u32, 1, true>), dim3(256), dim3(1024), 0, 0, (const u32 *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
-				                   cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const u32 *)nullptr);
-			else if (which == 1)
-				hipLaunchKernelGGL((rsx_pass32a_kernel<u32, 2, true>), dim3(256), dim3(1024), 0, 0, (const u32 *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
-				                   cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const u32 *)d_spl);
-			else
-				hipLaunchKernelGGL((rsx_pass32a_kernel<u32, 1, false>), dim3(256), dim3(1024), 0, 0, (const u32 *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
-				                   cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const u32 *)nullptr);
+				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, 1, true, CFG>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
+				                   cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const KT *)nullptr);
+			else if (which == 1) {
+				if constexpr (sizeof(KT) == 4)
+					hipLaunchKernelGGL((rsx_pass32a_kernel<KT, 2, true, CFG>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u,
+					                   0u, cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const KT *)d_spl);
+			} else
+				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, 1, false, CFG>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
+				                   cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const KT *)nullptr);
 			CK(hipEventRecord(e1, 0));
 			CK(hipEventSynchronize(e1));
 			float ms;
@@ -144,7 +144,7 @@ int main(int argc, char **argv)
 		CK(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
 		u64 got[4];
 		CK(hipMemset(d_chk, 0, 64));
-		hipLaunchKernelGGL(check_kernel, dim3(256), dim3(1024), 0, 0, (const u32 *)d_slots, (const u32 *)d_cur, cap, PASS32_BACK, (const u32 *)d_spl,
+		hipLaunchKernelGGL((check_kernel<KT>), dim3(256), dim3(1024), 0, 0, (const KT *)d_slots, (const u32 *)d_cur, cap, PASS32_BACK, (const KT *)d_spl,
 		                   d_chk);
 		CK(hipMemcpy(got, d_chk, 32, hipMemcpyDeviceToHost));
 		std::vector<u32> cur(512);
@@ -153,7 +153,7 @@ int main(int argc, char **argv)
 		for (u32 d = 0; d < 256; ++d)
 			mx = std::max(mx, cur[d] + cur[256 + d]);
 		printf("%-46s %.3f ms = %.0f GB/s   overflow %u, misplaced %llu, keys %llu (%s), sum %s, mix %s; largest bucket %.2f x the mean\n", name, best,
-		       n * 8.0 / best / 1e6, ovf, (unsigned long long)got[0], (unsigned long long)got[3], got[3] == n ? "all" : "NOT ALL",
+		       n * 2.0 * sizeof(KT) / best / 1e6, ovf, (unsigned long long)got[0], (unsigned long long)got[3], got[3] == n ? "all" : "NOT ALL",
 		       got[1] == want[1] ? "ok" : "DIFFERENT", got[2] == want[2] ? "ok" : "DIFFERENT", (double)mx / mean);
 		fflush(stdout);
 	};
@@ -161,8 +161,19 @@ int main(int argc, char **argv)
 		run("by the top byte (rsx_pass32a_kernel)", 0);
 		run("by the top byte, no prefetch", 2);
 	}
-	run("by 255 splitters searched in the LDS", 1);
+	if (sizeof(KT) == 4)
+		run("by 255 splitters searched in the LDS", 1);
 	if (mode == 0)
 		run("by the top byte (again)", 0);
 	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	const int log2n = argc > 1 ? atoi(argv[1]) : 28;
+	const u32 mode = argc > 2 ? (u32)atoi(argv[2]) : 0;
+	const int key_bytes = argc > 3 ? atoi(argv[3]) : 4;
+	if (key_bytes == 8)
+		return run_all<u64, Pass32aCfgT<14>>(log2n, 0);
+	return run_all<u32, Pass32aCfg>(log2n, mode);
 }
