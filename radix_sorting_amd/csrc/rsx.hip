@@ -331,6 +331,7 @@ struct Ctx {
 	const SegCtl *pass_gate = nullptr;
 	bool async_tried_blind = false;   // ... whether the last rsx_sort_inplace_async of this context enqueued such an attempt
 	bool ws_blind = false;            // a context in a caller's workspace that has room for the slots of a sort without a histogram (borrow_ctx)
+	bool boff_forget = false;   // rsx_reload_env since the last attempt: SegCtl::boff_* are zeroed before the next one
 	bool async_small = false;         // ... or was the one-launch sort of a small array (rsx_async_route: 0, whatever the device's words say)
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
 	DevBuf vsum;        // RSX_VERIFY=2: [descents, sum, mix] of the input and of the result
@@ -1622,7 +1623,11 @@ template <typename KT> int seg_layout(Ctx &c, size_t n)
 	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 514 : rows;   // (rsx_pass16a_kernel's tiles are smaller; a bucket may end in a tile of its own for what lies at its slot's end)
 	c.seg_btile_off = c.seg_tiles_off + tile_rows * sizeof(SegTile);
 	c.seg_redo_off = c.seg_btile_off + 260 * sizeof(u32);   // the leaves rsx_leaf16_kernel leaves to rsx_leaf_sort_kernel
-	return c.seg.ensure(c.seg_redo_off + 65536 * sizeof(u32));
+	const void *before = c.seg.p;
+	RSX_TRY(c.seg.ensure(c.seg_redo_off + 65536 * sizeof(u32)));
+	if (c.seg.p != before || c.seg.external)   // (a new control block -- or a caller's workspace, whose contents are scratch: SegCtl::boff_*)
+		HIP_TRY(hipMemsetAsync(c.seg.p, 0, 256, c.stream));
+	return RSX_OK;
 }
 
 // What a sort of n keys WITHOUT a histogram needs on top of that (blind_enqueue): the level-1 slots that do not fit the
@@ -1777,7 +1782,17 @@ inline void blind_refresh(Ctx &c)
 		c.blind_no_room = false;
 		for (int k = 0; k < 4; ++k)
 			c.blind_skip[k] = c.blind_backoff[k] = 0;
+		c.boff_forget = true;   // (... and the device-side one of the device-scheduled sorts, SegCtl::boff_*: zeroed by the next attempt)
 	}
+}
+// rsx_reload_env: the context forgets the attempts it lost -- the host's counters above, the device's here (in front of the sample kernel)
+inline int blind_forget_device_backoff(Ctx &c)
+{
+	if (c.boff_forget && c.seg.p) {
+		HIP_TRY(hipMemsetAsync(&((SegCtl *)c.seg.p)->boff_skip, 0, 2 * sizeof(u32), c.stream));
+		c.boff_forget = false;
+	}
+	return RSX_OK;
 }
 // Where the keys-only sorts without a histogram end: 2^30 keys (32-bit offsets in the leaf and tile tables; level-2 slots of more
 // than 32 Ki whole keys have no leaf) -- or, 4-byte keys in two-byte slots (rsx_leafc.hpp: slots of up to 40960 values), where the
@@ -1940,13 +1955,16 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	c.slack_cap = cap2;
 	// the sample (workgroup 0: control block, plan) and the zeroing of both passes' status words, one launch
 	static_assert(sizeof(SegCtl) <= 256, "the control block is not part of what is zeroed");
+	RSX_TRY(blind_forget_device_backoff(c));
 	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl,
 	                   c.plan(), c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
 	                   4u,   // (two levels want four kept columns: two for the passes, two or more for the leaves)
 	                   // 4-byte keys whose leaves read two-byte slots (rsx_leaf16.hpp): the MSB digits may lie below constant top bits
 	                   (u32)(sizeof(KT) == 4 && dense_slots<KT>(c) && !env().no_leaf16 && !env().no_shift ? 1 : 0),
 	                   // 8-byte keys in slots rsx_leafk_kernel takes: four-byte slots where the leaves' columns lie in the low word
-	                   (u32)(narrow_slots_ok<KT>(cap2) ? 1 : 0));
+	                   (u32)(narrow_slots_ok<KT>(cap2) ? 1 : 0), 0u,
+	                   // a device-scheduled sort keeps its back-off on the device (SegCtl::boff_skip); the blocking sorts keep theirs on the host
+	                   (u32)(g_in_async ? 1 : 0));
 	// 4-byte keys from 64 Mi keys on: the level-1 pass in whole 64-byte atoms (rsx_pass32a_kernel: a workgroup per CU takes a range
 	// of tiles and carries what does not fill an atom; a bucket then lies at both ends of its slot)
 	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
@@ -2447,7 +2465,12 @@ int pairs_two_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
 	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
 	c.seg_btile_off = c.seg_tiles_off + rows * sizeof(SegTile);
-	RSX_TRY(c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32)));
+	{
+		const void *before = c.seg.p;
+		RSX_TRY(c.seg.ensure(c.seg_btile_off + 257 * sizeof(u32)));
+		if (c.seg.p != before)
+			HIP_TRY(hipMemsetAsync(c.seg.p, 0, 256, c.stream));
+	}
 	const u32 mean = (u32)(n >> 16);
 	const u32 cap = slot_cap_for(mean);
 	if (cap > (u32)L::CAP)
@@ -2554,13 +2577,14 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	if (!c.seg_ev)
 		HIP_TRY(hipEventCreateWithFlags(&c.seg_ev, hipEventDisableTiming));
 	c.host_segctl->mode = SEG_MODE_NONE;
+	RSX_TRY(blind_forget_device_backoff(c));
 	hipLaunchKernelGGL((rsx_blind_precheck_kernel<KT>), dim3(1 + 512), dim3(1024), 0, c.stream, kin, (u64)n, ka, ctl, c.plan(),
 	                   c.dev_host_plan, (u32x4 *)((char *)c.seg.p + c.seg_status_off), (u64)(2 * st_bytes / 16),
 	                   (u32)sizeof(KT),   // (every column kept: the callers' parity rule below counts on it)
 	                   0u, 0u,
 	                   // rank sorts (no keys wanted back): keys whose byte columns do not spread but whose VARYING bits would, packed
 	                   // together, go by those (SegCtl::compact, README.md:716-758)
-	                   (u32)((vin == nullptr && kfinal == nullptr && !env().no_packed_keys) ? 1 : 0));
+	                   (u32)((vin == nullptr && kfinal == nullptr && !env().no_packed_keys) ? 1 : 0), (u32)(g_in_async ? 1 : 0));
 	SegArgs sa{};
 	sa.ctl = ctl;
 	sa.hist = (const u32 *)((char *)c.seg.p + c.seg_hist_off);

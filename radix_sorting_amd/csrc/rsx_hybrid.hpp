@@ -76,7 +76,19 @@ struct SegCtl {
 	// of `compact` bits, in the keys' order, and spreads as evenly as the values do.  The level-1 pass converts (and checks every
 	// key: finite, on the grid, in range, not -0.0, which the reference orders before +0.0 and an integer cannot).
 	u32 ckind;
+	// Device-scheduled sorts (rsx_sort_inplace_async): nobody reads a verdict back, so the back-off the host keeps for the blocking
+	// sorts lives here.  An attempt that is LOST after its sample let it through -- a slot overflowed, a key differed in a column
+	// taken for constant: one or two full passes wasted -- sets boff_skip = boff_next = 1, 2, 4 .. 64: the next boff_skip sorts in
+	// this context do not try (the sample kernel says no at once); an attempt that goes through resets boff_next.  Never zeroed
+	// by the sample kernel; zeroed where the control block is allocated.
+	u32 boff_skip, boff_next;
 };
+__device__ __forceinline__ void segctl_attempt_lost(SegCtl *ctl)
+{
+	const u32 nx = ctl->boff_next ? (ctl->boff_next < 32u ? 2u * ctl->boff_next : 64u) : 1u;
+	ctl->boff_next = nx;
+	ctl->boff_skip = nx;
+}
 enum : u32 { BLIND_NONE = 0, BLIND_GO = 1, BLIND_FAILED = 2 };
 
 // the packed key of `raw` (SegCtl::compact): the varying bits' runs moved together, then the KDF's flips in the packed space
@@ -187,8 +199,10 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
 		if (blockIdx.x == 0)
 			off1_out[d] = o;
 		if (__syncthreads_or(over ? 1 : 0)) {
-			if (blockIdx.x == 0 && d == 0)
+			if (blockIdx.x == 0 && d == 0) {
 				ctl->blind = BLIND_FAILED;
+				segctl_attempt_lost(ctl);
+			}
 			return;
 		}
 		s_beg[d] = d * blind_cap;
@@ -522,6 +536,12 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 		ctl->mode = mode;
 		ctl->nleaf = 65536;
 		ctl->maxleaf = slack_cap;   // (no leaf is larger: a run that leaves its slot sets the flag)
+		if (blind) {
+			if (mode == SEG_MODE_LEAVES)
+				ctl->boff_next = 0;
+			else
+				segctl_attempt_lost(ctl);
+		}
 		if (host_ctl) {
 			host_ctl->ntiles = ctl->ntiles;
 			host_ctl->maxleaf = slack_cap;
@@ -562,7 +582,8 @@ template <typename KT>
 __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka,
                                                                   SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
                                                                   Plan *host_plan, u32x4 *__restrict__ z, u64 nz, u32 min_cols,
-                                                                  u32 allow_shift = 0, u32 allow_narrow = 0, u32 allow_compact = 0)
+                                                                  u32 allow_shift = 0, u32 allow_narrow = 0, u32 allow_compact = 0,
+                                                                  u32 backoff = 0)   // (1: a device-scheduled sort, SegCtl::boff_skip)
 {
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
@@ -890,6 +911,11 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 				shift2 = compact - 16u;
 				cmask = 0;   // (what must not vary is checked on the keys as the caller wrote them: cvnot)
 			}
+		}
+		if (backoff && ctl->boff_skip) {   // (an attempt of this context was lost lately: SegCtl::boff_skip)
+			ctl->boff_skip -= 1u;
+			go = false;
+			compact = 0;
 		}
 		ctl->compact = compact;
 		ctl->ckind = compact ? s_ckind : 0u;

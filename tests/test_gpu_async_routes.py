@@ -300,3 +300,41 @@ def test_the_profile_books_what_the_device_chose():
     assert p.called_off_launches >= 1
     got = buf.cpu().numpy().view(np.uint32)
     assert np.array_equal(got, np.sort(a))
+
+
+def test_device_scheduled_sorts_back_off_on_the_device():
+    """An input that passes the sample and then overflows a level-1 slot (a top digit with 1.6 times its share) costs a
+    device-scheduled sort its attempt -- a full pass -- on every call, and nobody reads a verdict back: the back-off lives in the
+    control block (SegCtl::boff_skip).  After a lost attempt the next sort of the context does not try, the one after does, then
+    two do not: seen through rsx_profile, which books an attempt's pass under called_off_ms.  An attempt that goes through
+    resets it.  Every sort is checked against the oracle's order."""
+    n = (48 << 20) + 99
+    base = ol.splitmix_fill(n, ol.U32, 9200, 0xFFFFFFFF).view(np.uint32).copy()
+    a = base.copy()
+    extra = np.flatnonzero((a >> 24) == 0x11)[: int(0.6 * n / 256)]
+    a[extra] = (a[extra] & np.uint32(0x00FFFFFF)) | np.uint32(0x77000000)
+    want = np.sort(a)
+    src = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    buf = torch.empty_like(src)
+    scratch = torch.empty_like(src)
+    tried = []
+    for i in range(6):
+        buf.copy_(src)
+        torch.cuda.synchronize()
+        rsa.profile_begin()
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32)
+        route = rsa.async_route()
+        p = rsa.profile_end()
+        assert route == 0, (i, route)
+        assert np.array_equal(buf.cpu().numpy().view(np.uint32), want), i
+        tried.append(p.called_off_ms)     # (a lost attempt at 48 Mi keys: ~0.10 ms; the launches that return at once: ~0.02)
+    assert [t > 0.05 for t in tried] == [True, False, True, False, False, True], tried
+    # uniform keys: the attempt is made at once only when no skip is pending -- and going through clears the doubling
+    rsa.fill_splitmix(buf, 9201)
+    rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32)     # (skip 1 of 4 pending after the sixth sort above)
+    for _ in range(4):
+        rsa.fill_splitmix(buf, 9202)
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32)
+    assert rsa.async_route() == 5
+    got = buf.cpu().numpy().view(np.uint32)
+    assert np.all(got[1:] >= got[:-1])
