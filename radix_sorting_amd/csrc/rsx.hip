@@ -1853,7 +1853,7 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 // The device's part: the sample, both passes, the tables and the leaves, enqueued; *enqueued = 0: no room for the slots (or no
 // leaf shape for them): nothing was enqueued.  Nothing waits for the host; SegCtl::mode == SEG_MODE_LEAVES (and the pinned
 // copy the slack plan writes) says afterwards whether the sort went through.
-// ... for a device-scheduled sort (rsx_sort_inplace_async): the same sizes, no back-off (nothing is ever read back)
+// ... for a device-scheduled sort (rsx_sort_inplace_async): the same sizes; its back-off lives on the device (SegCtl::boff_skip: nothing is ever read back)
 template <typename KT> bool async_blind_ok(Ctx &c, size_t n)
 {
 	if constexpr (sizeof(KT) < 4)
@@ -2343,11 +2343,12 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 	//  * arrays the sort without a histogram is for: the whole attempt is enqueued first -- sample, two MSB passes
 	//    into slots, leaves -- and what follows (histogram, plan, one pass per kept column) looks at the attempt's verdict,
 	//    SegCtl::mode, and does nothing if the keys are sorted by then; an attempt that is called off has only read `buf`.
-	//    (There is no back-off here: the host never learns how an attempt went.  It costs a sample kernel and a few empty
-	//    launches when it is called off, and the empty launches of the histogram-first kernels when it goes through.)
+	//    (The host never learns how an attempt went: a context's back-off after a LOST attempt -- one that passed the sample and
+	//    then overflowed a slot -- is kept on the device, SegCtl::boff_skip.  An attempt the sample turns away costs a sample kernel
+	//    and a few empty launches, one that goes through the empty launches of the histogram-first kernels.)
 	//  * mid-size arrays: one MSB pass and leaves where the device-side plan says so (Plan::hyb) -- pass 0 then goes by the
 	//    highest kept column, the leaf launches behind it do nothing otherwise, and the passes 1 .. do nothing if they do.
-	// A caller-owned workspace (rsx_sort_inplace_async_ws) has no room for slots: one level only.
+	// A caller-owned workspace (rsx_sort_inplace_async_ws) makes the attempt if it was sized for the slots (rsx_workspace_bytes_fast).
 	HybCaps caps{0, 0, 0, 0};
 	int blind = 0;
 	ProfAsyncVerdict pverdict(c.stream);   // (rsx_profile books what the device chose: the attempt's launches or the ones behind it)
