@@ -252,6 +252,30 @@ def test_u64_level1_pass_in_whole_atoms(switch, monkeypatch):
     b = ol.splitmix_fill(n, ol.U64, 5201, 0xFFFFFFFFFF)
     info = _sort_and_compare(b, ol.U64, ol.ASC, 5, ("u64 & 0xFFFFFFFFFF", switch))
     assert info.result_in_aux == 1
+    if switch is None:
+        # every level-1 slot in scratch memory (none in the caller's second buffer); doubles of both signs, ascending
+        monkeypatch.setenv("RSX_NO_AUX_SLOTS", "1")
+        rsa.reload_env()
+        c = ol.splitmix_fill(48 * MI + 1, ol.F64, 5202, 0xFFFFFFFFFFFFFFFF)     # (random bit patterns: NaNs and both zeros among them)
+        _sort_and_compare(c, ol.F64, ol.ASC, 5, "f64, slots in scratch")
+
+
+def test_u64_device_scheduled_with_the_level1_pass_in_atoms():
+    """rsx_sort_inplace_async on 8-byte keys at a size whose level-1 pass writes atoms: the tile table and the chained level-2
+    pass's status words have a row more per bucket (two-ended slots), also inside a workspace sized by rsx_workspace_bytes_fast."""
+    n = 64 * MI + 17
+    a = ol.splitmix_fill(n, ol.U64, 5203, 0xFFFFFFFFFFFFFFFF)
+    want, _, _ = ol.oracle_sort(a, ol.U64, ol.ASC)
+    buf = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    scratch = torch.empty_like(buf)
+    rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U64)
+    assert rsa.async_route() == 5
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), want)
+    ws = torch.empty(rsa.workspace_bytes_fast(n, rsa.U64), dtype=torch.uint8, device="cuda")
+    buf.copy_(torch.from_numpy(a.view(np.int64)))
+    rsa.radix_sort_inplace_async_ws(buf, scratch, ws, dtype=rsa.U64)
+    assert rsa.async_route_ws(ws, n, rsa.U64) == 5
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), want)
 
 
 @pytest.mark.parametrize("n_mi,maxbin", [(7, "0"), (20, "0"), (80, "0"), (7, None), (20, None)])
