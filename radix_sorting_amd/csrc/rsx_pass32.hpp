@@ -23,8 +23,12 @@
 
 namespace rsx {
 
-template <int KPT_ = 28> struct Pass32aCfgT {
+template <int KPT_ = 28, bool RANK1_ = true> struct Pass32aCfgT {
 	static constexpr int BLOCK = 1024, KPT = KPT_, TILE = BLOCK * KPT;
+	// a key's place inside its digit's run is the value the COUNTING atomic returned (kept, sixteen bits per key): the staging phase
+	// reads the run's start and adds it -- one LDS atomic per key and tile instead of two (false: count, then a second returning atomic
+	// on the run's cursor, as rsx_pass16a_kernel does)
+	static constexpr bool RANK1 = RANK1_;
 	static constexpr int WPE = KPT_ <= 12 ? 8 : 4;   // (12 keys per lane: 81 KB of LDS, two workgroups per CU, 64 registers)
 	static constexpr int SB = KPT_ % 7 == 0 ? 7 : 6;  // staging atomics in flight
 	static constexpr u32 ATOM = 16;     // 4-byte keys per 64-byte atom (8-byte keys: 8 -- the kernel's own ATOM)
@@ -157,19 +161,26 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 		if constexpr (!PREFETCH)
 			request(t, tid);
 		// ---- the digits' counts; every key against the columns the sample took for constant
+		u32 rk[C::RANK1 ? (KPT + 1) / 2 : 1];   // RANK1: the keys' ranks in their digits' runs, two to a register
 		auto count = [&](auto full_c) {
 			constexpr bool FULL = decltype(full_c)::value;
 			KT bad = 0;
 #pragma unroll
 			for (int r = 0; r < KPT; ++r) {
+				u32 mine = 0;
 				if (FULL || tid + r * BLOCK < cnt) {
 					const KT k = DIG == 1 ? keep[r] : kdf_apply(keep[r], ka);
 					bad |= (k ^ key0) & cmask;
 					const u32 b = bucket_of(k, shift);
 					if constexpr (DIG == 2)
 						bkp[r >> 2] = (r & 3) ? bkp[r >> 2] | (b << (8 * (r & 3))) : b;
-					atomicAdd(&cell[b], 1u);
+					if constexpr (C::RANK1)
+						mine = __hip_atomic_fetch_add(&cell[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					else
+						atomicAdd(&cell[b], 1u);
 				}
+				if constexpr (C::RANK1)
+					rk[r >> 1] = (r & 1) ? rk[r >> 1] | (mine << 16) : mine;
 			}
 			if (__ballot(bad != 0) && lane == 0)
 				atomicOr(overflow, 1u);   // (a column that is not constant after all: the attempt is lost)
@@ -261,7 +272,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 							b = (bkp[(r0 + r) >> 2] >> (8 * ((r0 + r) & 3))) & 0xFFu;
 						else
 							b = bucket_of(k, shift_b);
-						pos[r] = __hip_atomic_fetch_add(&cell[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if constexpr (C::RANK1)
+							pos[r] = cell[b] + ((rk[(r0 + r) >> 1] >> (16 * ((r0 + r) & 1))) & 0xFFFFu);   // (the run's start: nobody moves it)
+						else
+							pos[r] = __hip_atomic_fetch_add(&cell[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
 #pragma unroll

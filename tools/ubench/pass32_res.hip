@@ -16,3 +16,6 @@ template __global__ void rsx_pass32a_kernel<u64, DIG_PLAIN, false, Pass32aCfgT<1
 template __global__ void rsx_pass32a_kernel<u64, DIG_GENERIC, false, Pass32aCfgT<14>>(const u64 *, u64, u64 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u64>, const u64 *);
 template __global__ void rsx_pass32a_kernel<u64, DIG_PLAIN, true, Pass32aCfgT<14>>(const u64 *, u64, u64 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u64>, const u64 *);
 }
+namespace rsx {
+template __global__ void rsx_pass32a_kernel<u32, DIG_PLAIN, false, Pass32aCfgT<28, false>>(const u32 *, u64, u32 *, u32, u32, u32, u32, const SegCtl *, u32 *, u32 *, KdfArgs<u32>, const u32 *);
+}
