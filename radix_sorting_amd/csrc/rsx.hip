@@ -111,6 +111,7 @@ struct Env {
 	bool no_blind = false;           // RSX_NO_BLIND=1: every sort starts with the histogram
 	unsigned blind_min_log2 = 0;     // RSX_BLIND_MIN_LOG2: keys-only sorts may skip the histogram from 2^this keys on (0: the measured floors)
 	bool no_leaf_prefix = false;     // RSX_NO_LEAF_PREFIX=1: leaves of 8-byte keys sort by every column they have left (rsx_hybrid.hpp)
+	bool no_leaf16w2k = false;       // RSX_NO_LEAF16W2K=1: slots of 1025 .. 2048 values take a 128-thread workgroup per leaf (rsx_leaf16_kernel) instead of a wave
 	bool no_leaf16q = false;         // RSX_NO_LEAF16Q=1: slots of up to 256 values take a wave per leaf (rsx_leaf16w_kernel) instead of a row of sixteen lanes
 	bool no_narrow_slots = false;    // RSX_NO_NARROW_SLOTS=1: the level-2 slots of 8-byte keys always hold whole keys (SegCtl::narrow)
 	bool no_aux_slots = false;       // RSX_NO_AUX_SLOTS=1: the level-1 slots of a sort without a histogram all lie in scratch memory
@@ -171,6 +172,7 @@ struct Env {
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
 		no_leafc = is_one("RSX_NO_LEAFC");
+		no_leaf16w2k = is_one("RSX_NO_LEAF16W2K");
 		if (const char *e = getenv("RSX_PASS32_PREFETCH"))
 			pass32_prefetch = e[0] == '1' ? 1 : 0;
 		if (const char *e = getenv("RSX_FORCE_LEAFC"))
@@ -1366,6 +1368,16 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			typedef Leaf16Cfg<128, 2560, 8, 11> L2k;
 			typedef Leaf16WCfg<1024, 10, 4> W1k;   // small slots (arrays of up to ~50 Mi keys): a wave per leaf
 			typedef Leaf16WCfg<512, 9, 4> W512;
+			// ... and, round 5, up to 2048 values (arrays of up to ~100 Mi keys: two chunks of sixteen values per lane in the register
+			// passes, slots read from both ends behind rsx_pass16a_kernel): tools/ubench/leaf16_probe against the 128-thread
+			// workgroup shape -- 54 Mi keys 0.110 against 0.119 ms, 64 Mi 0.131 / 0.143, 80 Mi 0.145 / 0.167, 96 Mi 0.162 / 0.180
+			typedef Leaf16WCfg<2048, 10, 4> W2k;
+			if (c.slack_cap > (u32)W1k::CAP && c.slack_cap <= (u32)W2k::CAP && !env().no_leaf16w2k) {
+				hipLaunchKernelGGL((rsx_leaf16w_kernel<KT, W2k>), dim3(grid_1 / W2k::NW), dim3(W2k::BLOCK), 0, c.stream, src, aux,
+				                   (const Plan *)c.plan(), segtab, wctl, ka, 0u, (u32)W2k::CAP, (const uint16_t *)slots, c.slack_cap);
+				HIP_TRY(hipGetLastError());
+				return RSX_OK;
+			}
 			if (c.slack_cap <= (u32)W1k::CAP) {
 				// (no list, no second launch: the wave kernel goes on until its leaf is in order)
 				typedef Leaf16QCfg<4> Q256;            // slots of up to 256 values (arrays of up to ~13 Mi keys): four leaves per wave

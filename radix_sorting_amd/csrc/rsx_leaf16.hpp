@@ -421,8 +421,9 @@ template <int CAP_, int NBITS_, int WAVES_> struct Leaf16WCfg {
 	static constexpr int NV = CAP / 512;                 // 16-byte vectors of eight values per lane
 	static constexpr int NBIN = 1 << NBITS, NCELLW = NBIN / 2;
 	static constexpr int PLANES = NCELLW / 4 / 64;       // 16-byte vectors of cells per lane
+	static constexpr int NCL = CAP > 1024 ? CAP / 1024 : 1;   // chunks of sixteen values per lane in the register passes
 	static constexpr u32 MAXBIN = 9;
-	static_assert(CAP == 512 || CAP == 1024, "a chunk of sixteen values per lane at most");
+	static_assert(CAP == 512 || CAP == 1024 || CAP == 2048, "one or two chunks of sixteen values per lane");
 	static_assert(PLANES == 1 || PLANES == 2, "");
 };
 
@@ -459,18 +460,24 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 		if (cnt == 0)
 			return;   // (next leaf)
 		const uint16_t *q = slots + (u64)(slot - 1) * slack_cap;
+		// (a slot filled by rsx_pass16a_kernel holds its values at both ends, as rsx_leaf16_kernel reads them: the front's vectors,
+		// then the back's -- slots of more than 1024 values; back == 0 otherwise)
+		const u32 back = ls.ncols >> 16, front = cnt - back;
+		const u32 VF = (front + 7u) >> 3, VB = (back + 7u) >> 3;
 		u32x4 kv[NV];
 		int nvalid[NV];
 #pragma unroll
 		for (int j = 0; j < NV; ++j) {
-			const u32 e0 = 8 * (lane + 64 * j);
-			const int left = (int)cnt - (int)e0;
+			const u32 v = lane + 64 * j;
+			const bool isback = v >= VF;
+			const u32 e0 = 8 * (isback ? v - VF : v);
+			const int left = (int)(isback ? back : front) - (int)e0;
 			nvalid[j] = left < 0 ? 0 : left > 8 ? 8 : left;
 			kv[j] = u32x4{0, 0, 0, 0};
 			if (left > 0)
-				kv[j] = *(const u32x4 *)(q + e0);
+				kv[j] = *(const u32x4 *)(q + (isback ? slack_cap - LEAF16_BACK : 0u) + e0);
 		}
-		auto wave_has = [&](int j) { return 8 * (64 * (u32)j) < cnt; };
+		auto wave_has = [&](int j) { return 64 * (u32)j < VF + VB; };
 		{
 			const u32x4 zero = {0, 0, 0, 0};
 #pragma unroll
@@ -557,31 +564,40 @@ __global__ __launch_bounds__(C::BLOCK, 8) void rsx_leaf16w_kernel(KT *__restrict
 		// touches) -- one round for bins of up to 9 keys, which is what evenly spread keys give; no leaf is handed on
 		const u32 nch = (cnt + 15) >> 4;
 		const u32 rounds = mx <= C::MAXBIN ? 1u : ((mx + 6) / 8 + 2) / 2;
+		constexpr int NCL = C::NCL;   // (lane l holds chunk l -- and, slots of 2048 values, chunk 64 + l: the chunk after lane 63's is lane 0's second)
 		for (u32 r = 0; r < rounds; ++r) {
-			u32 d[8];
-			{
-				const u32x4 *p = (const u32x4 *)&stage[16 * lane];
-				const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
-				const u32x4 x0 = lane < nch ? p[0] : ones, x1 = lane < nch ? p[1] : ones;
-				d[0] = x0[0], d[1] = x0[1], d[2] = x0[2], d[3] = x0[3];
-				d[4] = x1[0], d[5] = x1[1], d[6] = x1[2], d[7] = x1[3];
-			}
-			sort16_packed(d);
-			if (lane == 0)
-				*(u32x4 *)&stage[0] = u32x4{d[0], d[1], d[2], d[3]};   // (the first eight values are in place)
-			u32 lowa[4], nxt[4];
+			u32 d[NCL][8];
 #pragma unroll
-			for (int m = 0; m < 4; ++m) {
-				lowa[m] = d[4 + m];
-				const u32 y = from_next_lane(d[m]);
-				nxt[m] = lane == 63 ? ~0u : y;
+			for (int cl = 0; cl < NCL; ++cl) {
+				const u32 ci = lane + 64u * (u32)cl;
+				const u32x4 *p = (const u32x4 *)&stage[16 * ci];
+				const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+				const u32x4 x0 = ci < nch ? p[0] : ones, x1 = ci < nch ? p[1] : ones;
+				d[cl][0] = x0[0], d[cl][1] = x0[1], d[cl][2] = x0[2], d[cl][3] = x0[3];
+				d[cl][4] = x1[0], d[cl][5] = x1[1], d[cl][6] = x1[2], d[cl][7] = x1[3];
+				sort16_packed(d[cl]);
 			}
-			planes_of_two_runs(d, lowa, nxt);
-			merge16_packed(d);
-			if (lane < nch) {
-				u32x4 *p = (u32x4 *)&stage[16 * lane + 8];
-				p[0] = u32x4{d[0], d[1], d[2], d[3]};
-				p[1] = u32x4{d[4], d[5], d[6], d[7]};
+			if (lane == 0)
+				*(u32x4 *)&stage[0] = u32x4{d[0][0], d[0][1], d[0][2], d[0][3]};   // (the first eight values are in place)
+#pragma unroll
+			for (int cl = 0; cl < NCL; ++cl) {
+				const u32 ci = lane + 64u * (u32)cl;
+				u32 lowa[4], nxt[4], e[8];
+#pragma unroll
+				for (int m = 0; m < 4; ++m) {
+					lowa[m] = d[cl][4 + m];
+					const u32 y = from_next_lane(d[cl][m]);
+					// (the chunk after lane 63's: lane 0's next one -- still as sorted above --, or nothing)
+					const u32 wrap = cl + 1 < NCL ? (u32)__builtin_amdgcn_readfirstlane((int)d[cl + 1 < NCL ? cl + 1 : cl][m]) : ~0u;
+					nxt[m] = lane == 63 ? wrap : y;
+				}
+				planes_of_two_runs(e, lowa, nxt);
+				merge16_packed(e);
+				if (ci < nch) {
+					u32x4 *p = (u32x4 *)&stage[16 * ci + 8];
+					p[0] = u32x4{e[0], e[1], e[2], e[3]};
+					p[1] = u32x4{e[4], e[5], e[6], e[7]};
+				}
 			}
 			RSX_COMPILER_FENCE();
 		}

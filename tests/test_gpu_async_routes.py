@@ -328,7 +328,8 @@ def test_device_scheduled_sorts_back_off_on_the_device():
         assert route == 0, (i, route)
         assert np.array_equal(buf.cpu().numpy().view(np.uint32), want), i
         tried.append(p.called_off_ms)     # (a lost attempt at 48 Mi keys: ~0.10 ms; the launches that return at once: ~0.02)
-    assert [t > 0.05 for t in tried] == [True, False, True, False, False, True], tried
+    mid = (min(tried) + max(tried)) / 2     # (what the launches that return at once cost depends on what the context sorted before)
+    assert max(tried) > 1.5 * min(tried) and [t > mid for t in tried] == [True, False, True, False, False, True], tried
     # uniform keys: the attempt is made at once only when no skip is pending -- and going through clears the doubling
     rsa.fill_splitmix(buf, 9201)
     rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32)     # (skip 1 of 4 pending after the sixth sort above)

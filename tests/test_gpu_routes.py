@@ -139,6 +139,24 @@ def test_u32_mid_size_low_bits_clustered():
     _sort_and_compare(b, ol.U32, ol.ASC, 5, "16 values in some buckets")
 
 
+@pytest.mark.parametrize("case", ["clustered low bits", "16 values in some buckets", "a workgroup per leaf"])
+def test_u32_a_wave_per_leaf_up_to_2048_values(case, monkeypatch):
+    """Slots of 1025 .. 2048 values (52 .. 100 Mi keys) are one wave's too (rsx_leaf16w_kernel, two chunks of sixteen values per
+    lane; the slots are rsx_pass16a_kernel's: read from both ends).  Low sixteen bits from 1024 values everywhere, from 16 values
+    in some buckets (the wave goes on until its leaf is in order); RSX_NO_LEAF16W2K=1: the 128-thread workgroup shape as before."""
+    n = 72 * MI + 333
+    if case == "clustered low bits":
+        a = ol.splitmix_fill(n, ol.U32, 5300, 0xFFFFFC0F)
+    elif case == "16 values in some buckets":
+        a = ol.splitmix_fill(n, ol.U32, 5301, 0xFFFFFFFF).view(np.uint32).copy()
+        a[((a >> 16) % 389) == 7] &= np.uint32(0xFFFF000F)
+    else:
+        monkeypatch.setenv("RSX_NO_LEAF16W2K", "1")
+        a = ol.splitmix_fill(n, ol.U32, 5302, 0xFFFFFFFF)
+    _sort_and_compare(a, ol.U32, ol.ASC, 5, case)
+    _sort_and_compare(a, ol.F32, ol.DESC, 5, (case, "f32 desc"))
+
+
 @pytest.mark.parametrize("n_mi,mask,base", [(128, 0x07FFFFFF, 0x18000000), (40, 0x3FFFFFFF, 0), (200, 0x1FFFFFFF, 0xE0000000)])
 def test_u32_constant_top_bits_at_production_sizes(n_mi, mask, base):
     """One rank's sub-range of a distributed sort (2^27 keys whose top byte lies in [24, 32)), values below 2^30, keys with

@@ -231,6 +231,11 @@ int main(int argc, char **argv)
 			WAVE(512, 9, 8, nleaf / 8);
 		}
 	}
+	if (cap <= 2048) {
+		WAVE(2048, 10, 4, nleaf / 4);
+		WAVE(2048, 10, 2, nleaf / 2);
+		WAVE(2048, 10, 8, nleaf / 8);
+	}
 	if (cap <= 1536) {
 		NEW(128, 1536, 8, 11, nleaf);
 		NEW(128, 1536, 8, 10, nleaf);

@@ -27,3 +27,6 @@ INST_16W(Leaf16WCfg<1024, 10, 4>);
 INST_16W(Leaf16WCfg<512, 9, 4>);
 INST_16Q(Leaf16QCfg<4>);
 }
+namespace rsx {
+INST_16W(Leaf16WCfg<2048, 10, 4>);
+}
