@@ -64,6 +64,7 @@
  *   RSX_NO_AUX_SLOTS=1      level-1 slots all in scratch memory; RSX_NO_NARROW_SLOTS=1: 8-byte keys always in whole-key slots;
  *   RSX_LEAF16_MAXBIN=k     (tests) the fullest bin a leaf may have before it goes to those; RSX_NO_SHIFT=1: MSB digits on bytes only;
  *   RSX_NO_LEAF16Q=1        slots of up to 256 values take a wave per leaf instead of a row of sixteen lanes;
+ *   RSX_NO_LEAF16W2K=1      slots of 1025 .. 2048 values take a 128-thread workgroup per leaf instead of a wave;
  *   RSX_NO_PASS16A=1        the level-2 pass of such a sort of 4-byte keys writes ragged runs (rsx_pass16_kernel) instead of whole
  *                           64-byte atoms (rsx_pass16a_kernel); RSX_NO_PASS32A=1: the level-1 pass is the chained kernel of round 4
  *                           (rsx_scatter2_kernel) instead of rsx_pass32a_kernel; RSX_NO_PASS16=1: so is the level-2 pass;
