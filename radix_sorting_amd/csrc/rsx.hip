@@ -341,6 +341,7 @@ struct Ctx {
 	DevBuf slack_v;     // ... the payloads' slots (key + payload and rank sorts)
 	DevBuf slack;       // two-level sorts, slack attempt: 65536 slots of slack_cap keys (+ a tile of padding)
 	u32 slack_cap = 0;
+	u32 slack_mean = 0;   // the mean number of keys of a level-2 slot of the sort being enqueued (n / 65536: pass16a_wanted)
 	DevBuf slack1_v;    // ... and of as many payloads (pairs_blind)
 	DevBuf slack1;      // sorts without a histogram (sort_keys_blind): the level-1 pass's 256 slots of slack1_cap keys
 	u32 slack1_cap = 0;
@@ -1455,7 +1456,22 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 template <typename KT> bool pass16a_wanted(const Ctx &c)
 {
 	if constexpr (sizeof(KT) == 4)
-		return dense_slots<KT>(c) && !env().no_pass16 && !env().no_pass16a && !env().no_unstable && !env().no_leaf16 && c.slack_cap > 1024u;
+	{
+		if (!dense_slots<KT>(c) || env().no_pass16 || env().no_pass16a || env().no_unstable || env().no_leaf16)
+			return false;
+		if (c.slack_cap > 1024u)
+			return true;
+		// slots of 1024 values (38 .. 52 M keys; the wave per leaf reads both ends since round 5): where the 128 places kept for a
+		// slot's back still leave its front the room slot_cap_for wanted for the whole slot -- mean + 7 standard deviations:
+		// 37.7 M .. 45.9 M keys (the reference's own headline size, 4 * 10^7, among them)
+		if (c.slack_cap == 1024u && c.slack_mean) {
+			u32 r = 0;
+			while ((u64)(r + 1) * (r + 1) <= c.slack_mean)
+				++r;
+			return c.slack_mean + 7 * (r + 1) + 8 <= c.slack_cap - LEAF16_BACK;
+		}
+		return false;
+	}
 	return false;
 }
 
@@ -1914,6 +1930,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	// rsx_scatter2.hpp); RSX_NO_AUX_SLOTS=1: all slots in scratch memory.
 	u32 lo = (aux && !env().no_aux_slots && cap1 >= (u32)C2::TILE) ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
 	c.slack_cap = cap2;   // (dense_slots asks for it)
+	c.slack_mean = mean2;
 	const size_t slot2_bytes = dense_slots<KT>(c) ? 2 : sizeof(KT);
 	if (c.slack1.ensure(((size_t)(256 - lo) * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * slot2_bytes) != RSX_OK) {

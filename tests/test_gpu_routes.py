@@ -111,11 +111,12 @@ def test_u32_1e7_a_row_of_sixteen_lanes_per_leaf(case, monkeypatch):
     _sort_and_compare(a, ol.I32, ol.DESC, 5, ("1e7 i32 desc", case))
 
 
-@pytest.mark.parametrize("n", [13000000, 13369344, 26738688])
+@pytest.mark.parametrize("n", [13000000, 13369344, 26738688, 45600000])
 def test_slots_hold_an_even_array_whatever_its_size(n):
     """A slot's capacity is 1.25 times the mean bucket AND at least seven standard deviations above it (rsx.hip, slot_cap_for).
     With 1.25 x alone these sizes -- mean buckets of 198, 204 and 408 keys in slots of 256 / 512 -- lost nearly every attempt
-    (13 Mi keys: 147 of 150) to one overflowing slot of the 65536 and fell back to one pass per column."""
+    (13 Mi keys: 147 of 150) to one overflowing slot of the 65536 and fell back to one pass per column.  45.6 M keys: the largest
+    array whose 1024-value slots are filled by rsx_pass16a_kernel (128 of their places kept for the slot's back, round 5)."""
     src = torch.empty(n, dtype=torch.int32, device="cuda")
     aux = torch.empty_like(src)
     for seed in range(12):
