@@ -123,6 +123,7 @@ struct Env {
 	unsigned pass16_wgs = 2;         // RSX_PASS16_WGS=1: ... one workgroup per CU (probe)
 	bool no_packed_keys = false;     // RSX_NO_PACKED_KEYS=1: rank sorts without a histogram go by byte columns only (SegCtl::compact never set)
 	bool no_pass32a = false;         // RSX_NO_PASS32A=1: the level-1 pass of such a sort is rsx_scatter2_kernel<..., SEG> with its look-back chain (rsx_pass32.hpp)
+	unsigned pass32_min_mi = 0;      // RSX_PASS32_MIN_MI=k (probe): the level-1 atom pass from k Mi keys on (default: 52 Mi 4-byte keys, 24 Mi 8-byte keys)
 	int pass32_prefetch = -1;        // RSX_PASS32_PREFETCH=0|1 (probe): rsx_pass32a_kernel requests a tile's keys while it writes the tile before (1) or when it starts on the tile (0); unset: by the array's size
 	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
@@ -173,6 +174,8 @@ struct Env {
 		no_leaf16 = is_one("RSX_NO_LEAF16");
 		no_leafc = is_one("RSX_NO_LEAFC");
 		no_leaf16w2k = is_one("RSX_NO_LEAF16W2K");
+		if (const char *e = getenv("RSX_PASS32_MIN_MI"))
+			pass32_min_mi = (unsigned)atoi(e);
 		if (const char *e = getenv("RSX_PASS32_PREFETCH"))
 			pass32_prefetch = e[0] == '1' ? 1 : 0;
 		if (const char *e = getenv("RSX_FORCE_LEAFC"))
@@ -2000,14 +2003,16 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	bool atoms1 = false;
 	{
 		// 4-byte keys: only in front of rsx_pass16a_kernel (a bucket that lies at both ends of its slot is one tile more: that pass's
-		// tile table has room for it); from 96 Mi keys: tools/atoms_threshold_probe.py, profiles/r05/atoms_threshold_probe.txt --
-		// level with the chained pass at 64-80 Mi, 1 % ahead at 96 Mi, 3.3 % at 2^28; the level-2 pass in atoms pays from its first
-		// size, 52 Mi.
+		// tile table has room for it); from 52 Mi keys, where that pass starts for good -- as first built (the next tile requested
+		// ahead, two LDS atomics per key) it was level with the chained pass at 64-80 Mi and 1 % ahead at 96 Mi
+		// (profiles/r05/atoms_threshold_probe.txt); as it is now: 0-4 % ahead at 54 .. 95 Mi keys, never behind
+		// (tools/ab_sizes.py RSX_PASS32_MIN_MI 96 40 u32 ...), 2-5 % behind in the 1024-value-slot window around 40 Mi.
 		// 8-byte keys (atoms of eight keys, 14 Ki-key tiles): in front of the CHAINED level-2 pass, whose status words have a row
-		// more per bucket for that (seg_extra_rows); from 48 Mi keys (the same bytes) -- tools/ubench/pass32_probe, 2^28 u64 keys:
-		// 0.926 ms against 1.01 for the chained pass, 2^27: 0.447 against 0.50.
+		// more per bucket for that (seg_extra_rows); from 24 Mi keys (1.3-2.5 % ahead at 24 .. 44 Mi, level at 20 Mi:
+		// tools/ab_sizes.py RSX_PASS32_MIN_MI 48 16 u64 ...) -- tools/ubench/pass32_probe, 2^28 u64 keys: 0.926 ms against 1.01 for
+		// the chained pass, 2^27: 0.447 against 0.50.
 		typedef Pass32aCfgT<sizeof(KT) == 8 ? 14 : 28> P32;
-		const size_t min32 = sizeof(KT) == 8 ? (size_t)3 << 24 : (size_t)3 << 25;
+		const size_t min32 = env().pass32_min_mi ? (size_t)env().pass32_min_mi << 20 : sizeof(KT) == 8 ? (size_t)3 << 23 : (size_t)13 << 22;
 		atoms1 = (sizeof(KT) == 4 ? atoms : !env().no_unstable) && !env().no_pass32a && n >= min32 &&
 		         cap1 >= (u32)P32::TILE + 2 * PASS32_BACK;
 		if (atoms1) {
