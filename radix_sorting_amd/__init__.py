@@ -17,7 +17,8 @@ import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsx.so")
+# (RSX_LIB: another build of the library, for A/B measurements of compile-time variants inside one gpurun call)
+LIB_PATH = os.environ.get("RSX_LIB") or os.path.join(_HERE, "librsx.so")
 
 # rsx_dtype (include/rsx.h)
 U8, U16, U32, U64, I8, I16, I32, I64, F32, F64 = range(10)

@@ -60,6 +60,34 @@ template <int U> __global__ __launch_bounds__(1024) void write_kernel(const u32x
 	}
 }
 
+// the same write with NON-TEMPORAL stores (the compiler's nt bit: streaming, not kept in the caches)
+template <int U> __global__ __launch_bounds__(1024) void write_nt_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t nvec)
+{
+	const size_t stride = (size_t)gridDim.x * 1024 * U;
+	const u32x4 x = {(unsigned)blockIdx.x, 1, 2, 3};
+	for (size_t v0 = (size_t)blockIdx.x * 1024 * U + threadIdx.x; v0 < nvec; v0 += stride) {
+#pragma unroll
+		for (int u = 0; u < U; ++u)
+			if (v0 + (size_t)u * 1024 < nvec)
+				__builtin_nontemporal_store(x, &dst[v0 + (size_t)u * 1024]);
+	}
+}
+template <int U> __global__ __launch_bounds__(1024) void copy_nt_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t nvec)
+{
+	const size_t stride = (size_t)gridDim.x * 1024 * U;
+	for (size_t v0 = (size_t)blockIdx.x * 1024 * U + threadIdx.x; v0 < nvec; v0 += stride) {
+		u32x4 x[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u)
+			if (v0 + (size_t)u * 1024 < nvec)
+				x[u] = __builtin_nontemporal_load(&src[v0 + (size_t)u * 1024]);
+#pragma unroll
+		for (int u = 0; u < U; ++u)
+			if (v0 + (size_t)u * 1024 < nvec)
+				__builtin_nontemporal_store(x[u], &dst[v0 + (size_t)u * 1024]);
+	}
+}
+
 // the buffer read from its end to its beginning (workgroup b takes the b-th stretch from the END)
 template <int U> __global__ __launch_bounds__(1024) void read_backward_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t nvec)
 {
@@ -163,6 +191,38 @@ int main()
 		printf("%-34s %-28s grid %4u: best %.3f ms = %.0f GB/s, mean %.3f ms = %.0f GB/s\n", name, "the buffer just written", grid, best,
 		       1.0 * bytes / best / 1e6, sum / reps, 1.0 * bytes / (sum / reps) / 1e6);
 	};
+	// ... behind a writer whose stores are non-temporal
+	auto run_behind = [&](const char *name, const char *what, auto pre, auto kernel, double bytes_moved, unsigned grid) {
+		float best = 1e9f, sum = 0;
+		const int reps = 16;
+		for (int r = 0; r < reps + 2; ++r) {
+			const int w = (3 * r) % NB, a = (3 * r + 1) % NB, b = (3 * r + 2) % NB;
+			hipLaunchKernelGGL(pre, dim3(2048), dim3(1024), 0, 0, (const u32x4 *)buf[a], buf[w], nvec);
+			hipEvent_t e0, e1;
+			CK(hipEventCreate(&e0));
+			CK(hipEventCreate(&e1));
+			CK(hipEventRecord(e0, 0));
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(1024), 0, 0, (const u32x4 *)buf[a], buf[b], nvec);
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			if (r >= 2) {
+				best = std::min(best, ms);
+				sum += ms;
+			}
+			CK(hipEventDestroy(e0));
+			CK(hipEventDestroy(e1));
+		}
+		printf("%-34s %-28s grid %4u: best %.3f ms = %.0f GB/s, mean %.3f ms = %.0f GB/s\n", name, what, grid, best, bytes_moved / best / 1e6,
+		       sum / reps, bytes_moved / (sum / reps) / 1e6);
+	};
+	run_behind("read 1 GiB", "behind a NON-TEMPORAL 1 GiB write", write_nt_kernel<4>, read_kernel<4>, 1.0 * bytes, 512);
+	run_behind("copy 1 GiB -> 1 GiB (2 GiB moved)", "behind a NON-TEMPORAL 1 GiB write", write_nt_kernel<4>, copy_kernel<4>, 2.0 * bytes, 512);
+	run_behind("copy, nt loads and stores", "behind a NON-TEMPORAL copy", copy_nt_kernel<4>, copy_nt_kernel<4>, 2.0 * bytes, 512);
+	run_behind("copy 1 GiB -> 1 GiB (2 GiB moved)", "behind an ordinary copy", copy_kernel<4>, copy_kernel<4>, 2.0 * bytes, 512);
+	run("write 1 GiB, non-temporal", write_nt_kernel<4>, 1.0 * bytes, true, 512);
+	run("copy, nt loads and stores", copy_nt_kernel<4>, 2.0 * bytes, true, 512);
 	run_own("read 1 GiB, forward", read_kernel<4>, 512);
 	run_own("read 1 GiB, from its end", read_backward_kernel<4>, 512);
 	for (unsigned grid : {512u, 2048u}) {
