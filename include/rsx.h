@@ -69,8 +69,8 @@
  *                           64-byte atoms (rsx_pass16a_kernel); RSX_NO_PASS32A=1: the level-1 pass is the chained kernel of round 4
  *                           (rsx_scatter2_kernel) instead of rsx_pass32a_kernel; RSX_NO_PASS16=1: so is the level-2 pass;
  *                           RSX_PASS16_WGS=1, RSX_PASS16_DBG=1|2: probes of rsx_pass16_kernel (DBG gives WRONG output);
- *   RSX_PASS32_PREFETCH=0|1 (probe) rsx_pass32a_kernel requests the next tile's keys while it writes the current one (default: below
- *                           192 Mi keys only);
+ *   RSX_PASS32_PREFETCH=1   (probe) rsx_pass32a_kernel requests the next tile's keys while it writes the current one (default: when it
+ *                           starts on the tile); RSX_PASS32_MIN_MI=k: that pass from k Mi keys on (default 52 / 24 Mi 4- / 8-byte keys);
  *   RSX_NO_LEAFC=1          no two-byte slots of more than 5120 values: keys-only sorts of 4-byte keys beyond 2^28 keys run as in
  *                           round 4 (whole-key slots up to 2^30 keys, one pass per column beyond; rsx_leafc.hpp);
  *   RSX_FORCE_LEAFC=1..6    (tests) two-byte slots of any size go through the leaves of the large ones: 1 the counting leaves,

@@ -124,7 +124,7 @@ struct Env {
 	bool no_packed_keys = false;     // RSX_NO_PACKED_KEYS=1: rank sorts without a histogram go by byte columns only (SegCtl::compact never set)
 	bool no_pass32a = false;         // RSX_NO_PASS32A=1: the level-1 pass of such a sort is rsx_scatter2_kernel<..., SEG> with its look-back chain (rsx_pass32.hpp)
 	unsigned pass32_min_mi = 0;      // RSX_PASS32_MIN_MI=k (probe): the level-1 atom pass from k Mi keys on (default: 52 Mi 4-byte keys, 24 Mi 8-byte keys)
-	int pass32_prefetch = -1;        // RSX_PASS32_PREFETCH=0|1 (probe): rsx_pass32a_kernel requests a tile's keys while it writes the tile before (1) or when it starts on the tile (0); unset: by the array's size
+	int pass32_prefetch = -1;        // RSX_PASS32_PREFETCH=0|1 (probe): rsx_pass32a_kernel requests a tile's keys while it writes the tile before (1) or when it starts on the tile (0, the default)
 	bool no_pass16a = false;         // RSX_NO_PASS16A=1: ... whose runs are ragged (rsx_pass16_kernel) instead of whole 64-byte atoms (rsx_pass16a_kernel)
 	unsigned pass16_dbg = 0;         // RSX_PASS16_DBG=1|2 (probe, WRONG OUTPUT): no stores / only whole aligned 64-byte atoms stored
 	bool no_leafc = false;           // RSX_NO_LEAFC=1: no two-byte slots of more than 5120 values (rsx_leafc.hpp): sorts without a histogram of 4-byte keys end below 2^30 keys and their larger leaves sort whole keys, as in round 4
@@ -2036,7 +2036,9 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 			// level-1 pass of 2^28 keys 0.485 -> 0.457 ms without, three rounds alternating in one process, tools/blind_ab.py;
 			// 380 M keys 1.975 -> 1.929 ms, 2^30 5.157 -> 5.130: reads and writes in flight together cost more than the gap between tiles)
 			// (8-byte keys: never ahead -- 2^27 keys 0.447 against 0.455 ms, 2^28 0.926 against 0.951)
-			const bool prefetch = sizeof(KT) == 4 && (env().pass32_prefetch >= 0 ? env().pass32_prefetch != 0 : n < ((size_t)3 << 26));
+			// (later, with one LDS atomic per key: never ahead at 54 .. 224 Mi keys either -- 54 Mi 0.340 -> 0.330 ms, 192 Mi 0.983 -> 0.961,
+			// level at 80 and 128 Mi, tools/ab_sizes.py RSX_PASS32_PREFETCH 1 0 u32 ...: off unless RSX_PASS32_PREFETCH=1 asks for it)
+			const bool prefetch = sizeof(KT) == 4 && env().pass32_prefetch > 0;
 #define RSX_LAUNCH_P32(DIGV, PF)                                                                                             \
 			hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIGV, PF, P32>), dim3(256), dim3(P32::BLOCK), 0, c.stream, (const KT *)src,   \
 			                   (u64)n, kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka)
