@@ -190,31 +190,83 @@ def cpu_baseline(log2n=28, reps=5):
 def launch_ranks(args_list, gpus, script=None):
     """`python bench.py --gpus N` without a launcher: this process stays free of the GPU, starts the N ranks as
     `python -m torch.distributed.run ... bench.py <same arguments>`, relays their output and ends with rank 0's JSON line
-    as its own last line of stdout and with their exit status."""
+    as its own last line of stdout and with their exit status.
+
+    The result does not travel through the pipe all ranks write to (a 5 KB line is several writes; another rank's text can
+    land inside it): rank 0 writes it to the file named by RSX_BENCH_RESULT, and the parent prints that file after the
+    ranks have exited.  Lines of the relayed output that look like a result line are dropped, so nothing glued to one
+    can reach the parent's stdout either."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    fd, result_path = tempfile.mkstemp(prefix="rsx_bench_", suffix=".json")
+    os.close(fd)
+    env["RSX_BENCH_RESULT"] = result_path
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), script or os.path.abspath(__file__)] + args_list
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
-    line_json = None
-    for line in proc.stdout:
-        text = line.rstrip("\n")
-        if text.startswith("{") and '"metric"' in text:
-            line_json = text                     # held back: it must be the LAST line
-        else:
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+        for line in proc.stdout:
+            text = line.rstrip("\n")
+            if '"metric"' in text and "{" in text:
+                continue                         # a rank's copy of the result (possibly with another rank's text glued on)
             print(text, flush=True)
-    rc = proc.wait()
-    if line_json is not None:
-        print(line_json, flush=True)
+        rc = proc.wait()
+        with open(result_path) as f:
+            line_json = f.read().strip()
+    finally:
+        try:
+            os.unlink(result_path)
+        except OSError:
+            pass
+    if line_json:
+        json.loads(line_json)                    # (a torn file would be a bug here: fail loudly rather than print it)
+        sys.stdout.write(line_json + "\n")
+        sys.stdout.flush()
     elif rc == 0:
         rc = 1
-        print("bench: the ranks printed no result line", file=sys.stderr)
+        print("bench: the ranks wrote no result line", file=sys.stderr)
     raise SystemExit(rc)
+
+
+def emit_result(out, rank):
+    """Rank 0's one JSON line: to the file the launching parent named (RSX_BENCH_RESULT, written whole and renamed), and
+    to stdout as ONE write after everything else of this process has been flushed."""
+    if rank != 0:
+        return
+    text = json.dumps(out)
+    path = os.environ.get("RSX_BENCH_RESULT")
+    if path:
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            f.write(text + "\n")
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    data = (text + "\n").encode()
+    while data:                                   # (a pipe takes 64 KiB at once; the loop is for a short write)
+        data = data[os.write(1, data):]
+
+
+def quiet_this_rank():
+    """A rank other than 0 has nothing more to say once its checks are through: what its teardown (RCCL, the runtime)
+    still prints must not land inside or behind rank 0's result line on the shared stdout / stderr."""
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    null = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(null, 1)
+    os.dup2(null, 2)
+    os.close(null)
 
 
 def main():
@@ -347,6 +399,7 @@ def main():
         lsd_only = (time.perf_counter() - t1) / reps
         del os.environ["RSX_NO_HYBRID"]
         rsa.reload_env()
+    out = None
     if rank == 0:
         total_keys = float(K) * n * world
         classes = kernel_classes(how)
@@ -444,9 +497,15 @@ def main():
                             "imbalance": last[1].get("imbalance")}
         if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if sharded:
+        # the result line is the LAST thing the job prints: the other ranks go quiet, the process group is torn down
+        # (RCCL's own chatter comes out here), and only then does rank 0 write its line
+        if rank != 0:
+            quiet_this_rank()
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+    emit_result(out if rank == 0 else None, rank)
 
 
 if __name__ == "__main__":

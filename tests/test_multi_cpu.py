@@ -315,15 +315,23 @@ def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus N` without a launcher: the GPU-free parent starts N ranks through
     torch.distributed.run, relays their output and prints rank 0's JSON line LAST; a failing rank fails the parent."""
     import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "fake_bench.py"
+    # every rank prints 100 lines of noise before and after rank 0's result, unsynchronised, on the pipe they share; the
+    # result itself is longer than PIPE_BUF (as the real line is) so a torn or glued line would show
     script.write_text(
         "import os, sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
         "r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE'])\n"
         "assert os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
-        "if r == 0:\n"
-        "    print(json.dumps({'metric': 'm', 'value': 1.5, 'n_gpus': w, 'argv': sys.argv[1:]}), flush=True)\n"
-        "print('noise from rank %d' % r, flush=True)\n"
-        "sys.exit(3 if '--fail' in sys.argv and r == 1 else 0)\n")
+        "for i in range(100):\n"
+        "    print('noise from rank %%d line %%d' %% (r, i), flush=True)\n"
+        "bench.emit_result({'metric': 'm', 'value': 1.5, 'n_gpus': w, 'argv': sys.argv[1:], 'pad': 'x' * 6000}, r)\n"
+        "for i in range(100):\n"
+        "    sys.stdout.write('late noise from rank %%d line %%d' %% (r, i) + ('\\n' if i %% 3 else ''))\n"
+        "    sys.stdout.flush()\n"
+        "sys.exit(3 if '--fail' in sys.argv and r == 1 else 0)\n" % root)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     driver = ("import sys; sys.path.insert(0, %r); import bench; bench.launch_ranks(sys.argv[1:], 2, script=%r)" % (root, str(script)))
     out = subprocess.run([sys.executable, "-c", driver, "--gpus", "2", "--steps", "3"], capture_output=True, text=True, timeout=300)
@@ -331,8 +339,10 @@ def test_bench_launches_its_own_ranks(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     import json
     last = json.loads(lines[-1])
-    assert last["n_gpus"] == 2 and last["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert out.stdout.endswith(lines[-1] + "\n")
+    assert last["n_gpus"] == 2 and last["argv"] == ["--gpus", "2", "--steps", "3"] and last["pad"] == "x" * 6000
     assert any("noise from rank 1" in l for l in lines[:-1])
+    assert sum('"metric"' in l for l in lines) == 1
     bad = subprocess.run([sys.executable, "-c", driver, "--fail"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
 
