@@ -78,6 +78,8 @@
  *   RSX_NO_PACKED_KEYS=1    rank sorts without a histogram go by byte columns only: neither the keys' packed varying bits nor, for
  *                           floats on a grid, their fixed-point integers are tried (SegCtl::compact);
  *   RSX_NO_UNSTABLE=1       the MSB passes of a sort without a histogram rank per wave (stable) as every other pass does;
+ *   RSX_NO_LOG=1            8-byte keys never go by (bit length, mantissa) digits (rsx_info.hybrid never 6; rsx_logroute.hpp);
+ *                           RSX_LOG_MIN_LOG2=k (tests): that route from 2^k keys on (default 24, at least 20);
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,
@@ -132,7 +134,12 @@ typedef struct rsx_info {
 	                           has PROVED the input unsorted and which columns are kept (the two facts radix_sort.hpp:60-70
 	                           takes from the histogram; columns the sample found constant are checked on every key by
 	                           the first pass), both passes write into slots, the bucket sizes come off the look-back
-	                           chains (large arrays; blocking keys-only, rank and key + payload sorts).  The
+	                           chains (large arrays; blocking keys-only, rank and key + payload sorts);
+	                           6: 8-byte keys whose magnitudes spread where their bytes do not (Zipf-like keys): the keys
+	                           below 2^12 are counted and written out, the others go by (bit length, leading mantissa bits)
+	                           into buckets of exactly counted sizes, by the next eight bits into slots, and through leaves
+	                           (rsx_logroute.hpp; the pre-sorted exit and the kept columns come from that route's own
+	                           one-read histogram kernel, exactly).  The
 	                           result and the returned buffer are the same whichever it is. */
 } rsx_info;
 

@@ -15,6 +15,7 @@
 #include "rsx_pass16.hpp"
 #include "rsx_pass32.hpp"
 #include "rsx_leafc.hpp"
+#include "rsx_logroute.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -133,6 +134,8 @@ struct Env {
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
+	bool no_log = false;             // RSX_NO_LOG=1: 8-byte keys never take the (bit length, mantissa) digits of rsx_logroute.hpp (rsx_info.hybrid never 6)
+	unsigned log_min_log2 = 24;      // RSX_LOG_MIN_LOG2: ... from 2^this keys on (tests: 20)
 	void load()
 	{
 		auto is_set = [](const char *name) { return getenv(name) != nullptr; };
@@ -198,6 +201,10 @@ struct Env {
 		leaf_grid = 65536;
 		if (const char *e = getenv("RSX_LEAF_GRID"))
 			leaf_grid = std::max(256, std::min(65536, atoi(e)));
+		no_log = is_one("RSX_NO_LOG");
+		log_min_log2 = 24;
+		if (const char *e = getenv("RSX_LOG_MIN_LOG2"))
+			log_min_log2 = (unsigned)std::max(20, std::min(29, atoi(e)));
 		two_level_min_log2 = 27;
 		if (const char *e = getenv("RSX_TWO_LEVEL_MIN_LOG2")) {
 			const int v = atoi(e);
@@ -347,6 +354,10 @@ struct Ctx {
 	u32 slack_mean = 0;   // the mean number of keys of a level-2 slot of the sort being enqueued (n / 65536: pass16a_wanted)
 	DevBuf slack1_v;    // ... and of as many payloads (pairs_blind)
 	DevBuf slack1;      // sorts without a histogram (sort_keys_blind): the level-1 pass's 256 slots of slack1_cap keys
+	DevBuf logb;        // rsx_logroute.hpp: [LogCtl][LogTabs][level-2 cursors 2 x 65536][level-2 tiles]
+	DevBuf logslots;    // ... the level-2 slots (four bytes per key)
+	LogCtl *host_logctl = nullptr;   // pinned: the control block as the device left it
+	hipEvent_t log_ev = nullptr;
 	u32 slack1_cap = 0;
 	u32 slack1_lo = 0;  // ... of which the first slack1_lo lie in the caller's second buffer (keys-only sorts; 0: all in slack1)
 	// ... sorts to go before the next attempt, doubled by every attempt that is called off; per kind of sort (4- / 8-byte keys,
@@ -435,6 +446,14 @@ struct Ctx {
 		seg.release();
 		slack.release();
 		slack1.release();
+		logb.release();
+		logslots.release();
+		if (host_logctl)
+			(void)hipHostFree(host_logctl);
+		host_logctl = nullptr;
+		if (log_ev)
+			(void)hipEventDestroy(log_ev);
+		log_ev = nullptr;
 		slack1_v.release();
 		slack_v.release();
 		vasync.release();
@@ -2112,6 +2131,108 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	return RSX_OK;
 }
 
+// ---- 8-byte keys by (bit length, mantissa) digits: rsx_logroute.hpp ----------------------------------------------------------
+// Tried where the sorts without a histogram do not go (their sample said no, or they are backing off): the route's own sample
+// says at once whether it is worth the histogram; everything behind it is device-scheduled and the verdict is read once.
+template <typename KT> bool log_wanted(Ctx &c, size_t n, const KT *src, const KT *aux)
+{
+	if constexpr (sizeof(KT) != 8)
+		return false;
+	if (env().no_log || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() || c.small.external || env().no_speculation)
+		return false;
+	if (n < ((size_t)1 << env().log_min_log2) || n > ((size_t)1 << 29))
+		return false;
+	return ((((uintptr_t)src) & 15) | (((uintptr_t)aux) & 63)) == 0;   // (16-byte loads of the input, 64-byte atoms into aux)
+}
+
+template <typename KT>
+int sort_keys_log(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **result, rsx_info *info, int *done)
+{
+	*done = 0;
+	if constexpr (sizeof(KT) == 8) {
+		typedef LogP2Cfg P2;
+		const size_t tiles_cap = n / P2::TILE + 257;
+		const size_t cur2_off = sizeof(LogCtl), tabs_off = cur2_off + 2 * 65536 * sizeof(u32);
+		const size_t tiles_off = (tabs_off + sizeof(LogTabs) + 255) & ~(size_t)255;
+		const size_t zero_bytes = tabs_off + offsetof(LogTabs, offs_small);
+		const size_t l2_cap = n + n / 8 + (size_t)65536 * 700;   // level-2 slots: values (rsx_log_plan_kernel checks the exact sum)
+		if (c.logb.ensure(tiles_off + tiles_cap * sizeof(LogTile)) != RSX_OK ||
+		    c.logslots.ensure((l2_cap + P2::TILE + 64) * sizeof(u32)) != RSX_OK) {
+			(void)hipGetLastError();
+			return RSX_OK;   // (no room: the ordinary path)
+		}
+		if (!c.host_logctl)
+			HIP_TRY(hipHostMalloc((void **)&c.host_logctl, sizeof(LogCtl), hipHostMallocDefault));
+		if (!c.log_ev)
+			HIP_TRY(hipEventCreateWithFlags(&c.log_ev, hipEventDisableTiming));
+		LogCtl *ctl = (LogCtl *)c.logb.p;
+		u32 *cur2 = (u32 *)((char *)c.logb.p + cur2_off);
+		LogTabs *tabs = (LogTabs *)((char *)c.logb.p + tabs_off);
+		LogTile *tiles = (LogTile *)((char *)c.logb.p + tiles_off);
+		u32 *slots = (u32 *)c.logslots.p;
+		const size_t pmark = prof_mark();
+		HIP_TRY(hipMemsetAsync(c.logb.p, 0, zero_bytes, c.stream));
+		hipLaunchKernelGGL((rsx_log_sample_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl);
+		{
+			ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
+			hipLaunchKernelGGL((rsx_log_hist_kernel<KT>), dim3(512), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl, tabs);
+		}
+		hipLaunchKernelGGL(rsx_log_plan_kernel, dim3(1), dim3(1024), 0, c.stream, ctl, tabs, tiles, (u64)n, (u32)n, (u32)l2_cap,
+		                   (u32)tiles_cap, (u32)P2::TILE, (u32)P2::GRID, (Plan *)nullptr, c.dev_host_plan);
+		{
+			ProfScope prof(1, 0, c.stream);
+			hipLaunchKernelGGL((rsx_log_pass1_kernel<KT>), dim3(256), dim3(LogP1Cfg::BLOCK), 0, c.stream, (const KT *)src, (u64)n, aux,
+			                   ctl, tabs, ka);
+		}
+		{
+			ProfScope prof(3, 0, c.stream);
+			hipLaunchKernelGGL((rsx_log_pass2_kernel<KT>), dim3(P2::GRID), dim3(P2::BLOCK), 0, c.stream, (const KT *)aux, slots,
+			                   (const LogTile *)tiles, ctl, (const LogTabs *)tabs, cur2, (u32)l2_cap);
+		}
+		{
+			ProfScope prof(2, 0, c.stream);
+			hipLaunchKernelGGL((rsx_log_fill_kernel<KT>), dim3(2048), dim3(256), 0, c.stream, src, aux, (const LogCtl *)ctl,
+			                   (const LogTabs *)tabs, ka);
+			hipLaunchKernelGGL((rsx_log_leaf_kernel<KT>), dim3(65536), dim3(LogLeafCfg::BLOCK), 0, c.stream, src, aux,
+			                   (const u32 *)slots, (const LogCtl *)ctl, (const LogTabs *)tabs, (const u32 *)cur2, ka);
+		}
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(c.host_logctl, ctl, sizeof(LogCtl), hipMemcpyDeviceToHost, c.stream));
+		HIP_TRY(hipEventRecord(c.log_ev, c.stream));
+		HIP_TRY(hipEventSynchronize(c.log_ev));
+		const LogCtl h = *c.host_logctl;
+		if (!h.go || h.fail || (!h.ok && !h.sorted)) {
+			prof_called_off(pmark, c.stream);   // (not this route's keys, or an attempt that was lost: the ordinary path)
+			return RSX_OK;
+		}
+		const Plan plan = *c.host_plan;
+		info_from_plan(info, plan);
+		*done = 1;
+		if (h.sorted) {   // radix_sort.hpp:60-62
+			prof_called_off(pmark, c.stream, 1);
+			prof_called_off(pmark, c.stream, 2);
+			prof_called_off(pmark, c.stream, 3);
+			if (info) {
+				info->early_exit = 2;
+				info->ncols = 0;
+			}
+			*result = src;
+			return RSX_OK;
+		}
+		const u64 nsmall = h.nsmall, nbig = n - nsmall;
+		prof_rebook(pmark, c.stream, 1, (u64)n * sizeof(KT) + nbig * sizeof(KT));
+		prof_rebook(pmark, c.stream, 3, nbig * (sizeof(KT) + 4));
+		prof_rebook(pmark, c.stream, 2, nbig * (4 + sizeof(KT)) + nsmall * sizeof(KT));
+		KT *final = (plan.ncols & 1) ? aux : src;   // radix_sort.hpp:92
+		*result = final;
+		if (info) {
+			info->result_in_aux = final == aux;
+			info->hybrid = 6u;
+		}
+	}
+	return RSX_OK;
+}
+
 // ---- keys only -------------------------------------------------------------------
 template <typename KT>
 int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int order, void **result, rsx_info *info);
@@ -2197,6 +2318,18 @@ int sort_keys_device_impl(Ctx &c, KT *src, KT *aux, size_t n, int dtype, int ord
 			int done = 0;
 			KT *res = nullptr;
 			RSX_TRY(sort_keys_blind<KT>(c, src, aux, n, ka, &res, info, &done));
+			if (done) {
+				*result = res;
+				return RSX_OK;
+			}
+		}
+	}
+	if constexpr (sizeof(KT) == 8) {
+		// 8-byte keys the byte columns do not spread (heavy-tailed magnitudes): digits of (bit length, mantissa), rsx_logroute.hpp
+		if (log_wanted<KT>(c, n, src, aux)) {
+			int done = 0;
+			KT *res = nullptr;
+			RSX_TRY(sort_keys_log<KT>(c, src, aux, n, ka, &res, info, &done));
 			if (done) {
 				*result = res;
 				return RSX_OK;

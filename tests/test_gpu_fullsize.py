@@ -16,8 +16,8 @@ torch = pytest.importorskip("torch")
 
 N = 1 << 28
 # the routes (rsx_info.hybrid) BASELINE.json's configurations take at this size: 5 = no histogram, two MSB passes into slots and
-# leaves; 0 = histogram and one pass per kept column (the skewed inputs); DESIGN.md 4b / 4c
-ZIPF_ROUTE = 0
+# leaves; 6 = 8-byte keys by (bit length, mantissa) digits -- the Zipf-like keys (rsx_logroute.hpp); DESIGN.md 4b / 4c / 4g
+ZIPF_ROUTE = 6
 RANK_ROUTE = {"random_bits": 5, "uniform_pm1": 5, "duplicate_heavy": 5}   # (duplicate_heavy: by its packed varying bits, SegCtl::compact; uniform_pm1: floats on a grid as fixed-point integers, SegCtl::ckind)
 SIGN64 = -(1 << 63)
 SIGN32 = -(1 << 31)
@@ -71,20 +71,27 @@ def test_cfg3_u64_column_skipping(mask, cols, in_aux):
 
 
 def test_cfg3_u64_zipf_like():
-    """SURVEY.md 8d cfg 3 (iv): key = 2^(b-1) + low bits, b = 1 + (r >> 58) % 40 -- heavy duplicates, skewed high digits, P = 5."""
-    r = torch.empty(N, dtype=torch.int64, device="cuda")
-    rsa.fill_splitmix(r, seed=33)
-    b = 1 + (((r >> 58) & 63) % 40)
-    one = torch.ones_like(r)
-    keys = (one << (b - 1)) + (r & ((one << (b - 1)) - 1))
-    del r, b, one
+    """SURVEY.md 8d cfg 3 (iv): key = 2^(b-1) + low bits, b = 1 + (r >> 58) % 40 -- heavy duplicates, skewed high digits, P = 5.
+    The keys are made on the HOST (the oracle's splitmix64 + numpy, integer-only) and the whole result is compared with the oracle's
+    (rs_sort_main restated, radix_sort.hpp:31-93): bit for bit, the returned buffer and the kept columns included."""
+    r = ol.splitmix_fill(N, ol.U64, 33)
+    one = np.uint64(1)
+    b = one + ((r >> np.uint64(58)) % np.uint64(40))
+    a = (one << (b - one)) + (r & ((one << (b - one)) - one))
+    del r, b
+    keys = torch.from_numpy(a.view(np.int64)).cuda()
     before = _checksums(keys)
     aux = torch.empty_like(keys)
     res, info = rsa.radix_sort(keys, aux, dtype=rsa.U64)
     torch.cuda.synchronize()
     assert info.ncols == 5 and info.result_in_aux == 1
-    assert info.hybrid == ZIPF_ROUTE, info.hybrid                       # dominant top digits: no slot scheme takes them
+    assert info.hybrid == ZIPF_ROUTE, info.hybrid                       # (bit length, mantissa) digits: rsx_logroute.hpp
     assert _sorted_unsigned64(res) and _checksums(res) == before
+    got = res.cpu().numpy().view(np.uint64)
+    del keys, aux, res
+    want, want_aux, winfo = ol.oracle_sort(a, ol.U64)
+    assert want_aux == 1 and list(winfo.cols[:winfo.ncols]) == info.kept_columns()
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("variant", ["random_bits", "uniform_pm1", "duplicate_heavy"])
