@@ -317,6 +317,7 @@ def main():
         rsa.fill_splitmix(t, seed=1 + b, first_index=rank * n)
         batches.append(t)
     engine = multi.HipEngine(rsa.U32)
+    engine.host_marks = {}
     cap = n + n // 4 if sharded else n
     scratch = {"aux": torch.empty(cap, dtype=torch.int32, device=dev)}
     if sharded:
@@ -490,7 +491,8 @@ def main():
             # pass on the device) and to submit the exchange and the local sorts (nothing of it waits for the device)
             out["host"] = {"ms_split_and_counts_last_step": last[1]["host_ms_split_and_counts"],
                            "ms_submit_exchange_and_sorts_last_step": last[1]["host_ms_submit_exchange_and_sorts"],
-                           "chunks": last[1].get("chunks"), "heavy_digits": last[1].get("heavy_digits")}
+                           "chunks": last[1].get("chunks"), "heavy_digits": last[1].get("heavy_digits"),
+                           "split_and_counts_parts_ms": dict(engine.host_marks)}
         if sharded and isinstance(last[1], dict):
             out["multi"] = {"phases_last_step_max_over_ranks_ms": phase_max, "safe_mode": bool(last[1].get("safe_mode")),
                             "safe_why": last[1].get("safe_why"), "overlap_stream": last[1].get("overlap_stream"),

@@ -79,7 +79,7 @@
  *                           floats on a grid, their fixed-point integers are tried (SegCtl::compact);
  *   RSX_NO_UNSTABLE=1       the MSB passes of a sort without a histogram rank per wave (stable) as every other pass does;
  *   RSX_NO_LOG=1            8-byte keys never go by (bit length, mantissa) digits (rsx_info.hybrid never 6; rsx_logroute.hpp);
- *                           RSX_LOG_MIN_LOG2=k (tests): that route from 2^k keys on (default 24, at least 20);
+ *                           RSX_LOG_MIN_LOG2=k (tests): that route from 2^k keys on (default: from 24 Mi keys; at least 2^20);
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,

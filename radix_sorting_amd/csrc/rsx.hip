@@ -134,8 +134,9 @@ struct Env {
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
+	unsigned probe = 0;              // RSX_PROBE=bits (measurements only): 1 the leaf table of a sort without a histogram in reverse slot order
 	bool no_log = false;             // RSX_NO_LOG=1: 8-byte keys never take the (bit length, mantissa) digits of rsx_logroute.hpp (rsx_info.hybrid never 6)
-	unsigned log_min_log2 = 24;      // RSX_LOG_MIN_LOG2: ... from 2^this keys on (tests: 20)
+	unsigned log_min_log2 = 0;       // RSX_LOG_MIN_LOG2: ... from 2^this keys on (tests: 20; default: from 24 Mi keys)
 	void load()
 	{
 		auto is_set = [](const char *name) { return getenv(name) != nullptr; };
@@ -201,8 +202,11 @@ struct Env {
 		leaf_grid = 65536;
 		if (const char *e = getenv("RSX_LEAF_GRID"))
 			leaf_grid = std::max(256, std::min(65536, atoi(e)));
+		probe = 0;
+		if (const char *e = getenv("RSX_PROBE"))
+			probe = (unsigned)atoi(e);
 		no_log = is_one("RSX_NO_LOG");
-		log_min_log2 = 24;
+		log_min_log2 = 0;
 		if (const char *e = getenv("RSX_LOG_MIN_LOG2"))
 			log_min_log2 = (unsigned)std::max(20, std::min(29, atoi(e)));
 		two_level_min_log2 = 27;
@@ -1423,7 +1427,7 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			if (c.slack_cap <= (u32)L2k::CAP)
 				RSX_LAUNCH_L16(rsx_leaf16_kernel, L2k, grid_1);
 			else
-				RSX_LAUNCH_L16(rsx_leaf16_kernel, L5k, grid_1);
+				RSX_LAUNCH_L16(rsx_leaf16_kernel, L5k, (env().probe & 2u) ? 16384u : grid_1);
 #undef RSX_LAUNCH_L16
 			typedef typename LeafShapes<KT>::Fit F_;
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F_, uint16_t, true>), dim3(4096), dim3(F_::BLOCK), 0, c.stream, src, aux,
@@ -1570,15 +1574,18 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	if constexpr (sizeof(KT) == 4) {
 		if (dense && pass16a_wanted<KT>(c)) {
 			// ... and with whole 64-byte atoms: a workgroup takes a range of tiles and carries what does not fill an atom
-			const unsigned pgrid = 512;
+			const unsigned pgrid = (env().probe & 2u) ? 192 : 512;   // (the probe: a bucket's tiles shared by at most four workgroups, as in the whole pass)
+			// (RSX_PROBE & 2, a measurement with a WRONG result: the first quarter of the level-1 buckets only, here and in the leaves)
+			const u32 *bt = (env().probe & 2u) ? (const u32 *)((char *)c.seg.p + c.seg_btile_off) : nullptr;
+			const u32 bhi = (env().probe & 2u) ? 64u : 256u;
 			if (plain)
 				hipLaunchKernelGGL((rsx_pass16a_kernel<KT, DIG_PLAIN>), dim3(pgrid), dim3(Pass16aCfg::BLOCK), 0, c.stream, (const KT *)aux,
 				                   (const KT *)sa.kin_hi, sa.lo_slots, (unsigned short *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
-				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
+				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka, bt, 0u, bhi);
 			else
 				hipLaunchKernelGGL((rsx_pass16a_kernel<KT, DIG_GENERIC>), dim3(pgrid), dim3(Pass16aCfg::BLOCK), 0, c.stream, (const KT *)aux,
 				                   (const KT *)sa.kin_hi, sa.lo_slots, (unsigned short *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
-				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
+				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka, bt, 0u, bhi);
 			HIP_TRY(hipGetLastError());
 			return RSX_OK;
 		}
@@ -2083,7 +2090,8 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	RSX_TRY(launch_seg_pass<KT>(c, lo ? aux : nullptr, nullptr, n, ka, -2, 2));
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
-	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, atoms ? 2u : 1u);
+	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1,
+	                   (atoms ? 2u : 1u) | ((env().probe & 1u) << 8));
 	HIP_TRY(hipGetLastError());
 	if (c.seg_ev)
 		HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
@@ -2140,7 +2148,13 @@ template <typename KT> bool log_wanted(Ctx &c, size_t n, const KT *src, const KT
 		return false;
 	if (env().no_log || !hybrid_enabled() || !c.fast || capture_armed() || verify_mode() || c.small.external || env().no_speculation)
 		return false;
-	if (n < ((size_t)1 << env().log_min_log2) || n > ((size_t)1 << 29))
+	// from 24 Mi keys: Zipf-like keys (BASELINE.json's cfg 3 (iv)) against one pass per kept column, one box, tools/log_sizes.py --
+	// 16 Mi 0.49 against 0.43 ms (65536 leaf workgroups are a fixed 0.24 ms), 24 Mi 0.55 against 0.61, 32 Mi 0.63 against 0.78,
+	// 64 Mi 0.89 against 1.46, 128 Mi 1.43 against 2.65, 256 Mi 2.46 against 5.09 (profiles/r06/log_sizes.txt)
+	const size_t floor_keys = env().log_min_log2 ? (size_t)1 << env().log_min_log2 : (size_t)3 << 23;
+	// (up to 2^28 + 2^24 keys: a level-1 bucket must fit 256 leaves of 5120 values -- the heaviest digits of Zipf-like keys hold
+	// 1 / 256 of the array -- and larger arrays would pay for the histogram before the plan kernel says no)
+	if (n < floor_keys || n > ((size_t)17 << 24))
 		return false;
 	return ((((uintptr_t)src) & 15) | (((uintptr_t)aux) & 63)) == 0;   // (16-byte loads of the input, 64-byte atoms into aux)
 }
@@ -2187,7 +2201,7 @@ int sort_keys_log(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **resul
 		{
 			ProfScope prof(3, 0, c.stream);
 			hipLaunchKernelGGL((rsx_log_pass2_kernel<KT>), dim3(P2::GRID), dim3(P2::BLOCK), 0, c.stream, (const KT *)aux, slots,
-			                   (const LogTile *)tiles, ctl, (const LogTabs *)tabs, cur2, (u32)l2_cap);
+			                   (const LogTile *)tiles, ctl, (const LogTabs *)tabs, cur2, (u32)l2_cap, ka);
 		}
 		{
 			ProfScope prof(2, 0, c.stream);
@@ -2783,7 +2797,8 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 		                   (const u32 *)nullptr, sa);
 	}
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream, (const u32 *)(base0 + 256), (const u32 *)btile,
-	                   (const u64 *)c.ghist(), (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1, 1u);
+	                   (const u64 *)c.ghist(), (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1,
+	                   1u | ((env().probe & 1u) << 8));
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	{

@@ -510,8 +510,9 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
                                                                  const u64 *__restrict__ ghist, const Plan *__restrict__ plan,
                                                                  SegCtl *__restrict__ ctl, LeafSeg *__restrict__ segtab,
                                                                  u32 slack_cap, SegCtl *host_ctl,
-                                                                 const u64 *__restrict__ off1_given = nullptr, u32 blind = 0)
+                                                                 const u64 *__restrict__ off1_given = nullptr, u32 blind_ = 0)
 {
+	const u32 blind = blind_ & 0xFFu, rev = blind_ >> 8;   // (rev: the table in reverse slot order -- the leaves then start with the slots written last)
 	if (plan->hyb != HYB_TWO_LEVEL || (blind && ctl->blind != BLIND_GO))
 		return;
 	typedef StatusBits<ST> SB_;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
 	ls.cnt = c <= slack_cap ? c : 0u;   // (an overflowed slot: the attempt is discarded anyway)
 	ls.ncols = (ncols - 2) | (back << 16);   // (the upper half: how many of the values lie at the slot's end, rsx_leaf16_kernel)
 	ls.slot = b * 256 + d + 1;
-	segtab[b * 256 + d] = ls;   // (the buckets' order in the table makes no difference to the leaves: tools/blind_ab.py)
+	segtab[rev ? 65535u - (b * 256 + d) : b * 256 + d] = ls;
 }
 
 // ---- sorts without a histogram ("blind") ------------------------------------------------------------------------------------

@@ -222,8 +222,13 @@ __global__ __launch_bounds__(1024, 2) void rsx_log_hist_kernel(const KT *__restr
 		const u64 i = base + lane;
 		const bool act = i < nvec;
 		vec_t x = {0, 0};
-		if (act)
+		if (act) {
+#ifdef LOG_NT_HIST_LOAD
+			x = __builtin_nontemporal_load(&vp[i]);
+#else
 			x = vp[i];
+#endif
+		}
 		// the key behind this lane's pair: the next lane's first (a DPP wave shift); the wave's last lane, and the lane in front
 		// of an odd array's last key, load it
 		const bool has_next = act && 2 * i + 2 < n;
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(LogP1Cfg::BLOCK, 4) void rsx_log_pass1_kernel(const
 // tile table, carries per digit the up to fifteen values that do not fill a 64-byte atom, flushes them to the slot's back when
 // the bucket changes or the range ends.  The digit: eight bits at the bucket's own shift.
 struct LogP2Cfg {
-	static constexpr int BLOCK = 1024, KPT = 12, TILE = BLOCK * KPT, SB = 6;
+	static constexpr int BLOCK = 1024, KPT = 12, TILE = BLOCK * KPT, SB = 4;
 	static constexpr u32 ATOM = 16, VEC = 4;
 	static constexpr int STAGE = TILE + 256 * 6;
 	static constexpr int GRID = 512;
@@ -762,7 +767,7 @@ template <typename KT>
 __global__ __launch_bounds__(LogP2Cfg::BLOCK, 8) void rsx_log_pass2_kernel(const KT *__restrict__ kin, u32 *__restrict__ kout,
                                                                           const LogTile *__restrict__ tiles,
                                                                           LogCtl *__restrict__ ctl, const LogTabs *__restrict__ tabs,
-                                                                          u32 *__restrict__ cur2, u32 dump)
+                                                                          u32 *__restrict__ cur2, u32 dump, KdfArgs<KT> ka)
 {
 	typedef LogP2Cfg C;
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
@@ -839,7 +844,11 @@ __global__ __launch_bounds__(LogP2Cfg::BLOCK, 8) void rsx_log_pass2_kernel(const
 				const vec_t *vp = (const vec_t *)p + tid;
 #pragma unroll
 				for (int i = 0; i < KPT / 2; ++i) {
+#ifdef LOG_NT_P2_LOAD
+					const vec_t v = __builtin_nontemporal_load(&vp[i * BLOCK]);
+#else
 					const vec_t v = vp[i * BLOCK];
+#endif
 					keep[2 * i] = v[0];
 					keep[2 * i + 1] = v[1];
 				}
@@ -851,8 +860,11 @@ __global__ __launch_bounds__(LogP2Cfg::BLOCK, 8) void rsx_log_pass2_kernel(const
 				}
 			}
 		}
-		// (the level-1 array holds the caller's element images: derived again here; the bits above B do not reach the digit
+		// (the level-1 array holds the caller's element images: derived again here, once; the bits above B do not reach the digit
 		// or the value -- the digit lies below bit 44, the value is the low word)
+#pragma unroll
+		for (int r = 0; r < KPT; ++r)
+			keep[r] = kdf_apply(keep[r], ka);
 		u32 rk[KPT / 2];
 		auto count = [&](auto full_c) {
 			constexpr bool FULL = decltype(full_c)::value;
@@ -1009,45 +1021,32 @@ struct LogLeafCfg {
 };
 
 template <typename KT>
-__global__ __launch_bounds__(LogLeafCfg::BLOCK, 4) void rsx_log_leaf_kernel(KT *__restrict__ src, KT *__restrict__ aux,
+__global__ __launch_bounds__(LogLeafCfg::BLOCK, 5) void rsx_log_leaf_kernel(KT *__restrict__ src, KT *__restrict__ aux,
                                                                            const u32 *__restrict__ slots,
                                                                            const LogCtl *__restrict__ ctl,
                                                                            const LogTabs *__restrict__ tabs,
-                                                                           const u32 *__restrict__ cur2, KdfArgs<KT> ka)
+                                                                           const u32 *__restrict__ cur2, KdfArgs<KT> ka,
+                                                                           u32 d1_lo = 0, u32 d1_hi = 256)   // (the probe: a range of level-1 digits)
 {
 	typedef LogLeafCfg C;
 	constexpr int BLOCK = C::BLOCK, NK = C::NK, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES, S = C::S;
-	if (ctl->ok != 1u || ctl->fail)
-		return;
+	// everything the leaf needs to find its values is requested at once: the control block, the slot's two cursors, those of the
+	// slots before it in its bucket, the bucket's row of the tables (one round trip in front of the values' instead of four)
 	const u32 d1 = blockIdx.x >> 8, d2 = blockIdx.x & 255u;
-	if (d1 >= ctl->ndig)
-		return;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const u32 ok = ctl->ok, lost = ctl->fail, ndig = ctl->ndig, m = ctl->m, B = ctl->B, ncols = ctl->ncols;
+	const u64 key0 = ((u64)ctl->key0_hi << 32) | ctl->key0_lo;
 	const u32 front = cur2[blockIdx.x], back = cur2[65536u + blockIdx.x], cnt = front + back;
-	if (cnt == 0)
-		return;
+	u32 c_before = tid < d2 ? cur2[d1 * 256u + tid] + cur2[65536u + d1 * 256u + tid] : 0u;
+	const u32 cap = tabs->cap2[d1], base2 = tabs->base2[d1], out1 = tabs->out1[d1];
+	if (ok != 1u || lost || d1 >= ndig || d1 < d1_lo || d1 >= d1_hi || cnt == 0 || cnt > (u32)C::CAP)
+		return;   // (cnt > CAP cannot happen: a slot that would hold more has set LogCtl::fail)
+	const u32 *q = slots + base2 + d2 * cap;
 	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
 	__shared__ __attribute__((aligned(16))) u32 stage[16 * S + 64];
-	__shared__ u32 ws[NW], wmax[NW];
-	// the sizes of the slots before this one in its bucket
-	u32 pre;
-	{
-		u32 c = tid < d2 ? cur2[d1 * 256u + tid] + cur2[65536u + d1 * 256u + tid] : 0u;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1)
-			c += (u32)__shfl_xor((int)c, o);
-		if (lane == 0)
-			ws[wid] = c;
-		__syncthreads();
-		pre = ws[0] + ws[1] + ws[2] + ws[3];
-		__syncthreads();
-	}
-	const u32 m = ctl->m, cap = tabs->cap2[d1];
+	__shared__ u32 ws[NW], wmax[NW], wpre[NW];
 	const u32 blen = log_blen(d1, m), s2 = log_shift2(d1, m);
 	const u32 nb = s2 < 12u ? s2 : 12u, bsh = s2 - nb, bmask = (1u << nb) - 1u;
-	const u32 *q = slots + tabs->base2[d1] + d2 * cap;
-	if (cnt > (u32)C::CAP)
-		return;   // (cannot happen: a slot that would hold more has set LogCtl::fail)
 	auto at = [](u32 p) { return (p & 15u) * (u32)S + (p >> 4); };
 	u32 kv[NK];
 #pragma unroll
@@ -1055,6 +1054,12 @@ __global__ __launch_bounds__(LogLeafCfg::BLOCK, 4) void rsx_log_leaf_kernel(KT *
 		const u32 e = tid + BLOCK * j;
 		kv[j] = e < front ? q[e] : e < cnt ? q[cap - LOG_BACK2 + (e - front)] : 0u;
 	}
+	// (the sizes of the slots before this one in its bucket, summed: through the first barrier the leaf has anyway)
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		c_before += (u32)__shfl_xor((int)c_before, o);
+	if (lane == 0)
+		wpre[wid] = c_before;
 	{
 		const u32x4 zero = {0, 0, 0, 0};
 #pragma unroll
@@ -1062,8 +1067,12 @@ __global__ __launch_bounds__(LogLeafCfg::BLOCK, 4) void rsx_log_leaf_kernel(KT *
 			((u32x4 *)cell)[tid + BLOCK * j] = zero;
 	}
 	__syncthreads();
+	// (fewer than twelve undecided bits: every value has 2^rep bins, one per lane class -- equal values are equal keys, any order
+	// among them will do, and the lanes of a wave that hold the same value no longer queue at one LDS word: the leaves of bit
+	// lengths 13 .. 16 of 2^28 Zipf-like keys, two to sixteen values per leaf, took 0.165 ms against 0.093 for the next four)
+	const u32 rep = 12u - nb, repmask = (1u << rep) - 1u;
 	auto cell_of = [&](u32 v, bool valid, u32 &sh) -> u32 * {
-		const u32 bin = (v >> bsh) & bmask;
+		const u32 bin = (((v >> bsh) & bmask) << rep) | (lane & repmask);
 		sh = (bin & 1u) << 4;
 		return &cell[valid ? bin >> 1 : NCELLW + lane];
 	};
@@ -1182,10 +1191,11 @@ __global__ __launch_bounds__(LogLeafCfg::BLOCK, 4) void rsx_log_leaf_kernel(KT *
 	{
 		// what every key of the leaf has above its low word: the first key's constant top bits, the leading one, the mantissa
 		// bits and the level-2 digit where they lie above bit 32
-		const u64 lowmask = ((u64)1 << ctl->B) - 1u;
-		u64 up = (((u64)ctl->key0_hi << 32) | ctl->key0_lo) & ~lowmask;
+		const u64 lowmask = ((u64)1 << B) - 1u;
+		u64 up = key0 & ~lowmask;
 		up |= (((u64)1 << (blen - 1u)) | ((u64)(d1 & ((1u << m) - 1u)) << (blen - 1u - m)) | ((u64)d2 << s2)) & ~(u64)0xFFFFFFFFu;
-		KT *o = ((ctl->ncols & 1u) ? aux : src) + tabs->out1[d1] + pre;   // radix_sort.hpp:92
+		const u32 pre = wpre[0] + wpre[1] + wpre[2] + wpre[3];
+		KT *o = ((ncols & 1u) ? aux : src) + out1 + pre;   // radix_sort.hpp:92
 		for (u32 i0 = 2 * tid; i0 < cnt; i0 += 2 * BLOCK) {
 			KT kk[2];
 			kk[0] = kdf_invert((KT)(up | stage[at(i0)]), ka);

@@ -274,11 +274,19 @@ def split_plan(shard, part, engine, group, world, tmp=None, slices=1):
     # every byte column's counts in ONE read of the shard, one all-gather: the byte to split by is the highest one that
     # varies over ALL ranks (a byte that is constant everywhere would send every key to one rank) -- every rank sees the
     # same gathered counts and decides the same, without a trial pass per constant byte
+    import time
+    marks = getattr(engine, "host_marks", None)      # (bench.py: where the host's share of the step goes)
+    t0 = time.perf_counter()
     slices = max(1, int(slices))
     bounds = slice_bounds(shard.numel(), slices)
     halls = [engine.histogram(shard[bounds[i]:bounds[i + 1]]) if bounds[i + 1] > bounds[i]
              else torch.zeros(engine.kb * 256, dtype=torch.int64, device=shard.device) for i in range(slices)]
+    t1 = time.perf_counter()
     every_s = gather(torch.cat(halls) if slices > 1 else halls[0]).reshape(world, slices, engine.kb, 256)
+    t2 = time.perf_counter()
+    if marks is not None:
+        marks["histogram_enqueue_ms"] = (t1 - t0) * 1e3
+        marks["gather_counts_ms"] = (t2 - t1) * 1e3      # (waits for the histogram kernel: one read of the shard)
     every = every_s.sum(axis=1)
     column = 0
     for c in range(engine.kb - 1, -1, -1):

@@ -60,9 +60,17 @@ def _check(a, dt, want_route, order=rsa.ASCENDING, what=""):
     return info
 
 
-@pytest.mark.parametrize("log2n", [24, 26])
-def test_cfg3_zipf_like_against_the_oracle(log2n):
+@pytest.mark.parametrize("log2n", [24, 25, 26])
+def test_cfg3_zipf_like_against_the_oracle(log2n, monkeypatch):
+    if log2n == 24:      # (16 Mi keys lie below the route's floor of 24 Mi keys, where one pass per column is as fast: lowered)
+        monkeypatch.setenv("RSX_LOG_MIN_LOG2", "20")
     _check(zipf_like(1 << log2n, 33), rsa.U64, LOG_ROUTE, what="2^%d" % log2n)
+
+
+def test_the_floor():
+    info = _check(zipf_like(1 << 24, 34), rsa.U64, None, what="2^24, default floor")
+    assert info.hybrid != LOG_ROUTE
+    _check(zipf_like(3 << 23, 34), rsa.U64, LOG_ROUTE, what="24 Mi, default floor")
 
 
 @pytest.mark.parametrize("n", [(1 << 20), (1 << 20) + 1, (1 << 21) + 12345, (3 << 20) - 7])
@@ -109,6 +117,17 @@ def test_the_window_of_bit_lengths(bmax, taken, monkeypatch):
     assert (info.hybrid == LOG_ROUTE) == taken, (bmax, info.hybrid)
 
 
+def test_derived_keys_that_are_not_the_element_images(monkeypatch):
+    """What spreads is the DERIVED key: complemented Zipf-like keys sorted descending, and negative doubles whose bit patterns,
+    complemented by the KDF (radix_sort_basic_kdf.hpp:32-46), are Zipf-like -- every kernel of the route must derive before it cuts."""
+    monkeypatch.setenv("RSX_LOG_MIN_LOG2", "20")
+    z = zipf_like(1 << 21, 15)
+    _check(~z, rsa.U64, LOG_ROUTE, order=rsa.DESCENDING, what="~zipf descending")
+    neg = ~z                                     # sign bit set, exponent field all ones above the varying bits ... as raw bits of doubles:
+    neg = (neg & np.uint64(0x800FFFFFFFFFFFFF)) | np.uint64(0x3FF0000000000000)   # finite negative doubles -(1.x): the KDF complements them
+    _check(neg, rsa.F64, None, what="negative doubles")
+
+
 def test_descending_and_switched_off(monkeypatch):
     monkeypatch.setenv("RSX_LOG_MIN_LOG2", "20")
     a = zipf_like(1 << 21, 13)
@@ -122,4 +141,4 @@ def test_descending_and_switched_off(monkeypatch):
 def test_whole_result_verified_on_the_device(monkeypatch):
     """RSX_VERIFY=2 brackets any route with the checksum kernel: sortedness and the multiset of keys, on the device."""
     monkeypatch.setenv("RSX_VERIFY", "2")
-    _check(zipf_like(1 << 24, 14), rsa.U64, LOG_ROUTE, what="RSX_VERIFY=2")
+    _check(zipf_like(1 << 25, 14), rsa.U64, LOG_ROUTE, what="RSX_VERIFY=2")

@@ -105,7 +105,7 @@ int main(int argc, char **argv)
 		CK(hipEventRecord(ev[3]));
 		rsx_log_pass1_kernel<KT><<<256, LogP1Cfg::BLOCK>>>(src, n, aux, ctl, tabs, ka);
 		CK(hipEventRecord(ev[4]));
-		rsx_log_pass2_kernel<KT><<<P2::GRID, P2::BLOCK>>>(aux, slots, tiles, ctl, tabs, cur2, (u32)l2_cap);
+		rsx_log_pass2_kernel<KT><<<P2::GRID, P2::BLOCK>>>(aux, slots, tiles, ctl, tabs, cur2, (u32)l2_cap, ka);
 		CK(hipEventRecord(ev[5]));
 		rsx_log_fill_kernel<KT><<<2048, 256>>>(src, aux, ctl, tabs, ka);
 		CK(hipEventRecord(ev[6]));
@@ -137,6 +137,18 @@ int main(int argc, char **argv)
 	if (!h.ok || h.fail) {
 		printf("the route did not run\n");
 		return 1;
+	}
+	if (getenv("LOG_PROBE_LEAF_RANGES")) {
+		// the leaves of four exponents at a time (a level-1 digit is (bit length - 13) << m | mantissa bits): where their time goes
+		for (u32 e0 = 0; (e0 << h.m) < h.ndig; e0 += 4) {
+			CK(hipEventRecord(ev[0]));
+			rsx_log_leaf_kernel<KT><<<65536, LogLeafCfg::BLOCK>>>(src, aux, slots, ctl, tabs, cur2, ka, e0 << h.m, (e0 + 4) << h.m);
+			CK(hipEventRecord(ev[1]));
+			CK(hipDeviceSynchronize());
+			float ms;
+			CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+			printf("  leaves of bit lengths %2u..%2u: %.3f ms\n", LOG_C + 1 + e0, LOG_C + 4 + e0, ms);
+		}
 	}
 	const KT *res = (h.ncols & 1) ? aux : src;
 	CK(hipMemset(chk, 0, 6 * 8));
