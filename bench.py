@@ -335,6 +335,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def checksums(t):
+        """order-independent sums of a batch (wrap-around int64): the keys' sum and the sum of key * (key >> 7)"""
+        return torch.stack([t.sum(dtype=torch.int64), (t * (t >> 7)).sum(dtype=torch.int64)])
+
+    # (the last step's input, summed before anything sorts it: its output must be the same keys -- a sorted array of OTHER keys
+    # passes a sortedness test, and round 5's one-rank forced exchange of 2^31 bytes delivered just that)
+    sums_in = checksums(batches[W + K - 1])
     for i in range(W):
         step(i)
     fence()
@@ -356,12 +363,17 @@ def main():
     res = last[0]
     flipped = res ^ torch.tensor(-2 ** 31, dtype=torch.int32, device=dev)
     ok = bool((flipped[1:] >= flipped[:-1]).all().item()) if res.numel() > 1 else True
+    sums_out = checksums(res)
     if sharded:
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
+        dist.all_reduce(sums_in, op=dist.ReduceOp.SUM)      # (int64, wrap-around: the ranks' keys move between ranks)
+        dist.all_reduce(sums_out, op=dist.ReduceOp.SUM)
     if not ok:
         raise SystemExit("bench: output of the last step is not sorted")
+    if not bool((sums_in == sums_out).all().item()):
+        raise SystemExit("bench: the output of the last step is sorted but does not hold the input's keys (checksums differ)")
     # per-phase GPU time of the LAST step, max over ranks (split / exchange / sort; the chunk pipeline overlaps the last two):
     # a first run on several GPUs should explain itself
     phase_max = None
@@ -443,7 +455,7 @@ def main():
                 ("%d x 2^%d u32 keys sharded by MSD digit, RCCL all-to-all-v, local LSD (BASELINE.json configs[4])"
                  % (world, log2n)),
                 "keys_per_gpu": n, "total_keys": n * world, "generator": "splitmix64 seed 1+batch",
-                "parallelism": "msd%d" % world if sharded else "1 gpu", "output_sorted": ok,
+                "parallelism": "msd%d" % world if sharded else "1 gpu", "output_sorted": ok, "output_checksums_match_input": True,
                 "passes": {0: "one scatter pass per kept column, LSB first (radix_sort.hpp:82-90)",
                            1: "one MSB scatter pass, then the other kept columns per bucket in LDS (README.md:647-650)",
                            2: "two MSB scatter passes, then the other kept columns per bucket in LDS (README.md:647-650)",

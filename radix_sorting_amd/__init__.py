@@ -62,6 +62,7 @@ ABI = [
     ("rsx_sort", _I, [_VP, _VP, _SZ, _I, _I, _PVP, _PINFO]),
     ("rsx_release_stream", None, [_VP]),
     ("rsx_sort_inplace_async", _I, [_VP, _VP, _SZ, _I, _I, _VP]),
+    ("rsx_sort_inplace_async_hint", _I, [_VP, _VP, _SZ, _I, _I, _VP, C.c_uint32]),
     ("rsx_sort_inplace_async_ws", _I, [_VP, _VP, _SZ, _I, _I, _VP, _SZ, _VP]),
     ("rsx_workspace_bytes_fast", _SZ, [_SZ, _I]),
     ("rsx_async_route_ws", _I, [_VP, _SZ, _SZ, _I, _VP, C.POINTER(C.c_uint32)]),
@@ -229,14 +230,22 @@ def radix_sort(src, aux, dtype=None, order=ASCENDING, stream=None):
     return (aux if info.result_in_aux else src), info
 
 
-def radix_sort_inplace_async(buf, scratch, dtype=None, order=ASCENDING, stream=None):
-    """rsx_sort_inplace_async: no host synchronisation, the sorted keys always end in ``buf`` (graph-capturable)."""
+HINT_EVEN_TOP_DIGITS = 1
+
+
+def radix_sort_inplace_async(buf, scratch, dtype=None, order=ASCENDING, stream=None, hints=0):
+    """rsx_sort_inplace_async: no host synchronisation, the sorted keys always end in ``buf`` (graph-capturable).
+    ``hints`` (rsx_sort_inplace_async_hint): HINT_EVEN_TOP_DIGITS -- the caller has counted the keys by their top varying byte."""
     _check_dev(buf, scratch)
     code = _torch_dtype_code(buf) if dtype is None else dtype
     if buf.element_size() != DTYPE_SIZE[code]:
         raise RsxError("buf does not match the key type")
     _same_shape(buf, scratch, "scratch")
-    check(lib().rsx_sort_inplace_async(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream)))
+    if hints:
+        check(lib().rsx_sort_inplace_async_hint(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream),
+                                                int(hints)))
+    else:
+        check(lib().rsx_sort_inplace_async(buf.data_ptr(), scratch.data_ptr(), buf.numel(), code, order, _stream_ptr(stream)))
     return buf
 
 

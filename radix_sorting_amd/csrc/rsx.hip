@@ -348,6 +348,7 @@ struct Ctx {
 	bool async_tried_blind = false;   // ... whether the last rsx_sort_inplace_async of this context enqueued such an attempt
 	bool ws_blind = false;            // a context in a caller's workspace that has room for the slots of a sort without a histogram (borrow_ctx)
 	bool boff_forget = false;   // rsx_reload_env since the last attempt: SegCtl::boff_* are zeroed before the next one
+	u32 hints = 0;                    // what the caller of the sort being enqueued has said about its keys (rsx_sort_inplace_async_hint)
 	bool async_small = false;         // ... or was the one-launch sort of a small array (rsx_async_route: 0, whatever the device's words say)
 	const void *pass_alt = nullptr;   // rsx_sort_rank_inplace_async: the second work copy of the keys (SCATTER_RANK_ASYNC passes)
 	DevBuf vsum;        // RSX_VERIFY=2: [descents, sum, mix] of the input and of the result
@@ -2022,7 +2023,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	                   // 8-byte keys in slots rsx_leafk_kernel takes: four-byte slots where the leaves' columns lie in the low word
 	                   (u32)(narrow_slots_ok<KT>(cap2) ? 1 : 0), 0u,
 	                   // a device-scheduled sort keeps its back-off on the device (SegCtl::boff_skip); the blocking sorts keep theirs on the host
-	                   (u32)(g_in_async ? 1 : 0));
+	                   (u32)(g_in_async ? 1 : 0), (u32)((env().probe & 4u) ? 1u : c.hints));
 	// 4-byte keys from 64 Mi keys on: the level-1 pass in whole 64-byte atoms (rsx_pass32a_kernel: a workgroup per CU takes a range
 	// of tiles and carries what does not fill an atom; a bucket then lies at both ends of its slot)
 	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
@@ -2065,9 +2066,18 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 			// (later, with one LDS atomic per key: never ahead at 54 .. 224 Mi keys either -- 54 Mi 0.340 -> 0.330 ms, 192 Mi 0.983 -> 0.961,
 			// level at 80 and 128 Mi, tools/ab_sizes.py RSX_PASS32_PREFETCH 1 0 u32 ...: off unless RSX_PASS32_PREFETCH=1 asks for it)
 			const bool prefetch = sizeof(KT) == 4 && env().pass32_prefetch > 0;
+#define RSX_LAUNCH_P32R(DIGV, PF, REPV)                                                                                      \
+			hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIGV, PF, P32, REPV>), dim3(256), dim3(P32::BLOCK), 0, c.stream,              \
+			                   (const KT *)src, (u64)n, kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka)
+			// (keys the caller says arrive in order of their top digit, piece by piece: four counters per digit, rsx_pass32.hpp)
+			const bool rep4 = (c.hints & 1u) != 0 || (env().probe & 4u) != 0;
 #define RSX_LAUNCH_P32(DIGV, PF)                                                                                             \
-			hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIGV, PF, P32>), dim3(256), dim3(P32::BLOCK), 0, c.stream, (const KT *)src,   \
-			                   (u64)n, kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka)
+			do {                                                                                                                 \
+				if (rep4 && !(PF))                                                                                               \
+					RSX_LAUNCH_P32R(DIGV, false, 4);                                                                             \
+				else                                                                                                             \
+					RSX_LAUNCH_P32R(DIGV, PF, 1);                                                                                \
+			} while (0)
 			if constexpr (sizeof(KT) == 4) {
 				if (plain && prefetch)
 					RSX_LAUNCH_P32(DIG_PLAIN, true);
@@ -2079,6 +2089,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 			else if (!prefetch)
 				RSX_LAUNCH_P32(DIG_GENERIC, false);
 #undef RSX_LAUNCH_P32
+#undef RSX_LAUNCH_P32R
 			HIP_TRY(hipGetLastError());
 		}
 	}
@@ -3500,6 +3511,25 @@ int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dty
 	return RSX_OK;
 }
 
+int rsx_sort_inplace_async_hint(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order, void *stream, uint32_t hints)
+{
+	if (!dtype_size(dtype) || (n && (!d_buf || !d_scratch)))
+		return fail(RSX_EINVAL, "rsx_sort_inplace_async_hint: bad argument");
+	if (n < 2)
+		return RSX_OK;
+	Ctx *c;
+	RSX_TRY(get_ctx(stream, &c));
+	std::lock_guard<std::recursive_mutex> ctx_lock(c->mu);
+	AsyncScope async_scope((hipStream_t)stream);
+	struct HintScope {   // (the sample kernel of the attempt enqueued by this call reads them: blind_enqueue)
+		Ctx &c;
+		HintScope(Ctx &c_, u32 h) : c(c_) { c.hints = h; }
+		~HintScope() { c.hints = 0; }
+	} hint_scope(*c, (u32)hints);
+	RSX_DISPATCH_KT(dtype, return sort_keys_inplace_async<KT>(*c, (KT *)d_buf, (KT *)d_scratch, n, dtype, order));
+	return RSX_OK;
+}
+
 int rsx_sort_inplace_async_ws(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order, void *d_workspace,
                               size_t workspace_bytes, void *stream)
 {
@@ -3744,6 +3774,11 @@ int rsx_async_route(void *stream, uint32_t *route)
 	if (c->async_tried_blind && c->seg.p) {
 		SegCtl ctl;
 		HIP_TRY(hipMemcpy(&ctl, c->seg.p, sizeof(ctl), hipMemcpyDeviceToHost));
+		if (getenv("RSX_DEBUG_ROUTE"))   // (what the device left behind: which test ended an attempt)
+			fprintf(stderr, "rsx_async_route: blind %u mode %u overflow %u ntiles %u nleaf %u maxleaf %u shift1 %u shift2 %u cmask %08x%08x "
+			                "narrow %u compact %u leaf16 %u boff_skip %u boff_next %u slots in the second buffer %u cap1 %u cap2 %u\n",
+			        ctl.blind, ctl.mode, ctl.overflow, ctl.ntiles, ctl.nleaf, ctl.maxleaf, ctl.shift1, ctl.shift2, ctl.cmask_hi, ctl.cmask_lo,
+			        ctl.narrow, ctl.compact, ctl.leaf16, ctl.boff_skip, ctl.boff_next, c->slack1_lo, c->slack1_cap, c->slack_cap);
 		if (ctl.mode == SEG_MODE_LEAVES) {
 			*route = 5;
 			return RSX_OK;

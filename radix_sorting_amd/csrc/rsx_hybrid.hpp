@@ -584,7 +584,8 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
                                                                   SegCtl *__restrict__ ctl, Plan *__restrict__ plan,
                                                                   Plan *host_plan, u32x4 *__restrict__ z, u64 nz, u32 min_cols,
                                                                   u32 allow_shift = 0, u32 allow_narrow = 0, u32 allow_compact = 0,
-                                                                  u32 backoff = 0)   // (1: a device-scheduled sort, SegCtl::boff_skip)
+                                                                  u32 backoff = 0,   // (1: a device-scheduled sort, SegCtl::boff_skip)
+                                                                  u32 hints = 0)     // (1: the caller has COUNTED the level-1 digits and found them even)
 {
 	constexpr u32 W = sizeof(KT), S = 8, NS = 1024 * S;
 	__shared__ u32 h[W][256];
@@ -893,7 +894,9 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		}
 		// the two digits the MSB passes go by (at their bit positions: the two highest kept columns, or below the highest
 		// varying bit): none with twice its share of the sample (a slot holds 1.25 times the mean)
-		go = go && s_maxs[0] <= 2 * NS / 256 && s_maxs[1] <= 2 * NS / 256;
+		// (hints & 1: the level-1 digit's test is the caller's -- keys that an MSD split has ordered by their top byte, piece by piece,
+		// are even over the array and clustered at every one of the sample's 64 places: the local sorts of a distributed sort)
+		go = go && ((hints & 1u) || s_maxs[0] <= 2 * NS / 256) && s_maxs[1] <= 2 * NS / 256;
 		// (digits that are not bytes: the leaves of round 3, which take over when the bins are uneven, sort by bytes)
 		// the leaves' bins (4096 of them, fewer when fewer than twelve bits are left below the MSB digits): NS samples give each
 		// NS / bins on average; a bin with three times that (and a margin for the small counts) means clustered low bits

@@ -11,14 +11,14 @@ SURVEY.md section 8e is the contract implemented here, one process per GPU:
      waits for the host) and derives, from the same gathered counts, the same splitters -- contiguous digit ranges
      holding ~n/G keys each -- and the whole G x G count matrix (no second count exchange);
   3. a destination's keys are a contiguous range of the split shard, so the
-     buckets go out as they lie (RCCL all-to-all-v over xGMI as grouped
-     send/recv; each directed pair of GPUs has its own link) -- in CHUNKS: a
-     destination's digit range is cut into sub-ranges, which are independent
-     sorting problems, and sub-range j is sorted (step 4) while sub-range j+1 is
-     still on the links;
-  4. each rank LSD-sorts every sub-range it received, in place and without a host
-     synchronisation (rsx_sort_inplace_async).  Sub-ranges are in digit order, so
-     the receive buffer ends up sorted as a whole.
+     buckets go out as they lie (RCCL all-to-all-v over xGMI; each directed pair of GPUs has its own link) -- as ONE
+     all_to_all_single by default, or (RSX_MULTI_CHUNKS > 1, grouped send/recv) in CHUNKS: a destination's digit range
+     is cut into sub-ranges, which are independent sorting problems, and sub-range j is sorted (step 4) while
+     sub-range j+1 is still on the links;
+  4. each rank sorts what it received (every sub-range of it), in place and without a host synchronisation
+     (rsx_sort_inplace_async_hint: the gathered counts say whether the received digits are even, which a sample of keys that
+     arrive in digit order, piece by piece, cannot see).  Sub-ranges are in digit order, so the receive buffer ends up
+     sorted as a whole.
   (split_slices > 1: step 2's pass runs in consecutive parts of the shard and the first sub-range's pieces of part 0 are
   on the links while the other parts are split; see split_plan.)
 
@@ -131,6 +131,8 @@ class HipEngine:
 
         self.split_passes = 0      # stable passes over a whole shard or a run of it (tests count them)
 
+    takes_even_hint = True     # sort_inplace_async(buf, scratch, even=...)
+
     def msd_split(self, shard, out, column=-1):
         """out = shard in stable order of KDF byte `column` (-1: the top one), enqueued; returns the byte's 256 counts (host)."""
         hist = np.zeros(256, dtype=np.uint64)
@@ -159,9 +161,12 @@ class HipEngine:
         res, info = radix_sort(keys, aux, dtype=self.dtype, order=self.order)
         return res, info
 
-    def sort_inplace_async(self, buf, scratch):
-        """Stable sort of buf in place (scratch: as many elements), only enqueued on the current stream."""
-        radix_sort_inplace_async(buf, scratch, dtype=self.dtype, order=self.order)
+    def sort_inplace_async(self, buf, scratch, even=False):
+        """Stable sort of buf in place (scratch: as many elements), only enqueued on the current stream.
+        even: the caller has counted the keys of buf by their top varying byte and found no digit with twice its share
+        (rsx_sort_inplace_async_hint: what arrives here was put in order of that byte by the senders' split passes, piece by
+        piece, and would look clustered to the sample of a sort without a histogram)."""
+        radix_sort_inplace_async(buf, scratch, dtype=self.dtype, order=self.order, hints=1 if even else 0)
 
     def overlap_stream(self, group=None, to_self=False):
         """A stream whose kernels run concurrently with the process group's send/recv kernels, or None.
@@ -349,7 +354,9 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     allocation out of a timed region.  ``force_exchange`` runs every exchange step even in a one-rank group (the
     rank then sends to itself): that is how the RCCL path is exercised on a one-GPU box.  ``chunks``: sub-ranges a
     destination's digit range is cut into; the exchange of sub-range j+1 overlaps the local sort of sub-range j
-    (default: RSX_MULTI_CHUNKS or 4; 1 = one ``all_to_all_single`` and one local sort, nothing overlapped).
+    (default: RSX_MULTI_CHUNKS or 1 = one ``all_to_all_single`` and one local sort, nothing overlapped.  Round 6, one rank sending
+    itself 2^29 keys: 6.75 ms per step with 1 sub-range, 8.3 with 2, 8.45 with 4 -- a sub-range's sort and grouped send / receive
+    cost more than the whole range's, and what the overlap wins on real links is not measured: the pipeline is opt-in).
     ``split_slices`` (default: RSX_MULTI_SPLIT_SLICES or 1): the split pass itself in that many consecutive parts of the
     shard, so that the first sub-range's pieces of part 0 are on the links while the rest of the shard is still being split
     (only with chunks > 1 and no bin heavy enough to be refined; a piece is then one run per part).
@@ -372,7 +379,7 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # preallocated scratch is used when it is large enough and replaced when it is not.
     part = scratch["part"][:n] if scratch else engine.empty(n, shard)
     if chunks is None:
-        chunks = int(os.environ.get("RSX_MULTI_CHUNKS", "4"))
+        chunks = int(os.environ.get("RSX_MULTI_CHUNKS", "1"))
     nchunks = max(1, min(int(chunks), 64))
     if split_slices is None:
         split_slices = int(os.environ.get("RSX_MULTI_SPLIT_SLICES", "1"))
@@ -410,6 +417,20 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     # sub-range is on the links.  The split shard is in digit order: piece (destination d, sub-range j) of this rank is
     # part[first[a] : first[b]] for the digits [a, b) of that sub-range.  Receive layout: sub-range major, source minor.
     recorded = {"xchg": False}
+    total_bins = hists.sum(axis=0).astype(np.float64)
+
+    def local_sort(lo, hi, sel):
+        """the received keys recv[lo:hi] -- the bins `sel` of the split, in pieces that are each in bin order -- sorted in place.
+        The engine is told when the gathered counts say those bins are even (no bin with 1.5 times the mean, nothing refined):
+        what a sample of the pieces cannot see (rsx_sort_inplace_async_hint)."""
+        if hi - lo <= 1:
+            return
+        if getattr(engine, "takes_even_hint", False):
+            c = total_bins[sel]
+            even = levels == 0 and c.size >= 2 and float(c.max()) <= 1.5 * float(c.mean())
+            engine.sort_inplace_async(recv[lo:hi], aux[lo:hi], even=even)
+        else:
+            engine.sort_inplace_async(recv[lo:hi], aux[lo:hi])
 
     def phases():
         """GPU time of the step's phases on this rank (ms; needs a synchronisation: called by bench.py after its own)"""
@@ -424,16 +445,49 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
             out["exchange_and_sort_ms"] = e_split.elapsed_time(e_end)   # (the chunk pipeline overlaps the two)
         return out
 
+    # the exchange moves opaque units of the widest integer type that divides the element size (every key width on every backend)
+    es = shard.element_size()
+    xdt = {8: torch.int64, 4: torch.int32}.get(es, torch.uint8)      # (NCCL has no 16-bit integer type)
+    xu = es // {torch.int64: 8, torch.int32: 4, torch.uint8: 1}[xdt]      # units per element
+    PIECE_LIMIT = 1 << 30      # bytes one send / receive may carry (see one_exchange)
+
     def one_exchange():
-        es = shard.element_size()
-        dist.all_to_all_single(recv.view(torch.uint8), part.view(torch.uint8),
-                               output_split_sizes=[int(x) * es for x in recv_counts],
-                               input_split_sizes=[int(x) * es for x in send_counts], group=group)
+        # A piece of 2^31 bytes or more does not arrive whole: the one-rank forced exchange of bench.py's 2^29 four-byte keys (ONE
+        # piece of 2 GiB, the rank to itself) delivered a part of it, whatever the unit of the counts, and the sort behind it put
+        # out a sorted array of the wrong keys (found in round 6 by comparing with torch.sort; bench.py checks checksums since).
+        # Between G >= 2 ranks a piece is at most half a shard: bench.py's sizes stay below the limit.  Above it the pieces go in
+        # parts of at most 1 GiB: slices of the one piece in a one-rank group, grouped send / receive otherwise.
+        big = max(int(recv_counts.max()), int(send_counts.max())) * es >= (1 << 31)
+        if not big:
+            dist.all_to_all_single(recv.view(xdt), part.view(xdt),
+                                   output_split_sizes=[int(x) * xu for x in recv_counts],
+                                   input_split_sizes=[int(x) * xu for x in send_counts], group=group)
+        elif world == 1:
+            step_elems = PIECE_LIMIT // es
+            rv, pv = recv.view(xdt), part.view(xdt)
+            for a in range(0, n_recv, step_elems):
+                b = min(a + step_elems, n_recv)
+                dist.all_to_all_single(rv[a * xu:b * xu], pv[a * xu:b * xu], output_split_sizes=[(b - a) * xu],
+                                       input_split_sizes=[(b - a) * xu], group=group)
+        else:
+            rv, pv = recv.view(xdt), part.view(xdt)
+            soffs = np.concatenate([[0], np.cumsum(send_counts.astype(np.int64))])
+            roffs1 = np.concatenate([[0], np.cumsum(recv_counts.astype(np.int64))])
+            step_elems = PIECE_LIMIT // es
+            ops = []
+            for p in range(world):
+                for a in range(0, int(send_counts[p]), step_elems):
+                    b = min(a + step_elems, int(send_counts[p]))
+                    ops.append(dist.P2POp(dist.isend, pv[(int(soffs[p]) + a) * xu:(int(soffs[p]) + b) * xu], p, group))
+                for a in range(0, int(recv_counts[p]), step_elems):
+                    b = min(a + step_elems, int(recv_counts[p]))
+                    ops.append(dist.P2POp(dist.irecv, rv[(int(roffs1[p]) + a) * xu:(int(roffs1[p]) + b) * xu], p, group))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
         if on_gpu:
             e_xchg.record()
             recorded["xchg"] = True
-        if n_recv > 1:
-            engine.sort_inplace_async(recv, aux)
+        local_sort(0, n_recv, np.nonzero(lut.astype(np.int64) == rank)[0])
         if on_gpu:
             e_end.record()
 
@@ -450,8 +504,7 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
     sl_hists = sliced["hists"] if sliced else hists[:, None, :]                  # [world, parts, bins]
     sl_begin = sliced["bounds"] if sliced else [0, n]
     first = [np.concatenate([[0], np.cumsum(sl_hists[rank][i].astype(np.int64))]) + sl_begin[i] for i in range(nslices)]
-    es = shard.element_size()
-    part_b, recv_b = part.view(torch.uint8), recv.view(torch.uint8)
+    part_b, recv_b = part.view(xdt), recv.view(xdt)
     lut64 = lut.astype(np.int64)
     mine_digits = lut64 == rank
     # first contact: the calibration (a 20 ms spin and four dummy exchanges) and the grouped send/recv below are what has never
@@ -494,16 +547,17 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
                 rcnt = int(roffs[j, p, i + 1]) - roff                               # what rank p's part i sends me
                 scnt = int(sl_hists[rank][i][sel_s].sum()) if sel_s.size else 0
                 soff = int(first[i][sel_s[0]]) if sel_s.size else 0
-                dst = recv_b[roff * es:(roff + rcnt) * es]
-                src = part_b[soff * es:(soff + scnt) * es]
+                dst = recv_b[roff * xu:(roff + rcnt) * xu]
+                src = part_b[soff * xu:(soff + scnt) * xu]
                 if p == rank and not force_exchange:
                     if rcnt:
                         dst.copy_(src)
                 else:
-                    if scnt:
-                        ops.append(dist.P2POp(dist.isend, src, p, group))
-                    if rcnt:
-                        ops.append(dist.P2POp(dist.irecv, dst, p, group))
+                    lim = PIECE_LIMIT // es * xu      # (units one send / receive may carry: see one_exchange)
+                    for a in range(0, scnt * xu, lim):
+                        ops.append(dist.P2POp(dist.isend, src[a:a + lim], p, group))
+                    for a in range(0, rcnt * xu, lim):
+                        ops.append(dist.P2POp(dist.irecv, dst[a:a + lim], p, group))
         return dist.batch_isend_irecv(ops) if ops else []
 
     # sub-range j+1 is submitted before sub-range j is sorted: with the sorts on a stream of their own (another hardware
@@ -529,13 +583,11 @@ def distributed_sort(shard, engine, group=None, recv_capacity=None, scratch=None
             with torch.cuda.stream(side):
                 for w in works:
                     w.wait()
-                if end - begin > 1:
-                    engine.sort_inplace_async(recv[begin:end], aux[begin:end])
+                local_sort(begin, end, np.nonzero(mine_digits & (chunk_of == j))[0])
         else:
             for w in works:
                 w.wait()                               # (NCCL: the current stream waits; gloo: the host does)
-            if end - begin > 1:
-                engine.sort_inplace_async(recv[begin:end], aux[begin:end])
+            local_sort(begin, end, np.nonzero(mine_digits & (chunk_of == j))[0])
     if side is not None:
         main.wait_stream(side)
     if on_gpu:

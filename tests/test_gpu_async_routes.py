@@ -339,3 +339,43 @@ def test_device_scheduled_sorts_back_off_on_the_device():
     assert rsa.async_route() == 5
     got = buf.cpu().numpy().view(np.uint32)
     assert np.all(got[1:] >= got[:-1])
+
+
+def _presplit(n, G, seed):
+    """What rank 0 of G receives in a distributed sort: keys below 2^32 / G in G pieces, each in stable order of its top byte."""
+    a = ol.splitmix_fill(n, ol.U32, seed) & np.uint32((1 << 32) // G - 1)
+    pieces = []
+    for p in range(G):
+        piece = a[p * (n // G):(p + 1) * (n // G)]
+        pieces.append(piece[np.argsort(piece >> np.uint32(24), kind="stable")])
+    return np.concatenate(pieces)
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+def test_keys_an_msd_split_has_ordered_take_the_fast_route_with_the_callers_word(G):
+    """rsx_sort_inplace_async_hint (RSX_HINT_EVEN_TOP_DIGITS): keys in pieces that are each in order of their top byte are even over
+    the array and clustered at every place the sample reads -- without the hint the attempt without a histogram is called off
+    (G = 1, 2), with it the sort takes route 5; the result is the oracle's either way.  A hint that is WRONG (keys that do cluster)
+    costs the attempt, not the result."""
+    n = 1 << 24
+    a = _presplit(n, G, 40 + G)
+    want, _, _ = ol.oracle_sort(a, ol.U32)
+    routes = []
+    for hints in (0, rsa.HINT_EVEN_TOP_DIGITS):
+        rsa.reload_env()
+        buf = to_dev(a)
+        scratch = torch.empty_like(buf)
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=rsa.U32, hints=hints)
+        routes.append(rsa.async_route())
+        assert np.array_equal(buf.cpu().numpy().view(np.uint32), want), (G, hints)
+    assert routes[1] == 5, routes
+    if G <= 2:
+        assert routes[0] != 5, routes
+    # a wrong hint: half the keys share their top two bytes
+    b = a.copy()
+    b[::2] = (b[::2] & np.uint32(0xFFFF)) | np.uint32(0x12340000 & ((1 << 32) // G - 1))
+    rsa.reload_env()
+    buf = to_dev(b)
+    rsa.radix_sort_inplace_async(buf, torch.empty_like(buf), dtype=rsa.U32, hints=rsa.HINT_EVEN_TOP_DIGITS)
+    assert rsa.async_route() != 5
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), ol.oracle_sort(b, ol.U32)[0])

@@ -46,9 +46,9 @@ def main():
     del pieces
     buf, aux = torch.empty_like(keys), torch.empty_like(keys)
     for name, data in (("shuffled", keys), ("pre-split", presplit)):
-        for sw in ("", "RSX_NO_BLIND"):
+        for sw in ("", "RSX_PROBE"):
             if sw:
-                os.environ[sw] = "1"
+                os.environ[sw] = "4"
             rsa.reload_env()
 
             def run(prepare):

@@ -3,10 +3,10 @@
 // style level-1 pass would cost against the byte pass (round-4 review, item 2b).  With splitters i << 24 the two make the same
 // partition, so one check serves both: every key of slot d has top byte d, the slots hold n keys, their key sum and key mix are
 // the input's.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc tools/ubench/pass32_probe.hip -o tools/ubench/pass32_probe.bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc -I tools/ubench tools/ubench/pass32_probe.hip -o tools/ubench/pass32_probe.bin
 // Run:   pass32_probe.bin [log2 n = 28] [mode: 0 uniform keys | 1 Zipf-like 32-bit keys with quantile splitters] [key bytes: 4 | 8] [1 | 0: the rank kept from the counting atomic | a second atomic]
 #include "rsx_scatter2.hpp"
-#include "rsx_pass32.hpp"
+#include "rsx_pass32_splitters.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -122,14 +122,14 @@ template <typename KT, typename CFG> int run_all(int log2n, u32 mode)
 			CK(hipEventCreate(&e1));
 			CK(hipEventRecord(e0, 0));
 			if (which == 0)
-				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, 1, true, CFG>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
+				hipLaunchKernelGGL((rsx_pass32s_kernel<KT, 1, true, CFG>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
 				                   cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const KT *)nullptr);
 			else if (which == 1) {
 				if constexpr (sizeof(KT) == 4)
-					hipLaunchKernelGGL((rsx_pass32a_kernel<KT, 2, true, Pass32aCfgT<CFG::KPT, false>>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u,
+					hipLaunchKernelGGL((rsx_pass32s_kernel<KT, 2, true, Pass32sCfgT<CFG::KPT, false>>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u,
 					                   0u, cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const KT *)d_spl);
 			} else
-				hipLaunchKernelGGL((rsx_pass32a_kernel<KT, 1, false, CFG>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
+				hipLaunchKernelGGL((rsx_pass32s_kernel<KT, 1, false, CFG>), dim3(256), dim3(1024), 0, 0, (const KT *)d_in, (u64)n, d_slots, 0u, 0u, 0u,
 				                   cap, (const SegCtl *)d_ctl, d_cur, d_ovf, ka, (const KT *)nullptr);
 			CK(hipEventRecord(e1, 0));
 			CK(hipEventSynchronize(e1));
@@ -144,7 +144,7 @@ template <typename KT, typename CFG> int run_all(int log2n, u32 mode)
 		CK(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
 		u64 got[4];
 		CK(hipMemset(d_chk, 0, 64));
-		hipLaunchKernelGGL((check_kernel<KT>), dim3(256), dim3(1024), 0, 0, (const KT *)d_slots, (const u32 *)d_cur, cap, PASS32_BACK, (const KT *)d_spl,
+		hipLaunchKernelGGL((check_kernel<KT>), dim3(256), dim3(1024), 0, 0, (const KT *)d_slots, (const u32 *)d_cur, cap, PASS32S_BACK, (const KT *)d_spl,
 		                   d_chk);
 		CK(hipMemcpy(got, d_chk, 32, hipMemcpyDeviceToHost));
 		std::vector<u32> cur(512);
@@ -158,7 +158,7 @@ template <typename KT, typename CFG> int run_all(int log2n, u32 mode)
 		fflush(stdout);
 	};
 	if (mode == 0) {
-		run("by the top byte (rsx_pass32a_kernel)", 0);
+		run("by the top byte (rsx_pass32s_kernel)", 0);
 		run("by the top byte, no prefetch", 2);
 	}
 	if (sizeof(KT) == 4)
@@ -173,9 +173,9 @@ int main(int argc, char **argv)
 	const int log2n = argc > 1 ? atoi(argv[1]) : 28;
 	const u32 mode = argc > 2 ? (u32)atoi(argv[2]) : 0;
 	const int key_bytes = argc > 3 ? atoi(argv[3]) : 4;
-	// (argv[4] = 0: a second returning atomic in the staging phase instead of the kept rank, Pass32aCfgT<.., false>)
+	// (argv[4] = 0: a second returning atomic in the staging phase instead of the kept rank, Pass32sCfgT<.., false>)
 	const bool rank1 = argc > 4 ? atoi(argv[4]) != 0 : true;
 	if (key_bytes == 8)
-		return rank1 ? run_all<u64, Pass32aCfgT<14>>(log2n, 0) : run_all<u64, Pass32aCfgT<14, false>>(log2n, 0);
-	return rank1 ? run_all<u32, Pass32aCfg>(log2n, mode) : run_all<u32, Pass32aCfgT<28, false>>(log2n, mode);
+		return rank1 ? run_all<u64, Pass32sCfgT<14>>(log2n, 0) : run_all<u64, Pass32sCfgT<14, false>>(log2n, 0);
+	return rank1 ? run_all<u32, Pass32sCfg>(log2n, mode) : run_all<u32, Pass32sCfgT<28, false>>(log2n, mode);
 }

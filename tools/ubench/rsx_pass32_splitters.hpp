@@ -1,3 +1,7 @@
+// rsx_pass32_splitters.hpp -- PROBE ONLY (tools/ubench/pass32_probe.hip): csrc/rsx_pass32.hpp as it stood in round 5, WITH the
+// DIG == 2 branch -- the bucket of a key found by a search among 255 sampled splitters in the LDS instead of a byte of the key (the
+// round-4 review asked what a sample-sort style level-1 pass would cost: 0.65 / 1.12 ms against 0.48 by the byte,
+// profiles/r05/pass32_splitter_probe.txt).  The product header has no such branch any more.
 // rsx_pass32.hpp -- the LEVEL-1 pass of a keys-only sort of 4-byte keys without a histogram, in whole 64-byte atoms (round 5).
 //
 // The pass (rsx_hybrid.hpp): every key of the caller's array goes to slot d of 256, d = its level-1 digit
@@ -11,7 +15,7 @@
 // taken from the slot's cursor by one returning global atomic per tile and digit.  No look-back chain (the order of the tiles
 // inside a slot is free: the leaves sort), no partly written atom anywhere -- the ragged run ends of the chained pass were what
 // its stores cost (tools/ubench/store_spacing.hip; the level-2 pass: 0.458 -> 0.397 ms for 2^28 keys).  What a workgroup still
-// carries when its range ends goes to the last PASS32_BACK keys of the slot (a cursor of its own): a bucket then lies at both
+// carries when its range ends goes to the last PASS32S_BACK keys of the slot (a cursor of its own): a bucket then lies at both
 // ends of its slot and rsx_seg_tiles_kernel cuts the level-2 pass's tiles from both.
 // One workgroup per CU (150 KB of LDS: a 28 Ki-key tile, the carried keys, the tables); the next tile's keys are requested
 // while this one is written out.
@@ -23,7 +27,7 @@
 
 namespace rsx {
 
-template <int KPT_ = 28, bool RANK1_ = true> struct Pass32aCfgT {
+template <int KPT_ = 28, bool RANK1_ = true> struct Pass32sCfgT {
 	static constexpr int BLOCK = 1024, KPT = KPT_, TILE = BLOCK * KPT;
 	// a key's place inside its digit's run is the value the COUNTING atomic returned (kept, sixteen bits per key): the staging phase
 	// reads the run's start and adds it -- one LDS atomic per key and tile instead of two (false: count, then a second returning atomic
@@ -35,41 +39,37 @@ template <int KPT_ = 28, bool RANK1_ = true> struct Pass32aCfgT {
 	static constexpr u32 BACK = 8192;   // keys at the end of every slot for what is carried when a range ends (up to 512 workgroups x 15)
 	static constexpr int STAGE = TILE + 256 * 6;   // + what the 16-byte alignment of 256 runs can cost
 };
-typedef Pass32aCfgT<28> Pass32aCfg;
-constexpr u32 PASS32_BACK = Pass32aCfg::BACK;
+typedef Pass32sCfgT<28> Pass32sCfg;
+constexpr u32 PASS32S_BACK = Pass32sCfg::BACK;
 
-template <typename KT, typename C, int REP = 1> struct Pass32aSmem {
+template <typename KT, typename C, bool SPLITTERS = false> struct Pass32sSmem {
 	__attribute__((aligned(16))) KT stage[C::STAGE];
 	__attribute__((aligned(16))) KT carry[256][64 / sizeof(KT)];
-	__attribute__((aligned(16))) u32 cell[2][256 * REP];   // per (digit, lane class): count, then the class's part of the run (tile-local start / cursor); tiles alternate between the two
+	u32 cell[2][256];   // per digit: count, then the run's cursor (tile-local); tiles alternate between the two
 	u32 delta[256];     // slot position of a body key minus its tile-local position
 	u32 info[256];      // carried before (5 bits) | head (5) | tail (5) | atom completed | enough for an atom | offset in the region
 	unsigned short rbeg[256], bbeg[256], bend[256];
 	unsigned char group_digit[C::STAGE / (16 / sizeof(KT))];   // per 16-byte group of staged keys
 	u32 wsum[4];
+	KT spl[SPLITTERS ? 256 : 1];   // DIG == 2 (probe): 255 ascending splitters; a key's bucket is the number of splitters <= it
+	unsigned char tbl[SPLITTERS ? 4104 : 4];   // DIG == 2: the bucket of the first key of every 2^-12 of the key range (and 255 behind the last)
 };
 
 // kout: the lower of the two arrays the slots lie in; slot d starts (d < lo_slots ? off_lo : off_hi) + d * cap keys from there
 // (SegArgs, rsx_scatter2.hpp).  cursors: [256] front cursors, [256] back cursors (zeroed by rsx_blind_precheck_kernel).
-// REP: counters per digit, one per lane class (lane & (REP - 1)).  An LDS atomic serialises the lanes of one instruction that hit one
-// word; keys that arrive in ORDER of their level-1 digit -- what the local sorts of a distributed sort receive from the senders'
-// split passes, piece by piece (rsx_sort_inplace_async_hint) -- put all 64 lanes on one counter: 2^29 such keys took 4.5 ms on this
-// route, no better than one pass per column.  With four counters per digit: 3.25 ms (one piece), 2.78 (two pieces: 3.42), 2.59
-// (four: 2.88), 2.54 (eight: 2.62).  Evenly spread digits pay 1-3 % of this pass for the wider tables (0.430 -> 0.437-0.450 ms at
-// 2^28 keys), so the hinted sorts take REP = 4 and everybody else REP = 1 (profiles/r06/presplit_probe.txt).
-template <typename KT, int DIG, bool PREFETCH = true, typename C = Pass32aCfg, int REP_ = 1>
-__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT *__restrict__ kin, u64 n, KT *__restrict__ kout,
+template <typename KT, int DIG, bool PREFETCH = true, typename C = Pass32sCfg>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32s_kernel(const KT *__restrict__ kin, u64 n, KT *__restrict__ kout,
                                                                           u32 lo_slots, u32 off_lo, u32 off_hi, u32 cap,
                                                                           const SegCtl *__restrict__ ctl,
                                                                           u32 *__restrict__ cursors, u32 *__restrict__ overflow,
-                                                                          KdfArgs<KT> ka)
+                                                                          KdfArgs<KT> ka, const KT *__restrict__ splitters = nullptr)
 {
 	static_assert(sizeof(KT) == 4 || sizeof(KT) == 8, "4- or 8-byte keys");
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
 	constexpr u32 VEC = 16 / sizeof(KT);    // keys per 16-byte vector (what a copying thread moves: a quarter of an atom)
 	constexpr u32 ATOM = 64 / sizeof(KT);   // keys per 64-byte atom
 	static_assert(KPT % (int)VEC == 0, "whole vectors per lane");
-	static_assert(sizeof(KT) == 4 || C::STAGE * sizeof(KT) + 256 * 64 <= 150 * 1024, "8-byte keys: 14 Ki-key tiles (Pass32aCfgT<14>)");
+	static_assert(sizeof(KT) == 4 || C::STAGE * sizeof(KT) + 256 * 64 <= 150 * 1024, "8-byte keys: 14 Ki-key tiles (Pass32sCfgT<14>)");
 	if (ctl->blind != BLIND_GO)
 		return;   // (the sample has called the attempt off: rsx_hybrid.hpp)
 	const u32 ntiles = (u32)((n + TILE - 1) / TILE);
@@ -81,18 +81,51 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 	// the bits the sample took for constant, and the first key's (derived)
 	const KT cmask = sizeof(KT) == 8 ? (KT)(((u64)ctl->cmask_hi << 32) | ctl->cmask_lo) : (KT)ctl->cmask_lo;
 	const KT key0 = sizeof(KT) == 8 ? (KT)(((u64)ctl->key0_hi << 32) | ctl->key0_lo) : (KT)ctl->key0_lo;
-	__shared__ Pass32aSmem<KT, C, REP_> sm;
+	__shared__ Pass32sSmem<KT, C, DIG == 2> sm;
 	const u32 tid0 = threadIdx.x;
 	auto sidx = [](u32 pos) { return stage_swz<true>(pos * (u32)sizeof(KT)); };
 	auto staged = [&](u32 pos) -> KT & { return *(KT *)((char *)sm.stage + sidx(pos)); };
 	auto slot_base = [&](u32 d) { return (d < lo_slots ? off_lo : off_hi) + d * cap; };
 	u32 cc = 0;   // digit thread: keys of its digit carried from the tiles before
-	constexpr u32 REP = REP_;
-	static_assert(REP == 1 || REP == 4, "one counter per digit, or one per lane class");
-	if (tid0 < 256 * REP)
+	if (tid0 < 256) {
 		sm.cell[0][tid0] = 0;
+		if constexpr (DIG == 2)
+			sm.spl[tid0] = tid0 < 255 ? splitters[tid0] : (KT)~(KT)0;
+	}
 	__syncthreads();
-	auto bucket_of = [&](KT k, u32 sh) -> u32 { return (u32)(k >> sh) & 0xFFu; };
+	// DIG == 2 (tools/ubench/pass32_probe.hip: what a level-1 pass by 255 SAMPLED SPLITTERS instead of a byte would cost -- the
+	// review's question for keys no byte scheme spreads).  A key's bucket: a table by its top 12 bits gives the buckets its 2^-12 of
+	// the key range touches, a search among those splitters the rest (no step at all where the range holds no splitter); found once
+	// per key, kept as a byte for the staging phase.
+	auto search_all = [&](KT k) -> u32 {
+		u32 d = 0;
+#pragma unroll
+		for (u32 step = 128; step >= 1; step >>= 1)
+			d += k >= sm.spl[d + step - 1] ? step : 0u;
+		return d;
+	};
+	if constexpr (DIG == 2) {
+		for (u32 c = tid0; c <= 4096u; c += BLOCK)
+			sm.tbl[c] = (unsigned char)(c == 4096u ? 255u : search_all((KT)c << 20));
+		__syncthreads();
+	}
+	auto bucket_of = [&](KT k, u32 sh) -> u32 {
+		if constexpr (DIG == 2) {
+			const u32 c = (u32)(k >> 20);
+			u32 lo = sm.tbl[c], hi = sm.tbl[c + 1];
+			while (lo < hi) {
+				const u32 mid = (lo + hi) >> 1;
+				if (k >= sm.spl[mid])
+					lo = mid + 1;
+				else
+					hi = mid;
+			}
+			return lo;
+		} else {
+			return (u32)(k >> sh) & 0xFFu;
+		}
+	};
+	u32 bkp[DIG == 2 ? (KPT + 3) / 4 : 1];   // DIG == 2: the keys' buckets, a byte each
 	KT keep[KPT];
 	auto request = [&](const u32 t, const u32 tid) {
 		const u64 beg = (u64)t * TILE;
@@ -146,7 +179,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 				if (FULL || tid + r * BLOCK < cnt) {
 					const KT k = DIG == 1 ? keep[r] : kdf_apply(keep[r], ka);
 					bad |= (k ^ key0) & cmask;
-					const u32 b = bucket_of(k, shift) * REP + (lane & (REP - 1u));
+					const u32 b = bucket_of(k, shift);
+					if constexpr (DIG == 2)
+						bkp[r >> 2] = (r & 3) ? bkp[r >> 2] | (b << (8 * (r & 3))) : b;
 					if constexpr (C::RANK1)
 						mine = __hip_atomic_fetch_add(&cell[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					else
@@ -168,14 +203,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 		u32 base = 0;
 		{
 			u32 rlen = 0, rstart = 0;
-			u32 crep[REP];   // digit thread: its digit's keys per lane class
 			if (tid < 256) {
-				u32 c = 0;
-#pragma unroll
-				for (u32 q = 0; q < REP; ++q) {
-					crep[q] = cell[tid * REP + q];
-					c += crep[q];
-				}
+				const u32 c = cell[tid];
 				u32 h, body = 0, tail = 0, atom = 0;
 				const bool enough = cc + c >= ATOM;
 				if (enough) {
@@ -211,13 +240,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 					rstart += sm.wsum[k];
 				const u32 inf = sm.info[tid];
 				const u32 rb = rstart + (inf >> 17), bb = rb + ((inf >> 5) & 31u), be = bb + sm.bend[tid];
-				u32 rq = rb;
-#pragma unroll
-				for (u32 q = 0; q < REP; ++q) {
-					cell[tid * REP + q] = rq;   // (the classes' parts of the run, one behind the other)
-					rq += crep[q];
-					sm.cell[((t - t0) & 1u) ^ 1u][tid * REP + q] = 0;   // (the next tile's counters: last used as the cursors of the tile before)
-				}
+				cell[tid] = rb;
+				sm.cell[((t - t0) & 1u) ^ 1u][tid] = 0;   // (the next tile's counters: last used as the cursors of the tile before)
 				sm.rbeg[tid] = (unsigned short)rb;
 				sm.bbeg[tid] = (unsigned short)bb;
 				sm.bend[tid] = (unsigned short)be;
@@ -251,7 +275,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 					pos[r] = 0;
 					if (FULL || tid + (r0 + r) * BLOCK < cnt) {
 						const KT k = DIG == 1 ? keep[r0 + r] : kdf_apply(keep[r0 + r], ka);
-						const u32 b = bucket_of(k, shift_b) * REP + (lane & (REP - 1u));
+						u32 b;
+						if constexpr (DIG == 2)
+							b = (bkp[(r0 + r) >> 2] >> (8 * ((r0 + r) & 3))) & 0xFFu;
+						else
+							b = bucket_of(k, shift_b);
 						if constexpr (C::RANK1)
 							pos[r] = cell[b] + ((rk[(r0 + r) >> 1] >> (16 * ((r0 + r) & 1))) & 0xFFFFu);   // (the run's start: nobody moves it)
 						else
