@@ -216,6 +216,48 @@ def test_exchange_steps_over_rccl_in_a_one_rank_group():
     assert out.returncode == 0 and "self-exchange OK" in out.stdout, out.stdout + out.stderr
 
 
+_RCCL_TWO_GIB_PIECE = r"""
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import radix_sorting_amd as rsa
+from radix_sorting_amd import multi
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+n = 1 << 29
+for chunks in (1, 2):
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    rsa.fill_splitmix(t, seed=90 + chunks)
+    want = torch.sort(t ^ -2**31).values ^ -2**31
+    scratch = {k: torch.empty(n + n // 4 if k != "part" else n, dtype=torch.int32, device="cuda") for k in ("aux", "part", "recv")}
+    res, stats = multi.distributed_sort(t, multi.HipEngine(rsa.U32), scratch=scratch, force_exchange=True, chunks=chunks)
+    torch.cuda.synchronize()
+    assert stats["received"] == n
+    assert bool((res == want).all().item()), "chunks=%d: the sorted output does not hold the input's keys" % chunks
+    if chunks == 1:
+        assert rsa.async_route() == 5, rsa.async_route()     # (the local sort was told that the received digits are even)
+    del t, want, scratch, res
+    torch.cuda.empty_cache()
+dist.barrier()
+dist.destroy_process_group()
+print("two-GiB piece OK")
+"""
+
+
+def test_a_piece_of_two_gib_arrives_whole():
+    """bench.py's N>1 step at its real size in a one-rank group: 2^29 keys, ONE piece of 2^31 bytes from the rank to itself.  Round 5
+    sorted what arrived of it -- part of the keys; the output was in order and wrong.  Compared here with torch.sort, element for
+    element; the route of the local sort is asserted (the gathered counts vouch for the digits the sample cannot judge)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _RCCL_TWO_GIB_PIECE, root], capture_output=True, text=True, timeout=900,
+                         env=_one_rank_env())
+    assert out.returncode == 0 and "two-GiB piece OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_bench_sharded_path_in_a_one_rank_group():
     """bench.py's N>1 branch (scratch buffers, barrier-fenced timing, max over ranks, JSON line) with --force-exchange."""
     import json
