@@ -134,6 +134,8 @@ struct Env {
 	unsigned leaf16_maxbin = 25;     // RSX_LEAF16_MAXBIN (tests): leaves with a fuller bin go to rsx_leaf_sort_kernel (0: every leaf)
 	unsigned leaf_grid = 65536;      // RSX_LEAF_GRID (probe): workgroups of a level-2 leaf launch (65536: one per table entry)
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
+	bool no_odd_stride = false;      // RSX_NO_ODD_STRIDE=1: the level-1 slots of a sort without a histogram lie 1.25 means apart, rounded to 1 KiB, as in round 5
+	unsigned cap1_pad_kib = 0;       // RSX_CAP1_PAD_KIB=k (probe): k KiB more per level-1 slot of a sort without a histogram
 	unsigned probe = 0;              // RSX_PROBE=bits (measurements only): 1 the leaf table of a sort without a histogram in reverse slot order
 	bool no_log = false;             // RSX_NO_LOG=1: 8-byte keys never take the (bit length, mantissa) digits of rsx_logroute.hpp (rsx_info.hybrid never 6)
 	unsigned log_min_log2 = 0;       // RSX_LOG_MIN_LOG2: ... from 2^this keys on (tests: 20; default: from 24 Mi keys)
@@ -202,6 +204,10 @@ struct Env {
 		leaf_grid = 65536;
 		if (const char *e = getenv("RSX_LEAF_GRID"))
 			leaf_grid = std::max(256, std::min(65536, atoi(e)));
+		no_odd_stride = is_one("RSX_NO_ODD_STRIDE");
+		cap1_pad_kib = 0;
+		if (const char *e = getenv("RSX_CAP1_PAD_KIB"))
+			cap1_pad_kib = (unsigned)std::max(0, std::min(65536, atoi(e)));
 		probe = 0;
 		if (const char *e = getenv("RSX_PROBE"))
 			probe = (unsigned)atoi(e);
@@ -1208,6 +1214,24 @@ static inline u32 slot_cap_for(u32 mean)
 	return ((need + 255) / 256) * 256;
 }
 
+// The capacity -- and the spacing -- of the 256 level-1 slots of a keys-only sort without a histogram.
+// The slots fill at the same rate, so the 256 write streams of the level-1 pass stand at the same offset of their slots at any
+// time, one slot stride apart: with strides of 15 or 17 x 2 MiB (1.5 x 2^30 four-byte keys: 30 MiB) they meet in the same memory
+// channels and the pass runs at 3.6 TB/s instead of 4.5 (tools/stride_probe.py, profiles/r06/stride_probe.txt: +64 KiB .. +1 MiB
+// per slot restore it, +4 MiB = 17 x 2 MiB is as bad again).  Slots of a MiB and more are an ODD number of 64 KiB apart
+// (RSX_NO_ODD_STRIDE=1: as round 5).  RSX_CAP1_PAD_KIB: that many KiB more per slot (the probe).
+template <typename KT> u32 level1_slot_cap(u32 mean)
+{
+	u32 cap1 = slot_cap_for(mean) + env().cap1_pad_kib * (1024u / (u32)sizeof(KT));
+	if (!env().no_odd_stride && (size_t)cap1 * sizeof(KT) >= ((size_t)1 << 20)) {
+		const u32 unit = 65536u / (u32)sizeof(KT);
+		cap1 = (cap1 + unit - 1) / unit * unit;
+		if ((cap1 / unit) % 2u == 0)
+			cap1 += unit;
+	}
+	return cap1;
+}
+
 // 8-byte keys: may the sample choose four-byte level-2 slots (SegCtl::narrow)?  Where rsx_leafk_kernel sorts the slots, from
 // slots of 512 keys (arrays of ~13 Mi keys) on: the second form of the level-2 pass and of the leaves are two more launches, which
 // 8 Mi keys notice (0.267 against 0.252 ms; 16 Mi: 0.328 against 0.337, 64 Mi 0.77 against 0.87, 192 Mi 2.06 against 2.29:
@@ -1693,7 +1717,7 @@ template <typename KT> int seg_layout(Ctx &c, size_t n)
 template <typename KT> void blind_sizes(size_t n, size_t *gscan, size_t *seg, size_t *slack1, size_t *slack)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
-	const u32 cap1 = slot_cap_for((u32)(n >> 8)), cap2 = slot_cap_for((u32)(n >> 16));
+	const u32 cap1 = level1_slot_cap<KT>((u32)(n >> 8)), cap2 = slot_cap_for((u32)(n >> 16));
 	const u32 lo = cap1 >= (u32)C2::TILE ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
 	const size_t slot2 = (sizeof(KT) == 4 && cap2 <= dense_cap_max<KT>()) ? 2 : sizeof(KT);
 	*gscan = 256 * sizeof(u64);
@@ -1947,7 +1971,8 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	typedef Sc2Cfg<KT, NoVal> C2;
 	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
-	const u32 cap1 = slot_cap_for(mean1), cap2 = slot_cap_for(mean2);
+	const u32 cap1 = level1_slot_cap<KT>(mean1);
+	const u32 cap2 = slot_cap_for(mean2);
 	if (cap2 > std::max((u32)LeafShapes<KT>::Big::CAP, dense_cap_max<KT>()))
 		return RSX_OK;
 	if (c.blind_no_room)
