@@ -10,7 +10,7 @@ all: lib oracle cpp cli
 
 lib: radix_sorting_amd/librsx.so
 
-radix_sorting_amd/librsx.so: $(CSRC)/rsx.hip $(CSRC)/rsx_kernels.hpp $(CSRC)/rsx_hist.hpp $(CSRC)/rsx_scatter2.hpp $(CSRC)/rsx_small.hpp $(CSRC)/rsx_hybrid.hpp $(CSRC)/rsx_leaf16.hpp $(CSRC)/rsx_pass16.hpp $(CSRC)/rsx_pass32.hpp $(CSRC)/rsx_multi_state.hpp $(CSRC)/rsx_multi_entry.hpp $(CSRC)/rsx_records.hpp $(CSRC)/rsx_logroute.hpp $(CSRC)/rsx_leafc.hpp include/rsx.h
+radix_sorting_amd/librsx.so: $(CSRC)/rsx.hip $(CSRC)/rsx_kernels.hpp $(CSRC)/rsx_hist.hpp $(CSRC)/rsx_scatter2.hpp $(CSRC)/rsx_small.hpp $(CSRC)/rsx_hybrid.hpp $(CSRC)/rsx_leaf16.hpp $(CSRC)/rsx_pass16.hpp $(CSRC)/rsx_pass32.hpp $(CSRC)/rsx_multi_state.hpp $(CSRC)/rsx_multi_entry.hpp $(CSRC)/rsx_records.hpp $(CSRC)/rsx_logroute.hpp $(CSRC)/rsx_pass2w.hpp $(CSRC)/rsx_pass64.hpp $(CSRC)/rsx_leafc.hpp include/rsx.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/rsx.hip -o $@
 
 oracle: lib

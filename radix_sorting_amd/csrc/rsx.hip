@@ -16,6 +16,7 @@
 #include "rsx_pass32.hpp"
 #include "rsx_leafc.hpp"
 #include "rsx_logroute.hpp"
+#include "rsx_pass64.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -137,6 +138,7 @@ struct Env {
 	bool no_odd_stride = false;      // RSX_NO_ODD_STRIDE=1: the level-1 slots of a sort without a histogram lie 1.25 means apart, rounded to 1 KiB, as in round 5
 	unsigned cap1_pad_kib = 0;       // RSX_CAP1_PAD_KIB=k (probe): k KiB more per level-1 slot of a sort without a histogram
 	unsigned probe = 0;              // RSX_PROBE=bits (measurements only): 1 the leaf table of a sort without a histogram in reverse slot order
+	bool no_pass64a = false;         // RSX_NO_PASS64A=1: the level-2 pass of 8-byte keys into four-byte slots is the chained rsx_scatter2_kernel of round 4 (rsx_pass64.hpp)
 	bool no_log = false;             // RSX_NO_LOG=1: 8-byte keys never take the (bit length, mantissa) digits of rsx_logroute.hpp (rsx_info.hybrid never 6)
 	unsigned log_min_log2 = 0;       // RSX_LOG_MIN_LOG2: ... from 2^this keys on (tests: 20; default: from 24 Mi keys)
 	void load()
@@ -211,6 +213,7 @@ struct Env {
 		probe = 0;
 		if (const char *e = getenv("RSX_PROBE"))
 			probe = (unsigned)atoi(e);
+		no_pass64a = is_one("RSX_NO_PASS64A");
 		no_log = is_one("RSX_NO_LOG");
 		log_min_log2 = 0;
 		if (const char *e = getenv("RSX_LOG_MIN_LOG2"))
@@ -1536,6 +1539,21 @@ template <typename KT> bool pass16a_wanted(const Ctx &c)
 // what lies at its slot's end (rsx_seg_tiles_kernel, back_cap).
 template <typename KT> constexpr u64 seg_extra_rows() { return sizeof(KT) == 8 ? 512 : 256; }
 
+// 8-byte keys, the level-2 pass into FOUR-byte slots (SegCtl::narrow) as rsx_pass64a_kernel: whole atoms, cursors, two-ended slots
+// (rsx_leafk_kernel's SLOT32 form reads both ends whatever its shape)
+template <typename KT> bool pass64a_narrow_wanted(const Ctx &c)
+{
+	if (sizeof(KT) != 8 || !narrow_slots_ok<KT>(c.slack_cap) || env().no_pass64a || env().no_unstable || !c.slack_mean)
+		return false;
+	// the 128 places kept for a slot's back must leave its front mean + 6 standard deviations (what is carried to the back, a
+	// few dozen values per slot, comes on top): just below a step of slot_cap_for they do not -- 64 Mi keys, mean 1024 in slots
+	// of 1280, lost the attempt -- and the chained pass, whose slots have no back, stays
+	u32 r = 0;
+	while ((u64)(r + 1) * (r + 1) <= c.slack_mean)
+		++r;
+	return c.slack_mean + 6 * (r + 1) + 8 <= c.slack_cap - Pass2wCfg<u32>::BACK;
+}
+
 template <typename KT>
 int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, int j, int blind = 0)
 {
@@ -1668,7 +1686,12 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	                   dim3(C2::BLOCK), 0, c.stream, aux, (u32 *)src, (const NoVal *)nullptr, (NoVal *)nullptr, (u64)n,     \
 	                   shift0, (const u64 *)c.ghist(), 1u, (u32 *)(base + 256), (u32 *)base, ka, flags, (u64 *)nullptr,     \
 	                   (const Plan *)c.plan(), pi, 0u, (const u32 *)nullptr, sa)
-			if (plain)
+			if (pass64a_narrow_wanted<KT>(c)) {
+				typedef Pass2wCfg<u32> P64;
+				hipLaunchKernelGGL((rsx_pass64a_kernel<KT, u32>), dim3(P64::GRID), dim3(P64::BLOCK), 0, c.stream, (const KT *)aux,
+				                   (const KT *)sa.kin_hi, sa.lo_slots, (u32 *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
+				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
+			} else if (plain)
 				RSX_LAUNCH_SEG32(DIG_PLAIN);
 			else
 				RSX_LAUNCH_SEG32(DIG_GENERIC);
@@ -1681,13 +1704,22 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 
 // where the parts of a two-level sort's device-side state lie in c.seg
 // bytes of c.seg for a two-level sort of n keys (seg_layout below)
+// rows of the tile table of a two-level sort's level-2 pass: the tiles of the pass that may run (the chained pass's, or the smaller
+// ones of rsx_pass16a_kernel / rsx_pass64a_kernel) + per bucket a partial tile and one for what lies at its slot's end
+template <typename KT> u64 seg_tile_rows(size_t n, u64 rows)
+{
+	if (sizeof(KT) == 4)
+		return (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 514;
+	return std::max<u64>(rows, (n + Pass2wCfg<u32>::TILE - 1) / Pass2wCfg<u32>::TILE + 514);
+}
+
 template <typename KT> size_t seg_bytes(size_t n)
 {
 	typedef Sc2Cfg<KT, NoVal> C2;
 	const u64 rows = (n + C2::TILE - 1) / C2::TILE + seg_extra_rows<KT>();
 	const size_t st_bytes = 256 + rows * 256 * 4;
 	const size_t hist_bytes = (size_t)256 * (sizeof(KT) - 1) * 256 * sizeof(u32);
-	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 514 : rows;
+	const u64 tile_rows = seg_tile_rows<KT>(n, rows);
 	return 256 + hist_bytes + (sizeof(KT) - 1) * st_bytes + 65536 * sizeof(LeafSeg) + tile_rows * sizeof(SegTile) + 260 * sizeof(u32) +
 	       65536 * sizeof(u32);
 }
@@ -1702,7 +1734,7 @@ template <typename KT> int seg_layout(Ctx &c, size_t n)
 	c.seg_status_off = c.seg_hist_off + hist_bytes;
 	c.seg_segtab_off = c.seg_status_off + (sizeof(KT) - 1) * st_bytes;
 	c.seg_tiles_off = c.seg_segtab_off + 65536 * sizeof(LeafSeg);
-	const u64 tile_rows = sizeof(KT) == 4 ? (n + Pass16aCfg::TILE - 1) / Pass16aCfg::TILE + 514 : rows;   // (rsx_pass16a_kernel's tiles are smaller; a bucket may end in a tile of its own for what lies at its slot's end)
+	const u64 tile_rows = seg_tile_rows<KT>(n, rows);
 	c.seg_btile_off = c.seg_tiles_off + tile_rows * sizeof(SegTile);
 	c.seg_redo_off = c.seg_btile_off + 260 * sizeof(u32);   // the leaves rsx_leaf16_kernel leaves to rsx_leaf_sort_kernel
 	const void *before = c.seg.p;
@@ -2052,6 +2084,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	// 4-byte keys from 64 Mi keys on: the level-1 pass in whole 64-byte atoms (rsx_pass32a_kernel: a workgroup per CU takes a range
 	// of tiles and carries what does not fill an atom; a bucket then lies at both ends of its slot)
 	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
+	const bool atoms64 = pass64a_narrow_wanted<KT>(c);   // (8-byte keys: the same for the form that writes four-byte slots; the sample decides which form runs)
 	bool atoms1 = false;
 	{
 		// 4-byte keys: only in front of rsx_pass16a_kernel (a bucket that lies at both ends of its slot is one tile more: that pass's
@@ -2122,12 +2155,13 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 		RSX_TRY(launch_seg_pass<KT>(c, src, lo ? aux : nullptr, n, ka, -2, 1));
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   atoms ? (u32)Pass16aCfg::TILE : (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
-	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0, atoms1 ? PASS32_BACK : 0u);
+	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0, atoms1 ? PASS32_BACK : 0u,
+	                   atoms64 ? (u32)Pass2wCfg<u32>::TILE : 0u);
 	RSX_TRY(launch_seg_pass<KT>(c, lo ? aux : nullptr, nullptr, n, ka, -2, 2));
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),
 	                   (const Plan *)c.plan(), ctl, segtab, cap2, c.dev_host_segctl, (const u64 *)off1,
-	                   (atoms ? 2u : 1u) | ((env().probe & 1u) << 8));
+	                   (atoms ? 2u : atoms64 ? 3u : 1u) | ((env().probe & 1u) << 8));
 	HIP_TRY(hipGetLastError());
 	if (c.seg_ev)
 		HIP_TRY(hipEventRecord(c.seg_ev, c.stream));

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
                                                             u32 *__restrict__ btile,   // [257]: bucket k's tiles are [btile[k], btile[k + 1])
                                                             u64 *__restrict__ off1_out = nullptr, u32 blind_cap = 0,
                                                             const u32 *__restrict__ status0 = nullptr, u32 ntiles0 = 0,
-                                                            u32 back_cap = 0)
+                                                            u32 back_cap = 0, u32 tile_narrow = 0)   // (tile_narrow: the tile of the level-2 pass that runs when SegCtl::narrow is set, rsx_pass64.hpp)
 {
 	// blind_cap != 0 (a sort without a histogram): no offsets exist.  The inclusive prefix of the LAST tile of the level-1 pass
 	// (rsx_scatter2_kernel, SCATTER_BLIND_TOP; status0) is the size of every bucket; bucket k lies in ITS SLOT of blind_cap keys
@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
 	// (radix_sort.hpp:72-80) -- goes to off1_out[256]; a slot that overflowed ends the attempt.
 	if (plan->hyb != HYB_TWO_LEVEL || (blind_cap && ctl->blind != BLIND_GO))
 		return;
+	if (tile_narrow && ctl->narrow)
+		tile = tile_narrow;
 	__shared__ u32 s_size[256], s_tb[257], s_beg[256], s_w[4], s_back[256];
 	const u32 d = threadIdx.x;
 	u32 size, back = 0;
@@ -512,7 +514,10 @@ __global__ __launch_bounds__(256) void rsx_seg_slack_plan_kernel(const ST *__res
                                                                  u32 slack_cap, SegCtl *host_ctl,
                                                                  const u64 *__restrict__ off1_given = nullptr, u32 blind_ = 0)
 {
-	const u32 blind = blind_ & 0xFFu, rev = blind_ >> 8;   // (rev: the table in reverse slot order -- the leaves then start with the slots written last)
+	u32 blind = blind_ & 0xFFu;
+	const u32 rev = blind_ >> 8;   // (rev: the table in reverse slot order -- the leaves then start with the slots written last)
+	if (blind == 3u)               // (8-byte keys: the pass into four-byte slots keeps cursors, rsx_pass64.hpp, the one into whole-key slots a chain)
+		blind = ctl->narrow ? 2u : 1u;
 	if (plan->hyb != HYB_TWO_LEVEL || (blind && ctl->blind != BLIND_GO))
 		return;
 	typedef StatusBits<ST> SB_;

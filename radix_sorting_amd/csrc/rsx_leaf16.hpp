@@ -996,10 +996,13 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk_kernel(KT *__restr
 			up = (up & ~((KT)0xFFu << sh1)) | ((KT)((slot - 1) >> 8) << sh1);
 			up = (up & ~((KT)0xFFu << sh2)) | ((KT)((slot - 1) & 255u) << sh2);
 			first = up;
+			// (a slot filled by rsx_pass64a_kernel holds its values at both ends: `back` of them in its last LEAF16_BACK places)
+			const u32 back = ls.ncols >> 16, front = cnt - back;
 #pragma unroll
 			for (int j = 0; j < NK; ++j) {
 				const u32 e = tid + BLOCK * j;
-				kv[j] = e < cnt ? (CT)q32[e] : (CT)0;
+				const u32 at_e = e < front ? e : slack_cap - LEAF16_BACK + (e - front);   // (one load per value: the place is chosen, not the value)
+				kv[j] = e < cnt ? (CT)q32[at_e] : (CT)0;
 			}
 		} else {
 			first = kdf_apply(q[0], ka);

@@ -36,6 +36,7 @@
 #include "rsx_hybrid.hpp"
 #include "rsx_scatter2.hpp"
 #include "rsx_leaf16.hpp"
+#include "rsx_pass2w.hpp"
 
 namespace rsx {
 
@@ -743,269 +744,46 @@ __global__ __launch_bounds__(LogP1Cfg::BLOCK, 4) void rsx_log_pass1_kernel(const
 }
 
 // ---- level 2 ------------------------------------------------------------------------------------------------------------------
-// rsx_pass16a_kernel's scheme (rsx_pass16.hpp) for 8-byte keys into four-byte slots: a workgroup owns a contiguous range of the
-// tile table, carries per digit the up to fifteen values that do not fill a 64-byte atom, flushes them to the slot's back when
-// the bucket changes or the range ends.  The digit: eight bits at the bucket's own shift.
-struct LogP2Cfg {
-	static constexpr int BLOCK = 1024, KPT = 12, TILE = BLOCK * KPT, SB = 4;
-	static constexpr u32 ATOM = 16, VEC = 4;
-	static constexpr int STAGE = TILE + 256 * 6;
-	static constexpr int GRID = 512;
-};
-struct LogP2Smem {
-	__attribute__((aligned(16))) u32 stage[LogP2Cfg::STAGE];
-	__attribute__((aligned(16))) u32 carry[256][16];
-	u32 cell[2][256];
-	u32 delta[256];
-	u32 info[256];
-	unsigned short rbeg[256], bbeg[256], bend[256];
-	unsigned char group_digit[LogP2Cfg::STAGE / 4];
-	u32 wsum[4];
+// The pass of rsx_pass2w.hpp (8-byte keys in, four-byte values out, whole atoms, two cursors per slot) with this route's tables:
+// the tile table of the plan kernel, a shift and a slot capacity per bucket, LogCtl::fail as the verdict.
+typedef Pass2wCfg<u32> LogP2Cfg;
+static_assert(LogP2Cfg::BACK == LOG_BACK2, "the leaves read a slot's back where the pass writes it");
+
+template <typename KT> struct LogPass2Policy {
+	const KT *kin;
+	const LogTile *tiles;
+	LogCtl *ctl;
+	const LogTabs *tabs;
+	u32 *cur2;
+	u32 dump_at, m;
+	__device__ __forceinline__ bool go() const { return ctl->ok == 1u && ctl->fail == 0u; }
+	__device__ __forceinline__ u32 ntiles() const { return ctl->ntiles2; }
+	__device__ __forceinline__ u32 per(u32) const { return ctl->per2; }
+	__device__ __forceinline__ Pass2wTile<KT> tile(u32 t) const
+	{
+		const LogTile lt = tiles[t];
+		return Pass2wTile<KT>{kin + lt.beg, lt.cnt, lt.bucket};
+	}
+	__device__ __forceinline__ u32 shift(u32 bucket) const { return log_shift2(bucket, m); }
+	__device__ __forceinline__ u32 cap(u32 bucket) const { return tabs->cap2[bucket]; }
+	__device__ __forceinline__ u32 slot(u32 bucket, u32 d) const { return tabs->base2[bucket] + d * tabs->cap2[bucket]; }
+	__device__ __forceinline__ u32 *front(u32 bucket, u32 d) const { return cur2 + bucket * 256u + d; }
+	__device__ __forceinline__ u32 *back(u32 bucket, u32 d) const { return cur2 + 65536u + bucket * 256u + d; }
+	__device__ __forceinline__ void lost(u32 what) const { atomicOr(&ctl->fail, what == 1u ? 1024u : 2048u); }
+	__device__ __forceinline__ u32 dump() const { return dump_at; }
 };
 
+// (the level-1 array holds the caller's element images: the pass derives them again; the bits above B do not reach the digit or
+// the value -- the digit lies below bit 44, the value is the low word)
 template <typename KT>
 __global__ __launch_bounds__(LogP2Cfg::BLOCK, 8) void rsx_log_pass2_kernel(const KT *__restrict__ kin, u32 *__restrict__ kout,
                                                                           const LogTile *__restrict__ tiles,
                                                                           LogCtl *__restrict__ ctl, const LogTabs *__restrict__ tabs,
                                                                           u32 *__restrict__ cur2, u32 dump, KdfArgs<KT> ka)
 {
-	typedef LogP2Cfg C;
-	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
-	constexpr u32 VEC = C::VEC, ATOM = C::ATOM;
-	if (ctl->ok != 1u || ctl->fail)
-		return;
-	const u32 ntiles = ctl->ntiles2, per = ctl->per2;
-	const u32 t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
-	if (t0 >= t1)
-		return;
-	const u32 m = ctl->m;
-	__shared__ LogP2Smem sm;
-	const u32 tid0 = threadIdx.x;
-	auto sidx = [](u32 pos) { return stage_swz<true>(pos * 4u); };
-	auto staged = [&](u32 pos) -> u32 & { return *(u32 *)((char *)sm.stage + sidx(pos)); };
-	u32 cc = 0;
-	u32 bucket = tiles[t0].bucket;
-	if (tid0 < 256)
-		sm.cell[0][tid0] = 0;
-	auto flush = [&]() {
-		const u32 tid = tid0, cd = tid >> 2, part = tid & 3u;
-		__syncthreads();
-		if (tid < 256) {
-			u32 inf = 0, dest = 0;
-			if (cc) {
-				const u32 cap = tabs->cap2[bucket];
-				const u32 pos = __hip_atomic_fetch_add(cur2 + 65536u + bucket * 256u + tid, cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (pos + cc > LOG_BACK2)
-					atomicOr(&ctl->fail, 2048u);
-				else {
-					inf = cc;
-					dest = tabs->base2[bucket] + tid * cap + (cap - LOG_BACK2) + pos;
-				}
-			}
-			sm.info[tid] = inf;
-			sm.delta[tid] = dest;
-			cc = 0;
-		}
-		__syncthreads();
-		{
-			const u32 nk = sm.info[cd], dest = sm.delta[cd];
-#pragma unroll
-			for (u32 e = 0; e < VEC; ++e) {
-				const u32 k = part * VEC + e;
-				if (k < nk)
-					kout[dest + k] = sm.carry[cd][k];
-			}
-		}
-		__syncthreads();
-	};
-	__syncthreads();
-	// (the two workgroups of a CU start half a tile apart)
-	if (blockIdx.x >= gridDim.x / 2)
-		__builtin_amdgcn_s_sleep(127);
-	KT keep[KPT];
-	for (u32 t = t0; t < t1; ++t) {
-		u32 tid = tid0;
-		asm volatile("" : "+v"(tid));
-		const u32 lane = tid & 63, wid = tid >> 6;
-		const u32 cd = tid >> 2, part = tid & 3u;
-		u32 *const cell = sm.cell[(t - t0) & 1u];
-		const LogTile st = tiles[t];
-		if (st.bucket != bucket) {
-			flush();
-			bucket = st.bucket;
-		}
-		const u32 cnt = st.cnt;
-		const bool full = cnt == (u32)TILE;
-		const u32 shift = log_shift2(bucket, m);
-		{
-			const KT *p = kin + st.beg;
-			if (full) {
-				typedef KT vec_t __attribute__((ext_vector_type(2)));
-				const vec_t *vp = (const vec_t *)p + tid;
-#pragma unroll
-				for (int i = 0; i < KPT / 2; ++i) {
-#ifdef LOG_NT_P2_LOAD
-					const vec_t v = __builtin_nontemporal_load(&vp[i * BLOCK]);
-#else
-					const vec_t v = vp[i * BLOCK];
-#endif
-					keep[2 * i] = v[0];
-					keep[2 * i + 1] = v[1];
-				}
-			} else {
-#pragma unroll
-				for (int r = 0; r < KPT; ++r) {
-					const u32 o = tid + r * BLOCK;
-					keep[r] = o < cnt ? p[o] : (KT)0;
-				}
-			}
-		}
-		// (the level-1 array holds the caller's element images: derived again here, once; the bits above B do not reach the digit
-		// or the value -- the digit lies below bit 44, the value is the low word)
-#pragma unroll
-		for (int r = 0; r < KPT; ++r)
-			keep[r] = kdf_apply(keep[r], ka);
-		u32 rk[KPT / 2];
-		auto count = [&](auto full_c) {
-			constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-			for (int r = 0; r < KPT; ++r) {
-				u32 mine = 0;
-				if (FULL || tid + r * BLOCK < cnt)
-					mine = __hip_atomic_fetch_add(&cell[(u32)(keep[r] >> shift) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				rk[r >> 1] = (r & 1) ? rk[r >> 1] | (mine << 16) : mine;
-			}
-		};
-		if (full)
-			count(std::true_type{});
-		else
-			count(std::false_type{});
-		__syncthreads();
-
-		u32 base = 0;
-		{
-			u32 rlen = 0, rstart = 0;
-			if (tid < 256) {
-				const u32 c = cell[tid];
-				u32 h, body = 0, tail = 0, atom = 0;
-				const bool enough = cc + c >= ATOM;
-				if (enough) {
-					h = cc ? ATOM - cc : 0u;
-					atom = cc ? 1u : 0u;
-					body = (c - h) & ~(ATOM - 1u);
-					tail = (c - h) & (ATOM - 1u);
-				} else {
-					h = c;
-				}
-				const u32 mm = atom * ATOM + body;
-				if (mm)
-					base = __hip_atomic_fetch_add(cur2 + bucket * 256u + tid, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const u32 o = (VEC - (h & (VEC - 1u))) & (VEC - 1u);
-				rlen = (o + c + VEC - 1u) & ~(VEC - 1u);
-				sm.info[tid] = cc | (h << 5) | (tail << 10) | (atom << 15) | ((enough ? 1u : 0u) << 16) | (o << 17);
-				sm.bend[tid] = (unsigned short)body;
-				cc = enough ? tail : cc + c;
-				u32 x = rlen;
-#pragma unroll
-				for (int off = 1; off < 64; off <<= 1) {
-					const u32 y = __shfl_up(x, off);
-					if (lane >= (u32)off)
-						x += y;
-				}
-				if (lane == 63)
-					sm.wsum[wid] = x;
-				rstart = x - rlen;
-			}
-			__syncthreads();
-			if (tid < 256) {
-				for (u32 k = 0; k < wid; ++k)
-					rstart += sm.wsum[k];
-				const u32 inf = sm.info[tid];
-				const u32 rb = rstart + (inf >> 17), bb = rb + ((inf >> 5) & 31u), be = bb + sm.bend[tid];
-				cell[tid] = rb;
-				sm.cell[((t - t0) & 1u) ^ 1u][tid] = 0;
-				sm.rbeg[tid] = (unsigned short)rb;
-				sm.bbeg[tid] = (unsigned short)bb;
-				sm.bend[tid] = (unsigned short)be;
-				for (u32 g = bb / VEC; g < (be + VEC - 1u) / VEC; ++g)
-					sm.group_digit[g] = (unsigned char)tid;
-			}
-		}
-		__syncthreads();
-		if (tid < 256) {
-			const u32 cap = tabs->cap2[bucket];
-			const u32 atom = (sm.info[tid] >> 15) & 1u, bb = sm.bbeg[tid], mm = atom * ATOM + (sm.bend[tid] - bb);
-			u32 dest = tabs->base2[bucket] + tid * cap + base + atom * ATOM;
-			if (mm && base + mm > cap - LOG_BACK2) {
-				atomicOr(&ctl->fail, 1024u);   // the slot is too small: the attempt is lost, its values go to the dump area behind the slots
-				dest = dump + ATOM;
-			}
-			sm.delta[tid] = dest - bb;
-		}
-		u32 shift_b = shift;
-		asm volatile("" : "+s"(shift_b));
-		auto stage_keys = [&](auto full_c) {
-			constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-			for (int r0 = 0; r0 < KPT; r0 += SB) {
-				u32 pos[SB];
-#pragma unroll
-				for (int r = 0; r < SB; ++r) {
-					pos[r] = 0;
-					if (FULL || tid + (r0 + r) * BLOCK < cnt)
-						pos[r] = cell[(u32)(keep[r0 + r] >> shift_b) & 0xFFu] + ((rk[(r0 + r) >> 1] >> (16 * ((r0 + r) & 1))) & 0xFFFFu);
-				}
-#pragma unroll
-				for (int r = 0; r < SB; ++r) {
-					if (FULL || tid + (r0 + r) * BLOCK < cnt)
-						staged(pos[r]) = (u32)keep[r0 + r];
-				}
-			}
-		};
-		if (full)
-			stage_keys(std::true_type{});
-		else
-			stage_keys(std::false_type{});
-		__syncthreads();
-		{
-			const u32 inf = sm.info[cd];
-			const u32 ccd = inf & 31u, atomd = (inf >> 15) & 1u;
-			if (atomd) {
-				const u32 rb = sm.rbeg[cd];
-				typedef u32x4 avec_t __attribute__((aligned(16)));
-				u32x4 w;
-#pragma unroll
-				for (u32 e = 0; e < VEC; ++e) {
-					const u32 k = part * VEC + e;
-					w[e] = k < ccd ? sm.carry[cd][k] : staged(rb + (k - ccd));
-				}
-				*(avec_t *)(kout + (u32)(sm.delta[cd] + sm.bbeg[cd] - ATOM + part * VEC)) = w;
-			}
-		}
-		{
-			const u32 total = (u32)__builtin_amdgcn_readfirstlane((int)sm.wsum[0]) + sm.wsum[1] + sm.wsum[2] + sm.wsum[3];
-#pragma unroll 1
-			for (u32 i0 = VEC * tid; i0 < total; i0 += VEC * BLOCK) {
-				const u32 d = sm.group_digit[i0 / VEC];
-				if (i0 >= sm.bbeg[d] && i0 < sm.bend[d]) {
-					typedef u32x4 avec_t __attribute__((aligned(16)));
-					*(avec_t *)(kout + (u32)(sm.delta[d] + i0)) = *(const u32x4 *)((const char *)sm.stage + sidx(i0));
-				}
-			}
-		}
-		{
-			const u32 inf = sm.info[cd];
-			const u32 ccd = inf & 31u, hd = (inf >> 5) & 31u, taild = (inf >> 10) & 31u, enoughd = (inf >> 16) & 1u;
-			const u32 from = enoughd ? sm.bend[cd] : sm.rbeg[cd], to = enoughd ? 0u : ccd, nk = enoughd ? taild : hd;
-#pragma unroll
-			for (u32 e = 0; e < VEC; ++e) {
-				const u32 k = part * VEC + e;
-				if (k < nk)
-					sm.carry[cd][to + k] = staged(from + k);
-			}
-		}
-	}
-	flush();
+	__shared__ Pass2wSmem<u32> sm;
+	const LogPass2Policy<KT> pol{kin, tiles, ctl, tabs, cur2, dump, ctl->m};
+	pass2w_body<KT, u32, false>(pol, kout, ka, sm);
 }
 
 // ---- the leaves ---------------------------------------------------------------------------------------------------------------

@@ -313,7 +313,7 @@ def test_u64_small_leaves_lists_and_fat_bins(n_mi, maxbin, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["u64 asc", "i64 desc", "f64 asc", "f64 negative desc", "whole-key slots", "every leaf by the network",
-                                  "fat bins in some buckets"])
+                                  "fat bins in some buckets", "chained level-2 pass"])
 def test_u64_four_byte_slots(case, monkeypatch):
     """8-byte keys whose leaves sort columns of the low word only (here: 40 varying bits below constant ones): the level-2 pass
     writes the low word of every derived key (SegCtl::narrow) and rsx_leafk_kernel's SLOT32 form puts the upper word back from
@@ -335,11 +335,22 @@ def test_u64_four_byte_slots(case, monkeypatch):
         monkeypatch.setenv("RSX_NO_NARROW_SLOTS", "1")
     elif case == "every leaf by the network":
         monkeypatch.setenv("RSX_LEAF16_MAXBIN", "0")
+    elif case == "chained level-2 pass":          # (round 5's pass instead of rsx_pass64a_kernel: dense slots, no back)
+        monkeypatch.setenv("RSX_NO_PASS64A", "1")
     elif case == "fat bins in some buckets":
         top = (r >> np.uint64(24)) & np.uint64(0xFFFF)
         r[(top % np.uint64(53)) == 3] &= np.uint64(0xFFFFFFFFFF0F0FFF)     # the leaf's keys in 16 bins of ~20: two more register passes
         r[(top % np.uint64(211)) == 9] &= np.uint64(0xFFFFFFFFFF000FFF)    # ... in ONE bin: the network
     _sort_and_compare(r, dt, order, 5, ("u64 four-byte slots", case))
+
+
+@pytest.mark.parametrize("n_mi,mask", [(13, 0xFFFFFFFFFF), (48, 0xFFFFFFFF), (64, 0xFFFFFFFF), (80, 0xFFFFFFFFFF), (200, 0xFFFFFFFFFF)])
+def test_u64_level2_pass_in_whole_atoms(n_mi, mask):
+    """rsx_pass64a_kernel (rsx_pass64.hpp) at sizes that select the SLOT32 leaves' shapes (slots of 512 .. 5120 four-byte values read
+    from both ends), at 64 Mi keys -- where the 128 places of a slot's back would not leave its front mean + 6 sigma and the chained
+    pass stays -- and with an odd count: whole arrays against the oracle, route asserted."""
+    a = ol.splitmix_fill(n_mi * MI + 77, ol.U64, 5300 + n_mi, mask)
+    _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64 level-2 atoms", n_mi, hex(mask)))
 
 
 @pytest.mark.parametrize("n_mi", [5, 9, 16, 64, 160])

@@ -1,6 +1,6 @@
 """A/B of an environment switch over array sizes, inside one process (boxes differ by several percent): keys-only sorts of
 uniform u32 or u64 keys, best of a few device-event timings per setting, settings alternating.
-python tools/ab_sizes.py VAR v1 v2 u32|u64 n [n ...]      (n in Mi keys)"""
+python tools/ab_sizes.py VAR v1 v2 u32|u64 n [n ...]      (n in Mi keys; AB_MASK=0x.. : keys & mask)"""
 import os
 import sys
 
@@ -8,6 +8,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import radix_sorting_amd as rsa  # noqa: E402
+
+
+MASK = int(os.environ.get("AB_MASK", "0"), 0)
 
 
 def main():
@@ -25,7 +28,10 @@ def main():
                 os.environ[var] = v
                 rsa.reload_env()
                 for rep in range(4):
-                    rsa.fill_splitmix(src, seed=11 + rep)
+                    if MASK:
+                        rsa.fill_splitmix(src, seed=11 + rep, mask=MASK)
+                    else:
+                        rsa.fill_splitmix(src, seed=11 + rep)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     torch.cuda.synchronize()
                     e0.record()

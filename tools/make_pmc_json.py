@@ -11,7 +11,7 @@ rows = json.load(open(table))
 out = {
     "round": rnd,
     "measured_at_commit": commit,
-    "workload": "bench.py --steps 5 --warmup 1, 2^28 u32 keys per launch",
+    "workload": "bench.py --steps 20 --warmup 3, 2^28 u32 keys per launch",
     "source": "%s (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, per-dispatch "
               "averages over the working dispatches; fabric bytes = 2 x FETCH_SIZE + WRITE_SIZE in KiB units, the gfx950 "
               "correction of MI355X_MICROARCH.md's HBM section -- FETCH_SIZE reports half of the bytes of wide coalesced reads, "

@@ -24,7 +24,7 @@ profile() {   # <subdir> <program and arguments...>
 	find $OUT -name "*_agent_info.csv" -delete
 }
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
-	profile bench python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline
+	profile bench python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline   # (the driver's own K and W: a kernel's first dispatches after an idle second run 5-10 % faster than its steady state)
 fi
 if [ "$WHAT" = configs ] || [ "$WHAT" = all ]; then
 	profile configs python3 $REPO/tools/bench_configs.py --steps 2 --warmup 1 --out $REPO/gpurun_out/prof_$TAG/configs/bench_configs.json
