@@ -140,6 +140,7 @@ struct Env {
 	unsigned probe = 0;              // RSX_PROBE=bits (measurements only): 1 the leaf table of a sort without a histogram in reverse slot order
 	bool no_pass64a = false;         // RSX_NO_PASS64A=1: the level-2 pass of 8-byte keys into four-byte slots is the chained rsx_scatter2_kernel of round 4 (rsx_pass64.hpp)
 	bool no_log = false;             // RSX_NO_LOG=1: 8-byte keys never take the (bit length, mantissa) digits of rsx_logroute.hpp (rsx_info.hybrid never 6)
+	bool log_leaf_big = false;       // RSX_LOG_LEAF_BIG=1 (tests): that route's leaves in the shape for 10240 values at every size
 	unsigned log_min_log2 = 0;       // RSX_LOG_MIN_LOG2: ... from 2^this keys on (tests: 20; default: from 24 Mi keys)
 	void load()
 	{
@@ -215,6 +216,7 @@ struct Env {
 			probe = (unsigned)atoi(e);
 		no_pass64a = is_one("RSX_NO_PASS64A");
 		no_log = is_one("RSX_NO_LOG");
+		log_leaf_big = is_one("RSX_LOG_LEAF_BIG");
 		log_min_log2 = 0;
 		if (const char *e = getenv("RSX_LOG_MIN_LOG2"))
 			log_min_log2 = (unsigned)std::max(20, std::min(29, atoi(e)));
@@ -2222,9 +2224,10 @@ template <typename KT> bool log_wanted(Ctx &c, size_t n, const KT *src, const KT
 	// 16 Mi 0.49 against 0.43 ms (65536 leaf workgroups are a fixed 0.24 ms), 24 Mi 0.55 against 0.61, 32 Mi 0.63 against 0.78,
 	// 64 Mi 0.89 against 1.46, 128 Mi 1.43 against 2.65, 256 Mi 2.46 against 5.09 (profiles/r06/log_sizes.txt)
 	const size_t floor_keys = env().log_min_log2 ? (size_t)1 << env().log_min_log2 : (size_t)3 << 23;
-	// (up to 2^28 + 2^24 keys: a level-1 bucket must fit 256 leaves of 5120 values -- the heaviest digits of Zipf-like keys hold
-	// 1 / 256 of the array -- and larger arrays would pay for the histogram before the plan kernel says no)
-	if (n < floor_keys || n > ((size_t)17 << 24))
+	// (up to 2^29 + 2^25 keys: a level-1 bucket must fit 256 leaves -- of 5120 values up to 2^28 + 2^24 keys, of 10240 beyond; the
+	// heaviest digits of Zipf-like keys hold 1 / 256 of the array -- and larger arrays would pay for the histogram before the plan
+	// kernel says no)
+	if (n < floor_keys || n > ((size_t)17 << 25))
 		return false;
 	return ((((uintptr_t)src) & 15) | (((uintptr_t)aux) & 63)) == 0;   // (16-byte loads of the input, 64-byte atoms into aux)
 }
@@ -2256,7 +2259,10 @@ int sort_keys_log(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **resul
 		u32 *slots = (u32 *)c.logslots.p;
 		const size_t pmark = prof_mark();
 		HIP_TRY(hipMemsetAsync(c.logb.p, 0, zero_bytes, c.stream));
-		hipLaunchKernelGGL((rsx_log_sample_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl);
+		// the leaves' shape: 5120 values per slot (five workgroups of 256 threads per CU) up to 2^28 + 2^24 keys, 10240 beyond
+		const bool big_leaves = n > ((size_t)17 << 24) || env().log_leaf_big;
+		hipLaunchKernelGGL((rsx_log_sample_kernel<KT>), dim3(1), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl,
+		                   big_leaves ? LOG_LEAF_CAP_BIG : LOG_LEAF_CAP);
 		{
 			ProfScope prof(0, (u64)n * sizeof(KT), c.stream);
 			hipLaunchKernelGGL((rsx_log_hist_kernel<KT>), dim3(512), dim3(1024), 0, c.stream, (const KT *)src, (u64)n, ka, ctl, tabs);
@@ -2277,8 +2283,12 @@ int sort_keys_log(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **resul
 			ProfScope prof(2, 0, c.stream);
 			hipLaunchKernelGGL((rsx_log_fill_kernel<KT>), dim3(2048), dim3(256), 0, c.stream, src, aux, (const LogCtl *)ctl,
 			                   (const LogTabs *)tabs, ka);
-			hipLaunchKernelGGL((rsx_log_leaf_kernel<KT>), dim3(65536), dim3(LogLeafCfg::BLOCK), 0, c.stream, src, aux,
-			                   (const u32 *)slots, (const LogCtl *)ctl, (const LogTabs *)tabs, (const u32 *)cur2, ka);
+			if (big_leaves)
+				hipLaunchKernelGGL((rsx_log_leaf_kernel<KT, LogLeafCfgBig>), dim3(65536), dim3(LogLeafCfgBig::BLOCK), 0, c.stream, src, aux,
+				                   (const u32 *)slots, (const LogCtl *)ctl, (const LogTabs *)tabs, (const u32 *)cur2, ka, 0u, 256u);
+			else
+				hipLaunchKernelGGL((rsx_log_leaf_kernel<KT, LogLeafCfg>), dim3(65536), dim3(LogLeafCfg::BLOCK), 0, c.stream, src, aux,
+				                   (const u32 *)slots, (const LogCtl *)ctl, (const LogTabs *)tabs, (const u32 *)cur2, ka, 0u, 256u);
 		}
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(c.host_logctl, ctl, sizeof(LogCtl), hipMemcpyDeviceToHost, c.stream));

@@ -42,7 +42,8 @@ namespace rsx {
 
 constexpr u32 LOG_C = 12;                  // derived keys below 2^LOG_C are counted, not moved
 constexpr u32 LOG_NSMALL = 1u << LOG_C;
-constexpr u32 LOG_LEAF_CAP = 5120;         // values a leaf holds (rsx_log_leaf_kernel)
+constexpr u32 LOG_LEAF_CAP = 5120;         // values a leaf holds (rsx_log_leaf_kernel, LogLeafCfg<256, 5120, 12>) ...
+constexpr u32 LOG_LEAF_CAP_BIG = 10240;    // ... and the shape for arrays beyond 2^28 + 2^24 keys (LogLeafCfg<512, 10240, 13>)
 constexpr u32 LOG_BACK2 = 128;             // places at the end of every level-2 slot for what is carried when a range ends
 constexpr u32 LOG_MAX_B = 44;              // keys that vary in more low bits than this do not leave 32 undecided bits or fewer
 
@@ -62,7 +63,8 @@ struct LogCtl {   // 256 bytes; zeroed by the host, then: sample -> histogram ->
 	u32 per2;      // plan: tiles per workgroup of the level-2 pass
 	u32 maxh1;     // plan: the largest level-1 bucket
 	u32 ncols;     // plan: kept byte columns (radix_sort.hpp:64-70)
-	u32 pad[47];
+	u32 leaf_cap;  // host: values the leaf shape launched behind this attempt holds (LOG_LEAF_CAP or LOG_LEAF_CAP_BIG)
+	u32 pad[46];
 };
 static_assert(sizeof(LogCtl) == 256, "LogCtl");
 
@@ -102,7 +104,8 @@ __device__ __forceinline__ u32 log_cap2(u32 mean)
 // One workgroup, 64 places of 128 consecutive keys (as rsx_blind_precheck_kernel).  go = the sampled derived keys agree above
 // bit B (25 <= B <= 44), and no level-1 digit holds more of the sample than a leaf-sized share allows.
 template <typename KT>
-__global__ __launch_bounds__(1024) void rsx_log_sample_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka, LogCtl *__restrict__ ctl)
+__global__ __launch_bounds__(1024) void rsx_log_sample_kernel(const KT *__restrict__ src, u64 n, KdfArgs<KT> ka, LogCtl *__restrict__ ctl,
+                                                              u32 leaf_cap = LOG_LEAF_CAP)
 {
 	static_assert(sizeof(KT) == 8, "8-byte keys");
 	constexpr u32 S = 8, NS = 1024 * S;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(1024) void rsx_log_sample_kernel(const KT *__restri
 		if (go) {
 			// the largest level-1 bucket may hold 256 leaves' worth of keys: its share of the sample, a quarter and four standard
 			// deviations on top (the plan kernel decides exactly; this only keeps hopeless inputs from paying for the histogram)
-			const float share = (float)NS * 256.0f * (float)LOG_LEAF_CAP / (float)n;
+			const float share = (float)NS * 256.0f * (float)leaf_cap / (float)n;
 			const float lim = share + 0.25f * share + 4.0f * sqrtf(share) + 8.0f;
 			go = (float)s_max <= lim;
 		}
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(1024) void rsx_log_sample_kernel(const KT *__restri
 		ctl->ndig = go ? (B - LOG_C) << m : 0u;
 		ctl->key0_lo = (u32)key0;
 		ctl->key0_hi = (u32)(key0 >> 32);
+		ctl->leaf_cap = leaf_cap;
 	}
 }
 
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(1024) void rsx_log_plan_kernel(LogCtl *__restrict__
 	// large for leaves, 64 a digit the sample's bit length does not have)
 	u32 bad = ((u64)nsmall + nbig != n ? 2u : 0u) | (tot1 > l1_cap ? 4u : 0u) | (tot2 > l2_cap ? 8u : 0u) | (ntiles > tiles_cap ? 16u : 0u);
 	if (tid < 256)
-		bad |= (cap2 > LOG_LEAF_CAP ? 32u : 0u) | ((h != 0 && tid >= ndig) ? 64u : 0u);
+		bad |= (cap2 > ctl->leaf_cap ? 32u : 0u) | ((h != 0 && tid >= ndig) ? 64u : 0u);
 	if (bad)
 		atomicOr(&s_fail, bad);
 	__syncthreads();
@@ -791,40 +795,45 @@ __global__ __launch_bounds__(LogP2Cfg::BLOCK, 8) void rsx_log_pass2_kernel(const
 // by the top twelve of their undecided bits (all of them, if there are at most twelve: the placement then is the sort), finished
 // by Batcher's network on sixteen values per lane (or, bins too full for that, over the whole leaf in the LDS); where the leaf
 // begins in the sorted array = its bucket's start + the sizes of the slots before it.
-struct LogLeafCfg {
-	static constexpr int BLOCK = 256, CAP = LOG_LEAF_CAP, NW = 4, NBIN = 4096, NCELLW = 2048, PLANES = 2;
+template <int BLOCK_, int CAP_, int NBITS_> struct LogLeafCfgT {
+	static constexpr int BLOCK = BLOCK_, CAP = CAP_, NW = BLOCK_ / 64, NBITS = NBITS_, NBIN = 1 << NBITS_, NCELLW = NBIN / 2;
+	static constexpr int PLANES = NCELLW / 4 / BLOCK;   // 16-byte vectors of cells per thread
 	static constexpr int NK = CAP / BLOCK, NCH = (CAP / 16 + BLOCK - 1) / BLOCK;
 	static constexpr int S = CAP / 16 + 3;
+	static constexpr int WPE = BLOCK == 256 ? 5 : 4;    // (29 KiB / 58 KiB of LDS per workgroup: five / two per CU)
 	static_assert(S % 2 == 1, "rows that start in different banks");
+	static_assert(PLANES == 2 && NCELLW == 4 * BLOCK * PLANES && CAP % BLOCK == 0, "two vectors of cells per thread");
 };
+typedef LogLeafCfgT<256, LOG_LEAF_CAP, 12> LogLeafCfg;
+typedef LogLeafCfgT<512, LOG_LEAF_CAP_BIG, 13> LogLeafCfgBig;
 
-template <typename KT>
-__global__ __launch_bounds__(LogLeafCfg::BLOCK, 5) void rsx_log_leaf_kernel(KT *__restrict__ src, KT *__restrict__ aux,
+template <typename KT, typename C = LogLeafCfg>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_log_leaf_kernel(KT *__restrict__ src, KT *__restrict__ aux,
                                                                            const u32 *__restrict__ slots,
                                                                            const LogCtl *__restrict__ ctl,
                                                                            const LogTabs *__restrict__ tabs,
                                                                            const u32 *__restrict__ cur2, KdfArgs<KT> ka,
                                                                            u32 d1_lo = 0, u32 d1_hi = 256)   // (the probe: a range of level-1 digits)
 {
-	typedef LogLeafCfg C;
 	constexpr int BLOCK = C::BLOCK, NK = C::NK, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES, S = C::S;
+	constexpr u32 NBITS = C::NBITS;
 	// everything the leaf needs to find its values is requested at once: the control block, the slot's two cursors, those of the
 	// slots before it in its bucket, the bucket's row of the tables (one round trip in front of the values' instead of four)
 	const u32 d1 = blockIdx.x >> 8, d2 = blockIdx.x & 255u;
 	const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-	const u32 ok = ctl->ok, lost = ctl->fail, ndig = ctl->ndig, m = ctl->m, B = ctl->B, ncols = ctl->ncols;
+	const u32 ok = ctl->ok, lost = ctl->fail, ndig = ctl->ndig, m = ctl->m, B = ctl->B, ncols = ctl->ncols, shape = ctl->leaf_cap;
 	const u64 key0 = ((u64)ctl->key0_hi << 32) | ctl->key0_lo;
 	const u32 front = cur2[blockIdx.x], back = cur2[65536u + blockIdx.x], cnt = front + back;
 	u32 c_before = tid < d2 ? cur2[d1 * 256u + tid] + cur2[65536u + d1 * 256u + tid] : 0u;
 	const u32 cap = tabs->cap2[d1], base2 = tabs->base2[d1], out1 = tabs->out1[d1];
-	if (ok != 1u || lost || d1 >= ndig || d1 < d1_lo || d1 >= d1_hi || cnt == 0 || cnt > (u32)C::CAP)
-		return;   // (cnt > CAP cannot happen: a slot that would hold more has set LogCtl::fail)
+	if (ok != 1u || lost || shape != (u32)C::CAP || d1 >= ndig || d1 < d1_lo || d1 >= d1_hi || cnt == 0 || cnt > (u32)C::CAP)
+		return;   // (cnt > CAP cannot happen: a slot that would hold more has set LogCtl::fail; shape: the other launch's leaves)
 	const u32 *q = slots + base2 + d2 * cap;
 	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
 	__shared__ __attribute__((aligned(16))) u32 stage[16 * S + 64];
 	__shared__ u32 ws[NW], wmax[NW], wpre[NW];
 	const u32 blen = log_blen(d1, m), s2 = log_shift2(d1, m);
-	const u32 nb = s2 < 12u ? s2 : 12u, bsh = s2 - nb, bmask = (1u << nb) - 1u;
+	const u32 nb = s2 < NBITS ? s2 : NBITS, bsh = s2 - nb, bmask = (1u << nb) - 1u;
 	auto at = [](u32 p) { return (p & 15u) * (u32)S + (p >> 4); };
 	u32 kv[NK];
 #pragma unroll
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(LogLeafCfg::BLOCK, 5) void rsx_log_leaf_kernel(KT *
 	// (fewer than twelve undecided bits: every value has 2^rep bins, one per lane class -- equal values are equal keys, any order
 	// among them will do, and the lanes of a wave that hold the same value no longer queue at one LDS word: the leaves of bit
 	// lengths 13 .. 16 of 2^28 Zipf-like keys, two to sixteen values per leaf, took 0.165 ms against 0.093 for the next four)
-	const u32 rep = 12u - nb, repmask = (1u << rep) - 1u;
+	const u32 rep = NBITS - nb, repmask = (rep < 6u ? (1u << rep) : 64u) - 1u;   // (a lane class per bin copy: at most the wave's 64)
 	auto cell_of = [&](u32 v, bool valid, u32 &sh) -> u32 * {
 		const u32 bin = (((v >> bsh) & bmask) << rep) | (lane & repmask);
 		sh = (bin & 1u) << 4;
@@ -972,7 +981,10 @@ __global__ __launch_bounds__(LogLeafCfg::BLOCK, 5) void rsx_log_leaf_kernel(KT *
 		const u64 lowmask = ((u64)1 << B) - 1u;
 		u64 up = key0 & ~lowmask;
 		up |= (((u64)1 << (blen - 1u)) | ((u64)(d1 & ((1u << m) - 1u)) << (blen - 1u - m)) | ((u64)d2 << s2)) & ~(u64)0xFFFFFFFFu;
-		const u32 pre = wpre[0] + wpre[1] + wpre[2] + wpre[3];
+		u32 pre = 0;
+#pragma unroll
+		for (int w = 0; w < NW; ++w)
+			pre += wpre[w];
 		KT *o = ((ncols & 1u) ? aux : src) + out1 + pre;   // radix_sort.hpp:92
 		for (u32 i0 = 2 * tid; i0 < cnt; i0 += 2 * BLOCK) {
 			KT kk[2];

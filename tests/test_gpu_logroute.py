@@ -67,6 +67,32 @@ def test_cfg3_zipf_like_against_the_oracle(log2n, monkeypatch):
     _check(zipf_like(1 << log2n, 33), rsa.U64, LOG_ROUTE, what="2^%d" % log2n)
 
 
+def test_leaves_of_up_to_10240_values(monkeypatch):
+    """Arrays beyond 2^28 + 2^24 keys take the leaves' larger shape (512 threads, 8192 bins); forced here at a size the oracle sorts in
+    seconds, and at 2^29 keys -- where it is the shape the size selects -- checked by properties (tests/test_gpu_big.py style)."""
+    monkeypatch.setenv("RSX_LOG_LEAF_BIG", "1")
+    monkeypatch.setenv("RSX_LOG_MIN_LOG2", "20")
+    _check(zipf_like(1 << 24, 35), rsa.U64, LOG_ROUTE, what="2^24, leaves of 10240")
+    _check(zipf_like((1 << 22) + 3, 36, 44), rsa.U64, LOG_ROUTE, what="2^22 + 3, bmax 44, leaves of 10240")
+
+
+def test_two_to_the_29_zipf_like_keys():
+    n = 1 << 29
+    r = torch.empty(n, dtype=torch.int64, device="cuda")
+    rsa.fill_splitmix(r, seed=37)
+    b = 1 + (((r >> 58) & 63) % 40)
+    one = torch.ones_like(r)
+    keys = (one << (b - 1)) + (r & ((one << (b - 1)) - 1))
+    del r, b, one
+    before = (int(keys.sum().item()), int((keys * (keys >> 7)).sum().item()))
+    aux = torch.empty_like(keys)
+    res, info = rsa.radix_sort(keys, aux, dtype=rsa.U64)
+    torch.cuda.synchronize()
+    assert info.hybrid == LOG_ROUTE and info.ncols == 5 and info.result_in_aux == 1
+    assert bool((res[1:] >= res[:-1]).all().item())                      # (keys below 2^40: signed order is unsigned order)
+    assert (int(res.sum().item()), int((res * (res >> 7)).sum().item())) == before
+
+
 def test_the_floor():
     info = _check(zipf_like(1 << 24, 34), rsa.U64, None, what="2^24, default floor")
     assert info.hybrid != LOG_ROUTE

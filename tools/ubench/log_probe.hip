@@ -3,7 +3,7 @@
 // HIP events, the control block printed, the result compared with std::sort on the host (up to 2^26 keys) or checked for order
 // and checksums on the device.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I radix_sorting_amd/csrc tools/ubench/log_probe.hip -o tools/ubench/log_probe.bin
-// Run:   log_probe.bin [log2 n = 28] [bmax = 40] [reps = 5] [n offset = 0]
+// Run:   log_probe.bin [log2 n = 28] [bmax = 40] [reps = 5] [n offset = 0]      (LOG_PROBE_BIG=1: the leaves' 10240-value shape)
 #include "rsx_logroute.hpp"
 
 #include <algorithm>
@@ -83,6 +83,7 @@ int main(int argc, char **argv)
 	u64 *chk;
 	CK(hipMalloc(&chk, 6 * 8));
 	const KdfArgs<KT> ka{0, 0, 0};
+	const bool big = getenv("LOG_PROBE_BIG") != nullptr || log2n > 28;
 	gen_kernel<<<2048, 256>>>(keep, n, bmax, 12345);
 	CK(hipDeviceSynchronize());
 	hipEvent_t ev[9];
@@ -97,7 +98,7 @@ int main(int argc, char **argv)
 		CK(hipDeviceSynchronize());
 		CK(hipEventRecord(ev[0]));
 		CK(hipMemsetAsync(logb, 0, zero_bytes));
-		rsx_log_sample_kernel<KT><<<1, 1024>>>(src, n, ka, ctl);
+		rsx_log_sample_kernel<KT><<<1, 1024>>>(src, n, ka, ctl, big ? LOG_LEAF_CAP_BIG : LOG_LEAF_CAP);
 		CK(hipEventRecord(ev[1]));
 		rsx_log_hist_kernel<KT><<<512, 1024>>>(src, n, ka, ctl, tabs);
 		CK(hipEventRecord(ev[2]));
@@ -109,7 +110,10 @@ int main(int argc, char **argv)
 		CK(hipEventRecord(ev[5]));
 		rsx_log_fill_kernel<KT><<<2048, 256>>>(src, aux, ctl, tabs, ka);
 		CK(hipEventRecord(ev[6]));
-		rsx_log_leaf_kernel<KT><<<65536, LogLeafCfg::BLOCK>>>(src, aux, slots, ctl, tabs, cur2, ka);
+		if (big)
+			rsx_log_leaf_kernel<KT, LogLeafCfgBig><<<65536, LogLeafCfgBig::BLOCK>>>(src, aux, slots, ctl, tabs, cur2, ka, 0u, 256u);
+		else
+			rsx_log_leaf_kernel<KT, LogLeafCfg><<<65536, LogLeafCfg::BLOCK>>>(src, aux, slots, ctl, tabs, cur2, ka, 0u, 256u);
 		CK(hipEventRecord(ev[7]));
 		CK(hipGetLastError());
 		CK(hipDeviceSynchronize());
@@ -142,7 +146,7 @@ int main(int argc, char **argv)
 		// the leaves of four exponents at a time (a level-1 digit is (bit length - 13) << m | mantissa bits): where their time goes
 		for (u32 e0 = 0; (e0 << h.m) < h.ndig; e0 += 4) {
 			CK(hipEventRecord(ev[0]));
-			rsx_log_leaf_kernel<KT><<<65536, LogLeafCfg::BLOCK>>>(src, aux, slots, ctl, tabs, cur2, ka, e0 << h.m, (e0 + 4) << h.m);
+			rsx_log_leaf_kernel<KT, LogLeafCfg><<<65536, LogLeafCfg::BLOCK>>>(src, aux, slots, ctl, tabs, cur2, ka, e0 << h.m, (e0 + 4) << h.m);
 			CK(hipEventRecord(ev[1]));
 			CK(hipDeviceSynchronize());
 			float ms;
