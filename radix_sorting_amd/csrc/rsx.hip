@@ -137,7 +137,7 @@ struct Env {
 	unsigned two_level_min_log2 = 27; // RSX_TWO_LEVEL_MIN_LOG2: two MSB passes + leaves from 2^this keys on (tests: 22)
 	bool no_odd_stride = false;      // RSX_NO_ODD_STRIDE=1: the level-1 slots of a sort without a histogram lie 1.25 means apart, rounded to 1 KiB, as in round 5
 	unsigned cap1_pad_kib = 0;       // RSX_CAP1_PAD_KIB=k (probe): k KiB more per level-1 slot of a sort without a histogram
-	unsigned probe = 0;              // RSX_PROBE=bits (measurements only): 1 the leaf table of a sort without a histogram in reverse slot order
+	unsigned probe = 0;              // RSX_PROBE=bits (measurements; results stay right): 1 the leaf table of a sort without a histogram in reverse slot order, 4 every device-scheduled sort as if hinted (rsx_sort_inplace_async_hint)
 	bool no_pass64a = false;         // RSX_NO_PASS64A=1: the level-2 pass of 8-byte keys into four-byte slots is the chained rsx_scatter2_kernel of round 4 (rsx_pass64.hpp)
 	bool no_log = false;             // RSX_NO_LOG=1: 8-byte keys never take the (bit length, mantissa) digits of rsx_logroute.hpp (rsx_info.hybrid never 6)
 	bool log_leaf_big = false;       // RSX_LOG_LEAF_BIG=1 (tests): that route's leaves in the shape for 10240 values at every size
@@ -1457,7 +1457,7 @@ int launch_leaves(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, u32 level,
 			if (c.slack_cap <= (u32)L2k::CAP)
 				RSX_LAUNCH_L16(rsx_leaf16_kernel, L2k, grid_1);
 			else
-				RSX_LAUNCH_L16(rsx_leaf16_kernel, L5k, (env().probe & 2u) ? 16384u : grid_1);
+				RSX_LAUNCH_L16(rsx_leaf16_kernel, L5k, grid_1);
 #undef RSX_LAUNCH_L16
 			typedef typename LeafShapes<KT>::Fit F_;
 			hipLaunchKernelGGL((rsx_leaf_sort_kernel<KT, F_, uint16_t, true>), dim3(4096), dim3(F_::BLOCK), 0, c.stream, src, aux,
@@ -1619,18 +1619,15 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 	if constexpr (sizeof(KT) == 4) {
 		if (dense && pass16a_wanted<KT>(c)) {
 			// ... and with whole 64-byte atoms: a workgroup takes a range of tiles and carries what does not fill an atom
-			const unsigned pgrid = (env().probe & 2u) ? 192 : 512;   // (the probe: a bucket's tiles shared by at most four workgroups, as in the whole pass)
-			// (RSX_PROBE & 2, a measurement with a WRONG result: the first quarter of the level-1 buckets only, here and in the leaves)
-			const u32 *bt = (env().probe & 2u) ? (const u32 *)((char *)c.seg.p + c.seg_btile_off) : nullptr;
-			const u32 bhi = (env().probe & 2u) ? 64u : 256u;
+			const unsigned pgrid = 512;
 			if (plain)
 				hipLaunchKernelGGL((rsx_pass16a_kernel<KT, DIG_PLAIN>), dim3(pgrid), dim3(Pass16aCfg::BLOCK), 0, c.stream, (const KT *)aux,
 				                   (const KT *)sa.kin_hi, sa.lo_slots, (unsigned short *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
-				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka, bt, 0u, bhi);
+				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
 			else
 				hipLaunchKernelGGL((rsx_pass16a_kernel<KT, DIG_GENERIC>), dim3(pgrid), dim3(Pass16aCfg::BLOCK), 0, c.stream, (const KT *)aux,
 				                   (const KT *)sa.kin_hi, sa.lo_slots, (unsigned short *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
-				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka, bt, 0u, bhi);
+				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
 			HIP_TRY(hipGetLastError());
 			return RSX_OK;
 		}

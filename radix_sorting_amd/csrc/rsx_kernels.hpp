@@ -450,11 +450,7 @@ __device__ __forceinline__ void store_chunk(T *dst, const T (&v)[E])
 #pragma unroll
 	for (int e = 0; e < E; ++e)
 		x[e] = v[e];
-#ifdef RSX_PROBE_NT_STORE   // (measurement builds, tools/ab_lib.py: the leaves' results as non-temporal stores)
-	__builtin_nontemporal_store(x, (uvec_t *)dst);
-#else
 	*(uvec_t *)dst = x;
-#endif
 }
 
 // Keeps a stream busy for `ticks` of the 100 MHz wall clock (one wave): a known-length occupant for stream / queue

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
                                                                       const LeafSeg *__restrict__ segtab, SegCtl *__restrict__ ctl,
                                                                       KdfArgs<KT> ka, u32 lo, u32 hi,
                                                                       const uint16_t *__restrict__ slots, u32 slack_cap,
-                                                                      u32 *__restrict__ redo, u32 maxbin2 = C::MAXBIN2, u32 s_lo = 0)   // (s_lo: the first table entry of this launch)
+                                                                      u32 *__restrict__ redo, u32 maxbin2 = C::MAXBIN2)
 {
 	static_assert(sizeof(KT) == 4, "4-byte keys: two MSB digits in the slot, two bytes in the leaf");
 	constexpr int BLOCK = C::BLOCK, CAP = C::CAP, NV = C::NV, NCH = C::NCH, NCELLW = C::NCELLW, NW = C::NW, PLANES = C::PLANES;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 	// the leaf's values: the sh2 bits below the MSB digits (sixteen of them unless ...); their bins: the top NBITS of those
 	const u32 D = sh2 > (u32)C::NBITS ? sh2 - (u32)C::NBITS : 0u, nb = sh2 - D;
 	const KT above = sh1 + 8 >= 32u ? (KT)0 : (KT)(key0 >> (sh1 + 8) << (sh1 + 8));   // what every key has above the level-1 digit
-	for (u32 s = s_lo + blockIdx.x; s < nseg; s += gridDim.x) {
+	for (u32 s = blockIdx.x; s < nseg; s += gridDim.x) {
 		[&]() {   // (one leaf; see LEAF_ONE_PER_GROUP)
 		const LeafSeg ls = segtab[s];
 		const u32 cnt = ls.cnt, slot = ls.slot;
@@ -214,13 +214,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf16_kernel(KT *__rest
 			const int left = (int)(isback ? back : front) - (int)e0;
 			nvalid[j] = left < 0 ? 0 : left > 8 ? 8 : left;
 			kv[j] = u32x4{0, 0, 0, 0};
-			if (left > 0) {
-#ifdef RSX_PROBE_NT_LEAF_LOAD   // (measurement builds)
-				kv[j] = __builtin_nontemporal_load((const u32x4 *)(q + (isback ? slack_cap - LEAF16_BACK : 0u) + e0));
-#else
+			if (left > 0)
 				kv[j] = *(const u32x4 *)(q + (isback ? slack_cap - LEAF16_BACK : 0u) + e0);
-#endif
-			}
 		}
 		// vectors in which this WAVE has any value (the last round of a slot that is not full)
 		auto wave_has = [&](int j) { return 64 * swid + BLOCK * (u32)j < VF + VB; };

@@ -227,13 +227,8 @@ __global__ __launch_bounds__(1024, 2) void rsx_log_hist_kernel(const KT *__restr
 		const u64 i = base + lane;
 		const bool act = i < nvec;
 		vec_t x = {0, 0};
-		if (act) {
-#ifdef LOG_NT_HIST_LOAD
-			x = __builtin_nontemporal_load(&vp[i]);
-#else
+		if (act)
 			x = vp[i];
-#endif
-		}
 		// the key behind this lane's pair: the next lane's first (a DPP wave shift); the wave's last lane, and the lane in front
 		// of an odd array's last key, load it
 		const bool has_next = act && 2 * i + 2 < n;

@@ -274,18 +274,16 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
                                                                           const SegTile *__restrict__ tiles,
                                                                           const SegCtl *__restrict__ ctl,
                                                                           const Plan *__restrict__ plan, u32 *__restrict__ cursors,
-                                                                          u32 slack_cap, u32 *__restrict__ overflow, KdfArgs<KT> ka,
-                                                                          const u32 *__restrict__ btile = nullptr, u32 b_lo = 0, u32 b_hi = 256)
+                                                                          u32 slack_cap, u32 *__restrict__ overflow, KdfArgs<KT> ka)
 {
 	static_assert(sizeof(KT) == 4, "4-byte keys, two-byte values");
 	typedef Pass16aCfg C;
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE;
 	if (ctl->blind != BLIND_GO || plan->hyb != HYB_TWO_LEVEL)
 		return;
-	// btile (bucket k's tiles are [btile[k], btile[k + 1])): only the level-1 buckets [b_lo, b_hi) -- the pass group by group
-	const u32 tlo = btile ? btile[b_lo] : 0u, ntiles = btile ? btile[b_hi] : ctl->ntiles;
-	const u32 per = (ntiles - tlo + gridDim.x - 1) / gridDim.x;
-	const u32 t0 = tlo + blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+	const u32 ntiles = ctl->ntiles;
+	const u32 per = (ntiles + gridDim.x - 1) / gridDim.x;
+	const u32 t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
 	if (t0 >= t1)
 		return;
 	const u32 shift = ctl->shift2;
@@ -542,11 +540,7 @@ __global__ __launch_bounds__(Pass16aCfg::BLOCK, 8) void rsx_pass16a_kernel(const
 					const u32x4 x = *(const u32x4 *)((const char *)sm.stage + sidx(i0));
 					if (i0 + 8u <= be) {
 						typedef u32x4 uvec_t __attribute__((aligned(2)));
-#ifdef RSX_PROBE_NT_P16_STORE   // (measurement builds)
-						__builtin_nontemporal_store(x, (uvec_t *)(kout + (u32)(sm.delta[d] + i0)));
-#else
 						*(uvec_t *)(kout + (u32)(sm.delta[d] + i0)) = x;
-#endif
 					} else {
 						const u64 lo = ((u64)x[1] << 32) | x[0], hi = ((u64)x[3] << 32) | x[2];
 #pragma unroll 1

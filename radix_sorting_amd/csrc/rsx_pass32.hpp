@@ -103,11 +103,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 			const vec_t *vp = (const vec_t *)p + tid;
 #pragma unroll
 			for (int i = 0; i < KPT / (int)VEC; ++i) {
-#ifdef RSX_PROBE_NT_P32_LOAD   // (measurement builds, tools/ab_lib.py)
-				const vec_t v = __builtin_nontemporal_load(&vp[i * BLOCK]);
-#else
 				const vec_t v = vp[i * BLOCK];
-#endif
 #pragma unroll
 				for (int e = 0; e < (int)VEC; ++e)
 					keep[(int)VEC * i + e] = v[e];
@@ -303,11 +299,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 				if (i0 >= sm.bbeg[d] && i0 < sm.bend[d]) {
 					typedef KT kvec_t __attribute__((ext_vector_type(VEC)));
 					typedef kvec_t avec_t __attribute__((aligned(16)));
-#ifdef RSX_PROBE_NT_P32_STORE   // (measurement builds)
-					__builtin_nontemporal_store(*(const kvec_t *)((const char *)sm.stage + sidx(i0)), (avec_t *)(kout + (u32)(sm.delta[d] + i0)));
-#else
 					*(avec_t *)(kout + (u32)(sm.delta[d] + i0)) = *(const kvec_t *)((const char *)sm.stage + sidx(i0));
-#endif
 				}
 			}
 		}
