@@ -379,6 +379,7 @@ struct Ctx {
 	// ... sorts to go before the next attempt, doubled by every attempt that is called off; per kind of sort (4- / 8-byte keys,
 	// rank sorts, keys + payload): what one kind's inputs look like says nothing about another's
 	u32 blind_skip[4] = {0, 0, 0, 0}, blind_backoff[4] = {0, 0, 0, 0};
+	u32 log_skip = 0, log_backoff = 0;       // ... and the same for the attempts by (bit length, mantissa) digits (sort_keys_log): a refused or lost one costs 65 us and more
 	bool blind_no_room = false;              // the slots could not be allocated once: not asked for again (until rsx_reload_env)
 	u32 env_epoch = 0;                       // ... forgotten when rsx_reload_env() has run since
 	SegCtl *host_segctl = nullptr, *dev_host_segctl = nullptr;   // pinned, written by rsx_seg_plan_kernel
@@ -1895,6 +1896,7 @@ inline void blind_refresh(Ctx &c)
 		c.blind_no_room = false;
 		for (int k = 0; k < 4; ++k)
 			c.blind_skip[k] = c.blind_backoff[k] = 0;
+		c.log_skip = c.log_backoff = 0;
 		c.boff_forget = true;   // (... and the device-side one of the device-scheduled sorts, SegCtl::boff_*: zeroed by the next attempt)
 	}
 }
@@ -2226,7 +2228,17 @@ template <typename KT> bool log_wanted(Ctx &c, size_t n, const KT *src, const KT
 	// kernel says no)
 	if (n < floor_keys || n > ((size_t)17 << 25))
 		return false;
-	return ((((uintptr_t)src) & 15) | (((uintptr_t)aux) & 63)) == 0;   // (16-byte loads of the input, 64-byte atoms into aux)
+	if (((((uintptr_t)src) & 15) | (((uintptr_t)aux) & 63)) != 0)   // (16-byte loads of the input, 64-byte atoms into aux)
+		return false;
+	// an attempt that its sample refuses costs a memset, the sample and eight empty launches -- 65 us, 7 % of a sort of 24 Mi keys --,
+	// a lost one the histogram and a pass or two: after either the next 1, 3, 7 .. 31 sorts of the context do not ask
+	// (tools/log_overhead.py; rsx_reload_env() forgets, as for the sorts without a histogram)
+	blind_refresh(c);
+	if (c.log_skip) {
+		--c.log_skip;
+		return false;
+	}
+	return true;
 }
 
 template <typename KT>
@@ -2294,8 +2306,11 @@ int sort_keys_log(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **resul
 		const LogCtl h = *c.host_logctl;
 		if (!h.go || h.fail || (!h.ok && !h.sorted)) {
 			prof_called_off(pmark, c.stream);   // (not this route's keys, or an attempt that was lost: the ordinary path)
+			c.log_backoff = std::min<u32>(2 * c.log_backoff + 1, 31);
+			c.log_skip = c.log_backoff;
 			return RSX_OK;
 		}
+		c.log_backoff = 0;
 		const Plan plan = *c.host_plan;
 		info_from_plan(info, plan);
 		*done = 1;
