@@ -39,7 +39,10 @@
  *   one is freed, and nothing grows or is released inside a stream capture or a *_inplace_async call.  Measured
  *   (tools/footprint_probe.py, profiles/r05/footprint_probe.txt): 2^28 u32 keys 1.17 GiB in all, 2^27 u64 keys 1.72, 2^28 u64
  *   keys 3.43; 2^28 f32 keys -> ranks or key + payload pairs 5.5 GiB (those sorts keep all their level-1 slots, keys and
- *   payloads, in scratch memory).  If an allocation fails the sort takes the histogram-first
+ *   payloads, in scratch memory).  Round 6, 8-byte keys by (bit length, mantissa) digits (rsx_info.hybrid == 6): the level-1
+ *   buckets lie in the caller's second buffer, scratch memory holds the level-2 slots -- four bytes per key, sized
+ *   (1.125 n + 46 M) x 4 bytes for any distribution (2^28 keys: 1.4 GiB, of which BASELINE's Zipf-like keys use 0.8).
+ *   If an allocation fails the sort takes the histogram-first
  *   route and the (device, stream) context does not ask again until rsx_reload_env() or rsx_release_stream();
  *   RSX_NO_BLIND=1 never asks.
  *
