@@ -63,6 +63,8 @@ def algorithmic_bytes(name):
         return N * 2 * SIZES.get(t[0], 0)
     if "rsx_pass32a_kernel" in name and t:        # round 5: the level-1 pass in whole atoms: keys in, keys out
         return N * 2 * SIZES.get(t[0], 0)
+    if "rsx_pass64a_kernel" in name and len(t) >= 2:      # round 6: the level-2 pass of 8-byte keys in whole atoms: keys in, four- or eight-byte values out
+        return N * (SIZES.get(t[0], 0) + SIZES.get(t[1], 0))
     if ("rsx_pass16a_kernel" in name or "rsx_pass16_kernel" in name) and t:   # the level-2 pass: keys in, two bytes per key out
         return N * (SIZES.get(t[0], 0) + 2)
     if "rsx_leafk8_kernel" in name and t:         # 8-byte keys carried as 8-byte values: whole keys in and out
