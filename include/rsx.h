@@ -139,7 +139,7 @@ typedef struct rsx_info {
 	                           the first pass), both passes write into slots, the bucket sizes come off the look-back
 	                           chains (large arrays; blocking keys-only, rank and key + payload sorts);
 	                           6: 8-byte keys whose magnitudes spread where their bytes do not (Zipf-like keys): the keys
-	                           below 2^12 are counted and written out, the others go by (bit length, leading mantissa bits)
+	                           below 2^14 are counted and written out, the others go by (bit length, leading mantissa bits)
 	                           into buckets of exactly counted sizes, by the next eight bits into slots, and through leaves
 	                           (rsx_logroute.hpp; the pre-sorted exit and the kept columns come from that route's own
 	                           one-read histogram kernel, exactly).  The

@@ -2290,7 +2290,7 @@ int sort_keys_log(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **resul
 		}
 		{
 			ProfScope prof(2, 0, c.stream);
-			hipLaunchKernelGGL((rsx_log_fill_kernel<KT>), dim3(2048), dim3(256), 0, c.stream, src, aux, (const LogCtl *)ctl,
+			hipLaunchKernelGGL((rsx_log_fill_kernel<KT>), dim3(2048), dim3(LOG_FILL_BLOCK), 0, c.stream, src, aux, (const LogCtl *)ctl,
 			                   (const LogTabs *)tabs, ka);
 			if (big_leaves)
 				hipLaunchKernelGGL((rsx_log_leaf_kernel<KT, LogLeafCfgBig>), dim3(65536), dim3(LogLeafCfgBig::BLOCK), 0, c.stream, src, aux,

@@ -9,11 +9,11 @@
 // What spreads such keys is an order-preserving digit of (bit length, leading mantissa bits) -- a float's exponent and top
 // fraction bits, made from an integer with one count-leading-zeros:
 //
-//   small keys   derived keys below 2^12 (after the constant top bits are dropped) are COUNTED, in a 4096-entry table per
+//   small keys   derived keys below 2^14 (after the constant top bits are dropped) are COUNTED, in a 16384-entry table per
 //                workgroup of the histogram kernel; the sorted array's beginning is that table written out (rsx_log_fill_kernel:
 //                the precedent is rsx_fill_runs_kernel for one-column keys) -- they are read once and written once;
-//   level 1      the other keys go by  d1 = (bit length - 13) << m | the m bits below the leading one  (m = 3 for keys below
-//                2^44: 224 buckets for 2^40) into buckets whose EXACT sizes the histogram kernel counted: no slots, no slack;
+//   level 1      the other keys go by  d1 = (bit length - 15) << m | the m bits below the leading one  (m = 3 for keys below
+//                2^44: 208 buckets for 2^40) into buckets whose EXACT sizes the histogram kernel counted: no slots, no slack;
 //                whole 64-byte atoms from the bucket's front, what a workgroup still carries at its range's end from the
 //                bucket's back (the two meet exactly);
 //   level 2      inside a level-1 bucket by the next eight bits below those (a shift per bucket), into slots with slack, as
@@ -40,7 +40,12 @@
 
 namespace rsx {
 
-constexpr u32 LOG_C = 12;                  // derived keys below 2^LOG_C are counted, not moved
+#ifndef RSX_LOG_C
+#define RSX_LOG_C 14
+#endif
+constexpr u32 LOG_C = RSX_LOG_C;           // derived keys below 2^LOG_C are counted, not moved (2^28 Zipf-like keys, tools/ubench/log_probe:
+                                           // 2^12 2.39-2.41 ms, 2^13 2.34-2.37, 2^14 2.33-2.35 -- 64 KiB of counters per workgroup of the histogram kernel)
+static_assert(LOG_C >= 12 && LOG_C <= 14, "the level-2 digit lies below the level-1 digit's bits (LOG_C >= m + 8); the table fits the LDS");
 constexpr u32 LOG_NSMALL = 1u << LOG_C;
 constexpr u32 LOG_LEAF_CAP = 5120;         // values a leaf holds (rsx_log_leaf_kernel, LogLeafCfg<256, 5120, 12>) ...
 constexpr u32 LOG_LEAF_CAP_BIG = 10240;    // ... and the shape for arrays beyond 2^28 + 2^24 keys (LogLeafCfg<512, 10240, 13>)
@@ -347,19 +352,18 @@ __global__ __launch_bounds__(1024) void rsx_log_plan_kernel(LogCtl *__restrict__
 		total = tot;
 		return base + x - v;
 	};
-	// the small keys: four table entries per thread
-	u32 c4[4], sum4 = 0;
-#pragma unroll
-	for (u32 j = 0; j < 4; ++j) {
-		c4[j] = tabs->cnt[4 * tid + j];
-		sum4 += c4[j];
-	}
+	// the small keys: PER consecutive table entries per thread
+	constexpr u32 PER = LOG_NSMALL / 1024;
+	u32 sum4 = 0;
+#pragma unroll 4
+	for (u32 j = 0; j < PER; ++j)
+		sum4 += tabs->cnt[PER * tid + j];
 	u32 nsmall;
 	u32 o = scan1024(sum4, nsmall);
-#pragma unroll
-	for (u32 j = 0; j < 4; ++j) {
-		tabs->offs_small[4 * tid + j] = o;
-		o += c4[j];
+#pragma unroll 4
+	for (u32 j = 0; j < PER; ++j) {
+		tabs->offs_small[PER * tid + j] = o;
+		o += tabs->cnt[PER * tid + j];
 	}
 	if (tid == 0)
 		tabs->offs_small[LOG_NSMALL] = nsmall;
@@ -434,8 +438,9 @@ __global__ __launch_bounds__(1024) void rsx_log_plan_kernel(LogCtl *__restrict__
 
 // ---- the small keys, written out ---------------------------------------------------------------------------------------------
 // out[p] = the element image of value v for offs_small[v] <= p < offs_small[v + 1]: sixteen bytes per lane and step.
+constexpr int LOG_FILL_BLOCK = LOG_C <= 12 ? 256 : 1024;   // (the prefix table lies in the LDS: 16 .. 64 KiB per workgroup)
 template <typename KT>
-__global__ __launch_bounds__(256) void rsx_log_fill_kernel(KT *__restrict__ src, KT *__restrict__ aux,
+__global__ __launch_bounds__(LOG_FILL_BLOCK) void rsx_log_fill_kernel(KT *__restrict__ src, KT *__restrict__ aux,
                                                           const LogCtl *__restrict__ ctl, const LogTabs *__restrict__ tabs,
                                                           KdfArgs<KT> ka)
 {
@@ -445,10 +450,11 @@ __global__ __launch_bounds__(256) void rsx_log_fill_kernel(KT *__restrict__ src,
 	__shared__ u32 offs[LOG_NSMALL + 1];
 	const u32 tid = threadIdx.x;
 	const u32 nsmall = ctl->nsmall;
-	constexpr u32 CHUNK = 256 * 2 * 16;   // positions per workgroup and trip
+	constexpr u32 FB = LOG_FILL_BLOCK;
+	constexpr u32 CHUNK = FB * 2 * 16;   // positions per workgroup and trip
 	if ((u64)blockIdx.x * CHUNK >= nsmall)
 		return;
-	for (u32 i = tid; i <= LOG_NSMALL; i += 256)
+	for (u32 i = tid; i <= LOG_NSMALL; i += FB)
 		offs[i] = tabs->offs_small[i];
 	__syncthreads();
 	const u64 up = (((u64)ctl->key0_hi << 32) | ctl->key0_lo) & ~(((u64)1 << ctl->B) - 1u);
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256) void rsx_log_fill_kernel(KT *__restrict__ src,
 	for (u64 c0 = (u64)blockIdx.x * CHUNK; c0 < nsmall; c0 += (u64)gridDim.x * CHUNK) {
 #pragma unroll 1
 		for (u32 j = 0; j < 16; ++j) {
-			const u64 p = c0 + (u64)(j * 256 + tid) * 2;
+			const u64 p = c0 + (u64)(j * FB + tid) * 2;
 			if (p >= nsmall)
 				break;
 			const u32 v0 = value_at((u32)p);

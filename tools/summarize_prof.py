@@ -75,10 +75,10 @@ def algorithmic_bytes(name):
         return N * 2 * SIZES.get(t[0], 0)
     if ("rsx_leaf16_kernel" in name or "rsx_leaf16w_kernel" in name) and t:         # two-byte slots in, whole keys out (rsx_leaf16.hpp)
         return N * (2 + SIZES.get(t[0], 0))
-    # route 6 (rsx_logroute.hpp) on BASELINE's cfg 3 (iv), the only configuration that takes it: 12 of the 32 equally likely bit
+    # route 6 (rsx_logroute.hpp) on BASELINE's cfg 3 (iv), the only configuration that takes it: 14 of the 32 equally likely bit
     # lengths are "small" (counted, written out by the fill kernel), the other 20 / 32 of the keys go through both passes and the
     # leaves as four-byte values (the library's own profile books the exact counts: bench_configs.json)
-    SMALL = 12.0 / 32.0
+    SMALL = 14.0 / 32.0
     if "rsx_log_hist_kernel" in name:
         return N * 8
     if "rsx_log_pass1_kernel" in name:

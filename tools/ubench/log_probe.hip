@@ -108,7 +108,7 @@ int main(int argc, char **argv)
 		CK(hipEventRecord(ev[4]));
 		rsx_log_pass2_kernel<KT><<<P2::GRID, P2::BLOCK>>>(aux, slots, tiles, ctl, tabs, cur2, (u32)l2_cap, ka);
 		CK(hipEventRecord(ev[5]));
-		rsx_log_fill_kernel<KT><<<2048, 256>>>(src, aux, ctl, tabs, ka);
+		rsx_log_fill_kernel<KT><<<2048, LOG_FILL_BLOCK>>>(src, aux, ctl, tabs, ka);
 		CK(hipEventRecord(ev[6]));
 		if (big)
 			rsx_log_leaf_kernel<KT, LogLeafCfgBig><<<65536, LogLeafCfgBig::BLOCK>>>(src, aux, slots, ctl, tabs, cur2, ka, 0u, 256u);
