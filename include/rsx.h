@@ -83,6 +83,12 @@
  *   RSX_NO_UNSTABLE=1       the MSB passes of a sort without a histogram rank per wave (stable) as every other pass does;
  *   RSX_NO_LOG=1            8-byte keys never go by (bit length, mantissa) digits (rsx_info.hybrid never 6; rsx_logroute.hpp);
  *                           RSX_LOG_MIN_LOG2=k (tests): that route from 2^k keys on (default: from 24 Mi keys; at least 2^20);
+ *                           RSX_LOG_LEAF_BIG=1 (tests): its leaves in the shape for 10240 values at every size;
+ *   RSX_NO_PASS64A=1        the level-2 pass of 8-byte keys into four-byte slots is round 4's chained kernel (rsx_pass64.hpp);
+ *   RSX_NO_ODD_STRIDE=1     the level-1 slots of a sort without a histogram lie 1.25 means apart as in round 5 (default: an odd
+ *                           number of 64 KiB apart); RSX_CAP1_PAD_KIB=k (probe): k KiB more per level-1 slot;
+ *   RSX_PROBE=bits          (measurements; results stay right) 1: the leaf table in reverse slot order, 4: every device-scheduled
+ *                           sort as if called through rsx_sort_inplace_async_hint;
  *   RSX_NO_SLACK=1, RSX_TWO_LEVEL_MIN_LOG2=k, RSX_NO_SELF_PLAN=1, RSX_NO_FUSED_HIST=1
  *                           parts of the other routes.
  *   RSX_NO_SMALL_SORT, RSX_NO_HOST_SMALL, RSX_NO_FILL_RUNS, RSX_NO_SMALL_TILES, RSX_NO_SPECULATION,
