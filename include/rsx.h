@@ -34,12 +34,16 @@
  *   caller's SECOND buffer (keys-only sorts: the sample has proven the input unsorted before anything is written, so that
  *   buffer belongs to the sort as in the reference, radix_sort.hpp:82-92; the early exits leave it untouched as before) and
  *   the other 52 -- 0.25 n keys -- in scratch memory, and 65536 slots of 1.25 n / 65536 keys for the second pass (two bytes per
- *   key for 4-byte keys: 0.63 n keys' worth -- keys-only sorts of 4-byte keys up to 2^31 keys, round 5).  Buffers grow in steps
- *   of an eighth of the next power of two (a slightly larger n does not reallocate), the new one is allocated before the old
- *   one is freed, and nothing grows or is released inside a stream capture or a *_inplace_async call.  Measured
- *   (tools/footprint_probe.py, profiles/r05/footprint_probe.txt): 2^28 u32 keys 1.17 GiB in all, 2^27 u64 keys 1.72, 2^28 u64
- *   keys 3.43; 2^28 f32 keys -> ranks or key + payload pairs 5.5 GiB (those sorts keep all their level-1 slots, keys and
- *   payloads, in scratch memory).  Round 6, 8-byte keys by (bit length, mantissa) digits (rsx_info.hybrid == 6): the level-1
+ *   key for 4-byte keys: 0.63 n keys' worth -- keys-only sorts of 4-byte keys up to 2^31 keys, round 5).  Key + payload and rank
+ *   sorts (round 6): the level-1 slots of keys and payloads likewise in the spare buffers -- the second key and payload
+ *   buffers; of a rank sort the index buffer's second half for the keys and its first half, until the ranks are written there,
+ *   for the indices -- and whole (key, payload) slots for the second pass in scratch memory.  A buffer's first allocation is
+ *   what the sort needs; one that has to GROW grows in steps of an eighth of the next power of two (a slightly larger n does
+ *   not reallocate again), the new one is allocated before the old one is freed, and nothing grows or is released inside a
+ *   stream capture or a *_inplace_async call.  Measured (tools/footprint_probe.py, profiles/r06/footprint_probe.txt):
+ *   2^28 u32 keys 1.10 GiB in all, 2^27 u64 keys 1.58, 2^28 u64 keys 3.14; 2^28 f32 keys + u32 payloads 3.04 GiB, -> u32
+ *   ranks 3.04 (round 5: 5.5 for both, all slots in scratch memory; RSX_NO_AUX_SLOTS=1 is that form: 5.04).  Round 6, 8-byte keys by
+ *   (bit length, mantissa) digits (rsx_info.hybrid == 6): the level-1
  *   buckets lie in the caller's second buffer, scratch memory holds the level-2 slots -- four bytes per key, sized
  *   (1.125 n + 46 M) x 4 bytes for any distribution (2^28 keys: 1.4 GiB, of which BASELINE's Zipf-like keys use 0.8).
  *   If an allocation fails the sort takes the histogram-first

@@ -281,12 +281,16 @@ struct DevBuf {
 				            cap, bytes);
 			(void)hipGetLastError();
 		}
-		// Sizes are rounded up to an eighth of the power of two below them (buffers of 2 MiB and more; smaller ones get an eighth
-		// on top): a sort of slightly more keys than the last one -- the sub-ranges of a distributed sort, a growing table --
-		// finds room instead of paying hipFree + hipMalloc, and hipFree synchronises the device.  At most 12.5 % above the
-		// request (round 4 gave GiB-sized slot arrays no headroom at all and re-allocated on every record size).
+		// A buffer that GROWS is rounded up to an eighth of the power of two below its size (buffers of 2 MiB and more; smaller
+		// ones get an eighth on top): a sort of slightly more keys than the last one -- the sub-ranges of a distributed sort, a
+		// growing table -- finds room instead of paying hipFree + hipMalloc, and hipFree synchronises the device.  At most
+		// 12.5 % above the request (round 4 gave GiB-sized slot arrays no headroom at all and re-allocated on every record
+		// size).  A buffer's FIRST allocation is what was asked for (to 2 MiB): the four slot arrays of 2^28 pairs, a tile
+		// above 1.25 GiB each, took 1.375 -- half a GiB for sorts that never come; sizes that do vary pay one re-allocation.
 		size_t want = bytes + bytes / 8;
-		if (bytes >= ((size_t)2 << 20)) {
+		if (!p && bytes >= ((size_t)2 << 20)) {
+			want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+		} else if (bytes >= ((size_t)2 << 20)) {
 			size_t p2 = (size_t)1 << 21;
 			while ((p2 << 1) <= bytes)
 				p2 <<= 1;
@@ -2687,7 +2691,7 @@ int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int
 	ProfAsyncVerdict pverdict(c.stream);
 	if constexpr (sizeof(KT) == 4 && sizeof(VT) == 4) {
 		if (async_pairs_blind_ok<KT>(c, n, sizeof(VT)))
-			RSX_TRY((pairs_blind_enqueue<KT, VT>(c, k, v, k, v, n, ka, &blind)));
+			RSX_TRY((pairs_blind_enqueue<KT, VT>(c, k, v, k, v, n, ka, &blind, ks, vs)));
 	}
 	if (blind)
 		pverdict.attempt_enqueued((const SegCtl *)c.seg.p);
@@ -2813,7 +2817,8 @@ int pairs_one_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 // the pairs' leaves): both MSB passes into slots -- the first reads the caller's (kin, vin), or makes the indices (vin ==
 // nullptr) --, the leaves write to (kfinal, vfinal).  *done = 0: called off, nothing the caller owns has been written.
 template <typename KT, typename VT>
-int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, int *enqueued)
+int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, int *enqueued,
+                        KT *kspare = nullptr, VT *vspare = nullptr)
 {
 	typedef Sc2Cfg<KT, VT> C2;
 	typedef LeafCfg<u32, 4, 20, 3> L;
@@ -2824,8 +2829,32 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 		return RSX_OK;
 	if (c.blind_no_room)
 		return RSX_OK;
-	if (c.slack1.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
-	    c.slack1_v.ensure(((size_t)256 * cap1 + C2::TILE) * sizeof(VT)) != RSX_OK ||
+	// Where the level-1 slots lie (as blind_enqueue: nothing is written before the sample has proven the input unsorted and every
+	// column kept, after which the caller's spare buffers belong to the sort whatever route finishes it).  `kspare` / `vspare`: n
+	// elements each that the attempt may use -- the second key and payload buffers of a key + payload sort; of a rank sort the
+	// two halves of its index buffer (the first for the indices until the leaves write it, the second, through which the
+	// reference's passes ping-pong, for the 4-byte keys).  The slots that fit (n / cap1 of them: 204 of 256) lie there, the
+	// others in scratch; keys and payloads split at the same slot, either spare buffer may be missing.
+	u32 lo = (!env().no_aux_slots && cap1 >= (u32)C2::TILE && (kspare || vspare)) ? (u32)std::min<size_t>(n / cap1, 255) : 0u;
+	auto part_span = [&](const void *spare, const void *scratch, size_t esz) {   // both parts within 2^32 elements of the lower one?
+		const uintptr_t lo_a = (uintptr_t)spare, hi_a = (uintptr_t)scratch - (size_t)lo * cap1 * esz;
+		return (std::max(lo_a, hi_a) - std::min(lo_a, hi_a)) / esz + (size_t)257 * cap1 + C2::TILE;
+	};
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		const u32 klo = kspare ? lo : 0u, vlo = vspare ? lo : 0u;
+		if (c.slack1.ensure(((size_t)(256 - klo) * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
+		    c.slack1_v.ensure(((size_t)(256 - vlo) * cap1 + C2::TILE) * sizeof(VT)) != RSX_OK)
+			break;   // (the test below sees it)
+		if (lo && ((klo && part_span(kspare, c.slack1.p, sizeof(KT)) >= ((uintptr_t)1 << 32)) ||
+		           (vlo && part_span(vspare, c.slack1_v.p, sizeof(VT)) >= ((uintptr_t)1 << 32)))) {
+			lo = 0;   // too far apart for 32-bit element offsets: all slots in scratch
+			continue;
+		}
+		break;
+	}
+	const u32 klo = kspare ? lo : 0u, vlo = vspare ? lo : 0u;
+	if (c.slack1.ensure(((size_t)(256 - klo) * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
+	    c.slack1_v.ensure(((size_t)(256 - vlo) * cap1 + C2::TILE) * sizeof(VT)) != RSX_OK ||
 	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack_v.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(VT)) != RSX_OK) {
 		(void)hipGetLastError();   // (no room: as blind_enqueue -- what was allocated goes back, nobody asks again)
@@ -2868,22 +2897,47 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	sa.slots = (u32)sizeof(KT) - 1;
 	sa.overflow = &ctl->overflow;
 	char *base0 = (char *)c.seg.p + c.seg_status_off, *base1 = base0 + st_bytes;
+	// the two parts of the level-1 slots (SegArgs): one base per array for the level-1 pass's stores and the parts' offsets from it;
+	// for the level-2 pass the spare buffer as the array and the scratch part's virtual slot 0 as the other one
+	KT *k1out = (KT *)c.slack1.p, *k1lo = (KT *)c.slack1.p;
+	VT *v1out = (VT *)c.slack1_v.p, *v1lo = (VT *)c.slack1_v.p;
+	const void *k1hi = nullptr, *v1hi = nullptr;
+	sa.lo_slots = lo;
+	if (klo) {
+		const uintptr_t lo_a = (uintptr_t)kspare, hi_a = (uintptr_t)c.slack1.p - (size_t)lo * cap1 * sizeof(KT), base_a = std::min(lo_a, hi_a);
+		sa.out_off_lo = (u32)((lo_a - base_a) / sizeof(KT));
+		sa.out_off_hi = (u32)((hi_a - base_a) / sizeof(KT));
+		k1out = (KT *)base_a;
+		k1lo = kspare;
+		k1hi = (const void *)hi_a;
+	}
+	if (vlo) {
+		const uintptr_t lo_a = (uintptr_t)vspare, hi_a = (uintptr_t)c.slack1_v.p - (size_t)lo * cap1 * sizeof(VT), base_a = std::min(lo_a, hi_a);
+		sa.v_off_lo = (u32)((lo_a - base_a) / sizeof(VT));
+		sa.v_off_hi = (u32)((hi_a - base_a) / sizeof(VT));
+		v1out = (VT *)base_a;
+		v1lo = vspare;
+		v1hi = (const void *)hi_a;
+	}
 	{
 		ProfScope prof(1, (u64)n * (2 * sizeof(KT) + (vin ? 2 : 1) * sizeof(VT)), c.stream);
 		sa.slack_cap = cap1;
 		const u32 flags = (u32)SCATTER_SEG_SLACK | (u32)SCATTER_BLIND | (u32)SCATTER_BLIND_TOP | (vin ? 0u : (u32)SCATTER_GEN_INDEX);
 		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, KT, true>), dim3((unsigned)ntiles0),
-		                   dim3(C2::BLOCK), 0, c.stream, kin, (KT *)c.slack1.p, vin, (VT *)c.slack1_v.p, (u64)n, 0u,
+		                   dim3(C2::BLOCK), 0, c.stream, kin, k1out, vin, v1out, (u64)n, 0u,
 		                   (const u64 *)c.ghist(), 1u, (u32 *)(base1 + 256), (u32 *)base1, ka, flags, (u64 *)nullptr,
 		                   (const Plan *)c.plan(), 0u, 0u, (const u32 *)nullptr, sa);
 	}
+	sa.out_off_lo = sa.out_off_hi = sa.v_off_lo = sa.v_off_hi = 0;
+	sa.kin_hi = k1hi;
+	sa.vin_hi = v1hi;
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1, (const u32 *)(base1 + 256), (u32)ntiles0);
 	{
 		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
 		sa.slack_cap = cap2;
 		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, KT, true>), dim3((unsigned)rows),
-		                   dim3(C2::BLOCK), 0, c.stream, (const KT *)c.slack1.p, (KT *)c.slack.p, (const VT *)c.slack1_v.p,
+		                   dim3(C2::BLOCK), 0, c.stream, (const KT *)k1lo, (KT *)c.slack.p, (const VT *)v1lo,
 		                   (VT *)c.slack_v.p, (u64)n, 0u, (const u64 *)c.ghist(), 1u, (u32 *)(base0 + 256), (u32 *)base0, ka,
 		                   (u32)SCATTER_SEG_SLACK | (u32)SCATTER_BLIND, (u64 *)nullptr, (const Plan *)c.plan(), 0u, 0u,
 		                   (const u32 *)nullptr, sa);
@@ -2939,12 +2993,13 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 // ... and the blocking sorts' use of it: the host waits for the verdict (the event lies behind the slack plan kernel, in front of
 // the leaves) and remembers an attempt that was called off (blind_called_off: back-off)
 template <typename KT, typename VT>
-int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, rsx_info *info, int *done)
+int pairs_blind(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, rsx_info *info, int *done,
+                KT *kspare = nullptr, VT *vspare = nullptr)
 {
 	*done = 0;
 	int enqueued = 0;
 	const size_t pmark = prof_mark();
-	RSX_TRY((pairs_blind_enqueue<KT, VT>(c, kin, vin, kfinal, vfinal, n, ka, &enqueued)));
+	RSX_TRY((pairs_blind_enqueue<KT, VT>(c, kin, vin, kfinal, vfinal, n, ka, &enqueued, kspare, vspare)));
 	if (!enqueued)
 		return RSX_OK;
 	HIP_TRY(hipEventSynchronize(c.seg_ev));
@@ -3020,7 +3075,7 @@ int sort_pairs_device_impl(Ctx &c, KT *k0, KT *k1, VT *v0, VT *v1, size_t n, int
 		if (blind_wanted<KT>(c, n, sizeof(VT))) {
 			// all sizeof(KT) columns kept (pairs_blind: the sample proves it): the result lies where an even number of passes ends
 			int done = 0;
-			RSX_TRY((pairs_blind<KT, VT>(c, k0, v0, k0, v0, n, ka, info, &done)));
+			RSX_TRY((pairs_blind<KT, VT>(c, k0, v0, k0, v0, n, ka, info, &done, k1, v1)));
 			if (done) {
 				if (info)
 					info->result_in_aux = 0;
@@ -3180,7 +3235,9 @@ int sort_rank_device_impl(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, in
 	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
 		if (want_half < 0 && !env().compact_bits && blind_wanted<KT>(c, n, sizeof(IT), true)) {
 			int done = 0;
-			RSX_TRY((pairs_blind<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, info, &done)));
+			// (spare buffers: the index buffer's two halves -- the second one, which the reference's passes ping-pong through
+			// (radix_sort_rank.hpp:77-91), for the keys' level-1 slots)
+			RSX_TRY((pairs_blind<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, info, &done, (KT *)(ib + n), ib)));
 			if (done) {   // four kept columns: the ranks are in the first half (radix_sort_rank.hpp:91)
 				*result = ib;
 				if (info)
@@ -3380,7 +3437,7 @@ int sort_rank_inplace_async(Ctx &c, const KT *src, IT *ib, size_t n, int dtype, 
 	ProfAsyncVerdict pverdict(c.stream);
 	if constexpr (sizeof(KT) == 4 && sizeof(IT) == 4) {
 		if (async_pairs_blind_ok<KT>(c, n, sizeof(IT)))
-			RSX_TRY((pairs_blind_enqueue<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, &blind)));
+			RSX_TRY((pairs_blind_enqueue<KT, IT>(c, src, (const IT *)nullptr, (KT *)nullptr, ib, n, ka, &blind, (KT *)(ib + n), ib)));
 	}
 	if (blind)
 		pverdict.attempt_enqueued((const SegCtl *)c.seg.p);

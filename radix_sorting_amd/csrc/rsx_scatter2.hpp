@@ -136,6 +136,12 @@ struct SegArgs {
 	u32 out_off_lo, out_off_hi;
 	const void *kin_hi;
 	u32 lo_slots;
+	// Key + payload and rank sorts: the payloads' level-1 slots lie in two arrays of their own (the caller's second payload buffer,
+	// or the index buffer of a rank sort, and scratch), which need not lie as the keys' two do: their slot-0 offsets from `vout`
+	// (level-1 pass) and the array of buckets lo_slots .. (level-2 pass), the same way.  The keys of a rank sort have no second
+	// buffer: out_off_lo == out_off_hi, kin_hi null, while the indices' slots are split.
+	u32 v_off_lo, v_off_hi;
+	const void *vin_hi;
 };
 
 // SCATTER_SELF_PLAN (pass 0 of a blocking keys-only sort of a mid-size array): no plan kernel has run.  `gbase` is the
@@ -457,6 +463,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			seg_bucket = st.bucket;
 		}
 	}
+	u64 vdiff = 0;                                // (SEG with payloads: see SegArgs::vin_hi, v_off_*)
+	u32 vadj_lo = 0, vadj_hi = 0, vadj_n = 0;
 	if constexpr (SEG) {
 		// SegArgs::kin_hi: the tile lies in the other array -- the same element index from there, as a shift of the tile's bounds.
 		// (Where this stands matters to the compiler: the same lines next to the tile-table read above, or an assignment to
@@ -466,6 +474,16 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			shift_elems = (u64)(((const char *)seg.kin_hi - (const char *)kin) / (long long)sizeof(KT));
 		beg += shift_elems;
 		end += shift_elems;
+		if constexpr (HAS_VAL) {
+			// SegArgs::vin_hi: the payloads of this tile, as a difference to the keys' element index (modulo 2^64)
+			if (seg.vin_hi && seg_bucket >= seg.lo_slots)
+				vdiff = (u64)(((const char *)seg.vin_hi - (const char *)vin) / (long long)sizeof(VT)) - shift_elems;
+			if (flags & SCATTER_BLIND_TOP) {
+				vadj_lo = seg.v_off_lo - seg.out_off_lo;
+				vadj_hi = seg.v_off_hi - seg.out_off_hi;
+				vadj_n = seg.lo_slots;
+			}
+		}
 	}
 	const u32 wofs = wid * (64 * KPT) + lane;   // wave w owns [w*64*KPT, +64*KPT) of a tile; round r: element 64 r + lane
 	// Element `base + wofs + 64 r` of an array: a uniform (scalar) address for (base, r) plus ONE 32-bit lane offset,
@@ -969,7 +987,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 			if (pre) {
 #pragma unroll
 				for (int r = 0; r < KPT; ++r)
-					vpre[r] = elem(vin, base, r, wo);
+					vpre[r] = elem(vin, (SEG && HAS_VAL) ? base + vdiff : base, r, wo);
 			}
 		}
 		__syncthreads();
@@ -1044,7 +1062,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 					if (PREV && pre)
 						val[r] = vpre[PREV ? r0 + r : 0];
 					else
-						val[r] = gen_index ? (VT)(base + o) : ((full || o < cnt) ? elem(vin, base, r0 + r, wo) : (VT)0);
+						val[r] = gen_index ? (VT)(base + o) : ((full || o < cnt) ? elem(vin, (SEG && HAS_VAL) ? base + vdiff : base, r0 + r, wo) : (VT)0);
 				}
 #pragma unroll
 				for (int r = 0; r < SB; ++r) {
@@ -1074,7 +1092,19 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 				}
 				const u32 d0 = pk[j] & 0xFFu, dl = (pk[j] >> (8 * (CHUNK - 1))) & 0xFFu;
 				const bool whole = full || i0 + CHUNK <= cnt;
-				if (whole && d0 == dl) {
+				if constexpr (SEG) {
+					// (the payloads' slot arrays: SegArgs::v_off_*; zero wherever the slots lie as the keys' do)
+					if (whole && d0 == dl) {
+						store_chunk<VT, CHUNK>(vout + (ST)(delta[d0] + i0 + (d0 < vadj_n ? vadj_lo : vadj_hi)), vv);
+					} else {
+#pragma unroll
+						for (int e = 0; e < CHUNK; ++e)
+							if (full || i0 + e < cnt) {
+								const u32 de = (pk[j] >> (8 * e)) & 0xFFu;
+								vout[(ST)(delta[de] + i0 + e + (de < vadj_n ? vadj_lo : vadj_hi))] = vv[e];
+							}
+					}
+				} else if (whole && d0 == dl) {
 					store_chunk<VT, CHUNK>(vout + (ST)(delta[d0] + i0), vv);
 				} else {
 #pragma unroll

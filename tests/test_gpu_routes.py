@@ -353,13 +353,9 @@ def test_u64_level2_pass_in_whole_atoms(n_mi, mask):
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64 level-2 atoms", n_mi, hex(mask)))
 
 
-@pytest.mark.parametrize("n_mi", [5, 9, 16, 64, 160])
-def test_f32_ranks_and_pairs_without_histogram(n_mi):
-    """Rank sorts and key + payload sorts of 4-byte keys take the route from 4 Mi pairs on; the leaves (rsx_leafp_kernel) come
-    in five shapes chosen by the slots' capacity: a wave per leaf for up to 256 / 512 pairs (.. 27 Mi pairs), 1280 pairs and 1024 bins
-    (.. 64 Mi), 2560 and 2048 (.. 2^27), 5120 and 4096 (160 Mi here; 2^28: tests/test_gpu_fullsize.py)."""
-    n = n_mi * MI + 99
-    a = ol.splitmix_fill(n, ol.F32, 4600 + n_mi, 0xFFFFFFFF)
+def _ranks_and_pairs(a, want_route, what):
+    """A rank sort and a key + payload sort of the f32 keys `a` against the oracle's ranks; want_route None: any but 5."""
+    n = len(a)
     # up to 16 Mi keys the C restatement of rs_sort_rank with Listing 6's loop; above, the same ranks as sorted (key, index)
     # compounds (oracle_lib.want_ranks: pinned against each other in tests/test_oracle.py)
     want, want_aux = ol.want_ranks(a, ol.F32)
@@ -367,18 +363,76 @@ def test_f32_ranks_and_pairs_without_histogram(n_mi):
     ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
     ranks, info = rsa.radix_sort_rank(bits, ib, dtype=rsa.F32)
     torch.cuda.synchronize()
-    assert info.hybrid == 5, info.hybrid
-    assert info.result_in_aux == want_aux == (info.ncols & 1)
-    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)
+    assert (info.hybrid == 5) if want_route == 5 else (info.hybrid != 5), (what, info.hybrid)
+    assert info.result_in_aux == want_aux == (info.ncols & 1), what
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want), what
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), a.view(np.uint32)), what      # (a rank sort leaves its keys alone)
     del ib, ranks
     rsa.reload_env()
     vals = torch.arange(n, dtype=torch.int32, device="cuda")
     ka, va = torch.empty_like(bits), torch.empty_like(vals)
     kr, vr, info = rsa.radix_sort_pairs(bits, ka, vals, va, dtype=rsa.F32)
     torch.cuda.synchronize()
-    assert info.hybrid == 5, info.hybrid
-    assert np.array_equal(vr.cpu().numpy().view(np.uint32), want)
-    assert np.array_equal(kr.cpu().numpy().view(np.uint32), a.view(np.uint32)[want])
+    assert (info.hybrid == 5) if want_route == 5 else (info.hybrid != 5), (what, info.hybrid)
+    assert np.array_equal(vr.cpu().numpy().view(np.uint32), want), what
+    assert np.array_equal(kr.cpu().numpy().view(np.uint32), a.view(np.uint32)[want]), what
+
+
+@pytest.mark.parametrize("n_mi", [5, 9, 16, 64, 160])
+def test_f32_ranks_and_pairs_without_histogram(n_mi):
+    """Rank sorts and key + payload sorts of 4-byte keys take the route from 4 Mi pairs on; the leaves (rsx_leafp_kernel) come
+    in five shapes chosen by the slots' capacity: a wave per leaf for up to 256 / 512 pairs (.. 27 Mi pairs), 1280 pairs and 1024 bins
+    (.. 64 Mi), 2560 and 2048 (.. 2^27), 5120 and 4096 (160 Mi here; 2^28: tests/test_gpu_fullsize.py).  From 6.4 Mi pairs on (a
+    level-1 slot then holds a tile) the level-1 slots that fit lie in the caller's spare buffers: the second key / payload buffers
+    of a key + payload sort; of a rank sort the index buffer's first half for the indices and its second half for the keys."""
+    n = n_mi * MI + 99
+    _ranks_and_pairs(ol.splitmix_fill(n, ol.F32, 4600 + n_mi, 0xFFFFFFFF), 5, ("ranks and pairs", n_mi))
+
+
+def test_f32_ranks_and_pairs_level1_slots_all_in_scratch_memory(monkeypatch):
+    monkeypatch.setenv("RSX_NO_AUX_SLOTS", "1")
+    n = 24 * MI + 5
+    _ranks_and_pairs(ol.splitmix_fill(n, ol.F32, 4651, 0xFFFFFFFF), 5, "all four slot arrays in scratch")
+
+
+@pytest.mark.parametrize("digit", [0x05, 0xF3])
+def test_f32_pairs_level1_slot_overflows_after_the_spare_buffers_were_written(digit):
+    """test_level1_slot_overflows_after_the_second_buffer_was_written for (key, payload) and (key, index) compounds: one top digit
+    of the DERIVED key with 1.4 times its share -- in a slot that lies in the spare buffers (0x05) or in scratch (0xF3).  The
+    attempt is called off after its level-1 pass has written the second key / payload buffers (the index buffer); the sort behind it
+    starts from the untouched first ones."""
+    n = 16 * MI + 3
+    a = ol.splitmix_fill(n, ol.F32, 4660 + digit, 0xFFFFFFFF).view(np.uint32).copy()
+    idx = np.arange(1000, 1000 + 26000 * 7, 7)
+    # (f32 ascending: positive floats get their sign bit set, negative ones are complemented, radix_sort_basic_kdf.hpp:32-46)
+    top = (digit ^ 0x80) if digit >= 0x80 else (~digit & 0xFF)
+    a[idx] = (a[idx] & np.uint32(0x00FFFFFF)) | np.uint32(top << 24)
+    _ranks_and_pairs(a.view(np.float32), None, ("level-1 overflow", hex(digit)))
+
+
+def test_f32_pairs_hold_less_scratch_with_slots_in_the_spare_buffers(monkeypatch):
+    """What the library holds after one key + payload sort of 24 Mi pairs (hipMemGetInfo): level-1 slots of 2 x 120 MiB, of which
+    204 / 256 lie in the caller's second buffers by default."""
+    n = 24 * MI
+    held = {}
+    for name in ("spare", "scratch"):
+        if name == "scratch":
+            monkeypatch.setenv("RSX_NO_AUX_SLOTS", "1")
+        bits = torch.empty(n, dtype=torch.int32, device="cuda")
+        rsa.fill_splitmix(bits, seed=4670)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda")
+        ka, va = torch.empty_like(bits), torch.empty_like(vals)
+        rsa.release_stream()
+        rsa.reload_env()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        kr, vr, info = rsa.radix_sort_pairs(bits, ka, vals, va, dtype=rsa.F32)
+        torch.cuda.synchronize()
+        assert info.hybrid == 5
+        held[name] = free0 - torch.cuda.mem_get_info()[0]
+        del bits, vals, ka, va, kr, vr
+    rsa.release_stream()
+    assert held["spare"] + 150 * MI < held["scratch"], held
 
 
 @pytest.mark.parametrize("shape", ["every key twice", "every key twice, small leaves", "every key twice, a wave per leaf",
