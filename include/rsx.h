@@ -37,12 +37,13 @@
  *   key for 4-byte keys: 0.63 n keys' worth -- keys-only sorts of 4-byte keys up to 2^31 keys, round 5).  Key + payload and rank
  *   sorts (round 6): the level-1 slots of keys and payloads likewise in the spare buffers -- the second key and payload
  *   buffers; of a rank sort the index buffer's second half for the keys and its first half, until the ranks are written there,
- *   for the indices -- and whole (key, payload) slots for the second pass in scratch memory.  A buffer's first allocation is
+ *   for the indices -- and, for the second pass, slots of two bytes per key and whole payloads in scratch memory (the two MSB
+ *   digits are the slot, no leaf looks at more of a key than the two bytes below them).  A buffer's first allocation is
  *   what the sort needs; one that has to GROW grows in steps of an eighth of the next power of two (a slightly larger n does
  *   not reallocate again), the new one is allocated before the old one is freed, and nothing grows or is released inside a
  *   stream capture or a *_inplace_async call.  Measured (tools/footprint_probe.py, profiles/r06/footprint_probe.txt):
- *   2^28 u32 keys 1.10 GiB in all, 2^27 u64 keys 1.58, 2^28 u64 keys 3.14; 2^28 f32 keys + u32 payloads 3.04 GiB, -> u32
- *   ranks 3.04 (round 5: 5.5 for both, all slots in scratch memory; RSX_NO_AUX_SLOTS=1 is that form: 5.04).  Round 6, 8-byte keys by
+ *   2^28 u32 keys 1.10 GiB in all, 2^27 u64 keys 1.58, 2^28 u64 keys 3.14; 2^28 f32 keys + u32 payloads 2.42 GiB, -> u32
+ *   ranks 2.42 (round 5: 5.5 for both, whole keys and all slots in scratch memory; RSX_NO_AUX_SLOTS=1: 4.41).  Round 6, 8-byte keys by
  *   (bit length, mantissa) digits (rsx_info.hybrid == 6): the level-1
  *   buckets lie in the caller's second buffer, scratch memory holds the level-2 slots -- four bytes per key, sized
  *   (1.125 n + 46 M) x 4 bytes for any distribution (2^28 keys: 1.4 GiB, of which BASELINE's Zipf-like keys use 0.8).

@@ -2666,7 +2666,8 @@ int sort_keys_inplace_async(Ctx &c, KT *buf, KT *scratch, size_t n, int dtype, i
 
 // ---- key + payload, no host synchronisation: as sort_keys_inplace_async, the result always in (k, v) -----------------------
 template <typename KT, typename VT>
-int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, int *enqueued);
+int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, int *enqueued,
+                        KT *kspare = nullptr, VT *vspare = nullptr);
 
 template <typename KT, typename VT>
 int sort_pairs_inplace_async(Ctx &c, KT *k, KT *ks, VT *v, VT *vs, size_t n, int dtype, int order)
@@ -2818,10 +2819,14 @@ int pairs_one_level(Ctx &c, const KT *k1, const VT *v1, KT *kfinal, VT *vfinal, 
 // nullptr) --, the leaves write to (kfinal, vfinal).  *done = 0: called off, nothing the caller owns has been written.
 template <typename KT, typename VT>
 int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vfinal, size_t n, KdfArgs<KT> ka, int *enqueued,
-                        KT *kspare = nullptr, VT *vspare = nullptr)
+                        KT *kspare, VT *vspare)
 {
 	typedef Sc2Cfg<KT, VT> C2;
 	typedef LeafCfg<u32, 4, 20, 3> L;
+	// The level-2 slots hold the low two bytes of what the level-2 pass reads (derived keys, or the packed keys of SegCtl::compact):
+	// the two MSB passes have decided every bit above them, and no leaf ever looked at more of a key (rsx_leafp_kernel, K16)
+	typedef unsigned short K2;
+	static_assert(sizeof(KT) == 4, "two MSB digits above two bytes");
 	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
 	const u32 cap1 = slot_cap_for(mean1), cap2 = slot_cap_for(mean2);
@@ -2855,7 +2860,7 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	const u32 klo = kspare ? lo : 0u, vlo = vspare ? lo : 0u;
 	if (c.slack1.ensure(((size_t)(256 - klo) * cap1 + C2::TILE) * sizeof(KT)) != RSX_OK ||
 	    c.slack1_v.ensure(((size_t)(256 - vlo) * cap1 + C2::TILE) * sizeof(VT)) != RSX_OK ||
-	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(KT)) != RSX_OK ||
+	    c.slack.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(K2)) != RSX_OK ||
 	    c.slack_v.ensure(((size_t)65536 * cap2 + C2::TILE) * sizeof(VT)) != RSX_OK) {
 		(void)hipGetLastError();   // (no room: as blind_enqueue -- what was allocated goes back, nobody asks again)
 		c.slack1_cap = c.slack_cap = 0;
@@ -2934,10 +2939,10 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   (u32)C2::TILE, tiles, ctl, btile, off1, cap1, (const u32 *)(base1 + 256), (u32)ntiles0);
 	{
-		ProfScope prof(1, (u64)n * 2 * (sizeof(KT) + sizeof(VT)), c.stream);
+		ProfScope prof(1, (u64)n * (sizeof(KT) + sizeof(K2) + 2 * sizeof(VT)), c.stream);
 		sa.slack_cap = cap2;
-		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, KT, true>), dim3((unsigned)rows),
-		                   dim3(C2::BLOCK), 0, c.stream, (const KT *)k1lo, (KT *)c.slack.p, (const VT *)v1lo,
+		hipLaunchKernelGGL((rsx_scatter2_kernel<KT, VT, u32, C2, false, DIG_GENERIC, false, K2, true>), dim3((unsigned)rows),
+		                   dim3(C2::BLOCK), 0, c.stream, (const KT *)k1lo, (K2 *)c.slack.p, (const VT *)v1lo,
 		                   (VT *)c.slack_v.p, (u64)n, 0u, (const u64 *)c.ghist(), 1u, (u32 *)(base0 + 256), (u32 *)base0, ka,
 		                   (u32)SCATTER_SEG_SLACK | (u32)SCATTER_BLIND, (u64 *)nullptr, (const Plan *)c.plan(), 0u, 0u,
 		                   (const u32 *)nullptr, sa);
@@ -2948,7 +2953,7 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c.seg_ev, c.stream));
 	{
-		ProfScope prof(2, (u64)n * (sizeof(KT) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
+		ProfScope prof(2, (u64)n * (sizeof(K2) + 2 * sizeof(VT) + (kfinal ? sizeof(KT) : 0)), c.stream);
 		if (!env().no_leaf16) {
 			// the compounds (key half, position) through one placement and the register passes (rsx_leafp_kernel); what it
 			// leaves alone -- or everything, if the sample saw the keys' low bits cluster -- through the LDS passes of round 3
@@ -2960,7 +2965,7 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 			typedef LeafKCfg<128, 1280, 6, 10> P1;
 			u32 *redo = (u32 *)((char *)c.seg.p + c.seg_redo_off);
 #define RSX_LEAFP(P) \
-	hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P>), dim3(65536u), dim3(P::BLOCK), 0, c.stream, (const KT *)c.slack.p, \
+	hipLaunchKernelGGL((rsx_leafp_kernel<KT, VT, P, true>), dim3(65536u), dim3(P::BLOCK), 0, c.stream, (const KT *)c.slack.p, \
 	                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab, ctl, ka, redo, \
 	                   (u32)env().leaf16_maxbin)
 			typedef LeafKCfg<64, 256, 8, 9> P0;    // slots of up to 256 pairs: a wave per leaf
@@ -2976,11 +2981,11 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 			else
 				RSX_LEAFP(P5);
 #undef RSX_LEAFP
-			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(4096), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L, true>), dim3(4096), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
 			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
 			                   (const SegCtl *)ctl, ka, (u32)HYB_TWO_LEVEL, (const u64 *)nullptr, (u64)0, (const u32 *)redo);
 		} else {
-			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L, true>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
 			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
 			                   (const SegCtl *)ctl, ka);
 		}

@@ -1374,7 +1374,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_sort_kernel(KT *__r
 // and writes the payloads (and, for pair sorts, the keys) to its place in the dense result.  Rank sorts do not want the keys.
 // level == HYB_ONE_LEVEL (mid-size arrays): the 256 buckets of ONE pass by the highest kept column, read where that pass wrote
 // them (kslots / vslots are then its dense output, the bounds the column's offsets in `ghist`).
-template <typename KT, typename VT, typename C>
+// K16 (two levels, sorts without a histogram): the key slots hold the low two bytes of the derived (or packed) keys
+// (rsx_leafp_kernel, rsx_leaf16.hpp); the two bytes above them are the slot's two digits.
+template <typename KT, typename VT, typename C, bool K16 = false>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const KT *__restrict__ kslots, const VT *__restrict__ vslots,
                                                                            u32 slack_cap, KT *__restrict__ kout, VT *__restrict__ vout,
                                                                            const Plan *__restrict__ plan,
@@ -1431,8 +1433,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 		ng = ng < ngall ? ng : ngall;
 		const u32 wo0 = wid * per + lane;
 		const KT *kp = ls.slot ? kslots + (u64)(ls.slot - 1) * slack_cap : kslots + ls.beg;
+		const unsigned short *kp16 = (const unsigned short *)kslots + (u64)(ls.slot ? ls.slot - 1 : 0u) * slack_cap;
+		const KT upper16 = (KT)(((KT)((ls.slot - 1) >> 8) << 24) | ((KT)((ls.slot - 1) & 255u) << 16));
 		const VT *vp = ls.slot ? vslots + (u64)(ls.slot - 1) * slack_cap : vslots + ls.beg;
-		KT kr[KPT];
+		KT kr[KPT];   // (K16: derived keys)
 		VT vr[KPT];
 		{
 			const u32 wo = opaque(wo0);
@@ -1442,7 +1446,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 #pragma unroll
 					for (int r = g * G; r < (g + 1) * G; ++r) {
 						const u32 i = wo + r * 64;
-						kr[r] = i < cnt ? kp[i] : kdf_invert((KT)~(KT)0, ka);
+						if constexpr (K16)
+							kr[r] = i < cnt ? (KT)(upper16 | (KT)kp16[i]) : (KT)~(KT)0;
+						else
+							kr[r] = i < cnt ? kp[i] : kdf_invert((KT)~(KT)0, ka);
 						vr[r] = i < cnt ? vp[i] : (VT)0;
 					}
 				}
@@ -1451,7 +1458,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leaf_pairs_kernel(const 
 		u64 keep[KPT];   // derived key : payload (padding: all-ones keys, last in memory order: they stay behind the leaf's pairs)
 #pragma unroll
 		for (int r = 0; r < KPT; ++r)
-			keep[r] = ((u64)kdf_apply(kr[r], ka) << 32) | (u64)vr[r];
+			keep[r] = ((u64)(K16 ? kr[r] : kdf_apply(kr[r], ka)) << 32) | (u64)vr[r];
 		for (u32 c = 0; c < nrem; ++c) {
 			const u32 shift = 32 + 8 * ((colpack >> (4 * c)) & 15u);
 #pragma unroll

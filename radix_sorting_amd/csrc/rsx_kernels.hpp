@@ -38,6 +38,7 @@ namespace rsx {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
 struct NoVal {};  // "keys only" payload tag
 

@@ -1447,7 +1447,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafk8_kernel(KT *__rest
 // the placement by the key's top twelve bits and the register passes of rsx_leafk_kernel.  Four data-dependent LDS
 // operations per pair (count, cursor, staging store, payload gather) on 4-byte words instead of six on 8-byte ones
 // (rsx_leaf_pairs_kernel carries the pair as one 8-byte value through two LDS passes).
-template <typename KT, typename VT, typename C>
+// K16 (sorts without a histogram, round 6): the key slots hold the low two bytes of what the level-2 pass read -- the DERIVED
+// key's, or the packed key's -- which is all a leaf ever took from a key: `kslots` points to 2-byte values, a slot's keys are
+// 2 x slack_cap bytes apart (rsx_scatter2_kernel with KTO = u16; 16 -> 14 bytes per pair through the level-2 pass, 8 -> 6 into
+// the leaves, and the key slots of 2^28 pairs 0.63 instead of 1.25 GiB).
+template <typename KT, typename VT, typename C, bool K16 = false>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *__restrict__ kslots, const VT *__restrict__ vslots,
                                                                      u32 slack_cap, KT *__restrict__ kout, VT *__restrict__ vout,
                                                                      const Plan *__restrict__ plan,
@@ -1482,6 +1486,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 		if (cnt == 0)
 			return;   // (next leaf)
 		const KT *kp = kslots + (u64)(slot - 1) * slack_cap;
+		const unsigned short *kp16 = (const unsigned short *)kslots + (u64)(slot - 1) * slack_cap;
 		const VT *vp = vslots + (u64)(slot - 1) * slack_cap;
 		u32x4 kv[NV], vv[NV];
 #pragma unroll
@@ -1490,7 +1495,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 			kv[j] = u32x4{0, 0, 0, 0};
 			vv[j] = u32x4{0, 0, 0, 0};
 			if (e0 < cnt) {   // (a slot's capacity is a multiple of 256 pairs: the vector behind the last pair is the slot's own)
-				kv[j] = *(const u32x4 *)(kp + e0);
+				if constexpr (K16) {
+					const u32x2 h = *(const u32x2 *)(kp16 + e0);
+					kv[j] = u32x4{h[0] & 0xFFFFu, h[0] >> 16, h[1] & 0xFFFFu, h[1] >> 16};
+				} else {
+					kv[j] = *(const u32x4 *)(kp + e0);
+				}
 				vv[j] = *(const u32x4 *)(vp + e0);
 			}
 		}
@@ -1508,7 +1518,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 				*(u32x4 *)&pay[e0] = vv[j];
 #pragma unroll
 			for (int e = 0; e < 4; ++e)
-				kv[j][e] = (kdf_apply((KT)kv[j][e], ka) << shk) | ((e0 + e) << shi);
+				kv[j][e] = ((K16 ? kv[j][e] : (u32)kdf_apply((KT)kv[j][e], ka)) << shk) | ((e0 + e) << shi);
 		}
 		__syncthreads();
 		auto cell_of = [&](u32 c, bool valid, u32 &sh) -> u32 * {

@@ -187,6 +187,8 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 	// SegCtl::compact (rank sorts of 4-byte keys whose varying bits are few, rsx_hybrid.hpp): the level-1 pass packs them and every
 	// pass behind it sorts the packed keys -- plain unsigned keys, whatever the caller's type
 	constexpr bool CAN_COMPACT = SEG && sizeof(KT) == 4 && val_bytes<VT>::value == 4 && std::is_same<KTO, KT>::value;
+	// (... and the level-2 pass that writes the low two bytes of what it reads -- KTO = u16, pairs_blind_enqueue -- reads packed keys too)
+	constexpr bool SEES_COMPACT = SEG && sizeof(KT) == 4 && val_bytes<VT>::value == 4;
 	u32 cp_nb = 0, cp_raw0 = 0, cp_vnot = 0, cp_kind = 0;
 	u32 cp_piece[4] = {0, 0, 0, 0};
 	const KdfArgs<KT> ka_raw = ka;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(C::BLOCK) void rsx_scatter2_kernel(const KT *__rest
 		if ((flags & SCATTER_BLIND) && seg.ctl->blind != BLIND_GO)
 			return;   // (a sort without a histogram that has been called off: rsx_hybrid.hpp)
 		const u32 mode = seg.ctl->mode;
-		if constexpr (CAN_COMPACT) {
+		if constexpr (SEES_COMPACT) {
 			if ((flags & SCATTER_BLIND) && seg.ctl->compact) {
 				cp_nb = seg.ctl->compact;
 				if (flags & SCATTER_BLIND_TOP) {

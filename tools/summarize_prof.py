@@ -89,7 +89,8 @@ def algorithmic_bytes(name):
         return int(SMALL * N * 8)
     if ("rsx_leaf_pairs_kernel" in name or "rsx_leafp_kernel" in name) and len(t) >= 2:
         # key + payload slots in; payloads out, and the keys too for pair sorts (a rank sort writes ranks only): the lower figure
-        return N * (2 * SIZES.get(t[1], 0) + SIZES.get(t[0], 0))
+        # (<KT, VT, shape, K16 = true>, round 6: the key slots hold two bytes per key)
+        return N * (2 * SIZES.get(t[1], 0) + (2 if t[-1] == "true" else SIZES.get(t[0], 0)))
     return None
 
 
