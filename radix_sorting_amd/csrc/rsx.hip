@@ -117,6 +117,7 @@ struct Env {
 	bool no_leaf16q = false;         // RSX_NO_LEAF16Q=1: slots of up to 256 values take a wave per leaf (rsx_leaf16w_kernel) instead of a row of sixteen lanes
 	bool no_narrow_slots = false;    // RSX_NO_NARROW_SLOTS=1: the level-2 slots of 8-byte keys always hold whole keys (SegCtl::narrow)
 	bool no_aux_slots = false;       // RSX_NO_AUX_SLOTS=1: the level-1 slots of a sort without a histogram all lie in scratch memory
+	bool no_narrow1 = false;         // RSX_NO_NARROW_LEVEL1=1: the level-1 pass of 8-byte keys always writes whole keys (SegCtl::narrow stays below 2)
 	bool no_dense_slots = false;     // RSX_NO_DENSE_SLOTS=1: the level-2 pass of a sort without a histogram writes whole keys
 	bool force_dense_slots = false;  // RSX_DENSE_SLOTS=1: (kept for old scripts: two-byte slots are now written for every slot size rsx_leaf16_kernel takes)
 	bool no_unstable = false;        // RSX_NO_UNSTABLE=1: the MSB passes of a sort without a histogram rank per wave (stable), as every other pass
@@ -178,6 +179,7 @@ struct Env {
 		no_leaf16q = is_one("RSX_NO_LEAF16Q");
 		no_narrow_slots = is_one("RSX_NO_NARROW_SLOTS");
 		no_aux_slots = is_one("RSX_NO_AUX_SLOTS");
+		no_narrow1 = is_one("RSX_NO_NARROW_LEVEL1");
 		no_dense_slots = is_one("RSX_NO_DENSE_SLOTS");
 		force_dense_slots = is_one("RSX_DENSE_SLOTS");
 		no_leaf16 = is_one("RSX_NO_LEAF16");
@@ -380,6 +382,7 @@ struct Ctx {
 	hipEvent_t log_ev = nullptr;
 	u32 slack1_cap = 0;
 	u32 slack1_lo = 0;  // ... of which the first slack1_lo lie in the caller's second buffer (keys-only sorts; 0: all in slack1)
+	bool narrow1 = false;   // 8-byte keys: the forms that keep low words in the level-1 slots are enqueued too (SegCtl::narrow == 2 picks them)
 	// ... sorts to go before the next attempt, doubled by every attempt that is called off; per kind of sort (4- / 8-byte keys,
 	// rank sorts, keys + payload): what one kind's inputs look like says nothing about another's
 	u32 blind_skip[4] = {0, 0, 0, 0}, blind_backoff[4] = {0, 0, 0, 0};
@@ -1695,6 +1698,13 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 				hipLaunchKernelGGL((rsx_pass64a_kernel<KT, u32>), dim3(P64::GRID), dim3(P64::BLOCK), 0, c.stream, (const KT *)aux,
 				                   (const KT *)sa.kin_hi, sa.lo_slots, (u32 *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
 				                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, ka);
+				if (c.narrow1 && second) {
+					// SegCtl::narrow == 2: the level-1 slots are four-byte places in the caller's second buffer (blind_enqueue), the
+					// same element indices; what they hold is derived already
+					hipLaunchKernelGGL((rsx_pass64a_kernel<u32, u32>), dim3(P64::GRID), dim3(P64::BLOCK), 0, c.stream, (const u32 *)second,
+					                   (const u32 *)nullptr, 0u, (u32 *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
+					                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, KdfArgs<u32>{0, 0, 0});
+				}
 			} else if (plain)
 				RSX_LAUNCH_SEG32(DIG_PLAIN);
 			else
@@ -2074,6 +2084,20 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 		c.host_segctl->mode = SEG_MODE_NONE;
 	c.slack1_cap = cap1;
 	c.slack_cap = cap2;
+	// 4-byte keys from 64 Mi keys on: the level-1 pass in whole 64-byte atoms (rsx_pass32a_kernel: a workgroup per CU takes a range
+	// of tiles and carries what does not fill an atom; a bucket then lies at both ends of its slot)
+	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
+	const bool atoms64 = pass64a_narrow_wanted<KT>(c);   // (8-byte keys: the same for the form that writes four-byte slots; the sample decides which form runs)
+	typedef Pass32aCfgT<sizeof(KT) == 8 ? 14 : 28> P32;
+	const size_t min32 = env().pass32_min_mi ? (size_t)env().pass32_min_mi << 20 : sizeof(KT) == 8 ? (size_t)3 << 23 : (size_t)13 << 22;
+	const bool atoms1 = (sizeof(KT) == 4 ? atoms : !env().no_unstable) && !env().no_pass32a && n >= min32 &&
+	                    cap1 >= (u32)P32::TILE + 2 * PASS32_BACK;
+	// (keys the caller says arrive in order of their top digit, piece by piece: four counters per digit, rsx_pass32.hpp)
+	const bool rep4 = (c.hints & 1u) != 0 || (env().probe & 4u) != 0;
+	// 8-byte keys in which nothing below the level-1 digit varies above bit 32 (keys below 2^40: BASELINE.json's cfg 3 (ii), (iii)):
+	// the level-1 slots can hold low words -- all 256 of them then fit the caller's second buffer -- and the level-2 pass reads four
+	// bytes per key.  Both atom passes in both forms are enqueued; the sample decides (SegCtl::narrow == 2).
+	c.narrow1 = sizeof(KT) == 8 && atoms1 && atoms64 && lo != 0 && !rep4 && !env().no_narrow1 && (((uintptr_t)aux) & 63) == 0;
 	// the sample (workgroup 0: control block, plan) and the zeroing of both passes' status words, one launch
 	static_assert(sizeof(SegCtl) <= 256, "the control block is not part of what is zeroed");
 	RSX_TRY(blind_forget_device_backoff(c));
@@ -2083,14 +2107,9 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	                   // 4-byte keys whose leaves read two-byte slots (rsx_leaf16.hpp): the MSB digits may lie below constant top bits
 	                   (u32)(sizeof(KT) == 4 && dense_slots<KT>(c) && !env().no_leaf16 && !env().no_shift ? 1 : 0),
 	                   // 8-byte keys in slots rsx_leafk_kernel takes: four-byte slots where the leaves' columns lie in the low word
-	                   (u32)(narrow_slots_ok<KT>(cap2) ? 1 : 0), 0u,
+	                   (u32)(narrow_slots_ok<KT>(cap2) ? (c.narrow1 ? 2 : 1) : 0), 0u,
 	                   // a device-scheduled sort keeps its back-off on the device (SegCtl::boff_skip); the blocking sorts keep theirs on the host
 	                   (u32)(g_in_async ? 1 : 0), (u32)((env().probe & 4u) ? 1u : c.hints));
-	// 4-byte keys from 64 Mi keys on: the level-1 pass in whole 64-byte atoms (rsx_pass32a_kernel: a workgroup per CU takes a range
-	// of tiles and carries what does not fill an atom; a bucket then lies at both ends of its slot)
-	const bool atoms = pass16a_wanted<KT>(c);   // (the level-2 pass that writes whole atoms: smaller tiles, two cursors per slot)
-	const bool atoms64 = pass64a_narrow_wanted<KT>(c);   // (8-byte keys: the same for the form that writes four-byte slots; the sample decides which form runs)
-	bool atoms1 = false;
 	{
 		// 4-byte keys: only in front of rsx_pass16a_kernel (a bucket that lies at both ends of its slot is one tile more: that pass's
 		// tile table has room for it); from 52 Mi keys, where that pass starts for good -- as first built (the next tile requested
@@ -2101,10 +2120,6 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 		// more per bucket for that (seg_extra_rows); from 24 Mi keys (1.3-2.5 % ahead at 24 .. 44 Mi, level at 20 Mi:
 		// tools/ab_sizes.py RSX_PASS32_MIN_MI 48 16 u64 ...) -- tools/ubench/pass32_probe, 2^28 u64 keys: 0.926 ms against 1.01 for
 		// the chained pass, 2^27: 0.447 against 0.50.
-		typedef Pass32aCfgT<sizeof(KT) == 8 ? 14 : 28> P32;
-		const size_t min32 = env().pass32_min_mi ? (size_t)env().pass32_min_mi << 20 : sizeof(KT) == 8 ? (size_t)3 << 23 : (size_t)13 << 22;
-		atoms1 = (sizeof(KT) == 4 ? atoms : !env().no_unstable) && !env().no_pass32a && n >= min32 &&
-		         cap1 >= (u32)P32::TILE + 2 * PASS32_BACK;
 		if (atoms1) {
 			// one base for the stores, the parts' offsets in the slots' places (as launch_seg_pass does for the chained pass)
 			u32 off_lo = 0, off_hi = 0;
@@ -2132,8 +2147,6 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 #define RSX_LAUNCH_P32R(DIGV, PF, REPV)                                                                                      \
 			hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIGV, PF, P32, REPV>), dim3(256), dim3(P32::BLOCK), 0, c.stream,              \
 			                   (const KT *)src, (u64)n, kbase, lo, off_lo, off_hi, cap1, (const SegCtl *)ctl, cur1, ovf, ka)
-			// (keys the caller says arrive in order of their top digit, piece by piece: four counters per digit, rsx_pass32.hpp)
-			const bool rep4 = (c.hints & 1u) != 0 || (env().probe & 4u) != 0;
 #define RSX_LAUNCH_P32(DIGV, PF)                                                                                             \
 			do {                                                                                                                 \
 				if (rep4 && !(PF))                                                                                               \
@@ -2153,6 +2166,17 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 				RSX_LAUNCH_P32(DIG_GENERIC, false);
 #undef RSX_LAUNCH_P32
 #undef RSX_LAUNCH_P32R
+			if constexpr (sizeof(KT) == 8) {
+				if (c.narrow1) {
+					// ... and the form that writes low words: slot d = cap1 four-byte places at d x cap1 of the caller's second buffer
+					if (plain)
+						hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIG_PLAIN, false, P32, 1, u32>), dim3(256), dim3(P32::BLOCK), 0, c.stream,
+						                   (const KT *)src, (u64)n, (u32 *)aux, 256u, 0u, 0u, cap1, (const SegCtl *)ctl, cur1, ovf, ka);
+					else
+						hipLaunchKernelGGL((rsx_pass32a_kernel<KT, DIG_GENERIC, false, P32, 1, u32>), dim3(256), dim3(P32::BLOCK), 0, c.stream,
+						                   (const KT *)src, (u64)n, (u32 *)aux, 256u, 0u, 0u, cap1, (const SegCtl *)ctl, cur1, ovf, ka);
+				}
+			}
 			HIP_TRY(hipGetLastError());
 		}
 	}
@@ -2199,8 +2223,12 @@ int sort_keys_blind(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, KT **res
 	c.blind_backoff[blind_kind<KT>(0)] = 0;
 	if (sizeof(KT) == 8 && c.host_segctl->narrow) {
 		// the sample chose four-byte level-2 slots (SegCtl::narrow): the level-2 pass wrote 4 bytes per key, the leaves read 4
+		// (narrow == 2: the level-1 slots hold four bytes per key too)
+		const bool n1 = c.host_segctl->narrow == 2u;
 		prof_rebook(pmark, c.stream, 2, (u64)n * (4 + sizeof(KT)));
-		prof_rebook(pmark, c.stream, 1, (u64)n * (sizeof(KT) + 4), 3);   // (the whole-key form of the level-2 pass returned at once)
+		prof_rebook(pmark, c.stream, 1, (u64)n * ((n1 ? 4 : sizeof(KT)) + 4), 3);   // (the whole-key form of the level-2 pass returned at once)
+		if (n1)
+			prof_rebook(pmark, c.stream, 1, (u64)n * (sizeof(KT) + 4));            // (what is left of kind 1: the level-1 pass)
 	}
 	const Plan plan = *c.host_plan;
 	info_from_plan(info, plan);

@@ -57,7 +57,8 @@ struct SegCtl {
 	u32 shift1, shift2;
 	// 8-byte keys whose leaves sort columns of the low word only (keys below 2^40, say): the level-2 pass writes the low word
 	// of every DERIVED key into its slots (four bytes per key instead of eight) and rsx_leafk_kernel's SLOT32 form reads them;
-	// the upper word comes back from key0, the constant columns and the slot's two digits
+	// the upper word comes back from key0, the constant columns and the slot's two digits.  2: the level-1 slots hold low words
+	// too (nothing below the level-1 digit varies above bit 32: rsx_pass32a_kernel's OT = u32 form, rsx_pass64a_kernel<u32, u32>)
 	u32 narrow;
 	// Rank sorts of 4-byte keys whose VARYING bits are few (README.md:716-758, key compaction: f32 & 0xFFF000FF, BASELINE.json's
 	// cfg 4 (iii), varies in 20 bits -- and its byte columns hold 2, 32 and 256 values, which no slot scheme by bytes takes):
@@ -938,7 +939,12 @@ __global__ __launch_bounds__(1024) void rsx_blind_precheck_kernel(const KT *__re
 		// what the sample sees, and rsx_leaf16_kernel takes bins of up to 25 keys
 		ctl->leaf16 = (s_max12 <= max12_ok || compact) ? 1u : 0u;   // (packed keys: the leaves' own test of their bins decides)
 		// (8-byte keys, the leaves' columns all in the low word, their bins even: the leaves that read four-byte slots)
-		ctl->narrow = (W == 8 && allow_narrow && go && nk >= 4 && cols[nk - 3] <= 3u && s_max12 <= max12_ok) ? 1u : 0u;
+		// ... 2 (allow_narrow >= 2: the caller has enqueued that form of the level-1 pass too): nothing below the LEVEL-1 digit varies
+		// above bit 32 either -- the level-1 slots hold low words already (rsx_pass32a_kernel, OT = u32)
+		u32 narrow = (W == 8 && allow_narrow && go && nk >= 4 && cols[nk - 3] <= 3u && s_max12 <= max12_ok) ? 1u : 0u;
+		if (narrow && allow_narrow >= 2u && ((shift1 & 7u) ? shift1 <= 32u : cols[nk - 2] <= 3u))
+			narrow = 2u;
+		ctl->narrow = narrow;
 		ctl->shift1 = shift1;
 		ctl->shift2 = shift2;
 		ctl->cmask_lo = (u32)cmask;

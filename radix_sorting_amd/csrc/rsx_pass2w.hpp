@@ -62,11 +62,14 @@ template <typename OT> struct Pass2wSmem {
 template <typename KT, typename OT, bool NT_LOADS, typename Policy>
 __device__ __forceinline__ void pass2w_body(const Policy pol, OT *__restrict__ kout, const KdfArgs<KT> ka, Pass2wSmem<OT> &sm)
 {
-	static_assert(sizeof(KT) == 8 && (sizeof(OT) == 4 || sizeof(OT) == 8), "8-byte keys into four- or eight-byte slots");
+	// (KT = u32, OT = u32: the level-1 slots hold the low words of the derived keys already, SegCtl::narrow == 2 -- identity KDF)
+	static_assert((sizeof(KT) == 8 && (sizeof(OT) == 4 || sizeof(OT) == 8)) || (sizeof(KT) == 4 && sizeof(OT) == 4),
+	              "8-byte keys into four- or eight-byte slots, or four-byte values into four-byte slots");
+	constexpr int VIN = 16 / (int)sizeof(KT);
 	typedef Pass2wCfg<OT> C;
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
 	constexpr u32 VEC = C::VEC, ATOM = C::ATOM, BACK = C::BACK;
-	static_assert(KPT % 2 == 0 && KPT % SB == 0, "whole 16-byte loads, whole staging batches");
+	static_assert(KPT % VIN == 0 && KPT % SB == 0, "whole 16-byte loads, whole staging batches");
 	if (!pol.go())
 		return;
 	const u32 ntiles = pol.ntiles(), per = pol.per(gridDim.x);
@@ -134,13 +137,14 @@ __device__ __forceinline__ void pass2w_body(const Policy pol, OT *__restrict__ k
 		const bool full = cnt == (u32)TILE && (((uintptr_t)st.keys) & 15) == 0;
 		const u32 shift = pol.shift(bucket);
 		if (full) {
-			typedef KT vec_t __attribute__((ext_vector_type(2)));
+			typedef KT vec_t __attribute__((ext_vector_type(VIN)));
 			const vec_t *vp = (const vec_t *)st.keys + tid;
 #pragma unroll
-			for (int i = 0; i < KPT / 2; ++i) {
+			for (int i = 0; i < KPT / VIN; ++i) {
 				const vec_t v = NT_LOADS ? __builtin_nontemporal_load(&vp[i * BLOCK]) : vp[i * BLOCK];
-				keep[2 * i] = v[0];
-				keep[2 * i + 1] = v[1];
+#pragma unroll
+				for (int e = 0; e < VIN; ++e)
+					keep[VIN * i + e] = v[e];
 			}
 		} else {
 #pragma unroll

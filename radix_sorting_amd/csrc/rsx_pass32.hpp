@@ -57,8 +57,13 @@ template <typename KT, typename C, int REP = 1> struct Pass32aSmem {
 // route, no better than one pass per column.  With four counters per digit: 3.25 ms (one piece), 2.78 (two pieces: 3.42), 2.59
 // (four: 2.88), 2.54 (eight: 2.62).  Evenly spread digits pay 1-3 % of this pass for the wider tables (0.430 -> 0.437-0.450 ms at
 // 2^28 keys), so the hinted sorts take REP = 4 and everybody else REP = 1 (profiles/r06/presplit_probe.txt).
-template <typename KT, int DIG, bool PREFETCH = true, typename C = Pass32aCfg, int REP_ = 1>
-__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT *__restrict__ kin, u64 n, KT *__restrict__ kout,
+// OT (round 6): what a slot holds.  KT: the element images.  u32 with 8-byte keys: the low word of every DERIVED key -- where nothing
+// below the level-1 digit varies above bit 32 (SegCtl::narrow == 2: keys below 2^40, say, BASELINE.json's cfg 3 (ii) / (iii)) the
+// passes behind this one never look at more, and the leaves put the upper word back from the first key and the slot
+// (rsx_leafk_kernel, SLOT32): 12 instead of 16 bytes per key through this pass, 8 instead of 12 through the next.  Both forms are
+// enqueued; the sample decides which one works.
+template <typename KT, int DIG, bool PREFETCH = true, typename C = Pass32aCfg, int REP_ = 1, typename OT = KT>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT *__restrict__ kin, u64 n, OT *__restrict__ kout,
                                                                           u32 lo_slots, u32 off_lo, u32 off_hi, u32 cap,
                                                                           const SegCtl *__restrict__ ctl,
                                                                           u32 *__restrict__ cursors, u32 *__restrict__ overflow,
@@ -66,12 +71,19 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 {
 	static_assert(sizeof(KT) == 4 || sizeof(KT) == 8, "4- or 8-byte keys");
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
-	constexpr u32 VEC = 16 / sizeof(KT);    // keys per 16-byte vector (what a copying thread moves: a quarter of an atom)
-	constexpr u32 ATOM = 64 / sizeof(KT);   // keys per 64-byte atom
-	static_assert(KPT % (int)VEC == 0, "whole vectors per lane");
-	static_assert(sizeof(KT) == 4 || C::STAGE * sizeof(KT) + 256 * 64 <= 150 * 1024, "8-byte keys: 14 Ki-key tiles (Pass32aCfgT<14>)");
+	constexpr u32 VIN = 16 / sizeof(KT);    // keys per 16-byte load
+	constexpr u32 VEC = 16 / sizeof(OT);    // values per 16-byte vector (what a copying thread moves: a quarter of an atom)
+	constexpr u32 ATOM = 64 / sizeof(OT);   // values per 64-byte atom
+	constexpr bool NARROW = sizeof(OT) != sizeof(KT);
+	static_assert(!NARROW || (sizeof(KT) == 8 && sizeof(OT) == 4), "8-byte keys into four-byte slots, or the element images");
+	static_assert(KPT % (int)VIN == 0, "whole vectors per lane");
+	static_assert(sizeof(OT) == 4 || C::STAGE * sizeof(OT) + 256 * 64 <= 150 * 1024, "8-byte slots: 14 Ki-key tiles (Pass32aCfgT<14>)");
 	if (ctl->blind != BLIND_GO)
 		return;   // (the sample has called the attempt off: rsx_hybrid.hpp)
+	if constexpr (sizeof(KT) == 8) {
+		if ((ctl->narrow == 2u) != NARROW)
+			return;   // (the other form's keys)
+	}
 	const u32 ntiles = (u32)((n + TILE - 1) / TILE);
 	const u32 per = (ntiles + gridDim.x - 1) / gridDim.x;
 	const u32 t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
@@ -81,10 +93,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 	// the bits the sample took for constant, and the first key's (derived)
 	const KT cmask = sizeof(KT) == 8 ? (KT)(((u64)ctl->cmask_hi << 32) | ctl->cmask_lo) : (KT)ctl->cmask_lo;
 	const KT key0 = sizeof(KT) == 8 ? (KT)(((u64)ctl->key0_hi << 32) | ctl->key0_lo) : (KT)ctl->key0_lo;
-	__shared__ Pass32aSmem<KT, C, REP_> sm;
+	__shared__ Pass32aSmem<OT, C, REP_> sm;
 	const u32 tid0 = threadIdx.x;
-	auto sidx = [](u32 pos) { return stage_swz<true>(pos * (u32)sizeof(KT)); };
-	auto staged = [&](u32 pos) -> KT & { return *(KT *)((char *)sm.stage + sidx(pos)); };
+	auto sidx = [](u32 pos) { return stage_swz<true>(pos * (u32)sizeof(OT)); };
+	auto staged = [&](u32 pos) -> OT & { return *(OT *)((char *)sm.stage + sidx(pos)); };
 	auto slot_base = [&](u32 d) { return (d < lo_slots ? off_lo : off_hi) + d * cap; };
 	u32 cc = 0;   // digit thread: keys of its digit carried from the tiles before
 	constexpr u32 REP = REP_;
@@ -99,14 +111,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 		const u32 cnt = n - beg < (u64)TILE ? (u32)(n - beg) : (u32)TILE;
 		const KT *p = kin + beg;
 		if (cnt == (u32)TILE && (((uintptr_t)p) & 15) == 0) {
-			typedef KT vec_t __attribute__((ext_vector_type(VEC)));
+			typedef KT vec_t __attribute__((ext_vector_type(VIN)));
 			const vec_t *vp = (const vec_t *)p + tid;
 #pragma unroll
-			for (int i = 0; i < KPT / (int)VEC; ++i) {
+			for (int i = 0; i < KPT / (int)VIN; ++i) {
 				const vec_t v = vp[i * BLOCK];
 #pragma unroll
-				for (int e = 0; e < (int)VEC; ++e)
-					keep[(int)VEC * i + e] = v[e];
+				for (int e = 0; e < (int)VIN; ++e)
+					keep[(int)VIN * i + e] = v[e];
 			}
 		} else {
 #pragma unroll
@@ -256,8 +268,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 				}
 #pragma unroll
 				for (int r = 0; r < SB; ++r) {
-					if (FULL || tid + (r0 + r) * BLOCK < cnt)
-						staged(pos[r]) = keep[r0 + r];
+					if (FULL || tid + (r0 + r) * BLOCK < cnt) {
+						if constexpr (NARROW)
+							staged(pos[r]) = (OT)(DIG == 1 ? keep[r0 + r] : kdf_apply(keep[r0 + r], ka));
+						else
+							staged(pos[r]) = keep[r0 + r];
+					}
 				}
 			}
 		};
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 			const u32 ccd = inf & 31u, atomd = (inf >> 15) & 1u;
 			if (atomd) {
 				const u32 rb = sm.rbeg[cd];
-				typedef KT kvec_t __attribute__((ext_vector_type(VEC)));
+				typedef OT kvec_t __attribute__((ext_vector_type(VEC)));
 				typedef kvec_t avec_t __attribute__((aligned(16)));
 				kvec_t w;
 #pragma unroll
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_pass32a_kernel(const KT 
 			for (u32 i0 = VEC * tid; i0 < total; i0 += VEC * BLOCK) {
 				const u32 d = sm.group_digit[i0 / VEC];
 				if (i0 >= sm.bbeg[d] && i0 < sm.bend[d]) {
-					typedef KT kvec_t __attribute__((ext_vector_type(VEC)));
+					typedef OT kvec_t __attribute__((ext_vector_type(VEC)));
 					typedef kvec_t avec_t __attribute__((aligned(16)));
 					*(avec_t *)(kout + (u32)(sm.delta[d] + i0)) = *(const kvec_t *)((const char *)sm.stage + sidx(i0));
 				}

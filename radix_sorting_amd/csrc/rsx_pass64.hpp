@@ -26,10 +26,10 @@ template <typename KT> struct Pass64Policy {
 	u32 *cursors;             // [65536] front cursors, [65536] back cursors (zeroed by rsx_blind_precheck_kernel with the status words)
 	u32 slack_cap;
 	u32 *overflow;
-	u32 narrow;               // the form this launch is: 1 four-byte slots, 0 whole keys (SegCtl::narrow decides which of the two works)
+	u32 narrow;               // the form this launch is (SegCtl::narrow decides which one works): 0 whole keys in and out, 1 the low words of 8-byte keys out, 2 low words in (KT = u32: the level-1 pass wrote them) and out
 	__device__ __forceinline__ bool go() const
 	{
-		return ctl->blind == BLIND_GO && plan->hyb == HYB_TWO_LEVEL && (ctl->narrow != 0u) == (narrow != 0u);
+		return ctl->blind == BLIND_GO && plan->hyb == HYB_TWO_LEVEL && ctl->narrow == narrow;
 	}
 	__device__ __forceinline__ u32 ntiles() const { return ctl->ntiles; }
 	__device__ __forceinline__ u32 per(u32 grid) const { return (ctl->ntiles + grid - 1u) / grid; }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(Pass2wCfg<OT>::BLOCK, 8) void rsx_pass64a_kernel(co
                                                                              u32 *__restrict__ overflow, KdfArgs<KT> ka)
 {
 	__shared__ Pass2wSmem<OT> sm;
-	const Pass64Policy<KT> pol{kin, kin_hi, lo_slots, tiles, ctl, plan, cursors, slack_cap, overflow, sizeof(OT) == 4 ? 1u : 0u};
+	const Pass64Policy<KT> pol{kin, kin_hi, lo_slots, tiles, ctl, plan, cursors, slack_cap, overflow, sizeof(KT) == 4 ? 2u : sizeof(OT) == 4 ? 1u : 0u};
 	// (ordinary loads: with non-temporal ones this pass is 2 % shorter and the leaves behind it 4 % longer -- 2^28 keys & 0xFFFFFFFFFF:
 	// pass 0.795 / leaves 0.742 ms against 0.812 / 0.712, two rounds on one box, profiles/r06/pass64a_ab.txt)
 	pass2w_body<KT, OT, false>(pol, kout, ka, sm);

@@ -353,6 +353,58 @@ def test_u64_level2_pass_in_whole_atoms(n_mi, mask):
     _sort_and_compare(a, ol.U64, ol.ASC, 5, ("u64 level-2 atoms", n_mi, hex(mask)))
 
 
+@pytest.mark.parametrize("case", ["u64 & 0xFFFFFFFFFF", "u64 & 0xFFFFFFFF", "i64 descending", "f64 with a constant exponent", "constant top bytes",
+                                  "48 varying bits", "switched off", "one key varies above the level-1 digit"])
+def test_u64_level1_slots_of_low_words(case, monkeypatch):
+    """8-byte keys in which nothing below the level-1 digit varies above bit 32 (SegCtl::narrow == 2: BASELINE.json's cfg 3 (ii) and
+    (iii)): rsx_pass32a_kernel<u64, ..., OT = u32> writes the low word of every derived key into four-byte level-1 slots in the
+    caller's second buffer, rsx_pass64a_kernel<u32, u32> reads them: 12 instead of 16 and 8 instead of 12 bytes per key, which the
+    library's own profile shows.  Keys that vary in 48 bits keep whole keys at level 1 (narrow == 1); a key that differs from the
+    first one in a column the sample took for constant calls the attempt off after the narrow form has written."""
+    n = 40 * MI + 33
+    dt, order, route = ol.U64, ol.ASC, 5
+    l1_bytes, l2_bytes = 12, 8
+    if case == "u64 & 0xFFFFFFFFFF":
+        a = ol.splitmix_fill(n, ol.U64, 5401, 0xFFFFFFFFFF)
+    elif case == "u64 & 0xFFFFFFFF":
+        a = ol.splitmix_fill(n, ol.U64, 5402, 0xFFFFFFFF)
+    elif case == "i64 descending":
+        a = ol.splitmix_fill(n, ol.I64, 5403, 0xFFFFFFFFFF)
+        dt, order = ol.I64, ol.DESC
+    elif case == "f64 with a constant exponent":
+        a = ol.splitmix_fill(n, ol.U64, 5404, 0xFFFFFFFFFF) | np.uint64(0x3FF0000000000000)     # (bit patterns of doubles in [1, 1 + 2^-12))
+        dt = ol.F64
+    elif case == "constant top bytes":
+        a = ol.splitmix_fill(n, ol.U64, 5405, 0xFFFFFFFFFF) | np.uint64(0xAB00CD0000000000)
+    elif case == "48 varying bits":
+        a = ol.splitmix_fill(n, ol.U64, 5406, 0xFFFFFFFFFFFF)
+        l1_bytes, l2_bytes = 16, 12
+    elif case == "switched off":
+        monkeypatch.setenv("RSX_NO_NARROW_LEVEL1", "1")
+        rsa.reload_env()
+        a = ol.splitmix_fill(n, ol.U64, 5407, 0xFFFFFFFFFF)
+        l1_bytes, l2_bytes = 16, 12
+    else:
+        a = ol.splitmix_fill(n, ol.U64, 5408, 0xFFFFFFFFFF).view(np.uint64).copy()
+        a[n // 3] |= np.uint64(1 << 52)
+        route = None
+    want, want_aux, winfo = ol.oracle_sort(a, dt, order)
+    src = torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy()).cuda()
+    aux = torch.full_like(src, 0x5A5A5A5A)
+    rsa.profile_begin()
+    res, info = rsa.radix_sort(src, aux, dtype=dt, order=order)
+    torch.cuda.synchronize()
+    prof = rsa.profile_end()
+    if route is None:
+        assert info.hybrid != 5, (case, info.hybrid)
+    else:
+        assert info.hybrid == 5, (case, info.hybrid)
+        assert prof.scatter_bytes == n * l1_bytes and prof.narrow_bytes == n * l2_bytes and prof.leaf_bytes == n * 12, \
+            (case, prof.scatter_bytes / n, prof.narrow_bytes / n, prof.leaf_bytes / n)
+    assert info.result_in_aux == want_aux and info.kept_columns() == list(winfo.cols[:winfo.ncols]), case
+    assert np.array_equal(res.cpu().numpy().view(np.uint64), np.ascontiguousarray(want).view(np.uint64)), case
+
+
 def _ranks_and_pairs(a, want_route, what):
     """A rank sort and a key + payload sort of the f32 keys `a` against the oracle's ranks; want_route None: any but 5."""
     n = len(a)

@@ -54,7 +54,7 @@ while time.time() < t_end:
     if shape == 4:                       # low bits clustered in some (digit, digit) buckets only
         top = (src >> (bits - 16)) & 0xFFFF
         sel = (top % 97) == 5
-        src[sel] = src[sel] & ~0x0FF0
+        src.copy_(torch.where(sel, src & ~0x0FF0, src))   # (masked assignment overflows torch's index arithmetic above 2^31 elements)
         del top, sel
     elif shape == 5:                     # a few strays above constant top bits
         src &= full >> 3 if dt != rsa.U64 else full
