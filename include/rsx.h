@@ -70,6 +70,8 @@
  *   RSX_NO_DENSE_SLOTS=1    the second pass of such a sort writes whole keys into its slots;
  *   RSX_NO_LEAF16=1         its leaves are round 3's (two LDS passes per slot) instead of rsx_leaf16_kernel / rsx_leafk_kernel;
  *   RSX_NO_AUX_SLOTS=1      level-1 slots all in scratch memory; RSX_NO_NARROW_SLOTS=1: 8-byte keys always in whole-key slots;
+ *   RSX_NO_NARROW_LEVEL1=1  8-byte keys: the level-1 slots always hold whole keys (round 6: low words where nothing below the
+ *                           level-1 digit varies above bit 32 -- keys below 2^40 --, 12 + 8 + 12 instead of 16 + 12 + 12 bytes per key);
  *   RSX_LEAF16_MAXBIN=k     (tests) the fullest bin a leaf may have before it goes to those; RSX_NO_SHIFT=1: MSB digits on bytes only;
  *   RSX_NO_LEAF16Q=1        slots of up to 256 values take a wave per leaf instead of a row of sixteen lanes;
  *   RSX_NO_LEAF16W2K=1      slots of 1025 .. 2048 values take a 128-thread workgroup per leaf instead of a wave;
