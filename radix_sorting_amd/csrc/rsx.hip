@@ -1701,7 +1701,8 @@ int launch_seg_pass(Ctx &c, const KT *aux, KT *src, size_t n, KdfArgs<KT> ka, in
 				if (c.narrow1 && second) {
 					// SegCtl::narrow == 2: the level-1 slots are four-byte places in the caller's second buffer (blind_enqueue), the
 					// same element indices; what they hold is derived already
-					hipLaunchKernelGGL((rsx_pass64a_kernel<u32, u32>), dim3(P64::GRID), dim3(P64::BLOCK), 0, c.stream, (const u32 *)second,
+					typedef Pass64aCfgLow P64L;
+					hipLaunchKernelGGL((rsx_pass64a_kernel<u32, u32, P64L>), dim3(P64L::GRID), dim3(P64L::BLOCK), 0, c.stream, (const u32 *)second,
 					                   (const u32 *)nullptr, 0u, (u32 *)src, sa.tiles, sa.ctl, (const Plan *)c.plan(),
 					                   (u32 *)(base + 256), sa.slack_cap, sa.overflow, KdfArgs<u32>{0, 0, 0});
 				}
@@ -2185,7 +2186,7 @@ int blind_enqueue(Ctx &c, KT *src, KT *aux, size_t n, KdfArgs<KT> ka, int *enque
 	hipLaunchKernelGGL(rsx_seg_tiles_kernel, dim3(32), dim3(256), 0, c.stream, (const u64 *)c.ghist(), (u64)n, (const Plan *)c.plan(),
 	                   atoms ? (u32)Pass16aCfg::TILE : (u32)C2::TILE, tiles, ctl, btile, off1, cap1,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + st_bytes + 256), (u32)ntiles0, atoms1 ? PASS32_BACK : 0u,
-	                   atoms64 ? (u32)Pass2wCfg<u32>::TILE : 0u);
+	                   atoms64 ? (u32)Pass2wCfg<u32>::TILE : 0u, c.narrow1 ? (u32)Pass64aCfgLow::TILE : 0u);
 	RSX_TRY(launch_seg_pass<KT>(c, lo ? aux : nullptr, nullptr, n, ka, -2, 2));
 	hipLaunchKernelGGL((rsx_seg_slack_plan_kernel<u32>), dim3(256), dim3(256), 0, c.stream,
 	                   (const u32 *)((char *)c.seg.p + c.seg_status_off + 256), (const u32 *)btile, (const u64 *)c.ghist(),

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
                                                             u32 *__restrict__ btile,   // [257]: bucket k's tiles are [btile[k], btile[k + 1])
                                                             u64 *__restrict__ off1_out = nullptr, u32 blind_cap = 0,
                                                             const u32 *__restrict__ status0 = nullptr, u32 ntiles0 = 0,
-                                                            u32 back_cap = 0, u32 tile_narrow = 0)   // (tile_narrow: the tile of the level-2 pass that runs when SegCtl::narrow is set, rsx_pass64.hpp)
+                                                            u32 back_cap = 0, u32 tile_narrow = 0,   // (tile_narrow: the tile of the level-2 pass that runs when SegCtl::narrow is set, rsx_pass64.hpp)
+                                                            u32 tile_narrow2 = 0)                    // (... and when it is 2: the form that reads four-byte values)
 {
 	// blind_cap != 0 (a sort without a histogram): no offsets exist.  The inclusive prefix of the LAST tile of the level-1 pass
 	// (rsx_scatter2_kernel, SCATTER_BLIND_TOP; status0) is the size of every bucket; bucket k lies in ITS SLOT of blind_cap keys
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void rsx_seg_tiles_kernel(const u64 *__restric
 	if (plan->hyb != HYB_TWO_LEVEL || (blind_cap && ctl->blind != BLIND_GO))
 		return;
 	if (tile_narrow && ctl->narrow)
-		tile = tile_narrow;
+		tile = (tile_narrow2 && ctl->narrow == 2u) ? tile_narrow2 : tile_narrow;
 	__shared__ u32 s_size[256], s_tb[257], s_beg[256], s_w[4], s_back[256];
 	const u32 d = threadIdx.x;
 	u32 size, back = 0;

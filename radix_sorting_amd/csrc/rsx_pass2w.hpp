@@ -39,16 +39,19 @@ template <typename KT> struct Pass2wTile {
 
 // OT = u32: the low word of the derived key, atoms of sixteen values, twelve keys per lane (48 KiB staged);
 // OT = u64: the element image, atoms of eight keys, six keys per lane (the same 48 KiB)
-template <typename OT> struct Pass2wCfg {
-	static constexpr int BLOCK = 1024, KPT = sizeof(OT) == 4 ? 12 : 6, TILE = BLOCK * KPT, SB = sizeof(OT) == 4 ? 4 : 3;
+// KPT_ = 24 (four-byte values in AND out, rsx_pass64a_kernel<u32, u32>): 24 Ki-key tiles, 96 KiB staged, ONE workgroup per CU as
+// rsx_pass32a_kernel has it -- the per-tile costs (barriers, 256 global atomics) then stand against twice the bytes
+template <typename OT, int KPT_ = (sizeof(OT) == 4 ? 12 : 6)> struct Pass2wCfg {
+	static constexpr int BLOCK = 1024, KPT = KPT_, TILE = BLOCK * KPT, SB = sizeof(OT) == 4 ? 4 : 3;
 	static constexpr u32 ATOM = 64 / sizeof(OT), VEC = 16 / sizeof(OT);
 	static constexpr int STAGE = TILE + 256 * 2 * ((int)VEC - 1);   // + what the 16-byte alignment of 256 runs can cost
-	static constexpr int GRID = 512;
+	static constexpr int WGS = STAGE * (int)sizeof(OT) <= 56 * 1024 ? 2 : 1;   // workgroups per CU
+	static constexpr int GRID = 256 * WGS;
 	static constexpr u32 BACK = 128;   // places at a slot's end for what is carried when a range ends: a bucket's tiles are shared by at most eight workgroups
 };
 
-template <typename OT> struct Pass2wSmem {
-	typedef Pass2wCfg<OT> C;
+template <typename OT, typename C_ = Pass2wCfg<OT> > struct Pass2wSmem {
+	typedef C_ C;
 	__attribute__((aligned(16))) OT stage[C::STAGE];
 	__attribute__((aligned(16))) OT carry[256][C::ATOM];
 	u32 cell[2][256];   // per digit: count, then the run's tile-local start; tiles alternate between the two
@@ -59,14 +62,14 @@ template <typename OT> struct Pass2wSmem {
 	u32 wsum[4];
 };
 
-template <typename KT, typename OT, bool NT_LOADS, typename Policy>
-__device__ __forceinline__ void pass2w_body(const Policy pol, OT *__restrict__ kout, const KdfArgs<KT> ka, Pass2wSmem<OT> &sm)
+template <typename KT, typename OT, bool NT_LOADS, typename Policy, typename C_ = Pass2wCfg<OT> >
+__device__ __forceinline__ void pass2w_body(const Policy pol, OT *__restrict__ kout, const KdfArgs<KT> ka, Pass2wSmem<OT, C_> &sm)
 {
 	// (KT = u32, OT = u32: the level-1 slots hold the low words of the derived keys already, SegCtl::narrow == 2 -- identity KDF)
 	static_assert((sizeof(KT) == 8 && (sizeof(OT) == 4 || sizeof(OT) == 8)) || (sizeof(KT) == 4 && sizeof(OT) == 4),
 	              "8-byte keys into four- or eight-byte slots, or four-byte values into four-byte slots");
 	constexpr int VIN = 16 / (int)sizeof(KT);
-	typedef Pass2wCfg<OT> C;
+	typedef C_ C;
 	constexpr int BLOCK = C::BLOCK, KPT = C::KPT, TILE = C::TILE, SB = C::SB;
 	constexpr u32 VEC = C::VEC, ATOM = C::ATOM, BACK = C::BACK;
 	static_assert(KPT % VIN == 0 && KPT % SB == 0, "whole 16-byte loads, whole staging batches");
@@ -117,7 +120,7 @@ __device__ __forceinline__ void pass2w_body(const Policy pol, OT *__restrict__ k
 	};
 	__syncthreads();
 	// (the two workgroups of a CU start half a tile apart: started together they would load, rank and store in step)
-	if (blockIdx.x >= gridDim.x / 2)
+	if (C::WGS == 2 && blockIdx.x >= gridDim.x / 2)
 		__builtin_amdgcn_s_sleep(127);
 	KT keep[KPT];
 	for (u32 t = t0; t < t1; ++t) {

@@ -47,19 +47,22 @@ template <typename KT> struct Pass64Policy {
 	__device__ __forceinline__ u32 dump() const { return 65536u * slack_cap; }   // (a tile of padding behind the last slot)
 };
 
-template <typename KT, typename OT>
-__global__ __launch_bounds__(Pass2wCfg<OT>::BLOCK, 8) void rsx_pass64a_kernel(const KT *__restrict__ kin, const KT *__restrict__ kin_hi,
+// C: the tile shape (Pass2wCfg); the form that reads four-byte values takes 24 Ki-key tiles, one workgroup per CU (Pass64aCfgLow)
+typedef Pass2wCfg<u32, 24> Pass64aCfgLow;
+template <typename KT, typename OT, typename C = Pass2wCfg<OT> >
+__global__ __launch_bounds__(C::BLOCK, 4 * C::WGS) void rsx_pass64a_kernel(const KT *__restrict__ kin, const KT *__restrict__ kin_hi,
                                                                              u32 lo_slots, OT *__restrict__ kout,
                                                                              const SegTile *__restrict__ tiles,
                                                                              const SegCtl *__restrict__ ctl, const Plan *__restrict__ plan,
                                                                              u32 *__restrict__ cursors, u32 slack_cap,
                                                                              u32 *__restrict__ overflow, KdfArgs<KT> ka)
 {
-	__shared__ Pass2wSmem<OT> sm;
+	__shared__ Pass2wSmem<OT, C> sm;
 	const Pass64Policy<KT> pol{kin, kin_hi, lo_slots, tiles, ctl, plan, cursors, slack_cap, overflow, sizeof(KT) == 4 ? 2u : sizeof(OT) == 4 ? 1u : 0u};
 	// (ordinary loads: with non-temporal ones this pass is 2 % shorter and the leaves behind it 4 % longer -- 2^28 keys & 0xFFFFFFFFFF:
-	// pass 0.795 / leaves 0.742 ms against 0.812 / 0.712, two rounds on one box, profiles/r06/pass64a_ab.txt)
-	pass2w_body<KT, OT, false>(pol, kout, ka, sm);
+	// pass 0.795 / leaves 0.742 ms against 0.812 / 0.712, two rounds on one box, profiles/r06/pass64a_ab.txt; the form that reads
+	// four-byte values: pass 0.583 / leaves 0.759 against 0.545 / 0.734, three rounds, profiles/r06/narrow_level1_ab.txt)
+	pass2w_body<KT, OT, false, Pass64Policy<KT>, C>(pol, kout, ka, sm);
 }
 
 }  // namespace rsx

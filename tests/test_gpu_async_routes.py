@@ -115,6 +115,45 @@ def test_without_histogram_on_the_device(dt, n):
     assert route == 0, route
 
 
+def test_u64_below_two_to_the_40_on_the_device():
+    """8-byte keys in which nothing below the level-1 digit varies above bit 32 (SegCtl::narrow == 2): the device-scheduled sort
+    enqueues both forms of both MSB passes, the sample picks the one that keeps low words in the level-1 slots -- which lie in the
+    caller's scratch buffer; odd numbers of kept columns end there (the copy home); a key that varies above bit 40 after all calls
+    the attempt off and the gated passes sort; and one captured graph replays both."""
+    n = (96 << 20) + 3
+    a = ol.splitmix_fill(n, ol.U64, 7400, 0xFFFFFFFFFF)
+    for order in (ol.ASC, ol.DESC):
+        route, winfo = run(a, ol.U64, order)
+        assert route == 5 and winfo.ncols == 5, (order, route)
+    route, winfo = run(a & np.uint64(0xFFFFFFFF), ol.I64)
+    assert route == 5 and winfo.ncols == 4
+    b = a.copy()
+    b[n // 5] |= np.uint64(1 << 50)
+    route, _ = run(b, ol.U64)
+    assert route != 5, route
+    # one capture, replayed on keys the narrow form takes, on keys it must leave alone, and again
+    s = torch.cuda.Stream()
+    buf = to_dev(a)
+    scratch = torch.empty_like(buf)
+    with torch.cuda.stream(s):
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=ol.U64, stream=s)     # sizes the workspace outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        rsa.radix_sort_inplace_async(buf, scratch, dtype=ol.U64, stream=torch.cuda.current_stream())
+    for name, keys, want_route in (("below 2^40", a, 5), ("all 64 bits", ol.splitmix_fill(n, ol.U64, 7401, 0xFFFFFFFFFFFFFFFF), 5),
+                                  ("one key above", b, None), ("below 2^40 again", a[::-1].copy(), 5)):
+        buf.copy_(to_dev(keys))
+        scratch.fill_(0x6C6C6C6C)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        route = rsa.async_route(s)
+        assert (route == want_route) if want_route is not None else (route != 5), (name, route)
+        assert np.array_equal(buf.cpu().numpy().view(np.uint64), ol.oracle_sort(keys, ol.U64)[0]), name
+    rsa.release_stream(s)
+
+
 @pytest.mark.parametrize("n", [1 << 23, 1 << 27])
 def test_routes_inside_one_captured_graph(n, monkeypatch):
     """One capture, replayed on inputs that take different routes.  2^23 keys lie between the reach of one level and the

@@ -61,8 +61,8 @@ def algorithmic_bytes(name):
         if t[-1] == "true" and len(t) >= 3 and t[-2] in SIZES:      # <KT, shape, CT, DENSE>: the slots hold CT-wide values
             return N * (SIZES[t[-2]] + SIZES.get(t[0], 0))
         return N * 2 * SIZES.get(t[0], 0)
-    if "rsx_pass32a_kernel" in name and t:        # round 5: the level-1 pass in whole atoms: keys in, keys out
-        return N * 2 * SIZES.get(t[0], 0)
+    if "rsx_pass32a_kernel" in name and t:        # round 5: the level-1 pass in whole atoms: keys in, keys out (round 6: <..., OT>: what a slot holds)
+        return N * (SIZES.get(t[0], 0) + SIZES.get(t[-1] if len(t) >= 6 and t[-1] in SIZES else t[0], 0))
     if "rsx_pass64a_kernel" in name and len(t) >= 2:      # round 6: the level-2 pass of 8-byte keys in whole atoms: keys in, four- or eight-byte values out
         return N * (SIZES.get(t[0], 0) + SIZES.get(t[1], 0))
     if ("rsx_pass16a_kernel" in name or "rsx_pass16_kernel" in name) and t:   # the level-2 pass: keys in, two bytes per key out
