@@ -142,7 +142,9 @@ def test_u64_below_two_to_the_40_on_the_device():
     with torch.cuda.graph(g, stream=s):
         rsa.radix_sort_inplace_async(buf, scratch, dtype=ol.U64, stream=torch.cuda.current_stream())
     for name, keys, want_route in (("below 2^40", a, 5), ("all 64 bits", ol.splitmix_fill(n, ol.U64, 7401, 0xFFFFFFFFFFFFFFFF), 5),
-                                  ("one key above", b, None), ("below 2^40 again", a[::-1].copy(), 5)):
+                                  ("one key above", b, None),
+                                  # (a lost attempt: the device-side back-off lets the next sort of the context go by the gated passes)
+                                  ("below 2^40, backing off", a[::-1].copy(), None), ("below 2^40 again", a[::-1].copy(), 5)):
         buf.copy_(to_dev(keys))
         scratch.fill_(0x6C6C6C6C)
         torch.cuda.synchronize()
