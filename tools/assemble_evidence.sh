@@ -12,7 +12,7 @@ for w in bench configs; do
 done
 cp gpurun_out/prof_$P/configs/bench_configs.json profiles/$R/bench_configs_profiled_run.json
 cp gpurun_out/$F/pytest_gpu.txt gpurun_out/$F/smoke.txt gpurun_out/$F/bench.txt profiles/$R/final/
-echo "library, bench.py and the driver at commit $HEADC (git log -1 -- radix_sorting_amd/csrc include bench.py radix_sorting_amd/*.py: the last commit that changes code); the commits behind it add profiles and documentation only" > profiles/$R/final/head.txt
+echo "library, bench.py and the driver at commit $HEADC (git log -1 -- radix_sorting_amd/csrc include bench.py radix_sorting_amd/*.py: the last commit that changes code); the commits behind it add profiles, documentation and tests only" > profiles/$R/final/head.txt
 cp gpurun_out/$E/bench_line.json profiles/$R/bench_line.json
 cp gpurun_out/$E/bench_configs.json profiles/$R/bench_configs.json
 for f in size_sweep.txt radix_bench.txt footprint_probe.txt big_sizes.txt; do cp gpurun_out/$E/$f profiles/$R/$f; done
