@@ -91,6 +91,8 @@
  *   RSX_NO_LOG=1            8-byte keys never go by (bit length, mantissa) digits (rsx_info.hybrid never 6; rsx_logroute.hpp);
  *                           RSX_LOG_MIN_LOG2=k (tests): that route from 2^k keys on (default: from 24 Mi keys; at least 2^20);
  *                           RSX_LOG_LEAF_BIG=1 (tests): its leaves in the shape for 10240 values at every size;
+ *   RSX_PAIRS_LEAF_BIG=1    (tests) key + payload and rank sorts without a histogram: the leaves' shape for slots of 10240 pairs (what
+ *                           2^28 .. 2^29 pairs take, round 6) at every size;
  *   RSX_NO_PASS64A=1        the level-2 pass of 8-byte keys into four-byte slots is round 4's chained kernel (rsx_pass64.hpp);
  *   RSX_NO_ODD_STRIDE=1     the level-1 slots of a sort without a histogram lie 1.25 means apart as in round 5 (default: an odd
  *                           number of 64 KiB apart); RSX_CAP1_PAD_KIB=k (probe): k KiB more per level-1 slot;
@@ -206,7 +208,7 @@ int rsx_sort(void *src, void *aux, size_t n, rsx_dtype dtype, rsx_order order,
  * (once its sample has proven the input unsorted) and in slots in the (device, stream) workspace: 0.25 n + 0.625 n .. 1.25 n
  * keys of device memory (see "Scratch memory" above); rsx_sort_inplace_async_ws, whose state lies in the caller's
  * workspace, makes it when the workspace was sized by rsx_workspace_bytes_fast (below).  rsx_sort_pairs_inplace_async and rsx_sort_rank_inplace_async (4-byte keys with 4-byte
- * payloads / indices, 16 Mi .. 2^28 pairs) make the same attempt; rsx_async_route reports the last call's route for them too. */
+ * payloads / indices, 16 Mi .. 2^29 pairs) make the same attempt; rsx_async_route reports the last call's route for them too. */
 int rsx_sort_inplace_async(void *d_buf, void *d_scratch, size_t n, rsx_dtype dtype, rsx_order order,
                            void *stream);
 /* ... with what the caller knows about the keys.  RSX_HINT_EVEN_TOP_DIGITS: the caller has COUNTED the keys by their most

@@ -142,6 +142,7 @@ struct Env {
 	bool no_pass64a = false;         // RSX_NO_PASS64A=1: the level-2 pass of 8-byte keys into four-byte slots is the chained rsx_scatter2_kernel of round 4 (rsx_pass64.hpp)
 	bool no_log = false;             // RSX_NO_LOG=1: 8-byte keys never take the (bit length, mantissa) digits of rsx_logroute.hpp (rsx_info.hybrid never 6)
 	bool log_leaf_big = false;       // RSX_LOG_LEAF_BIG=1 (tests): that route's leaves in the shape for 10240 values at every size
+	bool pairs_leaf_big = false;     // RSX_PAIRS_LEAF_BIG=1 (tests): key + payload and rank sorts without a histogram: the leaves' shape for 10240 pairs at every size
 	unsigned log_min_log2 = 0;       // RSX_LOG_MIN_LOG2: ... from 2^this keys on (tests: 20; default: from 24 Mi keys)
 	void load()
 	{
@@ -219,6 +220,7 @@ struct Env {
 		no_pass64a = is_one("RSX_NO_PASS64A");
 		no_log = is_one("RSX_NO_LOG");
 		log_leaf_big = is_one("RSX_LOG_LEAF_BIG");
+		pairs_leaf_big = is_one("RSX_PAIRS_LEAF_BIG");
 		log_min_log2 = 0;
 		if (const char *e = getenv("RSX_LOG_MIN_LOG2"))
 			log_min_log2 = (unsigned)std::max(20, std::min(29, atoi(e)));
@@ -1951,7 +1953,8 @@ template <typename KT> bool blind_wanted(Ctx &c, size_t n, size_t payload_bytes 
 		// (tools/rank_threshold_probe.py, profiles/r04/rank_threshold_probe.txt); a lower RSX_TWO_LEVEL_MIN_LOG2 (tests) lowers the floor
 		// With a wave per leaf for slots of up to 256 / 512 pairs (LeafKCfg<64, 256, 8, 9>, <64, 512, 8, 10>): from 4 Mi pairs -- 8 Mi 0.169 / 0.170 against
 		// 0.176 / 0.177 ms, 10 Mi 0.180 / 0.186 against 0.229 / 0.233, 12 Mi 0.194 / 0.201 against 0.240 / 0.248.
-		if (sizeof(KT) != 4 || payload_bytes != 4 || n > ((size_t)1 << 28) ||
+		// Round 6: up to 2^29 pairs (slots of 10240 pairs: LeafKCfg<1024, 10240, 4, 13>, fourteen position bits)
+		if (sizeof(KT) != 4 || payload_bytes != 4 || n > ((size_t)1 << 29) ||
 		    n < std::min((size_t)1 << 22, (size_t)1 << env().two_level_min_log2))   // (4 Mi: 140 against 151 us, 6 Mi 148 against 161)
 			return false;
 	} else {
@@ -2010,7 +2013,7 @@ template <typename KT> bool async_pairs_blind_ok(Ctx &c, size_t n, size_t payloa
 	    env().no_speculation)
 		return false;
 	blind_refresh(c);
-	return n >= std::min((size_t)1 << 24, (size_t)1 << env().two_level_min_log2) && n >= ((size_t)1 << 22) && n <= ((size_t)1 << 28);
+	return n >= std::min((size_t)1 << 24, (size_t)1 << env().two_level_min_log2) && n >= ((size_t)1 << 22) && n <= ((size_t)1 << 29);
 }
 
 template <typename KT>
@@ -2859,8 +2862,11 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	*enqueued = 0;
 	const u32 mean1 = (u32)(n >> 8), mean2 = (u32)(n >> 16);
 	const u32 cap1 = slot_cap_for(mean1), cap2 = slot_cap_for(mean2);
-	if (cap2 > (u32)L::CAP)
+	typedef LeafCfg<u32, 16, 12, 1> LB;          // ... and up to 12288 (slots of 10240 pairs: 2^28 .. 2^29 pairs), one workgroup per CU
+	typedef LeafKCfg<1024, 10240, 4, 13> P10;   // the compound leaves' shape for those slots
+	if (cap2 > (u32)P10::CAP)
 		return RSX_OK;
+	const bool big = cap2 > (u32)L::CAP || env().pairs_leaf_big;
 	if (c.blind_no_room)
 		return RSX_OK;
 	// Where the level-1 slots lie (as blind_enqueue: nothing is written before the sample has proven the input unsorted and every
@@ -2999,7 +3005,9 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 	                   (u32)env().leaf16_maxbin)
 			typedef LeafKCfg<64, 256, 8, 9> P0;    // slots of up to 256 pairs: a wave per leaf
 			typedef LeafKCfg<64, 512, 8, 10> P0b;  // ... and of 512 (arrays of 11.5 .. 27 Mi pairs)
-			if (cap2 <= (u32)P0::CAP && !env().no_leaf16q)
+			if (big)
+				RSX_LEAFP(P10);
+			else if (cap2 <= (u32)P0::CAP && !env().no_leaf16q)
 				RSX_LEAFP(P0);
 			else if (cap2 <= (u32)P0b::CAP && !env().no_leaf16q)
 				RSX_LEAFP(P0b);
@@ -3010,13 +3018,23 @@ int pairs_blind_enqueue(Ctx &c, const KT *kin, const VT *vin, KT *kfinal, VT *vf
 			else
 				RSX_LEAFP(P5);
 #undef RSX_LEAFP
-			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L, true>), dim3(4096), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
-			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
-			                   (const SegCtl *)ctl, ka, (u32)HYB_TWO_LEVEL, (const u64 *)nullptr, (u64)0, (const u32 *)redo);
+			if (big)
+				hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, LB, true>), dim3(4096), dim3(LB::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+				                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+				                   (const SegCtl *)ctl, ka, (u32)HYB_TWO_LEVEL, (const u64 *)nullptr, (u64)0, (const u32 *)redo);
+			else
+				hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L, true>), dim3(4096), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+				                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+				                   (const SegCtl *)ctl, ka, (u32)HYB_TWO_LEVEL, (const u64 *)nullptr, (u64)0, (const u32 *)redo);
 		} else {
-			hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L, true>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
-			                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
-			                   (const SegCtl *)ctl, ka);
+			if (big)
+				hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, LB, true>), dim3(env().leaf_grid), dim3(LB::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+				                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+				                   (const SegCtl *)ctl, ka);
+			else
+				hipLaunchKernelGGL((rsx_leaf_pairs_kernel<KT, VT, L, true>), dim3(env().leaf_grid), dim3(L::BLOCK), 0, c.stream, (const KT *)c.slack.p,
+				                   (const VT *)c.slack_v.p, cap2, kfinal, vfinal, (const Plan *)c.plan(), (const LeafSeg *)segtab,
+				                   (const SegCtl *)ctl, ka);
 		}
 	}
 	HIP_TRY(hipGetLastError());

@@ -902,7 +902,8 @@ template <int BLOCK_, int CAP_, int WPE_, int NBITS_ = 12> struct LeafKCfg {
 	// four (two) bank groups, and the chunk traffic of 8-byte values cost more than the placement (first version: the u64
 	// leaves of cfg 3 1.95 ms against 1.87 with the LDS passes of round 3).
 	static constexpr int S = CAP / 16 + 3;   // columns: the chunks + what the shifted pass and the padding reach behind them (odd)
-	static_assert(CAP % 16 == 0 && CAP <= 8192, "whole chunks; bin starts fit 16 bits");
+	static_assert(CAP % 16 == 0 && CAP <= 16384, "whole chunks; bin starts fit 16 bits");
+	static constexpr u32 PBITS = CAP > 8192 ? 14u : 13u;   // rsx_leafp_kernel: bits of a pair's position in its slot
 	static_assert(PLANES == 1 || PLANES == 2, "one or two vectors of cells per thread");
 	static_assert(NCELLW == 4 * BLOCK * PLANES, "every cell in some thread's vectors");
 	static_assert(S % 2 == 1, "rows that start in different banks");
@@ -1472,7 +1473,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 	const u32 LB = ctl->compact ? ctl->shift2 : 16u;
 	if (ctl->compact)
 		ka.fmask = ka.sflip = ka.desc = 0;
-	const u32 shk = 32u - LB, shi = 19u - LB;   // (the position's thirteen bits right below the leaf's: no unused bit between them dilutes the bins)
+	const u32 shk = 32u - LB, shi = (32u - C::PBITS) - LB;   // (the position's thirteen -- slots beyond 8192 pairs: fourteen -- bits right below the leaf's: no unused bit between them dilutes the bins)
 	__shared__ __attribute__((aligned(16))) u32 cell[NCELLW + 64];
 	__shared__ __attribute__((aligned(16))) u32 stage[16 * S + 64];   // the compounds, transposed (LeafKCfg::S)
 	__shared__ __attribute__((aligned(16))) VT pay[CAP];
@@ -1646,7 +1647,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void rsx_leafp_kernel(const KT *_
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
 					const u32 x = stage[at(i0 + e)];
-					const u32 pi = (x >> shi) & 0x1FFFu;                  // (the pair's position in the slot: thirteen bits)
+					const u32 pi = (x >> shi) & ((1u << C::PBITS) - 1u);   // (the pair's position in the slot)
 					pv[e] = pay[pi < (u32)CAP ? pi : 0u];                  // (behind the leaf's end: padding)
 					kk[e] = kdf_invert((KT)(upper | (x >> 16)), ka);       // (keys out: key + payload sorts, never packed)
 				}

@@ -447,6 +447,72 @@ def test_f32_ranks_and_pairs_level1_slots_all_in_scratch_memory(monkeypatch):
     _ranks_and_pairs(ol.splitmix_fill(n, ol.F32, 4651, 0xFFFFFFFF), 5, "all four slot arrays in scratch")
 
 
+@pytest.mark.parametrize("case", ["random bits", "every key twice", "low byte from 16 values", "packed varying bits"])
+def test_f32_ranks_and_pairs_in_the_leaves_for_10240_pairs(case, monkeypatch):
+    """Beyond 2^28 pairs a slot holds up to 10240: rsx_leafp_kernel's LeafKCfg<1024, 10240, 4, 13> (fourteen position bits in the
+    compound) and, for leaves with fat bins, rsx_leaf_pairs_kernel's 12288-pair shape.  Forced here at sizes the oracle sorts in
+    seconds (RSX_PAIRS_LEAF_BIG=1); at 2^29 pairs -- where the size selects them -- checked by properties below."""
+    monkeypatch.setenv("RSX_PAIRS_LEAF_BIG", "1")
+    rsa.reload_env()
+    n = 12 * MI + 1234
+    a = ol.splitmix_fill(n, ol.F32, 4680, 0xFFFFFFFF).view(np.uint32).copy()
+    if case == "every key twice":
+        a[1::2] = a[:-1:2][: len(a[1::2])]
+    elif case == "low byte from 16 values":
+        a &= np.uint32(0xFFFFFF0F)
+    elif case == "packed varying bits":
+        # (rank sorts only: key + payload sorts hand the keys back and do not pack them)
+        a &= np.uint32(0xFFF000FF)
+        want, want_aux = ol.want_ranks(a, ol.F32)
+        ib = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+        ranks, info = rsa.radix_sort_rank(torch.from_numpy(a.view(np.int32).copy()).cuda(), ib, dtype=rsa.F32)
+        torch.cuda.synchronize()
+        assert info.hybrid == 5 and info.result_in_aux == want_aux, info.hybrid
+        assert np.array_equal(ranks.cpu().numpy().view(np.uint32), want)
+        return
+    _ranks_and_pairs(a, 5, ("leaves of 10240 pairs", case))
+
+
+@pytest.mark.parametrize("n", [(1 << 29), (3 << 27) + 4099])
+def test_f32_ranks_and_pairs_beyond_two_to_the_28(n):
+    """2^29 and 1.5 x 2^28 (f32, u32) pairs and rank sorts on the route without a histogram (round 5: one pass per column beyond 2^28):
+    order by the derived key, stability (payloads = indices ascend among equal keys), every payload still with its key, nothing lost."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * (1 << 30):
+        pytest.skip("needs 24 GiB of free HBM")
+    SIGN = -(1 << 31)
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    rsa.fill_splitmix(keys, seed=4690)
+    keys &= ~0x0101                                                      # (2^30 distinct keys: a third of the pairs share theirs with another)
+    orig = keys.clone()
+
+    def check(kr, vr):
+        kdf = torch.where(kr < 0, ~kr, kr ^ SIGN)                        # (radix_sort_basic_kdf.hpp:32-46 as signed order: ^ SIGN twice)
+        kdf = kdf ^ SIGN
+        assert bool((kdf[1:] >= kdf[:-1]).all().item())
+        same = kdf[1:] == kdf[:-1]
+        assert bool((vr[1:][same] > vr[:-1][same]).all().item())         # stable
+        del kdf, same
+        assert torch.equal(orig[vr.to(torch.int64)], kr)                 # every payload with its key
+        assert int(vr.to(torch.int64).sum().item()) == n * (n - 1) // 2  # ... and every index once (with the order above: a permutation)
+
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    ka, va = torch.empty_like(keys), torch.empty_like(vals)
+    kr, vr, info = rsa.radix_sort_pairs(keys, ka, vals, va, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert info.hybrid == 5, info.hybrid
+    check(kr, vr)
+    del vals, ka, va, kr, vr
+    torch.cuda.empty_cache()
+    keys.copy_(orig)
+    ib = torch.empty(2 * n, dtype=torch.int32, device="cuda")
+    ranks, info = rsa.radix_sort_rank(keys, ib, dtype=rsa.F32)
+    torch.cuda.synchronize()
+    assert info.hybrid == 5 and info.result_in_aux == 0, info.hybrid
+    assert torch.equal(keys, orig)                                       # (a rank sort leaves its keys alone)
+    check(orig[ranks.to(torch.int64)], ranks)
+
+
 @pytest.mark.parametrize("digit", [0x05, 0xF3])
 def test_f32_pairs_level1_slot_overflows_after_the_spare_buffers_were_written(digit):
     """test_level1_slot_overflows_after_the_second_buffer_was_written for (key, payload) and (key, index) compounds: one top digit
